@@ -1,0 +1,261 @@
+// Flash-style attention on bf16 MFMA (v_mfma_f32_32x32x16_bf16) for gfx950.
+//
+// Serves the three attention shapes of the CCEdit hot path (reference: CrossAttention.forward,
+// sgm/modules/attention.py:392-467, which calls F.scaled_dot_product_attention):
+//   spatial self-attention (Lq = Lk = h*w per frame, d = 40/80/160), text cross-attention (Lk = 77,
+//   K/V shared by the frames of a clip) and temporal self-attention (Lq = Lk = T per pixel).
+// q/k/v/o are row-major [rows][ld] with the heads side by side — exactly what the q/k/v GEMMs write in
+// the channels-last layout, so there is no 'b n (h d) -> b h n d' transpose anywhere.
+//
+// Structure (per workgroup: NW waves x 32 query rows, KV tiles of 64 rows):
+//   * "swapped" QK^T: S^T[kv][q] = K . Q^T with K as the MFMA A operand and Q (held in registers for
+//     the whole kernel) as B, so that every accumulator register of a lane belongs to ONE query
+//     (q = lane&31): the online-softmax max/sum are lane-local plus one lane^32 exchange.
+//   * the K rows feeding A-row i are permuted (bits 2,3 of i swapped) so that a lane's 8 consecutive
+//     S^T registers are 8 consecutive kv positions: exp'd and packed to bf16 they ARE the B operand of
+//     the PV product, no cross-lane shuffle.
+//   * O^T[dv][q] = V^T . P^T: V stays row-major [kv][d] in LDS and its transposed A-fragments come from
+//     ds_read_b64_tr_b16 (two per 16-kv step).  O^T again has q = lane&31 on every register, so the
+//     rescale by exp2(m_old - m_new) is a lane-scalar multiply.
+//   * K/V tiles are staged by global_load_lds_dwordx4 into a 2-deep LDS ring (tile j+1 in flight while
+//     tile j is consumed), one barrier per tile.  Pad columns / rows past Lk come from a zero page.
+#include "common.h"
+
+namespace {
+
+__device__ __attribute__((aligned(64))) char g_attn_zero_page[64];
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* p, int second_off) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(p + second_off));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(const CcAttnDesc a) {
+    constexpr int DK = (D + 15) / 16 * 16;    // K tile width (elements)
+    constexpr int DV = (D + 31) / 32 * 32;    // V tile width
+    constexpr int KS = DK / 16;               // QK^T k-steps
+    constexpr int NT = DV / 32;               // O^T row tiles
+    constexpr int GK = DK / 8, GV = DV / 8;   // 16-byte granules per tile row
+    constexpr int KB = 64 * DK * 2, VB = 64 * DV * 2;
+    constexpr int NTHR = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sK = smem;             // [2][KB]
+    char* const sV = smem + 2 * KB;    // [2][VB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int head = blockIdx.y;
+    const int qtiles = (a.Lq + NW * 32 - 1) / (NW * 32);
+    const int batch = blockIdx.x / qtiles;
+    const int q0 = (blockIdx.x - batch * qtiles) * (NW * 32) + wave * 32;
+
+    const bf16* zp = (const bf16*)g_attn_zero_page;
+    const int64_t qbase = (int64_t)(batch / a.q_inner) * a.q_outer_rows + (int64_t)(batch % a.q_inner) * a.q_inner_rows;
+    const int kvb = batch / a.kv_div;
+    const int64_t kvbase = (int64_t)(kvb / a.kv_inner) * a.kv_outer_rows + (int64_t)(kvb % a.kv_inner) * a.kv_inner_rows;
+    const bf16* __restrict__ Q = (const bf16*)a.q + head * D;
+    const bf16* __restrict__ K = (const bf16*)a.k + head * D;
+    const bf16* __restrict__ V = (const bf16*)a.v + head * D;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + l31][16 ks + 8 hi .. +8] ----
+    bf16x8 qf[KS];
+    {
+        const int qi = q0 + l31;
+        const bf16* qrow = Q + (size_t)(qbase + (int64_t)qi * a.q_seq_rows) * a.ldq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int dofs = ks * 16 + hi * 8;
+            const bf16* src = (qi < a.Lq && dofs < D) ? qrow + dofs : zp;
+            qf[ks] = *(const bf16x8*)src;
+        }
+    }
+
+    auto stage = [&](int j, int buf) {
+        // K tile
+#pragma unroll
+        for (int it = 0; it < (64 * GK + NTHR - 1) / NTHR; ++it) {
+            const int idx = it * NTHR + tid;
+            if (idx < 64 * GK) {
+                const int row = idx / GK, g = idx - row * GK;
+                const int kv = j * 64 + row;
+                const bf16* src = zp;
+                if (kv < a.Lk && g * 8 < D) src = K + (size_t)(kvbase + (int64_t)kv * a.kv_seq_rows) * a.ldk + g * 8;
+                glds16(src, sK + buf * KB + (it * NTHR + wave * 64) * 16);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < (64 * GV + NTHR - 1) / NTHR; ++it) {
+            const int idx = it * NTHR + tid;
+            if (idx < 64 * GV) {
+                const int row = idx / GV, g = idx - row * GV;
+                const int kv = j * 64 + row;
+                const bf16* src = zp;
+                if (kv < a.Lk && g * 8 < D) src = V + (size_t)(kvbase + (int64_t)kv * a.kv_seq_rows) * a.ldv + g * 8;
+                glds16(src, sV + buf * VB + (it * NTHR + wave * 64) * 16);
+            }
+        }
+    };
+
+    f32x16 o[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = a.scale * 1.4426950408889634f;   // fold log2(e): softmax via exp2
+
+    // A-row i of an S^T tile reads K row swap23(i): i = c | hi2<<2 | b<<3 | a4<<4  ->  c | b<<2 | hi2<<3 | a4<<4
+    const int krow_l = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int i16 = lane & 15, dvhalf = (lane >> 4) & 1;
+    const int ntiles = (a.Lk + 63) / 64;
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int j = 0; j < ntiles; ++j) {
+        if (j + 1 < ntiles) stage(j + 1, buf ^ 1);
+        const char* kb = sK + buf * KB;
+        const char* vb = sV + buf * VB;
+
+        // ---- S^T = K Q^T for the 64 kv rows of this tile ----
+        f32x16 s[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t2][r] = 0.f;
+            const char* kr = kb + (t2 * 32 + krow_l) * (DK * 2) + hi * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kr + ks * 32);
+                s[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t2], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (this lane: query q0 + l31, kv = 64 j + 32 t2 + 16 (r>>3) + 8 hi + (r&7)) ----
+        const bool tail = (j * 64 + 64 > a.Lk);
+        float mt = -INFINITY;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[t2][r] * sc;
+                if (tail) {
+                    const int kv = j * 64 + 32 * t2 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    if (kv >= a.Lk) v = -INFINITY;
+                }
+                s[t2][r] = v;
+                mt = fmaxf(mt, v);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(s[t2][r] - m_new);
+                s[t2][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = f2bf(s[sp >> 1][8 * (sp & 1) + e]);
+            const char* vr = vb + (16 * sp + 8 * hi + (i16 >> 2)) * (DV * 2) + (dvhalf * 16 + (i16 & 3) * 4) * 2;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const bf16x8 vf = tr_pair(vr + n * 64, 4 * DV * 2);
+                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[n], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- normalise and store: lane holds O^T[dv = 32 n + (r&3) + 8 (r>>2) + 4 hi][q = l31] ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + l31;
+    if (qi < a.Lq) {
+        bf16* orow = (bf16*)a.o + (size_t)(qbase + (int64_t)qi * a.q_seq_rows) * a.ldo + head * D;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int dv = 32 * n + 8 * qd + 4 * hi;
+                if (dv < D) {
+                    bf16x4 w = {f2bf(o[n][qd * 4 + 0] * inv), f2bf(o[n][qd * 4 + 1] * inv), f2bf(o[n][qd * 4 + 2] * inv),
+                                f2bf(o[n][qd * 4 + 3] * inv)};
+                    *(bf16x4*)(orow + dv) = w;
+                }
+            }
+    }
+}
+
+template <int D, int NW>
+int launch_attn(const CcAttnDesc& a, hipStream_t s) {
+    constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
+    constexpr int lds = 2 * 64 * DK * 2 + 2 * 64 * DV * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            cc_set_error("hipFuncSetAttribute(attn): %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    const int64_t qtiles = (a.Lq + NW * 32 - 1) / (NW * 32);
+    dim3 grid((unsigned)(qtiles * a.batches), a.heads);
+    hipLaunchKernelGGL((attn_kernel<D, NW>), grid, dim3(NW * 64), lds, s, a);
+    return cc_launch_status("attn_kernel");
+}
+
+template <int D>
+int dispatch_nw(const CcAttnDesc& a, hipStream_t s) {
+    if (a.Lq <= 32) return launch_attn<D, 1>(a, s);
+    return launch_attn<D, 4>(a, s);
+}
+
+}  // namespace
+
+extern "C" int ccedit_attention(const CcAttnDesc* desc, void* stream) {
+    CC_CHECK_ARG(desc != nullptr, "ccedit_attention: null descriptor");
+    const CcAttnDesc& a = *desc;
+    CC_CHECK_ARG(a.q && a.k && a.v && a.o, "ccedit_attention: null q/k/v/o");
+    CC_CHECK_ARG(a.heads > 0 && a.batches > 0 && a.Lq > 0 && a.Lk > 0 && a.q_inner > 0 && a.kv_inner > 0 && a.kv_div > 0,
+                 "ccedit_attention: bad sizes");
+    CC_UNSUPPORTED(a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4, "ccedit_attention: row strides must be multiples of 8");
+    CC_UNSUPPORTED(a.heads > 65535 || (int64_t)a.batches * ((a.Lq + 31) / 32) > 2147483647LL, "ccedit_attention: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    switch (a.d) {
+        case 8: return dispatch_nw<8>(a, s);
+        case 16: return dispatch_nw<16>(a, s);
+        case 32: return dispatch_nw<32>(a, s);
+        case 40: return dispatch_nw<40>(a, s);
+        case 64: return dispatch_nw<64>(a, s);
+        case 80: return dispatch_nw<80>(a, s);
+        case 128: return dispatch_nw<128>(a, s);
+        case 160: return dispatch_nw<160>(a, s);
+        default: break;
+    }
+    cc_set_error("ccedit_attention: head dim %d not instantiated (have 8,16,32,40,64,80,128,160)", a.d);
+    return CCEDIT_EUNSUPPORTED;
+}

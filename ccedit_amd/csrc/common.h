@@ -1,0 +1,64 @@
+// Shared device helpers for the gfx950 kernels of libccedit_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ccedit_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+// 16-byte asynchronous global -> LDS copy (global_load_lds_dwordx4).  The LDS destination is the
+// wave-uniform `lds_wave_base` + lane*16; the global source address is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+void cc_set_error(const char* fmt, ...);
+
+#define CC_CHECK_ARG(cond, ...)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            cc_set_error(__VA_ARGS__);   \
+            return CCEDIT_EINVAL;        \
+        }                                \
+    } while (0)
+
+#define CC_UNSUPPORTED(cond, ...)        \
+    do {                                 \
+        if (cond) {                      \
+            cc_set_error(__VA_ARGS__);   \
+            return CCEDIT_EUNSUPPORTED;  \
+        }                                \
+    } while (0)
+
+static inline int cc_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        cc_set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return CCEDIT_OK;
+}

@@ -1,0 +1,188 @@
+// Layout conversions and small elementwise kernels (all HBM-bound or negligible).
+#include "common.h"
+
+namespace {
+
+// fp32 (B, C, T, H, W) -> bf16 [B*T][H*W][Cpad]; y = x * scale(b) + shift, pad channels = 0.
+// Reads are coalesced along W for each channel; each thread assembles the Cpad channels of one pixel
+// (Cpad <= 8 on this path: latent C=4, hint C=3) and writes one 16-byte granule.
+__global__ void ncthw_to_nhwc_kernel(const float* __restrict__ x, bf16* __restrict__ y, int B, int C, int T, int H, int W,
+                                     int Cpad, const float* __restrict__ scale_per_b, float scale, float shift) {
+    const int64_t hw = (int64_t)H * W;
+    const int64_t total = (int64_t)B * T * hw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t frame = i / hw;
+        const int64_t pix = i - frame * hw;
+        const int b = (int)(frame / T), t = (int)(frame - (int64_t)b * T);
+        const float sc = scale_per_b ? scale_per_b[b] * scale : scale;
+        bf16* out = y + i * Cpad;
+        for (int c = 0; c < Cpad; ++c) {
+            float v = 0.f;
+            if (c < C) v = x[(((int64_t)b * C + c) * T + t) * hw + pix] * sc + shift;
+            out[c] = f2bf(v);
+        }
+    }
+}
+
+template <bool F32>
+__global__ void nhwc_to_ncthw_kernel(const void* __restrict__ x, int ld, float* __restrict__ y, int B, int C, int T, int H,
+                                     int W) {
+    const int64_t hw = (int64_t)H * W;
+    const int64_t total = (int64_t)B * C * T * hw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i % hw;
+        int64_t r = i / hw;
+        const int t = (int)(r % T);
+        r /= T;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        const int64_t row = ((int64_t)b * T + t) * hw + pix;
+        float v;
+        if (F32) v = ((const float*)x)[row * ld + c];
+        else v = bf2f(((const bf16*)x)[row * ld + c]);
+        y[i] = v;
+    }
+}
+
+// out[:, :C1] = a; out[:, C1:] = b + c   (16-byte granules)
+__global__ void cat_add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, const bf16* __restrict__ c,
+                               bf16* __restrict__ out, int64_t rows, int C1, int C2) {
+    const int g1 = C1 >> 3, g2 = C2 >> 3, gt = g1 + g2;
+    const int64_t total = rows * gt;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / gt;
+        const int g = (int)(i - row * gt);
+        bf16x8 v;
+        if (g < g1) {
+            v = *(const bf16x8*)(a + row * C1 + g * 8);
+        } else {
+            const bf16x8 u = *(const bf16x8*)(b + row * C2 + (g - g1) * 8);
+            if (c) {
+                const bf16x8 w = *(const bf16x8*)(c + row * C2 + (g - g1) * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(u[e]) + bf2f(w[e]));
+            } else {
+                v = u;
+            }
+        }
+        *(bf16x8*)(out + i * 8) = v;
+    }
+}
+
+__global__ void add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const bf16x8 u = *(const bf16x8*)(a + i * 8), w = *(const bf16x8*)(b + i * 8);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(u[e]) + bf2f(w[e]));
+        *(bf16x8*)(y + i * 8) = v;
+    }
+}
+
+__global__ void silu_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = f2bf(silu_f(bf2f(x[i])));
+}
+
+// [cos(t f_k) | sin(t f_k)], f_k = exp(-ln(10000) k / half)   (diffusionmodules/util.py:244-268)
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, bf16* __restrict__ out, int n, int dim, int ld) {
+    const int half = dim / 2;
+    const int i = blockIdx.x;
+    for (int k = threadIdx.x; k < half; k += blockDim.x) {
+        const float f = expf(-9.210340371976184f * (float)k / (float)half);
+        const float a = (float)t[i] * f;
+        out[(size_t)i * ld + k] = f2bf(cosf(a));
+        out[(size_t)i * ld + half + k] = f2bf(sinf(a));
+    }
+}
+
+__global__ void cfg_denoise_kernel(const float* __restrict__ x, const float* __restrict__ eps2, float* __restrict__ den,
+                                   int64_t n, float sigma, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        // DiscreteDenoiser: d = net * c_out + x * c_skip with c_out = -sigma, c_skip = 1, for each CFG half;
+        // VanillaCFG: d_u + scale * (d_c - d_u).  Evaluated in the reference's order of operations.
+        const float du = eps2[i] * (-sigma) + x[i];
+        const float dc = eps2[n + i] * (-sigma) + x[i];
+        den[i] = du + scale * (dc - du);
+    }
+}
+
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ y, int64_t n,
+                             float a, float b) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = a * x[i] + b * z[i];
+}
+
+inline unsigned grid_for(int64_t n, int threads) {
+    int64_t g = (n + threads - 1) / threads;
+    return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int ccedit_ncthw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
+                                    int32_t Cpad, const float* scale_per_b, float scale, float shift, void* stream) {
+    CC_CHECK_ARG(x && y && B > 0 && C > 0 && T > 0 && H > 0 && W > 0 && Cpad >= C, "ccedit_ncthw_to_nhwc: bad args");
+    const int64_t total = (int64_t)B * T * H * W;
+    hipLaunchKernelGGL(ncthw_to_nhwc_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y, B,
+                       C, T, H, W, Cpad, scale_per_b, scale, shift);
+    return cc_launch_status("ncthw_to_nhwc");
+}
+
+extern "C" int ccedit_nhwc_to_ncthw(const void* x, int32_t x_is_f32, int32_t ld, float* y, int32_t B, int32_t C, int32_t T,
+                                    int32_t H, int32_t W, void* stream) {
+    CC_CHECK_ARG(x && y && B > 0 && C > 0 && T > 0 && H > 0 && W > 0 && ld >= C, "ccedit_nhwc_to_ncthw: bad args");
+    const int64_t total = (int64_t)B * C * T * H * W;
+    if (x_is_f32)
+        hipLaunchKernelGGL(nhwc_to_ncthw_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, ld,
+                           y, B, C, T, H, W);
+    else
+        hipLaunchKernelGGL(nhwc_to_ncthw_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                           ld, y, B, C, T, H, W);
+    return cc_launch_status("nhwc_to_ncthw");
+}
+
+extern "C" int ccedit_cat_add(const void* a, const void* b, const void* c, void* out, int64_t rows, int32_t C1, int32_t C2,
+                              void* stream) {
+    CC_CHECK_ARG(a && b && out && rows > 0, "ccedit_cat_add: bad args");
+    CC_UNSUPPORTED(C1 % 8 || C2 % 8, "ccedit_cat_add: C1=%d C2=%d must be multiples of 8", C1, C2);
+    const int64_t total = rows * ((C1 + C2) / 8);
+    hipLaunchKernelGGL(cat_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)a,
+                       (const bf16*)b, (const bf16*)c, (bf16*)out, rows, C1, C2);
+    return cc_launch_status("cat_add");
+}
+
+extern "C" int ccedit_add(const void* a, const void* b, void* y, int64_t n, void* stream) {
+    CC_CHECK_ARG(a && b && y && n > 0, "ccedit_add: bad args");
+    CC_UNSUPPORTED(n % 8, "ccedit_add: n must be a multiple of 8");
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)a,
+                       (const bf16*)b, (bf16*)y, n / 8);
+    return cc_launch_status("add");
+}
+
+extern "C" int ccedit_silu(const void* x, void* y, int64_t n, void* stream) {
+    CC_CHECK_ARG(x && y && n > 0, "ccedit_silu: bad args");
+    hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, n);
+    return cc_launch_status("silu");
+}
+
+extern "C" int ccedit_timestep_embedding(const int64_t* t, void* out, int32_t n, int32_t dim, int32_t ld, void* stream) {
+    CC_CHECK_ARG(t && out && n > 0 && dim > 0 && ld >= dim, "ccedit_timestep_embedding: bad args");
+    CC_UNSUPPORTED(dim % 2, "ccedit_timestep_embedding: odd dim");
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, t, (bf16*)out, n, dim, ld);
+    return cc_launch_status("timestep_embedding");
+}
+
+extern "C" int ccedit_cfg_denoise(const float* x, const float* eps2, float* den, int64_t n, float sigma, float scale,
+                                  void* stream) {
+    CC_CHECK_ARG(x && eps2 && den && n > 0, "ccedit_cfg_denoise: bad args");
+    hipLaunchKernelGGL(cfg_denoise_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, eps2, den, n, sigma,
+                       scale);
+    return cc_launch_status("cfg_denoise");
+}
+
+extern "C" int ccedit_axpby(const float* x, const float* z, float* y, int64_t n, float a, float b, void* stream) {
+    CC_CHECK_ARG(x && z && y && n > 0, "ccedit_axpby: bad args");
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, z, y, n, a, b);
+    return cc_launch_status("axpby");
+}

@@ -1,0 +1,325 @@
+// GroupNorm(32) (+SiLU) in its spatial and temporal forms and LayerNorm, for the frames-outermost
+// channels-last layout [frames][pixels][C] (bf16 in/out, fp32 statistics).  All HBM-bound.
+//
+// Thread mapping shared by every kernel here: one wave reads one pixel row at a time; lane l owns the
+// 16-byte granules (8 channels) l, l+64, l+128, ... of the row, so a wave's load of one pixel is a
+// single contiguous, fully coalesced C*2-byte burst and per-channel affine parameters live in registers.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxCols = 5;    // C <= 2560
+
+// ------------------------------------------------------------------------------------------
+// spatial GroupNorm: statistics over (C/32 channels x H*W pixels) of one frame
+// ------------------------------------------------------------------------------------------
+constexpr int kGnWaves = 4;
+constexpr int kGnPixPerBlock = 64;
+
+__global__ __launch_bounds__(256) void gn_spatial_stats_kernel(const bf16* __restrict__ x, float* __restrict__ stats,
+                                                               int hw, int C) {
+    __shared__ float s_sum[32], s_sq[32];
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int G8 = C >> 3, cpg = C >> 5;
+    if (threadIdx.x < 32) {
+        s_sum[threadIdx.x] = 0.f;
+        s_sq[threadIdx.x] = 0.f;
+    }
+    __syncthreads();
+    float sum[kMaxCols][8], sq[kMaxCols][8];
+#pragma unroll
+    for (int k = 0; k < kMaxCols; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[k][e] = sq[k][e] = 0.f;
+    const int p0 = blockIdx.x * kGnPixPerBlock;
+    const int p1 = min(p0 + kGnPixPerBlock, hw);
+    const bf16* xf = x + (size_t)frame * hw * C;
+    for (int pix = p0 + wave; pix < p1; pix += kGnWaves) {
+        const bf16* row = xf + (size_t)pix * C;
+#pragma unroll
+        for (int k = 0; k < kMaxCols; ++k) {
+            const int gc = lane + 64 * k;
+            if (gc < G8) {
+                const bf16x8 v = *(const bf16x8*)(row + gc * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = bf2f(v[e]);
+                    sum[k][e] += f;
+                    sq[k][e] += f * f;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxCols; ++k) {
+        const int gc = lane + 64 * k;
+        if (gc < G8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int g = (gc * 8 + e) / cpg;
+                atomicAdd(&s_sum[g], sum[k][e]);
+                atomicAdd(&s_sq[g], sq[k][e]);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        atomicAdd(&stats[(frame * 32 + threadIdx.x) * 2 + 0], s_sum[threadIdx.x]);
+        atomicAdd(&stats[(frame * 32 + threadIdx.x) * 2 + 1], s_sq[threadIdx.x]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_spatial_apply_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                               const float* __restrict__ stats,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int hw, int C, float eps,
+                                                               int silu) {
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int G8 = C >> 3, cpg = C >> 5;
+    const float inv_n = 1.0f / ((float)cpg * (float)hw);
+    float a[kMaxCols][8], b[kMaxCols][8];
+#pragma unroll
+    for (int k = 0; k < kMaxCols; ++k) {
+        const int gc = lane + 64 * k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[k][e] = 0.f;
+            b[k][e] = 0.f;
+            if (gc < G8) {
+                const int c = gc * 8 + e;
+                const int g = c / cpg;
+                const float mean = stats[(frame * 32 + g) * 2] * inv_n;
+                const float var = fmaxf(stats[(frame * 32 + g) * 2 + 1] * inv_n - mean * mean, 0.f);
+                const float rstd = rsqrtf(var + eps);
+                a[k][e] = rstd * gamma[c];
+                b[k][e] = beta[c] - mean * a[k][e];
+            }
+        }
+    }
+    const int p0 = blockIdx.x * kGnPixPerBlock;
+    const int p1 = min(p0 + kGnPixPerBlock, hw);
+    const bf16* xf = x + (size_t)frame * hw * C;
+    bf16* yf = y + (size_t)frame * hw * C;
+    for (int pix = p0 + wave; pix < p1; pix += kGnWaves) {
+#pragma unroll
+        for (int k = 0; k < kMaxCols; ++k) {
+            const int gc = lane + 64 * k;
+            if (gc < G8) {
+                const bf16x8 v = *(const bf16x8*)(xf + (size_t)pix * C + gc * 8);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = bf2f(v[e]) * a[k][e] + b[k][e];
+                    if (silu) f = silu_f(f);
+                    o[e] = f2bf(f);
+                }
+                *(bf16x8*)(yf + (size_t)pix * C + gc * 8) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// temporal GroupNorm: statistics over (C/32 channels x T frames) at one pixel of one clip.
+// One wave per (clip b, pixel); two sweeps over the T rows (the second one hits L2).
+// ------------------------------------------------------------------------------------------
+constexpr int kGtCols = 3;     // temporal norms only see C in {320, 640, 1280} (<= 1536)
+
+__global__ __launch_bounds__(256) void gn_temporal_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int B, int T, int hw, int C,
+                                                          float eps, int silu) {
+    __shared__ float s_sum[4][32], s_sq[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wp = (int64_t)blockIdx.x * 4 + wave;     // (b, pixel) index
+    const bool active = wp < (int64_t)B * hw;
+    const int b = active ? (int)(wp / hw) : 0;
+    const int pix = active ? (int)(wp - (int64_t)b * hw) : 0;
+    const int G8 = C >> 3, cpg = C >> 5;
+    if (lane < 32) {
+        s_sum[wave][lane] = 0.f;
+        s_sq[wave][lane] = 0.f;
+    }
+    __syncthreads();
+    const size_t fstride = (size_t)hw * C;
+    const bf16* xb = x + ((size_t)b * T * hw + pix) * C;
+    bf16* yb = y + ((size_t)b * T * hw + pix) * C;
+    float sum[kGtCols][8], sq[kGtCols][8];
+#pragma unroll
+    for (int k = 0; k < kGtCols; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[k][e] = sq[k][e] = 0.f;
+    if (active) {
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int k = 0; k < kGtCols; ++k) {
+                const int gc = lane + 64 * k;
+                if (gc < G8) {
+                    const bf16x8 v = *(const bf16x8*)(xb + t * fstride + gc * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = bf2f(v[e]);
+                        sum[k][e] += f;
+                        sq[k][e] += f * f;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kGtCols; ++k) {
+            const int gc = lane + 64 * k;
+            if (gc < G8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int g = (gc * 8 + e) / cpg;
+                    atomicAdd(&s_sum[wave][g], sum[k][e]);
+                    atomicAdd(&s_sq[wave][g], sq[k][e]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const float inv_n = 1.0f / ((float)cpg * (float)T);
+    float a[kGtCols][8], bb[kGtCols][8];
+#pragma unroll
+    for (int k = 0; k < kGtCols; ++k) {
+        const int gc = lane + 64 * k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[k][e] = 0.f;
+            bb[k][e] = 0.f;
+            if (gc < G8) {
+                const int c = gc * 8 + e;
+                const int g = c / cpg;
+                const float mean = s_sum[wave][g] * inv_n;
+                const float var = fmaxf(s_sq[wave][g] * inv_n - mean * mean, 0.f);
+                const float rstd = rsqrtf(var + eps);
+                a[k][e] = rstd * gamma[c];
+                bb[k][e] = beta[c] - mean * a[k][e];
+            }
+        }
+    }
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int k = 0; k < kGtCols; ++k) {
+            const int gc = lane + 64 * k;
+            if (gc < G8) {
+                const bf16x8 v = *(const bf16x8*)(xb + t * fstride + gc * 8);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = bf2f(v[e]) * a[k][e] + bb[k][e];
+                    if (silu) f = silu_f(f);
+                    o[e] = f2bf(f);
+                }
+                *(bf16x8*)(yb + t * fstride + gc * 8) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over C: one wave per row, two-pass in registers
+// ------------------------------------------------------------------------------------------
+constexpr int kLnCols = 3;     // C <= 1536
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int G8 = C >> 3;
+    float v[kLnCols][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnCols; ++k) {
+        const int gc = lane + 64 * k;
+        if (gc < G8) {
+            const bf16x8 t = *(const bf16x8*)(x + (size_t)row * C + gc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[k][e] = bf2f(t[e]);
+                s += v[k][e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnCols; ++k) {
+        const int gc = lane + 64 * k;
+        if (gc < G8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float dlt = v[k][e] - mean;
+                q += dlt * dlt;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < kLnCols; ++k) {
+        const int gc = lane + 64 * k;
+        if (gc < G8) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = gc * 8 + e;
+                o[e] = f2bf((v[k][e] - mean) * rstd * gamma[c] + beta[c]);
+            }
+            *(bf16x8*)(y + (size_t)row * C + gc * 8) = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ccedit_groupnorm_spatial(const void* x, void* y, const float* gamma, const float* beta, float* stats_ws,
+                                        int32_t frames, int32_t hw, int32_t C, float eps, int32_t silu, void* stream) {
+    CC_CHECK_ARG(x && y && gamma && beta && stats_ws, "ccedit_groupnorm_spatial: null pointer");
+    CC_CHECK_ARG(frames > 0 && hw > 0 && C > 0, "ccedit_groupnorm_spatial: bad sizes");
+    CC_UNSUPPORTED(C % 32 != 0 || C > kMaxCols * 512, "ccedit_groupnorm_spatial: C=%d (need C%%32==0, C<=%d)", C,
+                   kMaxCols * 512);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * 32 * (size_t)frames, s);
+    if (e != hipSuccess) {
+        cc_set_error("groupnorm_spatial memset: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    dim3 grid((hw + kGnPixPerBlock - 1) / kGnPixPerBlock, frames);
+    hipLaunchKernelGGL(gn_spatial_stats_kernel, grid, dim3(256), 0, s, (const bf16*)x, stats_ws, hw, C);
+    hipLaunchKernelGGL(gn_spatial_apply_kernel, grid, dim3(256), 0, s, (const bf16*)x, (bf16*)y, stats_ws, gamma, beta, hw,
+                       C, eps, silu);
+    return cc_launch_status("groupnorm_spatial");
+}
+
+extern "C" int ccedit_groupnorm_temporal(const void* x, void* y, const float* gamma, const float* beta, int32_t B,
+                                         int32_t T, int32_t hw, int32_t C, float eps, int32_t silu, void* stream) {
+    CC_CHECK_ARG(x && y && gamma && beta, "ccedit_groupnorm_temporal: null pointer");
+    CC_CHECK_ARG(B > 0 && T > 0 && hw > 0 && C > 0, "ccedit_groupnorm_temporal: bad sizes");
+    CC_UNSUPPORTED(C % 32 != 0 || C > kGtCols * 512, "ccedit_groupnorm_temporal: C=%d (need C%%32==0, C<=%d)", C,
+                   kGtCols * 512);
+    const int64_t waves = (int64_t)B * hw;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    hipLaunchKernelGGL(gn_temporal_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, gamma, beta,
+                       B, T, hw, C, eps, silu);
+    return cc_launch_status("groupnorm_temporal");
+}
+
+extern "C" int ccedit_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t C,
+                                float eps, void* stream) {
+    CC_CHECK_ARG(x && y && gamma && beta, "ccedit_layernorm: null pointer");
+    CC_CHECK_ARG(rows > 0 && C > 0, "ccedit_layernorm: bad sizes");
+    CC_UNSUPPORTED(C % 8 != 0 || C > kLnCols * 512, "ccedit_layernorm: C=%d (need C%%8==0, C<=%d)", C, kLnCols * 512);
+    dim3 grid((unsigned)((rows + 3) / 4));
+    hipLaunchKernelGGL(layernorm_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, gamma, beta,
+                       rows, C, eps);
+    return cc_launch_status("layernorm");
+}

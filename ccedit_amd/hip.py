@@ -1,0 +1,109 @@
+"""ctypes binding of libccedit_hip.so (the C ABI declared in include/ccedit_hip.h).
+
+There is NO fallback: if the shared library is missing or a kernel reports an error, the product path
+raises.  Nothing here touches the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libccedit_hip.so")
+
+ABI_VERSION = 1
+
+GEMM_LINEAR, GEMM_CONV2D, GEMM_TEMPORAL = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+
+
+class CcGemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int64), ("N", C.c_int32), ("Cin", C.c_int32), ("Cin1", C.c_int32), ("taps", C.c_int32),
+        ("mode", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("stride", C.c_int32), ("pad", C.c_int32), ("ksize", C.c_int32), ("upsample", C.c_int32),
+        ("T", C.c_int32), ("HW", C.c_int32), ("lda", C.c_int32), ("lda2", C.c_int32), ("ldc", C.c_int32),
+        ("Kpad", C.c_int32), ("act", C.c_int32), ("out_f32", C.c_int32), ("group_rows", C.c_int32),
+        ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("tile", C.c_int32),
+        ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
+        ("group_bias", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p),
+    ]
+
+
+class CcAttnDesc(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
+        ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
+        ("heads", C.c_int32), ("d", C.c_int32), ("batches", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
+        ("q_inner", C.c_int32), ("q_outer_rows", C.c_int64), ("q_inner_rows", C.c_int64), ("q_seq_rows", C.c_int64),
+        ("kv_div", C.c_int32), ("kv_inner", C.c_int32), ("kv_outer_rows", C.c_int64), ("kv_inner_rows", C.c_int64),
+        ("kv_seq_rows", C.c_int64), ("scale", C.c_float),
+    ]
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+_SIGS = {
+    "ccedit_abi_version": (C.c_int, []),
+    "ccedit_last_error": (C.c_char_p, []),
+    "ccedit_device_info": (C.c_int, [C.c_char_p, C.c_int]),
+    "ccedit_gemm": (C.c_int, [C.POINTER(CcGemmDesc), C.c_void_p]),
+    "ccedit_groupnorm_spatial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "ccedit_groupnorm_temporal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "ccedit_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
+                                   C.c_void_p]),
+    "ccedit_attention": (C.c_int, [C.POINTER(CcAttnDesc), C.c_void_p]),
+    "ccedit_ncthw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
+    "ccedit_nhwc_to_ncthw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_void_p]),
+    "ccedit_cat_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                 C.c_void_p]),
+    "ccedit_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ccedit_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ccedit_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ccedit_cfg_denoise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]),
+    "ccedit_axpby": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the kernel library.  Raises HipLibraryError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing — build it with `python ccedit_amd/csrc/build.py` (or __graft_entry__.build()). "
+            "ccedit_amd has no CPU fallback.")
+    try:
+        l = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = l.ccedit_abi_version()
+    if v != ABI_VERSION:
+        raise HipLibraryError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
+    _lib = l
+    return l
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().ccedit_last_error()
+        raise HipLibraryError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")

@@ -1,0 +1,232 @@
+"""Python-side operator wrappers over the C ABI (include/ccedit_hip.h).
+
+PyTorch is used for device memory (torch.empty on the caching allocator) and the stream handle only;
+every arithmetic result below is produced by a hand-written HIP kernel in libccedit_hip.so.  All
+activations are bf16 tensors in the frames-outermost channels-last layout: (N, H, W, C) contiguous,
+N = B*T frames, equivalently a row-major [N*H*W][C] matrix.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import hip
+from .hip import ACT_GEGLU, ACT_NONE, ACT_SILU, CcAttnDesc, CcGemmDesc, GEMM_CONV2D, GEMM_LINEAR, GEMM_TEMPORAL
+from .packing import PackedWeight
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk_act(t: torch.Tensor, name: str):
+    if t.dtype != BF16 or not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous cuda bf16 tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+
+
+def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Optional[int] = None,
+         hin: int = 0, win: int = 0, hout: int = 0, wout: int = 0, stride: int = 1, pad: int = 0, upsample: bool = False,
+         t: int = 0, hw: int = 0, a2: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+         group_bias: Optional[torch.Tensor] = None, group_rows: int = 0,
+         res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
+         out: Optional[torch.Tensor] = None, out_f32: bool = False, use_bias: bool = True, tile: int = 0) -> torch.Tensor:
+    """out[m, :] = epilogue(sum_taps W . A[src(m, tap)]).  a2d: [rows, lda] bf16 (last dim contiguous)."""
+    assert a2d.dtype == BF16 and a2d.is_cuda and a2d.stride(-1) == 1
+    lda = a2d.stride(0)
+    cin1 = a2d.shape[1]
+    cin = cin1 + (a2.shape[1] if a2 is not None else 0)
+    if cin != pw.cin:
+        raise ValueError(f"gemm: source has {cin} channels, packed weight expects {pw.cin}")
+    if m is None:
+        m = a2d.shape[0]
+    n_store = pw.n_out if pw.geglu else pw.n
+    if out is None:
+        out = torch.empty((m, n_store), dtype=torch.float32 if out_f32 else BF16, device=a2d.device)
+    assert out.stride(-1) == 1 and out.shape[0] == m
+    d = CcGemmDesc()
+    d.M, d.N, d.Cin, d.Cin1, d.taps, d.mode = m, pw.n, pw.cin, cin1, pw.taps, mode
+    d.Hin, d.Win, d.Hout, d.Wout = hin, win, hout, wout
+    d.stride, d.pad, d.ksize, d.upsample = stride, pad, pw.ksize, int(upsample)
+    d.T, d.HW = t, hw
+    d.lda, d.lda2, d.ldc, d.Kpad = lda, (a2.stride(0) if a2 is not None else 0), out.stride(0), pw.kpad
+    d.act = ACT_GEGLU if pw.geglu else act
+    d.out_f32 = int(out.dtype == torch.float32)
+    d.group_rows = group_rows
+    d.ldr1 = res1.stride(0) if res1 is not None else 0
+    d.ldr2 = res2.stride(0) if res2 is not None else 0
+    d.tile = tile
+    d.A, d.A2, d.W = a2d.data_ptr(), _ptr(a2), pw.w.data_ptr()
+    d.bias = _ptr(pw.bias) if use_bias else None
+    d.group_bias = _ptr(group_bias)
+    d.res1, d.res2, d.out = _ptr(res1), _ptr(res2), out.data_ptr()
+    hip.check(hip.lib().ccedit_gemm(C.byref(d), _stream()), "ccedit_gemm")
+    return out
+
+
+def linear(x2d, pw, **kw):
+    return gemm(x2d, pw, mode=GEMM_LINEAR, **kw)
+
+
+def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, upsample: bool = False,
+           x2: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
+    """x: (N, H, W, C) -> (N, Hout, Wout, Cout); 3x3 (pad 1) or 1x1 (pad 0) by the packed kernel size."""
+    n, h, w, c = x.shape
+    if pw.ksize == 1:
+        pad = 0
+    hv, wv = (2 * h, 2 * w) if upsample else (h, w)
+    hout = (hv + 2 * pad - pw.ksize) // stride + 1
+    wout = (wv + 2 * pad - pw.ksize) // stride + 1
+    a2 = None if x2 is None else x2.reshape(-1, x2.shape[-1])
+    out = gemm(x.reshape(-1, c), pw, mode=GEMM_CONV2D, m=n * hout * wout, hin=h, win=w, hout=hout, wout=wout,
+               stride=stride, pad=pad, upsample=upsample, a2=a2, **kw)
+    return out.view(n, hout, wout, out.shape[-1])
+
+
+def conv_temporal(x: torch.Tensor, t: int, pw: PackedWeight, **kw) -> torch.Tensor:
+    """Conv1d over the T frames of each clip; x: (B*T, H, W, C)."""
+    n, h, w, c = x.shape
+    if pw.taps == 1:
+        out = gemm(x.reshape(-1, c), pw, mode=GEMM_LINEAR, **kw)
+    else:
+        out = gemm(x.reshape(-1, c), pw, mode=GEMM_TEMPORAL, t=t, hw=h * w, **kw)
+    return out.view(n, h, w, out.shape[-1])
+
+
+# ------------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def _stats_ws(frames: int, device) -> torch.Tensor:
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < frames * 64:
+        ws = torch.empty(max(frames * 64, 4096), dtype=torch.float32, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def groupnorm_spatial(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, silu: bool) -> torch.Tensor:
+    _chk_act(x, "groupnorm_spatial")
+    n, h, w, c = x.shape
+    y = torch.empty_like(x)
+    hip.check(hip.lib().ccedit_groupnorm_spatial(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                 _stats_ws(n, x.device).data_ptr(), n, h * w, c, eps, int(silu), _stream()),
+              "ccedit_groupnorm_spatial")
+    return y
+
+
+def groupnorm_temporal(x: torch.Tensor, b: int, t: int, gamma, beta, eps: float, silu: bool) -> torch.Tensor:
+    _chk_act(x, "groupnorm_temporal")
+    n, h, w, c = x.shape
+    assert n == b * t
+    y = torch.empty_like(x)
+    hip.check(hip.lib().ccedit_groupnorm_temporal(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                  b, t, h * w, c, eps, int(silu), _stream()), "ccedit_groupnorm_temporal")
+    return y
+
+
+def layernorm(x2d: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor:
+    _chk_act(x2d, "layernorm")
+    y = torch.empty_like(x2d)
+    hip.check(hip.lib().ccedit_layernorm(x2d.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                         x2d.shape[0], x2d.shape[1], eps, _stream()), "ccedit_layernorm")
+    return y
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, d: int, *, batches: int, lq: int, lk: int,
+              q_inner: int = 1, q_outer_rows: Optional[int] = None, q_inner_rows: int = 0, q_seq_rows: int = 1,
+              kv_div: int = 1, kv_inner: int = 1, kv_outer_rows: Optional[int] = None, kv_inner_rows: int = 0,
+              kv_seq_rows: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q/k/v: 2-D row-major views [rows, >= heads*d] (may be column slices of a fused buffer)."""
+    for tns in (q, k, v):
+        assert tns.dtype == BF16 and tns.is_cuda and tns.stride(-1) == 1
+    if out is None:
+        out = torch.empty((q.shape[0], heads * d), dtype=BF16, device=q.device)
+    a = CcAttnDesc()
+    a.q, a.k, a.v, a.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.heads, a.d, a.batches, a.Lq, a.Lk = heads, d, batches, lq, lk
+    a.q_inner, a.q_outer_rows, a.q_inner_rows, a.q_seq_rows = q_inner, (lq if q_outer_rows is None else q_outer_rows), q_inner_rows, q_seq_rows
+    a.kv_div, a.kv_inner = kv_div, kv_inner
+    a.kv_outer_rows, a.kv_inner_rows, a.kv_seq_rows = (lk if kv_outer_rows is None else kv_outer_rows), kv_inner_rows, kv_seq_rows
+    a.scale = float(d) ** -0.5
+    hip.check(hip.lib().ccedit_attention(C.byref(a), _stream()), "ccedit_attention")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+def ncthw_to_nhwc(x: torch.Tensor, cpad: int, scale_per_b: Optional[torch.Tensor] = None, scale: float = 1.0,
+                  shift: float = 0.0) -> torch.Tensor:
+    """fp32 (B, C, T, H, W) -> bf16 (B*T, H, W, cpad); y = x*scale(*scale_per_b[b]) + shift."""
+    assert x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and x.ndim == 5
+    b, c, t, h, w = x.shape
+    y = torch.empty((b * t, h, w, cpad), dtype=BF16, device=x.device)
+    hip.check(hip.lib().ccedit_ncthw_to_nhwc(x.data_ptr(), y.data_ptr(), b, c, t, h, w, cpad, _ptr(scale_per_b),
+                                             scale, shift, _stream()), "ccedit_ncthw_to_nhwc")
+    return y
+
+
+def nhwc_to_ncthw(x: torch.Tensor, b: int, t: int, c: int) -> torch.Tensor:
+    """(B*T, H, W, ld) bf16|fp32 -> fp32 (B, c, T, H, W) taking the first c channels."""
+    assert x.is_cuda and x.is_contiguous() and x.ndim == 4
+    n, h, w, ld = x.shape
+    y = torch.empty((b, c, t, h, w), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().ccedit_nhwc_to_ncthw(x.data_ptr(), int(x.dtype == torch.float32), ld, y.data_ptr(), b, c, t, h, w,
+                                             _stream()), "ccedit_nhwc_to_ncthw")
+    return y
+
+
+def cat_add(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor]) -> torch.Tensor:
+    """(..., C1) ++ ((..., C2) + (..., C2)) along channels."""
+    _chk_act(a, "cat_add.a"), _chk_act(b, "cat_add.b")
+    c1, c2 = a.shape[-1], b.shape[-1]
+    out = torch.empty((*a.shape[:-1], c1 + c2), dtype=BF16, device=a.device)
+    hip.check(hip.lib().ccedit_cat_add(a.data_ptr(), b.data_ptr(), _ptr(c), out.data_ptr(), a.numel() // c1, c1, c2,
+                                       _stream()), "ccedit_cat_add")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk_act(a, "add.a"), _chk_act(b, "add.b")
+    y = torch.empty_like(a) if out is None else out
+    hip.check(hip.lib().ccedit_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "ccedit_add")
+    return y
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    _chk_act(x, "silu")
+    y = torch.empty_like(x)
+    hip.check(hip.lib().ccedit_silu(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "ccedit_silu")
+    return y
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    assert t.dtype == torch.int64 and t.is_cuda
+    out = torch.empty((t.shape[0], dim), dtype=BF16, device=t.device)
+    hip.check(hip.lib().ccedit_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], dim, dim, _stream()),
+              "ccedit_timestep_embedding")
+    return out
+
+
+def cfg_denoise(x: torch.Tensor, eps2: torch.Tensor, sigma: float, scale: float) -> torch.Tensor:
+    """x: fp32 latent (n elems); eps2: fp32 [2, n] (uncond first). -> denoised (guided) fp32."""
+    assert x.dtype == torch.float32 and eps2.dtype == torch.float32 and x.is_contiguous() and eps2.is_contiguous()
+    den = torch.empty_like(x)
+    hip.check(hip.lib().ccedit_cfg_denoise(x.data_ptr(), eps2.data_ptr(), den.data_ptr(), x.numel(), sigma, scale, _stream()),
+              "ccedit_cfg_denoise")
+    return den
+
+
+def axpby(x: torch.Tensor, z: torch.Tensor, a: float, b: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert x.dtype == torch.float32 and z.dtype == torch.float32 and x.is_contiguous() and z.is_contiguous()
+    y = torch.empty_like(x) if out is None else out
+    hip.check(hip.lib().ccedit_axpby(x.data_ptr(), z.data_ptr(), y.data_ptr(), x.numel(), a, b, _stream()), "ccedit_axpby")
+    return y

@@ -1,0 +1,171 @@
+/*
+ * ccedit_hip.h — C ABI of libccedit_hip.so: the MI355X (gfx950) kernels behind CCEdit's denoising
+ * hot path (sgm pseudo-3D UNet + ControlNet2D + DPMPP2SAncestral + AutoencoderKL decode).
+ *
+ * The reference (RuoyuFeng/CCEdit) is pure Python on ATen and has NO FFI of its own: its operator
+ * API is `instantiate_from_config` (sgm/util.py:168-185).  This header is the boundary the build adds
+ * underneath that API.  Each entry point names the reference call sites whose vendor kernels
+ * (cuDNN / cuBLAS / SDPA / ATen elementwise) it replaces.  INTEGRATION.md shows the Python-side
+ * binding (ctypes) a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: device pointers as void*, sizes as int32/int64, scalars by value, one POD descriptor
+ *     struct per fused op; no torch types.
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*) and returns immediately;
+ *     no host synchronisation, no allocation, no ownership transfer.  Workspaces are caller-owned.
+ *   - return value: 0 = ok; <0 = CCEDIT_E* (invalid argument / unsupported shape); >0 = hipError_t.
+ *     `ccedit_last_error()` returns a thread-local message for the last non-zero return.
+ *   - activations: bf16, "frames-outermost channels-last": logical (B*T, C, H, W) stored with
+ *     strides (H*W*C, 1, W*C, C), i.e. a row-major [B*T*H*W pixels][C] matrix.  Weights: bf16,
+ *     packed [Cout_pad][taps][Cin_pad] (K contiguous) by ccedit_amd/packing.py from the reference's
+ *     OIHW / (O,I,K) / (O,I) fp32 tensors.  Biases, norm affine parameters, statistics: fp32.
+ */
+#ifndef CCEDIT_HIP_H
+#define CCEDIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCEDIT_ABI_VERSION 1
+
+#define CCEDIT_OK 0
+#define CCEDIT_EINVAL (-1)       /* null pointer / bad size */
+#define CCEDIT_EUNSUPPORTED (-2) /* shape or option outside what the kernels implement */
+
+int ccedit_abi_version(void);
+const char* ccedit_last_error(void);
+/* fills name with hipDeviceProp_t.gcnArchName of the current device; returns CU count or <0 */
+int ccedit_device_info(char* name, int name_len);
+
+/* ------------------------------------------------------------------------------------------
+ * Tap-gather GEMM on MFMA: out[m][n] = epilogue( sum_{tap,c} W[n][tap][c] * A[src(m,tap)][c] )
+ *
+ * One kernel family covers every contraction of the path (reference call sites):
+ *   mode LINEAR   nn.Linear (attention.py:377-383 to_q/to_k/to_v/to_out, :118 GEGLU proj, :136 FF out;
+ *                 openaimodel.py:1216-1223 time_embed, :470-476 emb_layers), Conv2d 1x1
+ *                 (attention.py:818-820 proj_in/out, openaimodel.py:508 skip_connection,
+ *                 controlmodel.py:249-250 zero convs, model.py:169-180 VAE q/k/v/proj), Conv1d k=1 over T
+ *                 (attention.py:1088-1130 proj_in/out_temporal, openaimodel.py:712-715) — all the same
+ *                 [pixels][C] x [Cout][C]^T product in the channels-last layout.
+ *   mode CONV2D   Conv2d 3x3 stride 1/2 pad 1 (openaimodel.py:445-449, 483-492, 369-376 Downsample op,
+ *                 controlmodel.py:215-231 hint stem, model.py:100-110 VAE), optional fused nearest-2x
+ *                 upsample of the source (openaimodel.py:254-263 Upsample3D, model.py:65-71).
+ *   mode TEMPORAL Conv1d k=3 pad 1 over the T keyframes of one clip (openaimodel.py:617-629, 674-687,
+ *                 250-252, 377-386, 1611-1621, 1627-1632): rows of frame t gather frames t-1, t, t+1
+ *                 at the same pixel (row distance H*W), zero outside [0, T).
+ * A second source (A2) supplies channels [Cin1, Cin) — the torch.cat([h, hs.pop()+control.pop()])
+ * of controlmodel.py:539-543 without materialising it.
+ * ------------------------------------------------------------------------------------------ */
+enum { CCEDIT_GEMM_LINEAR = 0, CCEDIT_GEMM_CONV2D = 1, CCEDIT_GEMM_TEMPORAL = 2 };
+enum { CCEDIT_ACT_NONE = 0, CCEDIT_ACT_SILU = 1, CCEDIT_ACT_GEGLU = 2 };
+
+typedef struct CcGemmDesc {
+    int64_t M;            /* output rows: pixels (B*T*Hout*Wout) or tokens */
+    int32_t N;            /* packed output rows of W actually used (Cout; 2*inner for GEGLU) */
+    int32_t Cin;          /* channels per tap (multiple of 8) */
+    int32_t Cin1;         /* channels taken from A (== Cin when A2 is null) */
+    int32_t taps;         /* 1, 3 (temporal) or 9 (3x3) */
+    int32_t mode;         /* CCEDIT_GEMM_* */
+    int32_t Hin, Win;     /* CONV2D: stored source frame size */
+    int32_t Hout, Wout;   /* CONV2D: output frame size */
+    int32_t stride, pad, ksize;
+    int32_t upsample;     /* CONV2D: 1 = source is nearest-2x upsampled on the fly */
+    int32_t T, HW;        /* TEMPORAL: frames per clip, pixels per frame */
+    int32_t lda, lda2;    /* source row strides (elements) */
+    int32_t ldc;          /* output row stride (elements) */
+    int32_t Kpad;         /* weight row stride (elements), multiple of 64, >= taps*Cin */
+    int32_t act;          /* CCEDIT_ACT_* (applied to acc + bias + group_bias, before residuals) */
+    int32_t out_f32;      /* 1: store fp32 instead of bf16 */
+    int32_t group_rows;   /* rows per group_bias row (T*H*W for the timestep-embedding add); 0 = unused */
+    int32_t ldr1, ldr2;   /* residual row strides */
+    int32_t tile;         /* 0 = auto, 1 = 128ch x 128pix, 2 = 64ch x 256pix */
+    const void* A;        /* bf16 [rows][lda] */
+    const void* A2;       /* optional second source */
+    const void* W;        /* bf16 [ceil(N,128)][Kpad] */
+    const float* bias;    /* [N] in packed row order, or null */
+    const float* group_bias; /* [M/group_rows][N] fp32 or null  (ResBlock: h + emb_out, openaimodel.py:762) */
+    const void* res1;     /* bf16 residuals added after the activation, or null */
+    const void* res2;
+    void* out;            /* bf16 (or fp32) [M][ldc]; GEGLU writes N/2 columns */
+} CcGemmDesc;
+
+int ccedit_gemm(const CcGemmDesc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation (fp32 statistics, bf16 in/out)
+ * ------------------------------------------------------------------------------------------ */
+/* GroupNorm(32, C) over (C/32 x H x W) per frame, optional fused SiLU.
+ * Replaces nn.GroupNorm + nn.SiLU of openaimodel.py:441-444, 479-482 (eps 1e-5), attention.py:153-156,
+ * model.py:50-53 (eps 1e-6).  x: [frames][hw][C]; stats workspace: float[frames*32*2] (zeroed here). */
+int ccedit_groupnorm_spatial(const void* x, void* y, const float* gamma, const float* beta,
+                             float* stats_ws, int32_t frames, int32_t hw, int32_t C, float eps,
+                             int32_t silu, void* stream);
+/* GroupNorm(32, C) over (C/32 x T) per pixel — the normalization() / norm_temporal applied to the
+ * '(b h w) c t' view (openaimodel.py:617-619, 674-676; attention.py:1085, 1176).
+ * x: [B*T][hw][C]; one statistics group = T frames x C/32 channels at one pixel. */
+int ccedit_groupnorm_temporal(const void* x, void* y, const float* gamma, const float* beta,
+                              int32_t B, int32_t T, int32_t hw, int32_t C, float eps, int32_t silu,
+                              void* stream);
+/* LayerNorm over C (eps 1e-5) — attention.py:667-669, 755-756. x,y: [rows][C] */
+int ccedit_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows,
+                     int32_t C, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention: softmax(q k^T * scale) v, bf16 MFMA, online softmax, fp32 accumulate.
+ * Replaces F.scaled_dot_product_attention in CrossAttention.forward (attention.py:392-467) for
+ *   - spatial self-attention      (Lq = Lk = h*w, one batch per frame)
+ *   - text cross-attention        (Lk = 77, K/V shared by the T frames of a clip: kv_batch = batch / kv_div)
+ *   - temporal self-attention     (Lq = Lk = T per pixel: rows of one sequence are H*W apart)
+ * q/k/v/o are [rows][ld] matrices with heads side by side: head h occupies columns [h*d, (h+1)*d).
+ * Row of (batch, i) = (batch / inner) * outer_rows + (batch % inner) * inner_rows + i * seq_rows.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct CcAttnDesc {
+    const void* q; const void* k; const void* v; void* o;
+    int32_t ldq, ldk, ldv, ldo;       /* row strides in elements */
+    int32_t heads, d;                 /* d in {40, 80, 160} or any multiple of 8 up to 160 */
+    int32_t batches;                  /* number of (sequence) batches */
+    int32_t Lq, Lk;
+    int32_t q_inner; int64_t q_outer_rows, q_inner_rows, q_seq_rows;
+    int32_t kv_div;                   /* kv batch = batch / kv_div (text K/V shared across frames) */
+    int32_t kv_inner; int64_t kv_outer_rows, kv_inner_rows, kv_seq_rows;
+    float scale;                      /* d^-0.5 */
+} CcAttnDesc;
+
+int ccedit_attention(const CcAttnDesc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout / elementwise helpers (all HBM-bound)
+ * ------------------------------------------------------------------------------------------ */
+/* fp32 (B, C, T, H, W) -> bf16 [B*T][H*W][Cpad] (zero-filled pad channels), y = x*scale + shift.
+ * Used for the latent (`x * c_in`, denoiser.py:40) and for the hint remap 1-(h+1)/2 (wrappers.py:160-162). */
+int ccedit_ncthw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
+                         int32_t Cpad, const float* scale_per_b, float scale, float shift, void* stream);
+/* bf16/fp32 [B*T][H*W][ld] (first C columns) -> fp32 (B, C, T, H, W) */
+int ccedit_nhwc_to_ncthw(const void* x, int32_t x_is_f32, int32_t ld, float* y, int32_t B, int32_t C,
+                         int32_t T, int32_t H, int32_t W, void* stream);
+/* out[:, :C1] = a ; out[:, C1:C1+C2] = b + c   (cat([h, hs.pop() + control.pop()]), controlmodel.py:543) */
+int ccedit_cat_add(const void* a, const void* b, const void* c, void* out, int64_t rows, int32_t C1,
+                   int32_t C2, void* stream);
+/* y = a + b (bf16), n elements — `h = h + control.pop()` (controlmodel.py:537), `h += guided_hint` (:300) */
+int ccedit_add(const void* a, const void* b, void* y, int64_t n, void* stream);
+/* y = silu(x), bf16 elementwise (out_temporal's leading nn.SiLU, openaimodel.py:1627-1632) */
+int ccedit_silu(const void* x, void* y, int64_t n, void* stream);
+/* timestep_embedding (diffusionmodules/util.py:244-268): out bf16 [n][ld], [cos | sin], dim even */
+int ccedit_timestep_embedding(const int64_t* t, void* out, int32_t n, int32_t dim, int32_t ld, void* stream);
+
+/* Sampler / guider / denoiser elementwise math on the fp32 latent (417,792 elements at 17x64x96):
+ *   ccedit_cfg_denoise : den = x + (-sigma) * (eps_u + scale*(eps_c - eps_u))        [denoiser.py:40 with
+ *                        c_skip=1, c_out=-sigma; guiders.py:25-29]   eps = fp32 [2][n]
+ *   ccedit_axpby       : y = a*x + b*z                                                [sampling.py:388, 398-402]
+ */
+int ccedit_cfg_denoise(const float* x, const float* eps2, float* den, int64_t n, float sigma, float scale,
+                       void* stream);
+int ccedit_axpby(const float* x, const float* z, float* y, int64_t n, float a, float b, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCEDIT_HIP_H */

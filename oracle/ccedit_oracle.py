@@ -1,0 +1,550 @@
+"""CPU oracle: a plain fp32 restatement of CCEdit's denoising hot path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s `cpu_baseline` leg may import it, and only as the checker.  `ccedit_amd/` never
+imports anything from `oracle/`; the product path has no CPU fallback.
+
+What it restates (reference = RuoyuFeng/CCEdit, paths relative to /root/reference):
+  * sgm/modules/diffusionmodules/wrappers.py:156-207   OpenAIWrapperControlLDM3DTV2V.forward
+  * sgm/modules/diffusionmodules/controlmodel.py:252-317  ControlNet2D.forward
+  * sgm/modules/diffusionmodules/controlmodel.py:471-550  ControlledUNetModel3DTV2V.forward
+  * sgm/modules/diffusionmodules/openaimodel.py:129-178 (spatial_temporal_forward), 528-554
+    (ResBlock), 730-775 (ResBlock3D), 254-263 / 388-394 (Up/Downsample3D), 1033-1527 (wiring)
+  * sgm/modules/attention.py:392-467 (CrossAttention), 695-716, 758-761 (transformer blocks),
+    865-889 (SpatialTransformer), 1141-1208 (SpatialTransformer3D), 115-141 (GEGLU/FeedForward)
+  * sgm/modules/diffusionmodules/{discretizer,denoiser,denoiser_scaling,guiders,sampling,
+    sampling_utils}.py  (sigma schedule, DiscreteDenoiser, VanillaCFGTV2V, DPMPP2SAncestral)
+  * sgm/modules/diffusionmodules/model.py:728-761 (VAE Decoder), sgm/models/autoencoder.py:334-343
+
+Style: the reference is an nn.Module tree; this oracle is *functional* — every function takes the
+reference-named state dict `sd` (key -> fp32 tensor) and a key prefix, so the weights contract
+ is the only coupling.  Arithmetic is torch fp32 on CPU in the reference's own
+(N, C, ...) layouts so that ATen's kernels are the same ones the reference's CPU path runs.
+
+Pinning: tests/test_oracle_golden.py checks every function here against vectors recorded from the
+reference itself (tests/golden/make_golden.py imports /root/reference in the authoring container).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+GN_EPS_RES = 1e-5    # diffusionmodules/util.py:296-302  normalization() = nn.GroupNorm(32, C)
+GN_EPS_ATTN = 1e-6   # attention.py:153-156 Normalize(); model.py:50-53 (VAE)
+
+
+# ----------------------------------------------------------------------------------------
+# configuration / topology
+# ----------------------------------------------------------------------------------------
+@dataclass
+class NetConfig:
+    """Hyper-parameters of configs/inference_ccedit/keyframe_no2ndca_depthmidas.yaml:25-56."""
+    in_channels: int = 4
+    out_channels: int = 4
+    model_channels: int = 320
+    attention_resolutions: Tuple[int, ...] = (4, 2, 1)
+    num_res_blocks: int = 2
+    channel_mult: Tuple[int, ...] = (1, 2, 4, 4)
+    num_heads: int = 8
+    context_dim: int = 768
+    hint_channels: int = 3
+    control_scales: float = 1.0
+
+
+@dataclass
+class BlockSpec:
+    kind: str                 # "conv_in" | "res" | "down" | "up-tail"
+    cin: int = 0
+    cout: int = 0
+    attn: bool = False
+    up: bool = False
+
+
+def unet_topology(cfg: NetConfig):
+    """Block list exactly as UNetModel.__init__ builds it (openaimodel.py:1230-1500)."""
+    mc = cfg.model_channels
+    inputs: List[BlockSpec] = [BlockSpec("conv_in", cfg.in_channels, mc)]
+    chans = [mc]
+    ch, ds = mc, 1
+    for level, mult in enumerate(cfg.channel_mult):
+        for _ in range(cfg.num_res_blocks):
+            inputs.append(BlockSpec("res", ch, mult * mc, attn=ds in cfg.attention_resolutions))
+            ch = mult * mc
+            chans.append(ch)
+        if level != len(cfg.channel_mult) - 1:
+            inputs.append(BlockSpec("down", ch, ch))
+            chans.append(ch)
+            ds *= 2
+    mid_ch = ch
+    outputs: List[BlockSpec] = []
+    for level, mult in list(enumerate(cfg.channel_mult))[::-1]:
+        for i in range(cfg.num_res_blocks + 1):
+            ich = chans.pop()
+            spec = BlockSpec("res", ch + ich, mc * mult, attn=ds in cfg.attention_resolutions)
+            ch = mc * mult
+            if level and i == cfg.num_res_blocks:
+                spec.up = True
+                ds //= 2
+            outputs.append(spec)
+    return inputs, mid_ch, outputs
+
+
+# ----------------------------------------------------------------------------------------
+# leaf ops
+# ----------------------------------------------------------------------------------------
+def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
+    """[cos, sin] sinusoidal embedding — diffusionmodules/util.py:244-268."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def _gn(sd: SD, p: str, x: torch.Tensor, eps: float) -> torch.Tensor:
+    return F.group_norm(x, 32, sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def _ln(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+
+def _conv2d(sd: SD, p: str, x, stride=1, padding=0):
+    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride=stride, padding=padding)
+
+
+def _conv1d(sd: SD, p: str, x, padding=0):
+    return F.conv1d(x, sd[p + ".weight"], sd.get(p + ".bias"), padding=padding)
+
+
+def _linear(sd: SD, p: str, x):
+    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+
+
+def time_embed(sd: SD, p: str, t: torch.Tensor, model_channels: int) -> torch.Tensor:
+    """timestep_embedding -> Linear, SiLU, Linear (openaimodel.py:1216-1223)."""
+    e = timestep_embedding(t, model_channels)
+    return _linear(sd, p + ".2", F.silu(_linear(sd, p + ".0", e)))
+
+
+# ----------------------------------------------------------------------------------------
+# 2D+1D factorisation
+# ----------------------------------------------------------------------------------------
+def _to_frames(x5):                      # (b c t h w) -> (b t) c h w
+    b, c, t, h, w = x5.shape
+    return x5.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+
+
+def _frames_to_pix(x4, b):               # (b t) c h w -> (b h w) c t
+    bt, c, h, w = x4.shape
+    t = bt // b
+    return x4.reshape(b, t, c, h, w).permute(0, 3, 4, 2, 1).reshape(b * h * w, c, t)
+
+
+def _pix_to_5d(xp, b, h, w):             # (b h w) c t -> b c t h w
+    _, c, t = xp.shape
+    return xp.reshape(b, h, w, c, t).permute(0, 3, 4, 1, 2).contiguous()
+
+
+def stf(x5, spatial: Callable, temporal: Optional[Callable]):
+    """spatial_temporal_forward (openaimodel.py:129-178): y = temporal(s) + s, s = spatial(x)."""
+    b = x5.shape[0]
+    s = spatial(_to_frames(x5))
+    h, w = s.shape[-2:]
+    sp = _frames_to_pix(s, b)
+    tmp = temporal(sp) if temporal is not None else torch.zeros_like(sp)
+    return _pix_to_5d(tmp + sp, b, h, w)
+
+
+# ----------------------------------------------------------------------------------------
+# residual blocks
+# ----------------------------------------------------------------------------------------
+def resblock2d(sd: SD, p: str, x, emb):
+    """ResBlock._forward, use_scale_shift_norm=False, no up/down (openaimodel.py:528-554)."""
+    h = _conv2d(sd, p + ".in_layers.2", F.silu(_gn(sd, p + ".in_layers.0", x, GN_EPS_RES)), padding=1)
+    h = h + _linear(sd, p + ".emb_layers.1", F.silu(emb))[:, :, None, None]
+    h = _conv2d(sd, p + ".out_layers.3", F.silu(_gn(sd, p + ".out_layers.0", h, GN_EPS_RES)), padding=1)
+    skip = x if (p + ".skip_connection.weight") not in sd else _conv2d(sd, p + ".skip_connection", x)
+    return skip + h
+
+
+def resblock3d(sd: SD, p: str, x5, emb):
+    """ResBlock3D._forward (openaimodel.py:730-775); emb is (B, E), broadcast over (t,h,w)."""
+    def sp_in(x):
+        return _conv2d(sd, p + ".in_layers.2", F.silu(_gn(sd, p + ".in_layers.0", x, GN_EPS_RES)), padding=1)
+
+    def tp_in(x):
+        return _conv1d(sd, p + ".in_layers_temporal.2",
+                       F.silu(_gn(sd, p + ".in_layers_temporal.0", x, GN_EPS_RES)), padding=1)
+
+    def sp_out(x):
+        return _conv2d(sd, p + ".out_layers.3", F.silu(_gn(sd, p + ".out_layers.0", x, GN_EPS_RES)), padding=1)
+
+    def tp_out(x):
+        return _conv1d(sd, p + ".out_layers_temporal.3",
+                       F.silu(_gn(sd, p + ".out_layers_temporal.0", x, GN_EPS_RES)), padding=1)
+
+    h = stf(x5, sp_in, tp_in)
+    h = h + _linear(sd, p + ".emb_layers.1", F.silu(emb))[:, :, None, None, None]
+    h = stf(h, sp_out, tp_out)
+    if (p + ".skip_connection.weight") in sd:
+        skip = stf(x5, lambda x: _conv2d(sd, p + ".skip_connection", x),
+                   lambda x: _conv1d(sd, p + ".skip_connection_temporal", x))
+    else:
+        skip = x5            # Identity spatial, temporal None -> zeros + identity
+    return skip + h
+
+
+# ----------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------
+def cross_attention(sd: SD, p: str, x, context, heads: int):
+    """CrossAttention.forward (attention.py:392-467): bias-free q/k/v, SDPA scale d^-0.5, out+bias."""
+    ctx = x if context is None else context
+    q, k, v = _linear(sd, p + ".to_q", x), _linear(sd, p + ".to_k", ctx), _linear(sd, p + ".to_v", ctx)
+    b, n, c = q.shape
+    d = c // heads
+    q = q.reshape(b, n, heads, d).transpose(1, 2)
+    k = k.reshape(b, -1, heads, d).transpose(1, 2)
+    v = v.reshape(b, -1, heads, d).transpose(1, 2)
+    o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, n, c)
+    return _linear(sd, p + ".to_out.0", o)
+
+
+def feed_forward(sd: SD, p: str, x):
+    """FeedForward with GEGLU (attention.py:115-141): proj -> (x, gate) -> x*gelu_erf(gate) -> Linear."""
+    a, gate = _linear(sd, p + ".net.0.proj", x).chunk(2, dim=-1)
+    return _linear(sd, p + ".net.2", a * F.gelu(gate))
+
+
+def basic_block(sd: SD, p: str, x, context, heads: int):
+    """BasicTransformerBlock._forward (attention.py:695-716)."""
+    x = cross_attention(sd, p + ".attn1", _ln(sd, p + ".norm1", x), None, heads) + x
+    x = cross_attention(sd, p + ".attn2", _ln(sd, p + ".norm2", x), context, heads) + x
+    return feed_forward(sd, p + ".ff", _ln(sd, p + ".norm3", x)) + x
+
+
+def single_block(sd: SD, p: str, x, context, heads: int):
+    """BasicTransformerSingleLayerBlock._forward (attention.py:758-761).  Callers pass
+    context = the *un-normalised* x (attention.py:1191-1192), so K/V skip the LayerNorm."""
+    x = cross_attention(sd, p + ".attn1", _ln(sd, p + ".norm1", x), context, heads) + x
+    return feed_forward(sd, p + ".ff", _ln(sd, p + ".norm2", x)) + x
+
+
+def spatial_transformer2d(sd: SD, p: str, x, context, heads: int):
+    """SpatialTransformer.forward, use_linear=False, depth 1 (attention.py:865-889)."""
+    b, c, h, w = x.shape
+    y = _conv2d(sd, p + ".proj_in", _gn(sd, p + ".norm", x, GN_EPS_ATTN))
+    tok = y.flatten(2).transpose(1, 2)
+    tok = basic_block(sd, p + ".transformer_blocks.0", tok, context, heads)
+    y = tok.transpose(1, 2).reshape(b, c, h, w)
+    return _conv2d(sd, p + ".proj_out", y) + x
+
+
+def spatial_transformer3d(sd: SD, p: str, x5, context, heads: int):
+    """SpatialTransformer3D.forward with disable_temporal_text_ca=True (attention.py:1141-1208)."""
+    b, c, t, h, w = x5.shape
+    x = _to_frames(x5)
+    ctx = context.repeat_interleave(t, dim=0)        # 'b l c -> (b t) l c'
+    x = spatial_transformer2d(sd, p, x, ctx, heads)  # same keys: norm, proj_in, transformer_blocks, proj_out
+    xp = _frames_to_pix(x, b)                        # (bhw, c, t)
+    y = _conv1d(sd, p + ".proj_in_temporal", _gn(sd, p + ".norm_temporal", xp, GN_EPS_ATTN))
+    tok = y.transpose(1, 2)                          # (bhw, t, c)
+    tok = single_block(sd, p + ".transformer_blocks_temporal.0", tok, tok, heads)
+    y = _conv1d(sd, p + ".proj_out_temporal", tok.transpose(1, 2))
+    return _pix_to_5d(xp + y, b, h, w)
+
+
+# ----------------------------------------------------------------------------------------
+# ControlNet2D
+# ----------------------------------------------------------------------------------------
+_HINT_STRIDES = (1, 1, 2, 1, 2, 1, 2, 1)             # controlmodel.py:215-231
+
+
+def hint_stem(sd: SD, p: str, hint):
+    """input_hint_block: 8 conv3x3, SiLU between them (none after the last)."""
+    h = hint
+    for i, s in enumerate(_HINT_STRIDES):
+        h = _conv2d(sd, f"{p}.{2 * i}", h, stride=s, padding=1)
+        if i != len(_HINT_STRIDES) - 1:
+            h = F.silu(h)
+    return h
+
+
+def controlnet2d_forward(sd: SD, p: str, cfg: NetConfig, x5, hint5, t, context, trace=None):
+    """ControlNet2D.forward on a 5-D clip (controlmodel.py:252-317) -> 13 residuals (b c t h w)."""
+    b, _, nt, _, _ = x5.shape
+    emb = time_embed(sd, p + ".time_embed", t, cfg.model_channels).repeat_interleave(nt, dim=0)
+    ctx = context.repeat_interleave(nt, dim=0)
+    x, hint = _to_frames(x5), _to_frames(hint5)
+    guided = hint_stem(sd, p + ".input_hint_block", hint)
+    inputs, _, _ = unet_topology(cfg)
+    heads = cfg.num_heads
+    outs = []
+    h = x
+    for i, spec in enumerate(inputs):
+        bp = f"{p}.input_blocks.{i}"
+        if spec.kind == "conv_in":
+            h = _conv2d(sd, bp + ".0", h, padding=1) + guided
+        elif spec.kind == "res":
+            h = resblock2d(sd, bp + ".0", h, emb)
+            if spec.attn:
+                h = spatial_transformer2d(sd, bp + ".1", h, ctx, heads)
+        else:
+            h = _conv2d(sd, bp + ".0.op", h, stride=2, padding=1)
+        outs.append(_conv2d(sd, f"{p}.zero_convs.{i}.0", h))
+        if trace is not None:
+            trace[bp] = h
+    mp = p + ".middle_block"
+    h = resblock2d(sd, mp + ".0", h, emb)
+    h = spatial_transformer2d(sd, mp + ".1", h, ctx, heads)
+    h = resblock2d(sd, mp + ".2", h, emb)
+    if trace is not None:
+        trace[mp] = h
+    outs.append(_conv2d(sd, p + ".middle_block_out.0", h))
+    res = []
+    for o in outs:
+        o = o * cfg.control_scales
+        bt, c, hh, ww = o.shape
+        res.append(o.reshape(b, nt, c, hh, ww).permute(0, 2, 1, 3, 4).contiguous())
+    return res
+
+
+# ----------------------------------------------------------------------------------------
+# pseudo-3D UNet
+# ----------------------------------------------------------------------------------------
+def unet3d_forward(sd: SD, p: str, cfg: NetConfig, x5, t, context, control: List[torch.Tensor], trace=None):
+    """ControlledUNetModel3DTV2V.forward (controlmodel.py:471-550), TV2V (no img_control)."""
+    control = list(control)
+    emb = time_embed(sd, p + ".time_embed", t, cfg.model_channels)
+    inputs, _, outputs = unet_topology(cfg)
+    heads = cfg.num_heads
+    hs = []
+    h = x5
+    for i, spec in enumerate(inputs):
+        bp = f"{p}.input_blocks.{i}"
+        if spec.kind == "conv_in":
+            h = stf(h, lambda x: _conv2d(sd, bp + ".0", x, padding=1),
+                    lambda x: _conv1d(sd, p + ".input_blocks_temporal.0", x, padding=1))
+        elif spec.kind == "res":
+            h = resblock3d(sd, bp + ".0", h, emb)
+            if spec.attn:
+                h = spatial_transformer3d(sd, bp + ".1", h, context, heads)
+        else:   # Downsample3D (openaimodel.py:388-394)
+            h = stf(h, lambda x: _conv2d(sd, bp + ".0.op", x, stride=2, padding=1),
+                    lambda x: _conv1d(sd, bp + ".0.conv_temporal", x, padding=1))
+        hs.append(h)
+        if trace is not None:
+            trace[bp] = h
+    mp = p + ".middle_block"
+    h = resblock3d(sd, mp + ".0", h, emb)
+    h = spatial_transformer3d(sd, mp + ".1", h, context, heads)
+    h = resblock3d(sd, mp + ".2", h, emb)
+    h = h + control.pop()
+    if trace is not None:
+        trace[mp] = h
+    for i, spec in enumerate(outputs):
+        bp = f"{p}.output_blocks.{i}"
+        h = torch.cat([h, hs.pop() + control.pop()], dim=1)
+        h = resblock3d(sd, bp + ".0", h, emb)
+        j = 1
+        if spec.attn:
+            h = spatial_transformer3d(sd, f"{bp}.{j}", h, context, heads)
+            j += 1
+        if spec.up:   # Upsample3D (openaimodel.py:254-263): nearest x(1,2,2) then conv3x3 + conv1d
+            up = F.interpolate(h, scale_factor=(1, 2, 2), mode="nearest")
+            h = stf(up, lambda x: _conv2d(sd, f"{bp}.{j}.conv", x, padding=1),
+                    lambda x: _conv1d(sd, f"{bp}.{j}.conv_temporal", x, padding=1))
+        if trace is not None:
+            trace[bp] = h
+    return stf(h, lambda x: _conv2d(sd, p + ".out.2", F.silu(_gn(sd, p + ".out.0", x, GN_EPS_RES)), padding=1),
+               lambda x: _conv1d(sd, p + ".out_temporal.1", F.silu(x), padding=1))
+
+
+def network_forward(sd: SD, cfg: NetConfig, x5, t, c: Dict[str, torch.Tensor],
+                    p: str = "model.diffusion_model", trace=None):
+    """OpenAIWrapperControlLDM3DTV2V.forward (wrappers.py:156-207)."""
+    hint = 1.0 - (c["control_hint"] + 1.0) / 2.0
+    control = controlnet2d_forward(sd, p + ".controlnet", cfg, x5, hint, t, c["crossattn"], trace)
+    return unet3d_forward(sd, p, cfg, x5, t, c["crossattn"], control, trace)
+
+
+# ----------------------------------------------------------------------------------------
+# sampling numerics
+# ----------------------------------------------------------------------------------------
+def ddpm_alphas_cumprod(num_timesteps=1000, linear_start=0.00085, linear_end=0.0120) -> np.ndarray:
+    """make_beta_schedule('linear') + cumprod, float64 (util.py:24-37, discretizer.py:42-55)."""
+    betas = (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, num_timesteps, dtype=torch.float64) ** 2).numpy()
+    return np.cumprod(1.0 - betas, axis=0)
+
+
+def legacy_ddpm_sigmas(n: int, num_timesteps: int = 1000) -> torch.Tensor:
+    """LegacyDDPMDiscretization.get_sigmas (discretizer.py:58-69): DEscending f32 (no zero appended)."""
+    ac = ddpm_alphas_cumprod(num_timesteps)
+    if n < num_timesteps:
+        ts = np.linspace(num_timesteps - 1, 0, n, endpoint=False).astype(int)[::-1]
+        ac = ac[ts]
+    elif n != num_timesteps:
+        raise ValueError
+    sig = torch.tensor((1 - ac) / ac, dtype=torch.float32) ** 0.5   # cast to f32 BEFORE the sqrt
+    return torch.flip(sig, (0,))
+
+
+def sampler_sigmas(n: int) -> torch.Tensor:
+    """Discretization.__call__(n) with do_append_zero=True (discretizer.py:17-21)."""
+    s = legacy_ddpm_sigmas(n)
+    return torch.cat([s, s.new_zeros([1])])
+
+
+def denoiser_sigmas(num_idx: int = 1000) -> torch.Tensor:
+    """DiscreteDenoiser buffer: flip=True, no zero -> ascending (denoiser.py:44-59)."""
+    return torch.flip(legacy_ddpm_sigmas(num_idx), (0,))
+
+
+def sigma_to_idx(table: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:
+    """argmin |sigma - table| (denoiser.py:61-63), int64."""
+    return (sigma - table[:, None]).abs().argmin(dim=0).view(sigma.shape)
+
+
+def discrete_denoise(network: Callable, table: torch.Tensor, x, sigma, cond):
+    """DiscreteDenoiser.__call__ with EpsScaling (denoiser.py:22-40; denoiser_scaling.py:16-22)."""
+    sigma = table[sigma_to_idx(table, sigma)]
+    shape = sigma.shape
+    s = sigma[(...,) + (None,) * (x.ndim - sigma.ndim)]
+    c_in = 1 / (s ** 2 + 1.0) ** 0.5
+    idx = sigma_to_idx(table, sigma.reshape(shape))
+    return network(x * c_in, idx, cond) * (-s) + x
+
+
+_CFG_CAT_KEYS = ("vector", "crossattn", "concat", "cond_feat", "control_hint",
+                 "interpolate_first", "interpolate_last", "interpolate_first_last")
+
+
+def cfg_prepare(x, s, c, uc):
+    """VanillaCFGTV2V.prepare_inputs (guiders.py:57-67): uc FIRST."""
+    out = {}
+    for k in c:
+        if k in _CFG_CAT_KEYS:
+            out[k] = torch.cat((uc[k], c[k]), 0)
+        else:
+            assert c[k] == uc[k]
+            out[k] = c[k]
+    return torch.cat([x] * 2), torch.cat([s] * 2), out
+
+
+def cfg_combine(x, scale: float):
+    """VanillaCFG.__call__ + NoDynamicThresholding (guiders.py:25-29; sampling_utils.py:7-9)."""
+    u, c = x.chunk(2)
+    return u + scale * (c - u)
+
+
+def ancestral_step_sigmas(sigma_from, sigma_to, eta=1.0):
+    """get_ancestral_step (sampling_utils.py:27-36)."""
+    up = torch.minimum(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    down = (sigma_to ** 2 - up ** 2) ** 0.5
+    return down, up
+
+
+def _bc(v, x):
+    return v[(...,) + (None,) * (x.ndim - v.ndim)]
+
+
+def dpmpp2s_ancestral_sample(denoiser: Callable, x, cond, uc, num_steps: int, scale: float,
+                             noise_fn: Callable[[torch.Tensor], torch.Tensor],
+                             eta: float = 1.0, s_noise: float = 1.0, trace: Optional[dict] = None):
+    """AncestralSampler.__call__ + DPMPP2SAncestralSampler.sampler_step (sampling.py:44-55,
+    190-205, 370-407).  `denoiser(x, sigma, c)` is the closure of sampling_tv2v.py:366-369;
+    `noise_fn(x)` stands for torch.randn_like (drawn once per step, including the last)."""
+    sigmas = sampler_sigmas(num_steps)
+    x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    s_in = x.new_ones([x.shape[0]])
+
+    def denoise(xx, sig):
+        d = denoiser(*cfg_prepare(xx, sig, cond, uc))
+        return cfg_combine(d, scale)
+
+    for i in range(num_steps):
+        sigma, nxt = s_in * sigmas[i], s_in * sigmas[i + 1]
+        down, up = ancestral_step_sigmas(sigma, nxt, eta)
+        den = denoise(x, sigma)
+        x_euler = x + (x - den) / _bc(sigma, x) * _bc(down - sigma, x)
+        if torch.sum(down) < 1e-14:
+            x = x_euler
+        else:
+            t, t_next = -sigma.log(), -down.log()
+            h = t_next - t
+            s = t + 0.5 * h
+            m1 = (-s).exp() / (-t).exp()
+            m2 = (-0.5 * h).expm1()
+            m3 = (-t_next).exp() / (-t).exp()
+            m4 = (-h).expm1()
+            x2 = _bc(m1, x) * x - _bc(m2, x) * den
+            den2 = denoise(x2, (-s).exp())
+            x_2s = _bc(m3, x) * x - _bc(m4, x) * den2
+            x = torch.where(_bc(down, x) > 0.0, x_2s, x_euler)
+        x = torch.where(_bc(nxt, x) > 0.0, x + noise_fn(x) * s_noise * _bc(up, x), x)
+        if trace is not None:
+            trace.setdefault("x", []).append(x.clone())
+    return x
+
+
+# ----------------------------------------------------------------------------------------
+# AutoencoderKL decode
+# ----------------------------------------------------------------------------------------
+@dataclass
+class VAEConfig:
+    """ddconfig of keyframe_no2ndca_depthmidas.yaml:83-95."""
+    ch: int = 128
+    ch_mult: Tuple[int, ...] = (1, 2, 4, 4)
+    num_res_blocks: int = 2
+    z_channels: int = 4
+    out_ch: int = 3
+    embed_dim: int = 4
+
+
+def _vae_resblock(sd: SD, p: str, x):
+    """model.py ResnetBlock.forward (:131-151), temb=None."""
+    h = _conv2d(sd, p + ".conv1", F.silu(_gn(sd, p + ".norm1", x, GN_EPS_ATTN)), padding=1)
+    h = _conv2d(sd, p + ".conv2", F.silu(_gn(sd, p + ".norm2", h, GN_EPS_ATTN)), padding=1)
+    if (p + ".nin_shortcut.weight") in sd:
+        x = _conv2d(sd, p + ".nin_shortcut", x)
+    return x + h
+
+
+def _vae_attn(sd: SD, p: str, x):
+    """model.py AttnBlock (:161-201): single head, d = C, scale C^-0.5."""
+    b, c, h, w = x.shape
+    y = _gn(sd, p + ".norm", x, GN_EPS_ATTN)
+    q, k, v = (_conv2d(sd, p + "." + n, y).flatten(2).transpose(1, 2) for n in ("q", "k", "v"))
+    a = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+    return x + _conv2d(sd, p + ".proj_out", a.transpose(1, 2).reshape(b, c, h, w))
+
+
+def vae_decode(sd: SD, p: str, cfg: VAEConfig, z, scale_factor: float = 0.18215):
+    """decode_first_stage (diffusion.py:151-156) -> AutoencoderKLInferenceWrapper.decode
+    (autoencoder.py:334-343) -> Decoder.forward (model.py:728-761).  z is 5-D (b c t h w)."""
+    b, c, t, h, w = z.shape
+    x = _to_frames(z * (1.0 / scale_factor))
+    x = _conv2d(sd, p + ".post_quant_conv", x)
+    d = p + ".decoder"
+    x = _conv2d(sd, d + ".conv_in", x, padding=1)
+    x = _vae_resblock(sd, d + ".mid.block_1", x)
+    x = _vae_attn(sd, d + ".mid.attn_1", x)
+    x = _vae_resblock(sd, d + ".mid.block_2", x)
+    for lvl in reversed(range(len(cfg.ch_mult))):
+        for i in range(cfg.num_res_blocks + 1):
+            x = _vae_resblock(sd, f"{d}.up.{lvl}.block.{i}", x)
+        if lvl != 0:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = _conv2d(sd, f"{d}.up.{lvl}.upsample.conv", x, padding=1)
+    x = _conv2d(sd, d + ".conv_out", F.silu(_gn(sd, d + ".norm_out", x, GN_EPS_ATTN)), padding=1)
+    return x.reshape(b, t, x.shape[1], x.shape[2], x.shape[3]).permute(0, 2, 1, 3, 4).contiguous()

@@ -1,0 +1,328 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against a plain PyTorch fp32 reference
+of the same op (computed on CPU from the same bf16-rounded inputs).
+
+Tolerances: outputs are bf16 (8 mantissa bits) with fp32 accumulation, so a correct kernel differs
+from the fp32 reference by rounding of the output only: max |err| <= 2^-7 * max|ref| (+ small abs).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).float()     # bf16-representable fp32
+
+
+def _close(got: torch.Tensor, ref: torch.Tensor, rel=2.0 ** -7, abs_=1e-3, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs().max().item()
+    lim = rel * ref.abs().max().item() + abs_
+    assert err <= lim, f"{what}: max err {err:.4g} > {lim:.4g} (ref absmax {ref.abs().max().item():.4g})"
+
+
+def _nhwc(x_nchw):   # fp32 (N,C,H,W) -> bf16 cuda (N,H,W,C)
+    return x_nchw.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+
+
+def _nchw(y_nhwc):
+    return y_nhwc.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (300, 320, 320), (77, 960, 768), (1000, 4, 320), (257, 1280, 2560),
+                                   (64, 640, 40)])
+@pytest.mark.parametrize("tile", [0, 1, 2])
+def test_linear(m, n, k, tile):
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    x, w, b = _rnd(m, k, seed=1), _rnd(n, k, seed=2, scale=k ** -0.5), _rnd(n, seed=3)
+    pw = pack_weight(w, b).to("cuda")
+    y = ops.linear(x.to(BF).cuda(), pw, tile=tile)
+    _close(y, F.linear(x, w, b), what=f"linear {m}x{n}x{k} tile{tile}")
+
+
+def test_linear_asymmetric_identity():
+    """A = I against an asymmetric B catches a transposed C-write (guide rule 16)."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    k = 128
+    x = torch.eye(k)
+    w = (torch.arange(256 * k).reshape(256, k) % 251).float() / 64.0
+    w = w.to(BF).float()
+    y = ops.linear(x.to(BF).cuda(), pack_weight(w).to("cuda"))
+    _close(y, w.t().contiguous(), what="identity x asymmetric")
+
+
+def test_linear_epilogues():
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    m, n, k = 3 * 50, 320, 640
+    x, w, b = _rnd(m, k, seed=1), _rnd(n, k, seed=2, scale=k ** -0.5), _rnd(n, seed=3)
+    r1, r2 = _rnd(m, n, seed=4), _rnd(m, n, seed=5)
+    gb = _rnd(3, n, seed=6)
+    pw = pack_weight(w, b).to("cuda")
+    y = ops.linear(x.to(BF).cuda(), pw, res1=r1.to(BF).cuda(), res2=r2.to(BF).cuda(), group_bias=gb.cuda(), group_rows=50)
+    ref = F.linear(x, w, b) + gb.repeat_interleave(50, 0) + r1 + r2
+    _close(y, ref, what="bias+group_bias+2 residuals")
+    y = ops.linear(x.to(BF).cuda(), pw, act=1)
+    _close(y, F.silu(F.linear(x, w, b)), what="silu epilogue")
+    y = ops.linear(x.to(BF).cuda(), pw, out_f32=True)
+    assert y.dtype == torch.float32
+    _close(y, F.linear(x, w, b), rel=1e-5, abs_=1e-4, what="fp32 out")
+    # strided output (column slice of a wider buffer) and strided source
+    wide = torch.zeros(m, 2 * n, dtype=BF, device="cuda")
+    ops.linear(x.to(BF).cuda(), pw, out=wide[:, n:])
+    _close(wide[:, n:], F.linear(x, w, b), what="strided out")
+    assert wide[:, :n].abs().max().item() == 0
+    xs = torch.cat([_rnd(m, 64, seed=9), x], dim=1).to(BF).cuda()
+    y = ops.linear(xs[:, 64:], pw)
+    _close(y, F.linear(x, w, b), what="strided source")
+
+
+def test_geglu():
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    m, c = 200, 320
+    inner = 4 * c
+    x, w, b = _rnd(m, c, seed=1), _rnd(2 * inner, c, seed=2, scale=c ** -0.5), _rnd(2 * inner, seed=3)
+    pw = pack_weight(w, b, geglu=True).to("cuda")
+    y = ops.linear(x.to(BF).cuda(), pw)
+    a, g = F.linear(x, w, b).chunk(2, dim=-1)
+    _close(y, a * F.gelu(g), what="GEGLU")
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride", [(320, 320, 16, 24, 1), (64, 128, 9, 7, 1), (320, 320, 16, 24, 2),
+                                                  (8, 320, 16, 24, 1), (16, 32, 32, 48, 2), (640, 4, 8, 12, 1)])
+def test_conv3x3(cin, cout, h, w, stride):
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    n = 3
+    x = _rnd(n, cin, h, w, seed=1)
+    wt, b = _rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), _rnd(cout, seed=3)
+    y = ops.conv2d(_nhwc(x), pack_weight(wt, b).to("cuda"), stride=stride)
+    ref = F.conv2d(x, wt, b, stride=stride, padding=1)
+    _close(_nchw(y)[:, :cout], ref, what=f"conv3x3 {cin}->{cout} s{stride}")
+
+
+def test_conv3x3_channel_padding():
+    """Cin = 4 (latent) / 3 (hint) are zero-padded to 8 channels at the layout boundary."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    x = _rnd(2, 4, 16, 24, seed=1)
+    wt, b = _rnd(320, 4, 3, 3, seed=2, scale=1 / 6), _rnd(320, seed=3)
+    x5 = x.reshape(1, 2, 4, 16, 24).permute(0, 2, 1, 3, 4).contiguous()       # (B=1, C, T=2, H, W)
+    xn = ops.ncthw_to_nhwc(x5.cuda(), 8)
+    assert xn.shape == (2, 16, 24, 8)
+    y = ops.conv2d(xn, pack_weight(wt, b).to("cuda"))
+    _close(_nchw(y), F.conv2d(x, wt, b, padding=1), what="conv_in 4->320")
+
+
+def test_conv3x3_upsample_and_concat():
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    n, c, h, w = 2, 64, 8, 12
+    x = _rnd(n, c, h, w, seed=1)
+    wt, b = _rnd(96, c, 3, 3, seed=2, scale=(9 * c) ** -0.5), _rnd(96, seed=3)
+    y = ops.conv2d(_nhwc(x), pack_weight(wt, b).to("cuda"), upsample=True)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, b, padding=1)
+    _close(_nchw(y), ref, what="upsample2x + conv3x3")
+    x2 = _rnd(n, 32, h, w, seed=4)
+    wt2 = _rnd(96, c + 32, 3, 3, seed=5, scale=(9 * (c + 32)) ** -0.5)
+    y = ops.conv2d(_nhwc(x), pack_weight(wt2, b).to("cuda"), x2=_nhwc(x2))
+    _close(_nchw(y), F.conv2d(torch.cat([x, x2], 1), wt2, b, padding=1), what="dual-source conv3x3")
+
+
+def test_conv1x1_and_temporal():
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    b_, t, c, h, w = 2, 5, 64, 6, 10
+    x = _rnd(b_ * t, c, h, w, seed=1)
+    w1, b1 = _rnd(128, c, 1, 1, seed=2, scale=c ** -0.5), _rnd(128, seed=3)
+    y = ops.conv2d(_nhwc(x), pack_weight(w1, b1).to("cuda"))
+    _close(_nchw(y), F.conv2d(x, w1, b1), what="conv1x1")
+    # temporal conv1d k3 over frames: reference on the '(b h w) c t' view
+    wt, bt = _rnd(c, c, 3, seed=4, scale=(3 * c) ** -0.5), _rnd(c, seed=5)
+    xp = x.reshape(b_, t, c, h, w).permute(0, 3, 4, 2, 1).reshape(b_ * h * w, c, t)
+    ref = F.conv1d(xp, wt, bt, padding=1).reshape(b_, h, w, c, t).permute(0, 4, 3, 1, 2).reshape(b_ * t, c, h, w)
+    res = _rnd(b_ * t, c, h, w, seed=6)
+    y = ops.conv_temporal(_nhwc(x), t, pack_weight(wt, bt).to("cuda"), res1=_nhwc(res).reshape(-1, c))
+    _close(_nchw(y), ref + res, what="conv1d k3 over T + residual")
+    wk1 = _rnd(c, c, 1, seed=7, scale=c ** -0.5)
+    y = ops.conv_temporal(_nhwc(x), t, pack_weight(wk1, bt).to("cuda"))
+    ref = F.conv1d(xp, wk1, bt).reshape(b_, h, w, c, t).permute(0, 4, 3, 1, 2).reshape(b_ * t, c, h, w)
+    _close(_nchw(y), ref, what="conv1d k1 over T")
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c,h,w,eps,silu", [(320, 16, 24, 1e-5, True), (64, 5, 7, 1e-6, False), (2560, 4, 6, 1e-5, True),
+                                            (160, 8, 12, 1e-5, True)])
+def test_groupnorm_spatial(c, h, w, eps, silu):
+    _dev()
+    from ccedit_amd import ops
+    x = _rnd(3, c, h, w, seed=1) * 2 + 0.5
+    x = x.to(BF).float()
+    g, b = _rnd(c, seed=2) * 0.1 + 1, _rnd(c, seed=3) * 0.1
+    y = ops.groupnorm_spatial(_nhwc(x), g.cuda(), b.cuda(), eps, silu)
+    ref = F.group_norm(x, 32, g, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    _close(_nchw(y), ref, rel=2.0 ** -6, what=f"GN spatial C={c}")
+
+
+@pytest.mark.parametrize("c,t,eps,silu", [(320, 17, 1e-5, True), (1280, 3, 1e-6, False), (160, 4, 1e-5, True)])
+def test_groupnorm_temporal(c, t, eps, silu):
+    _dev()
+    from ccedit_amd import ops
+    b_, h, w = 2, 3, 5
+    x = (_rnd(b_ * t, c, h, w, seed=1) * 1.5 - 0.3).to(BF).float()
+    g, b = _rnd(c, seed=2) * 0.1 + 1, _rnd(c, seed=3) * 0.1
+    y = ops.groupnorm_temporal(_nhwc(x), b_, t, g.cuda(), b.cuda(), eps, silu)
+    xp = x.reshape(b_, t, c, h, w).permute(0, 3, 4, 2, 1).reshape(b_ * h * w, c, t)
+    ref = F.group_norm(xp, 32, g, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.reshape(b_, h, w, c, t).permute(0, 4, 3, 1, 2).reshape(b_ * t, c, h, w)
+    _close(_nchw(y), ref, rel=2.0 ** -6, what=f"GN temporal C={c} T={t}")
+
+
+@pytest.mark.parametrize("c", [320, 640, 1280, 160])
+def test_layernorm(c):
+    _dev()
+    from ccedit_amd import ops
+    x = (_rnd(101, c, seed=1) * 3 + 1).to(BF).float()
+    g, b = _rnd(c, seed=2) * 0.1 + 1, _rnd(c, seed=3) * 0.1
+    y = ops.layernorm(x.to(BF).cuda(), g.cuda(), b.cuda())
+    _close(y, F.layer_norm(x, (c,), g, b, 1e-5), rel=2.0 ** -6, what=f"LayerNorm C={c}")
+
+
+# ------------------------------------------------------------------------------------------
+def _sdpa_ref(q, k, v, heads):
+    b, n, c = q.shape
+    d = c // heads
+    qh = q.reshape(b, n, heads, d).transpose(1, 2)
+    kh = k.reshape(b, -1, heads, d).transpose(1, 2)
+    vh = v.reshape(b, -1, heads, d).transpose(1, 2)
+    return F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(b, n, c)
+
+
+@pytest.mark.parametrize("d,heads,lq,lk", [(40, 8, 384, 384), (80, 4, 200, 200), (160, 2, 96, 96), (40, 8, 150, 77),
+                                           (64, 2, 129, 65), (32, 3, 64, 64), (8, 4, 40, 40), (128, 1, 70, 130)])
+def test_attention_spatial_and_text(d, heads, lq, lk):
+    _dev()
+    from ccedit_amd import ops
+    b = 3
+    c = heads * d
+    q, k, v = _rnd(b, lq, c, seed=1), _rnd(b, lk, c, seed=2), _rnd(b, lk, c, seed=3)
+    o = ops.attention(q.reshape(-1, c).to(BF).cuda(), k.reshape(-1, c).to(BF).cuda(), v.reshape(-1, c).to(BF).cuda(),
+                      heads, d, batches=b, lq=lq, lk=lk)
+    _close(o.reshape(b, lq, c), _sdpa_ref(q, k, v, heads), rel=2.0 ** -6, abs_=4e-3, what=f"attention d={d} {lq}x{lk}")
+
+
+def test_attention_forced_rescale():
+    """A late key with a huge score forces the online-softmax rescale branch (guide rule 26)."""
+    _dev()
+    from ccedit_amd import ops
+    heads, d, lq, lk = 2, 40, 64, 256
+    c = heads * d
+    q, k, v = _rnd(1, lq, c, seed=1), _rnd(1, lk, c, seed=2), _rnd(1, lk, c, seed=3)
+    k[0, 200] = q[0, 5] * 4.0        # spikes q-row 5 (and correlates with the rest) in the 4th KV tile
+    k = k.to(BF).float()
+    o = ops.attention(q.reshape(-1, c).to(BF).cuda(), k.reshape(-1, c).to(BF).cuda(), v.reshape(-1, c).to(BF).cuda(),
+                      heads, d, batches=1, lq=lq, lk=lk)
+    _close(o.reshape(1, lq, c), _sdpa_ref(q, k, v, heads), rel=2.0 ** -6, abs_=4e-3, what="attention with spike")
+
+
+def test_attention_fused_qkv_and_shared_text_kv():
+    _dev()
+    from ccedit_amd import ops
+    heads, d, frames_per_clip, clips, lq, lk = 8, 40, 3, 2, 96, 77
+    c = heads * d
+    n = clips * frames_per_clip
+    qkv = _rnd(n * lq, 3 * c, seed=1)
+    dev = qkv.to(BF).cuda()
+    o = ops.attention(dev[:, :c], dev[:, c:2 * c], dev[:, 2 * c:], heads, d, batches=n, lq=lq, lk=lq)
+    ref = _sdpa_ref(qkv[:, :c].reshape(n, lq, c), qkv[:, c:2 * c].reshape(n, lq, c), qkv[:, 2 * c:].reshape(n, lq, c), heads)
+    _close(o.reshape(n, lq, c), ref, rel=2.0 ** -6, abs_=4e-3, what="self-attention on a fused qkv buffer")
+    # text K/V: one per clip, shared by its frames
+    q = _rnd(n, lq, c, seed=2)
+    kv = _rnd(clips * lk, 2 * c, seed=3)
+    kvd = kv.to(BF).cuda()
+    o = ops.attention(q.reshape(-1, c).to(BF).cuda(), kvd[:, :c], kvd[:, c:], heads, d, batches=n, lq=lq, lk=lk,
+                      kv_div=frames_per_clip)
+    kk = kv[:, :c].reshape(clips, lk, c).repeat_interleave(frames_per_clip, 0)
+    vv = kv[:, c:].reshape(clips, lk, c).repeat_interleave(frames_per_clip, 0)
+    _close(o.reshape(n, lq, c), _sdpa_ref(q, kk, vv, heads), rel=2.0 ** -6, abs_=4e-3, what="text cross-attention")
+
+
+@pytest.mark.parametrize("d,heads,t", [(40, 8, 17), (160, 8, 3), (80, 4, 4)])
+def test_attention_temporal(d, heads, t):
+    """Sequences run over the T frames of one pixel: rows H*W apart, batch = (clip, pixel)."""
+    _dev()
+    from ccedit_amd import ops
+    clips, hw = 2, 12
+    c = heads * d
+    x = _rnd(clips * t * hw, 3 * c, seed=1)        # rows ordered (clip, frame, pixel)
+    dev = x.to(BF).cuda()
+    o = ops.attention(dev[:, :c], dev[:, c:2 * c], dev[:, 2 * c:], heads, d, batches=clips * hw, lq=t, lk=t,
+                      q_inner=hw, q_outer_rows=t * hw, q_inner_rows=1, q_seq_rows=hw,
+                      kv_inner=hw, kv_outer_rows=t * hw, kv_inner_rows=1, kv_seq_rows=hw)
+    xs = x.reshape(clips, t, hw, 3 * c).permute(0, 2, 1, 3).reshape(clips * hw, t, 3 * c)
+    ref = _sdpa_ref(xs[..., :c], xs[..., c:2 * c], xs[..., 2 * c:], heads)
+    ref = ref.reshape(clips, hw, t, c).permute(0, 2, 1, 3).reshape(clips * t * hw, c)
+    _close(o, ref, rel=2.0 ** -6, abs_=4e-3, what=f"temporal attention d={d} T={t}")
+
+
+# ------------------------------------------------------------------------------------------
+def test_layout_and_elementwise():
+    _dev()
+    from ccedit_amd import ops
+    b, c, t, h, w = 2, 3, 4, 6, 10
+    x = _rnd(b, c, t, h, w, seed=1)
+    sc = torch.tensor([0.5, 2.0])
+    y = ops.ncthw_to_nhwc(x.cuda(), 8, scale_per_b=sc.cuda(), scale=-0.5, shift=0.5)
+    ref = (x * sc.view(b, 1, 1, 1, 1) * -0.5 + 0.5).permute(0, 2, 3, 4, 1).reshape(b * t, h, w, c)
+    _close(y[..., :c], ref, what="ncthw_to_nhwc")
+    assert y[..., c:].abs().max().item() == 0
+    back = ops.nhwc_to_ncthw(y, b, t, c)
+    _close(back, ref.reshape(b, t, h, w, c).permute(0, 4, 1, 2, 3), rel=2.0 ** -7, what="nhwc_to_ncthw")
+    a, bb, cc = _rnd(5, 4, 6, 64, seed=2), _rnd(5, 4, 6, 32, seed=3), _rnd(5, 4, 6, 32, seed=4)
+    o = ops.cat_add(a.to(BF).cuda(), bb.to(BF).cuda(), cc.to(BF).cuda())
+    _close(o, torch.cat([a, bb + cc], -1), what="cat_add")
+    _close(ops.add(a.to(BF).cuda(), a.to(BF).cuda()), 2 * a, what="add")
+    _close(ops.silu(a.to(BF).cuda()), F.silu(a), what="silu")
+    tt = torch.tensor([999, 601, 0, 17], dtype=torch.int64)
+    emb = ops.timestep_embedding(tt.cuda(), 320)
+    half = 160
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    args = tt[:, None].float() * freqs[None]
+    _close(emb, torch.cat([torch.cos(args), torch.sin(args)], -1), rel=2.0 ** -7, abs_=2e-3, what="timestep_embedding")
+    x32, e2 = torch.randn(1000), torch.randn(2, 1000)
+    den = ops.cfg_denoise(x32.cuda(), e2.cuda(), 3.5, 7.5)
+    du, dc = e2[0] * -3.5 + x32, e2[1] * -3.5 + x32
+    _close(den, du + 7.5 * (dc - du), rel=1e-6, abs_=1e-5, what="cfg_denoise")
+    z = torch.randn(1000)
+    _close(ops.axpby(x32.cuda(), z.cuda(), 0.3, -1.7), 0.3 * x32 - 1.7 * z, rel=1e-6, abs_=1e-5, what="axpby")
