@@ -113,6 +113,45 @@ __global__ void axpby_kernel(const float* __restrict__ x, const float* __restric
         y[i] = a * x[i] + b * z[i];
 }
 
+// p[r][c] = softmax_c(s[r][c] * scale) for c < cols, 0 for cols <= c < cols_pad.  One block per row,
+// the row lives in registers (cols <= 256*32).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16* __restrict__ p, int cols,
+                                                           int cols_pad, int64_t lds_, int64_t ldp, float scale) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const float* sr = s + row * lds_;
+    bf16* pr = p + row * ldp;
+    float v[32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int c = threadIdx.x + k * 256;
+        v[k] = (c < cols) ? sr[c] * scale : -INFINITY;
+        mx = fmaxf(mx, v[k]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        v[k] = __expf(v[k] - mx);
+        sum += v[k];
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int c = threadIdx.x + k * 256;
+        if (c < cols_pad) pr[c] = f2bf(c < cols ? v[k] * inv : 0.f);
+    }
+}
+
 inline unsigned grid_for(int64_t n, int threads) {
     int64_t g = (n + threads - 1) / threads;
     return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -185,4 +224,13 @@ extern "C" int ccedit_axpby(const float* x, const float* z, float* y, int64_t n,
     CC_CHECK_ARG(x && z && y && n > 0, "ccedit_axpby: bad args");
     hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, z, y, n, a, b);
     return cc_launch_status("axpby");
+}
+
+extern "C" int ccedit_softmax_rows(const float* s, void* p, int64_t rows, int32_t cols, int32_t cols_pad, int64_t lds,
+                                   int64_t ldp, float scale, void* stream) {
+    CC_CHECK_ARG(s && p && rows > 0 && cols > 0 && cols_pad >= cols, "ccedit_softmax_rows: bad args");
+    CC_UNSUPPORTED(cols_pad > 256 * 32, "ccedit_softmax_rows: cols_pad=%d > 8192", cols_pad);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, (bf16*)p, cols,
+                       cols_pad, lds, ldp, scale);
+    return cc_launch_status("softmax_rows");
 }

@@ -1,0 +1,581 @@
+"""The CCEdit denoising network (ControlNet2D + pseudo-3D UNet) on the HIP kernels.
+
+Same classes, constructor arguments, attribute names, state-dict keys and forward signatures as the
+reference (sgm/modules/diffusionmodules/controlmodel.py, openaimodel.py, attention.py, wrappers.py),
+re-designed around ONE activation layout: frames-outermost channels-last, a bf16 (B*T, H, W, C)
+tensor == a row-major [pixels][C] matrix.  Consequences:
+
+  * spatial_temporal_forward's three full-tensor transposes per call (openaimodel.py:129-178, 74 calls
+    per UNet forward) disappear: spatial kernels index (frame, y, x), temporal kernels step H*W rows.
+  * 'b c h w -> b (h w) c' token views are free: proj_in / q,k,v / FF / proj_out are plain GEMMs on
+    the same matrix; 1x1 Conv2d, k=1 Conv1d and Linear are the same kernel.
+  * residual adds, the timestep-embedding add, GEGLU gating, SiLU of the hint stem, the nearest-2x
+    upsample and the skip concat + control add are epilogues / gather modes of the GEMM kernel.
+
+Only what the shipped inference configs use is implemented:
+use_spatial_transformer, transformer_depth 1, use_linear_in_transformer False, conv_resample True,
+no scale-shift norm, no resblock_updown, num_classes None, disable_temporal_text_ca True.
+Anything else raises NotImplementedError at construction.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .hip import ACT_SILU
+from .layers import Conv, Linear, Norm, Slot, pack_tree
+from .packing import pack_concat
+
+GN_EPS_RES = 1e-5     # reference: normalization() = nn.GroupNorm(32, C)     diffusionmodules/util.py:296-302
+GN_EPS_ATTN = 1e-6    # reference: Normalize()                               attention.py:153-156
+
+
+class Geometry:
+    """Clip geometry travelling with the activations: B clips x T frames."""
+
+    def __init__(self, b: int, t: int):
+        self.b, self.t = b, t
+
+
+def _seq(*mods) -> nn.Sequential:
+    return nn.Sequential(*mods)
+
+
+# ------------------------------------------------------------------------------------------
+# attention blocks
+# ------------------------------------------------------------------------------------------
+class CrossAttention(nn.Module):
+    """Parameters of sgm.modules.attention.CrossAttention (attention.py:365-390)."""
+
+    def __init__(self, query_dim: int, context_dim: Optional[int], heads: int, dim_head: int):
+        super().__init__()
+        inner = heads * dim_head
+        cdim = query_dim if context_dim is None else context_dim
+        self.heads, self.dim_head, self.inner = heads, dim_head, inner
+        self.to_q = Linear(query_dim, inner, bias=False)
+        self.to_k = Linear(cdim, inner, bias=False)
+        self.to_v = Linear(cdim, inner, bias=False)
+        self.to_out = _seq(Linear(inner, query_dim), Slot())
+        self.self_attn = context_dim is None
+        self.qkv = None
+        self.kv = None
+
+    def post_pack(self, device):
+        if self.self_attn:
+            self.qkv = pack_concat([self.to_q.weight, self.to_k.weight, self.to_v.weight], device=device)
+        self.kv = pack_concat([self.to_k.weight, self.to_v.weight], device=device)
+
+
+class FeedForward(nn.Module):
+    """FeedForward(glu=True): net.0 = GEGLU(proj), net.1 = Dropout, net.2 = Linear (attention.py:115-141)."""
+
+    def __init__(self, dim: int, mult: int = 4):
+        super().__init__()
+        inner = dim * mult
+        geglu = nn.Module()
+        geglu.proj = Linear(dim, inner * 2, geglu=True)
+        self.net = _seq(geglu, Slot(), Linear(inner, dim))
+
+    def run(self, x2d, residual):
+        g = ops.linear(x2d, self.net[0].proj.pw)
+        return ops.linear(g, self.net[2].pw, res1=residual)
+
+
+class BasicTransformerBlock(nn.Module):
+    """attention.py:598-716: x += attn1(LN(x)); x += attn2(LN(x), text); x += FF(LN(x))."""
+
+    def __init__(self, dim, n_heads, d_head, context_dim):
+        super().__init__()
+        self.attn1 = CrossAttention(dim, None, n_heads, d_head)
+        self.ff = FeedForward(dim)
+        self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head)
+        self.norm1, self.norm2, self.norm3 = Norm(dim, 1e-5), Norm(dim, 1e-5), Norm(dim, 1e-5)
+
+    def run(self, tok, frames: int, hw: int, ctx_kv_src, ctx_len: int, frames_per_clip: int):
+        a1, a2 = self.attn1, self.attn2
+        c = a1.inner
+        n1 = ops.layernorm(tok, self.norm1.g, self.norm1.b)
+        qkv = ops.linear(n1, a1.qkv)
+        o = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], a1.heads, a1.dim_head, batches=frames, lq=hw, lk=hw)
+        tok = ops.linear(o, a1.to_out[0].pw, res1=tok)
+        n2 = ops.layernorm(tok, self.norm2.g, self.norm2.b)
+        q = ops.linear(n2, a2.to_q.pw)
+        kv = ops.linear(ctx_kv_src, a2.kv)                     # [B*L, 2C]: once per clip, shared by its T frames
+        o = ops.attention(q, kv[:, :c], kv[:, c:], a2.heads, a2.dim_head, batches=frames, lq=hw, lk=ctx_len,
+                          kv_div=frames_per_clip)
+        tok = ops.linear(o, a2.to_out[0].pw, res1=tok)
+        n3 = ops.layernorm(tok, self.norm3.g, self.norm3.b)
+        return self.ff.run(n3, tok)
+
+
+class BasicTransformerSingleLayerBlock(nn.Module):
+    """attention.py:719-761, called as block(x, context=x): q from LN(x), k/v from the UN-normalised x."""
+
+    def __init__(self, dim, n_heads, d_head):
+        super().__init__()
+        self.attn1 = CrossAttention(dim, None, n_heads, d_head)
+        self.ff = FeedForward(dim)
+        self.norm1, self.norm2 = Norm(dim, 1e-5), Norm(dim, 1e-5)
+
+    def run_temporal(self, tok, geo: Geometry, hw: int):
+        a = self.attn1
+        c = a.inner
+        n1 = ops.layernorm(tok, self.norm1.g, self.norm1.b)
+        q = ops.linear(n1, a.to_q.pw)
+        kv = ops.linear(tok, a.kv)
+        t = geo.t
+        o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=geo.b * hw, lq=t, lk=t,
+                          q_inner=hw, q_outer_rows=t * hw, q_inner_rows=1, q_seq_rows=hw,
+                          kv_inner=hw, kv_outer_rows=t * hw, kv_inner_rows=1, kv_seq_rows=hw)
+        tok = ops.linear(o, a.to_out[0].pw, res1=tok)
+        n2 = ops.layernorm(tok, self.norm2.g, self.norm2.b)
+        return self.ff.run(n2, tok)
+
+
+class SpatialTransformer(nn.Module):
+    """2-D transformer of the ControlNet (attention.py:764-889), use_linear=False, depth 1."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, context_dim=None, **kw):
+        super().__init__()
+        if depth != 1 or kw.get("use_linear", False) or kw.get("disable_self_attn", False) or kw.get("disable_text_ca", False):
+            raise NotImplementedError("SpatialTransformer: only depth=1, conv projections, text cross-attn")
+        inner = n_heads * d_head
+        self.norm = Norm(in_channels, GN_EPS_ATTN)
+        self.proj_in = Conv(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, n_heads, d_head, context_dim)])
+        self.proj_out = Conv(inner, in_channels, 1)
+
+    def run_spatial(self, x, ctx2d, ctx_len, frames_per_clip):
+        n, h, w, c = x.shape
+        a = ops.groupnorm_spatial(x, self.norm.g, self.norm.b, self.norm.eps, False)
+        tok = ops.linear(a.view(-1, c), self.proj_in.pw)
+        tok = self.transformer_blocks[0].run(tok, n, h * w, ctx2d, ctx_len, frames_per_clip)
+        y = ops.linear(tok, self.proj_out.pw, res1=x.view(-1, c))
+        return y.view(n, h, w, c)
+
+    def run(self, x, geo, ctx2d, ctx_len):
+        return self.run_spatial(x, ctx2d, ctx_len, geo.t)
+
+
+class SpatialTransformer3D(SpatialTransformer):
+    """attention.py:1000-1208 with disable_temporal_text_ca=True: spatial block, then temporal
+    self-attention over the T keyframes at every pixel."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, context_dim=None, **kw):
+        if not kw.pop("disable_temporal_text_ca", False):
+            raise NotImplementedError("SpatialTransformer3D: only disable_temporal_text_ca=True (shipped configs)")
+        super().__init__(in_channels, n_heads, d_head, depth, context_dim, **kw)
+        inner = n_heads * d_head
+        self.norm_temporal = Norm(in_channels, GN_EPS_ATTN)
+        self.proj_in_temporal = Conv(in_channels, inner, 1, dims=1)
+        self.transformer_blocks_temporal = nn.ModuleList([BasicTransformerSingleLayerBlock(inner, n_heads, d_head)])
+        self.proj_out_temporal = Conv(inner, in_channels, 1, dims=1)
+
+    def run(self, x, geo, ctx2d, ctx_len):
+        y = self.run_spatial(x, ctx2d, ctx_len, geo.t)
+        n, h, w, c = y.shape
+        nt = self.norm_temporal
+        a = ops.groupnorm_temporal(y, geo.b, geo.t, nt.g, nt.b, nt.eps, False)
+        tok = ops.linear(a.view(-1, c), self.proj_in_temporal.pw)
+        tok = self.transformer_blocks_temporal[0].run_temporal(tok, geo, h * w)
+        z = ops.linear(tok, self.proj_out_temporal.pw, res1=y.view(-1, c))
+        return z.view(n, h, w, c)
+
+
+# ------------------------------------------------------------------------------------------
+# residual / resampling blocks
+# ------------------------------------------------------------------------------------------
+class ResBlock(nn.Module):
+    """2-D ResBlock of the ControlNet (openaimodel.py:397-554)."""
+
+    def __init__(self, channels, emb_channels, out_channels):
+        super().__init__()
+        self.in_layers = _seq(Norm(channels, GN_EPS_RES), Slot(), Conv(channels, out_channels, 3))
+        self.emb_layers = _seq(Slot(), Linear(emb_channels, out_channels))
+        self.out_layers = _seq(Norm(out_channels, GN_EPS_RES), Slot(), Slot(), Conv(out_channels, out_channels, 3))
+        self.skip_connection = Slot() if out_channels == channels else Conv(channels, out_channels, 1)
+
+    def run(self, x, emb_silu, geo: Geometry):
+        n, h, w, _ = x.shape
+        gn = self.in_layers[0]
+        a = ops.groupnorm_spatial(x, gn.g, gn.b, gn.eps, True)
+        e = ops.linear(emb_silu, self.emb_layers[1].pw, out_f32=True)              # (B, Cout) fp32
+        hid = ops.conv2d(a, self.in_layers[2].pw, group_bias=e, group_rows=geo.t * h * w)
+        gn = self.out_layers[0]
+        a = ops.groupnorm_spatial(hid, gn.g, gn.b, gn.eps, True)
+        skip = x if isinstance(self.skip_connection, Slot) else ops.conv2d(x, self.skip_connection.pw)
+        return ops.conv2d(a, self.out_layers[3].pw, res1=skip.view(-1, skip.shape[-1]))
+
+
+class ResBlock3D(nn.Module):
+    """Pseudo-3D ResBlock (openaimodel.py:557-775): every 3x3 conv is followed by a per-pixel
+    GroupNorm+SiLU+Conv1d(k3) over T with a residual around it."""
+
+    def __init__(self, channels, emb_channels, out_channels):
+        super().__init__()
+        co = out_channels
+        self.in_layers = _seq(Norm(channels, GN_EPS_RES), Slot(), Conv(channels, co, 3))
+        self.in_layers_temporal = _seq(Norm(co, GN_EPS_RES), Slot(), Conv(co, co, 3, dims=1))
+        self.emb_layers = _seq(Slot(), Linear(emb_channels, co))
+        self.out_layers = _seq(Norm(co, GN_EPS_RES), Slot(), Slot(), Conv(co, co, 3))
+        self.out_layers_temporal = _seq(Norm(co, GN_EPS_RES), Slot(), Slot(), Conv(co, co, 3, dims=1))
+        if co == channels:
+            self.skip_connection = Slot()
+            self.skip_connection_temporal = None
+        else:
+            self.skip_connection = Conv(channels, co, 1)
+            self.skip_connection_temporal = Conv(co, co, 1, dims=1)
+
+    def run(self, x, emb_silu, geo: Geometry):
+        n, h, w, _ = x.shape
+        gn = self.in_layers[0]
+        a = ops.groupnorm_spatial(x, gn.g, gn.b, gn.eps, True)
+        s = ops.conv2d(a, self.in_layers[2].pw)
+        co = s.shape[-1]
+        gn = self.in_layers_temporal[0]
+        at = ops.groupnorm_temporal(s, geo.b, geo.t, gn.g, gn.b, gn.eps, True)
+        e = ops.linear(emb_silu, self.emb_layers[1].pw, out_f32=True)
+        # stf output (s + conv_t) and the `+ emb_out` of openaimodel.py:762 in one epilogue
+        hid = ops.conv_temporal(at, geo.t, self.in_layers_temporal[2].pw, res1=s.view(-1, co), group_bias=e,
+                                group_rows=geo.t * h * w)
+        gn = self.out_layers[0]
+        a = ops.groupnorm_spatial(hid, gn.g, gn.b, gn.eps, True)
+        s2 = ops.conv2d(a, self.out_layers[3].pw)
+        gn = self.out_layers_temporal[0]
+        at = ops.groupnorm_temporal(s2, geo.b, geo.t, gn.g, gn.b, gn.eps, True)
+        if isinstance(self.skip_connection, Slot):
+            skip = x
+        else:
+            k = ops.conv2d(x, self.skip_connection.pw)
+            skip = ops.conv_temporal(k, geo.t, self.skip_connection_temporal.pw, res1=k.view(-1, co))
+        return ops.conv_temporal(at, geo.t, self.out_layers_temporal[3].pw, res1=s2.view(-1, co), res2=skip.view(-1, co))
+
+
+class Downsample(nn.Module):
+    """openaimodel.py:266-322 (conv_resample): Conv2d 3x3 stride 2."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.op = Conv(channels, channels, 3, stride=2)
+
+    def run(self, x, geo):
+        return ops.conv2d(x, self.op.pw, stride=2)
+
+
+class Downsample3D(nn.Module):
+    """openaimodel.py:325-394: stf(Conv2d s2, Conv1d k3) with identity skip."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.op = Conv(channels, channels, 3, stride=2)
+        self.conv_temporal = Conv(channels, channels, 3, dims=1)
+
+    def run(self, x, geo):
+        s = ops.conv2d(x, self.op.pw, stride=2)
+        return ops.conv_temporal(s, geo.t, self.conv_temporal.pw, res1=s.view(-1, s.shape[-1]))
+
+
+class Upsample3D(nn.Module):
+    """openaimodel.py:220-263: nearest x(1,2,2) then stf(Conv2d 3x3, Conv1d k3).  The upsample is a
+    gather mode of the conv kernel — the 4x larger tensor is never written."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = Conv(channels, channels, 3)
+        self.conv_temporal = Conv(channels, channels, 3, dims=1)
+
+    def run(self, x, geo):
+        s = ops.conv2d(x, self.conv.pw, upsample=True)
+        return ops.conv_temporal(s, geo.t, self.conv_temporal.pw, res1=s.view(-1, s.shape[-1]))
+
+
+class TimestepEmbedSequential(nn.Sequential):
+    """Container with the reference's name (openaimodel.py:85-126); dispatch happens in the nets."""
+
+    def run(self, x, emb_silu, geo, ctx2d, ctx_len):
+        for layer in self:
+            if isinstance(layer, (ResBlock, ResBlock3D)):
+                x = layer.run(x, emb_silu, geo)
+            elif isinstance(layer, SpatialTransformer):
+                x = layer.run(x, geo, ctx2d, ctx_len)
+            else:
+                x = layer.run(x, geo)
+        return x
+
+
+# ------------------------------------------------------------------------------------------
+# networks
+# ------------------------------------------------------------------------------------------
+_UNSUPPORTED_DEFAULTS = dict(dropout=0, conv_resample=True, dims=2, num_classes=None, use_scale_shift_norm=False,
+                             resblock_updown=False, use_linear_in_transformer=False, disable_self_attentions=None,
+                             num_attention_blocks=None, disable_middle_self_attn=False, adm_in_channels=None,
+                             transformer_depth_middle=None, n_embed=None, num_head_channels=-1,
+                             enable_attention3d_crossframe=False, disable_text_ca=False)
+
+
+def _check_supported(kw: dict, who: str):
+    for k, dflt in _UNSUPPORTED_DEFAULTS.items():
+        if k in kw and kw[k] != dflt and not (k == "dims" and kw[k] == 2):
+            raise NotImplementedError(f"{who}: option {k}={kw[k]!r} is outside the shipped inference configs")
+    if not kw.get("use_spatial_transformer", False):
+        raise NotImplementedError(f"{who}: use_spatial_transformer must be True")
+    td = kw.get("transformer_depth", 1)
+    if (td if isinstance(td, int) else max(td)) != 1:
+        raise NotImplementedError(f"{who}: transformer_depth must be 1")
+
+
+class UNetModel(nn.Module):
+    """Block wiring of sgm UNetModel.__init__ (openaimodel.py:1033-1527) for the supported options."""
+
+    THREE_D = False
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 channel_mult=(1, 2, 4, 8), num_heads=-1, context_dim=None, use_checkpoint=False, legacy=True,
+                 build_decoder=True, **kw):
+        super().__init__()
+        _check_supported(dict(kw), type(self).__name__)
+        if num_heads == -1:
+            raise NotImplementedError("num_head_channels-style head configuration is not used by the shipped configs")
+        if isinstance(context_dim, (list, tuple)):
+            context_dim = context_dim[0]
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.num_res_blocks = len(channel_mult) * [num_res_blocks] if isinstance(num_res_blocks, int) else list(num_res_blocks)
+        self.attention_resolutions = list(attention_resolutions)
+        self.channel_mult = list(channel_mult)
+        self.num_heads, self.context_dim = num_heads, context_dim
+        self.num_classes = None
+        self.use_checkpoint = use_checkpoint
+        res_cls = ResBlock3D if self.THREE_D else ResBlock
+        down_cls = Downsample3D if self.THREE_D else Downsample
+        tkw = dict(disable_temporal_text_ca=kw.get("disable_temporal_text_ca", False)) if self.THREE_D else {}
+        st_cls = SpatialTransformer3D if self.THREE_D else SpatialTransformer
+
+        def make_st(ch):
+            return st_cls(ch, num_heads, ch // num_heads, depth=1, context_dim=context_dim, **tkw)
+
+        ted = model_channels * 4
+        self.time_embed = _seq(Linear(model_channels, ted), Slot(), Linear(ted, ted))
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(Conv(in_channels, model_channels, 3))])
+        chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(self.channel_mult):
+            for _ in range(self.num_res_blocks[level]):
+                layers = [res_cls(ch, ted, mult * model_channels)]
+                ch = mult * model_channels
+                if ds in self.attention_resolutions:
+                    layers.append(make_st(ch))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                chans.append(ch)
+            if level != len(self.channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(down_cls(ch)))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = TimestepEmbedSequential(res_cls(ch, ted, ch), make_st(ch), res_cls(ch, ted, ch))
+        self._mid_ch = ch
+        if build_decoder:
+            self.output_blocks = nn.ModuleList([])
+            for level, mult in list(enumerate(self.channel_mult))[::-1]:
+                for i in range(self.num_res_blocks[level] + 1):
+                    ich = chans.pop()
+                    layers = [res_cls(ch + ich, ted, model_channels * mult)]
+                    ch = model_channels * mult
+                    if ds in self.attention_resolutions:
+                        layers.append(make_st(ch))
+                    if level and i == self.num_res_blocks[level]:
+                        layers.append(Upsample3D(ch))
+                        ds //= 2
+                    self.output_blocks.append(TimestepEmbedSequential(*layers))
+            self.out = _seq(Norm(ch, GN_EPS_RES), Slot(), Conv(model_channels, out_channels, 3))
+
+    # -- shared helpers --
+    def _emb_silu(self, timesteps: torch.Tensor) -> torch.Tensor:
+        """SiLU(time_embed(timestep_embedding(t))): (B, 4*model_channels) bf16.  Every ResBlock applies
+        nn.SiLU to emb before its own Linear (openaimodel.py:470-476), so it is hoisted here."""
+        te = ops.timestep_embedding(timesteps, self.model_channels)
+        h = ops.linear(te, self.time_embed[0].pw, act=ACT_SILU)
+        e = ops.linear(h, self.time_embed[2].pw)
+        return ops.silu(e)
+
+    def pack(self, device=None):
+        device = torch.device("cuda") if device is None else device
+        pack_tree(self, device)
+        return self
+
+
+class UNetModel3D(UNetModel):
+    """openaimodel.py:1581-1639: adds input_blocks_temporal and out_temporal."""
+
+    THREE_D = True
+
+    def __init__(self, *args, temporal_kernel_size=None, **kw):
+        if temporal_kernel_size not in (None, 3):
+            raise NotImplementedError("temporal_kernel_size != 3")
+        kw.pop("unet_type", None)
+        super().__init__(*args, **kw)
+        mc, oc = self.model_channels, self.out_channels
+        self.input_blocks_temporal = TimestepEmbedSequential(Conv(mc, mc, 3, dims=1))
+        self.out_temporal = _seq(Slot(), Conv(oc, oc, 3, dims=1))
+
+
+_HINT_PLAN = ((16, 1), (16, 1), (32, 2), (32, 1), (96, 2), (96, 1), (256, 2))    # controlmodel.py:215-231
+
+
+class ControlNet2D(UNetModel):
+    """Per-frame SD-1.5 encoder copy + hint stem + 13 zero convs (controlmodel.py:195-317)."""
+
+    def __init__(self, hint_channels, control_scales, no_add_x=False, set_input_hint_block_as_identity=False, *args, **kw):
+        if no_add_x or set_input_hint_block_as_identity:
+            raise NotImplementedError("controlnet_img variant (TVI2V) is a later scope row")
+        kw["out_channels"] = kw["in_channels"]
+        super().__init__(*args, build_decoder=False, **kw)
+        self.control_scales = float(control_scales)
+        mc = self.model_channels
+        mods, cin = [], hint_channels
+        for cout, stride in _HINT_PLAN:
+            mods += [Conv(cin, cout, 3, stride=stride), Slot()]
+            cin = cout
+        mods.append(Conv(cin, mc, 3))
+        self.input_hint_block = TimestepEmbedSequential(*mods)
+        self.zero_convs = nn.ModuleList([TimestepEmbedSequential(Conv(mc, mc, 1))])
+        ch = mc
+        for level, mult in enumerate(self.channel_mult):
+            for _ in range(self.num_res_blocks[level]):
+                ch = mult * mc
+                self.zero_convs.append(TimestepEmbedSequential(Conv(ch, ch, 1)))
+            if level != len(self.channel_mult) - 1:
+                self.zero_convs.append(TimestepEmbedSequential(Conv(ch, ch, 1)))
+        self.middle_block_out = TimestepEmbedSequential(Conv(ch, ch, 1))
+
+    def post_pack(self, device):
+        if self.control_scales != 1.0:       # `c * scale` (controlmodel.py:311-312) folded into the zero convs
+            for zc in list(self.zero_convs) + [self.middle_block_out]:
+                zc[0].pack(device, scale=self.control_scales)
+
+    def hint_stem(self, hint_nhwc):
+        h = hint_nhwc
+        convs = [m for m in self.input_hint_block if isinstance(m, Conv)]
+        for i, cv in enumerate(convs):
+            last = i == len(convs) - 1
+            h = ops.conv2d(h, cv.pw, stride=cv.stride, act=0 if last else ACT_SILU)
+        return h
+
+    def run(self, x_nhwc, hint_nhwc, timesteps, ctx2d, ctx_len, geo: Geometry) -> List[torch.Tensor]:
+        """x_nhwc (B*T, h, w, 8) bf16, hint_nhwc (B*T, 8h, 8w, 8) bf16 already remapped -> 13 residuals."""
+        emb_silu = self._emb_silu(timesteps)
+        guided = self.hint_stem(hint_nhwc)
+        outs = []
+        h = x_nhwc
+        for i, (block, zc) in enumerate(zip(self.input_blocks, self.zero_convs)):
+            if i == 0:
+                h = ops.conv2d(h, block[0].pw, res1=guided.view(-1, guided.shape[-1]))     # h = conv(x); h += guided_hint
+            else:
+                h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
+            outs.append(ops.conv2d(h, zc[0].pw))
+        h = self.middle_block.run(h, emb_silu, geo, ctx2d, ctx_len)
+        outs.append(ops.conv2d(h, self.middle_block_out[0].pw))
+        return outs
+
+    def forward(self, x, hint, timesteps=None, context=None, y=None, **kwargs):
+        """Reference signature (controlmodel.py:252): 5-D fp32 tensors in, list of 13 (b c t h w) out."""
+        assert y is None, "must specify y if and only if the model is class-conditional"
+        b, _, t, _, _ = x.shape
+        geo = Geometry(b, t)
+        ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
+        res = self.run(ops.ncthw_to_nhwc(x.float().contiguous(), 8), ops.ncthw_to_nhwc(hint.float().contiguous(), 8),
+                       timesteps, ctx2d, context.shape[1], geo)
+        return [ops.nhwc_to_ncthw(r, b, t, r.shape[-1]) for r in res]
+
+
+class ControlledUNetModel3DTV2V(UNetModel3D):
+    """controlmodel.py:320-553 (TV2V): pseudo-3D UNet that sums ControlNet residuals into its skips."""
+
+    def __init__(self, controlnet_config, *args, **kw):
+        if kw.get("controlnet_img_config") is not None or kw.get("crossframe_type") is not None:
+            raise NotImplementedError("controlnet_img / crossframe (TVI2V) is a later scope row")
+        super().__init__(*args, **kw)
+        from .config import instantiate_from_config
+        self.controlnet = instantiate_from_config(controlnet_config)
+
+    def run(self, x_nhwc, timesteps, ctx2d, ctx_len, control: List[torch.Tensor], geo: Geometry):
+        """x_nhwc (B*T, h, w, 8) bf16; control = 13 NHWC residuals (consumed) -> eps (B*T, h, w, out) fp32."""
+        emb_silu = self._emb_silu(timesteps)
+        hs = []
+        h = x_nhwc
+        for i, block in enumerate(self.input_blocks):
+            if i == 0:
+                s = ops.conv2d(h, block[0].pw)
+                h = ops.conv_temporal(s, geo.t, self.input_blocks_temporal[0].pw, res1=s.view(-1, s.shape[-1]))
+            else:
+                h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
+            hs.append(h)
+        h = self.middle_block.run(h, emb_silu, geo, ctx2d, ctx_len)
+        h = ops.add(h, control.pop())
+        for block in self.output_blocks:
+            h = ops.cat_add(h, hs.pop(), control.pop())          # cat([h, hs.pop() + control.pop()], dim=1)
+            h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
+        gn = self.out[0]
+        a = ops.groupnorm_spatial(h, gn.g, gn.b, gn.eps, True)
+        n, hh, ww, _ = a.shape
+        oc = self.out_channels
+        ocp = (oc + 7) // 8 * 8
+        s = torch.zeros((n * hh * ww, ocp), dtype=torch.bfloat16, device=a.device)
+        ops.conv2d(a, self.out[2].pw, out=s[:, : self.out[2].pw.n])
+        at = ops.silu(s)
+        eps = ops.conv_temporal(at.view(n, hh, ww, ocp), geo.t, self.out_temporal[1].pw, res1=s, out_f32=True)
+        return eps
+
+    def forward(self, x, timesteps=None, context=None, y=None, control=None, img_control=None, only_mid_control=False,
+                **kwargs):
+        """Reference signature (controlmodel.py:471-481); `control` (5-D fp32 list) is consumed."""
+        assert y is None, "must specify y if and only if the model is class-conditional"
+        if img_control is not None or only_mid_control or control is None:
+            raise NotImplementedError("img_control / only_mid_control / control=None")
+        b, _, t, _, _ = x.shape
+        geo = Geometry(b, t)
+        ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
+        ctrl = [ops.ncthw_to_nhwc(c.float().contiguous(), c.shape[1]) for c in control]
+        del control[:]
+        eps = self.run(ops.ncthw_to_nhwc(x.float().contiguous(), 8), timesteps, ctx2d, context.shape[1], ctrl, geo)
+        return ops.nhwc_to_ncthw(eps, b, t, self.out_channels)
+
+
+# ------------------------------------------------------------------------------------------
+# wrapper
+# ------------------------------------------------------------------------------------------
+class IdentityWrapper(nn.Module):
+    """wrappers.py:13-25"""
+
+    def __init__(self, diffusion_model, compile_model: bool = False):
+        super().__init__()
+        self.diffusion_model = diffusion_model
+
+    def forward(self, *args, **kwargs):
+        return self.diffusion_model(*args, **kwargs)
+
+
+class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
+    """wrappers.py:155-207: hint remap -> ControlNet -> UNet.  Stays in the channels-last layout between
+    the two networks; only x (4 ch) and the eps output (4 ch) cross the (B, C, T, H, W) boundary."""
+
+    hint_cache_key = None
+    _hint_cache = None
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, c: Dict[str, torch.Tensor], **kwargs) -> torch.Tensor:
+        if c.get("concat") is not None and c["concat"].numel():
+            raise NotImplementedError("'concat' conditioning is not used by the TV2V configs")
+        if c.get("cond_feat") is not None:
+            raise NotImplementedError("cond_feat (TVI2V) is a later scope row")
+        net = self.diffusion_model
+        b, _, nt, _, _ = x.shape
+        geo = Geometry(b, nt)
+        context = c["crossattn"]
+        ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
+        x8 = ops.ncthw_to_nhwc(x.float().contiguous(), 8)
+        # control_hint in [-1,1] -> 1 - (h+1)/2 (wrappers.py:160-162), fused into the layout change
+        hint8 = ops.ncthw_to_nhwc(c["control_hint"].float().contiguous(), 8, scale=-0.5, shift=0.5)
+        control = net.controlnet.run(x8, hint8, t, ctx2d, context.shape[1], geo)
+        eps = net.run(x8, t, ctx2d, context.shape[1], control, geo)
+        return ops.nhwc_to_ncthw(eps, b, nt, net.out_channels)

@@ -230,3 +230,12 @@ def axpby(x: torch.Tensor, z: torch.Tensor, a: float, b: float, out: Optional[to
     y = torch.empty_like(x) if out is None else out
     hip.check(hip.lib().ccedit_axpby(x.data_ptr(), z.data_ptr(), y.data_ptr(), x.numel(), a, b, _stream()), "ccedit_axpby")
     return y
+
+
+def softmax_rows(s: torch.Tensor, cols: int, cols_pad: int, scale: float) -> torch.Tensor:
+    """s: fp32 [rows, >= cols] -> bf16 [rows, cols_pad] = softmax(s[:, :cols] * scale), zero pad."""
+    assert s.dtype == torch.float32 and s.is_cuda and s.stride(-1) == 1
+    p = torch.empty((s.shape[0], cols_pad), dtype=BF16, device=s.device)
+    hip.check(hip.lib().ccedit_softmax_rows(s.data_ptr(), p.data_ptr(), s.shape[0], cols, cols_pad, s.stride(0), cols_pad,
+                                            scale, _stream()), "ccedit_softmax_rows")
+    return p

@@ -1,0 +1,362 @@
+"""Sampling numerics of the hot path: sigma schedule, DiscreteDenoiser (eps-prediction scaling),
+classifier-free guidance and the DPM-Solver++(2S) ancestral sampler.
+
+Mirrors the reference classes one-for-one (same names, constructor arguments, call signatures):
+  sgm/modules/diffusionmodules/discretizer.py   Discretization, LegacyDDPMDiscretization
+  sgm/modules/diffusionmodules/denoiser*.py     Denoiser, DiscreteDenoiser, EpsScaling, EpsWeighting
+  sgm/modules/diffusionmodules/guiders.py       VanillaCFG, VanillaCFGTV2V, IdentityGuider
+  sgm/modules/diffusionmodules/sampling.py      BaseDiffusionSampler ... DPMPP2SAncestralSampler
+  sgm/modules/diffusionmodules/sampling_utils.py get_ancestral_step, to_d, to_(neg_log_)sigma
+
+Design difference: every sigma-derived quantity (schedule, ancestral split, exponential-integrator
+multipliers, table quantisation, timestep indices) is a handful of fp32 scalars, so it is evaluated
+on the HOST with the reference's exact sequence of fp32 operations (1-element CPU tensors) — the
+schedule and index tensors are bit-exact by construction and the per-step device->host sync of the
+reference (`torch.sum(sigma_down) < 1e-14`, sampling.py:390) disappears.  Arithmetic on the latent
+(417,792 fp32 elements at 17x64x96) runs in the HIP kernels `ccedit_axpby` / `ccedit_cfg_denoise`.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Callable, Dict, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import instantiate_from_config
+
+DEFAULT_GUIDER = {"target": "sgm.modules.diffusionmodules.guiders.IdentityGuider"}
+
+
+def default(val, d):
+    return val if val is not None else (d() if callable(d) and not isinstance(d, dict) else d)
+
+
+def append_dims(x: torch.Tensor, target_dims: int) -> torch.Tensor:
+    """sgm/util.py:192-199"""
+    extra = target_dims - x.ndim
+    if extra < 0:
+        raise ValueError(f"input has {x.ndim} dims but target_dims is {target_dims}, which is less")
+    return x[(...,) + (None,) * extra]
+
+
+def append_zero(x: torch.Tensor) -> torch.Tensor:
+    return torch.cat([x, x.new_zeros([1])])
+
+
+# ------------------------------------------------------------------------------------------
+# discretisation
+# ------------------------------------------------------------------------------------------
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2):
+    """diffusionmodules/util.py:24-37 ("linear" = scaled-linear in sqrt space, float64)."""
+    if schedule != "linear":
+        raise NotImplementedError(schedule)
+    betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64, device="cpu") ** 2
+    return betas.numpy()
+
+
+def generate_roughly_equally_spaced_steps(num_substeps: int, max_step: int) -> np.ndarray:
+    return np.linspace(max_step - 1, 0, num_substeps, endpoint=False).astype(int)[::-1]
+
+
+class Discretization:
+    def __call__(self, n, do_append_zero=True, device="cpu", flip=False):
+        sigmas = self.get_sigmas(n, device=device)
+        sigmas = append_zero(sigmas) if do_append_zero else sigmas
+        return sigmas if not flip else torch.flip(sigmas, (0,))
+
+    def get_sigmas(self, n, device):
+        raise NotImplementedError
+
+
+class LegacyDDPMDiscretization(Discretization):
+    """discretizer.py:42-69.  sigma = ((1-abar)/abar) cast to f32, THEN sqrt; descending order."""
+
+    def __init__(self, linear_start=0.00085, linear_end=0.0120, num_timesteps=1000):
+        self.num_timesteps = num_timesteps
+        betas = make_beta_schedule("linear", num_timesteps, linear_start=linear_start, linear_end=linear_end)
+        self.alphas_cumprod = np.cumprod(1.0 - betas, axis=0)
+
+    def get_sigmas(self, n, device="cpu"):
+        if n < self.num_timesteps:
+            timesteps = generate_roughly_equally_spaced_steps(n, self.num_timesteps)
+            alphas_cumprod = self.alphas_cumprod[timesteps]
+        elif n == self.num_timesteps:
+            alphas_cumprod = self.alphas_cumprod
+        else:
+            raise ValueError
+        sigmas = torch.tensor((1 - alphas_cumprod) / alphas_cumprod, dtype=torch.float32, device="cpu") ** 0.5   # host math
+        return torch.flip(sigmas, (0,)).to(device)
+
+
+# ------------------------------------------------------------------------------------------
+# denoiser
+# ------------------------------------------------------------------------------------------
+class EpsWeighting:
+    def __call__(self, sigma):
+        return sigma ** -2.0
+
+
+class EpsScaling:
+    """denoiser_scaling.py:16-22"""
+
+    def __call__(self, sigma):
+        c_skip = torch.ones_like(sigma, device=sigma.device)
+        c_out = -sigma
+        c_in = 1 / (sigma ** 2 + 1.0) ** 0.5
+        c_noise = sigma.clone()
+        return c_skip, c_out, c_in, c_noise
+
+
+class Denoiser(nn.Module):
+    """denoiser.py:6-40.  `sigma` may live on any device; the scalar math runs on the host."""
+
+    def __init__(self, weighting_config, scaling_config):
+        super().__init__()
+        self.weighting = instantiate_from_config(weighting_config)
+        self.scaling = instantiate_from_config(scaling_config)
+
+    def possibly_quantize_sigma(self, sigma):
+        return sigma
+
+    def possibly_quantize_c_noise(self, c_noise):
+        return c_noise
+
+    def w(self, sigma):
+        return self.weighting(sigma)
+
+    def __call__(self, network, input, sigma, cond):
+        sigma = self.possibly_quantize_sigma(sigma.detach().to("cpu", torch.float32))
+        c_skip, c_out, c_in, c_noise = self.scaling(sigma)
+        c_noise = self.possibly_quantize_c_noise(c_noise)
+        if c_noise.dtype == torch.int64:
+            c_noise_dev = c_noise.to(input.device)
+        else:
+            c_noise_dev = c_noise.to(input.device)
+        b = input.shape[0]
+        x = input.float().contiguous()
+        xs = torch.empty_like(x)
+        for i in range(b):                                    # input * c_in
+            ops.axpby(x[i], x[i], float(c_in[i]), 0.0, out=xs[i])
+        net = network(xs, c_noise_dev, cond).float().contiguous()
+        out = torch.empty_like(x)
+        for i in range(b):                                    # net * c_out + input * c_skip
+            ops.axpby(net[i], x[i], float(c_out[i]), float(c_skip[i]), out=out[i])
+        return out
+
+
+class DiscreteDenoiser(Denoiser):
+    """denoiser.py:43-75: sigma and c_noise are quantised to the 1000-entry table by argmin."""
+
+    def __init__(self, weighting_config, scaling_config, num_idx, discretization_config, do_append_zero=False,
+                 quantize_c_noise=True, flip=True):
+        super().__init__(weighting_config, scaling_config)
+        sigmas = instantiate_from_config(discretization_config)(num_idx, do_append_zero=do_append_zero, flip=flip)
+        self.register_buffer("sigmas", sigmas)
+        self._host_sigmas = sigmas.detach().to("cpu", torch.float32).clone()
+        self.quantize_c_noise = quantize_c_noise
+
+    def _table(self, like: torch.Tensor) -> torch.Tensor:
+        return self._host_sigmas if like.device.type == "cpu" else self.sigmas.to(like.device)
+
+    def sigma_to_idx(self, sigma):
+        dists = sigma - self._table(sigma)[:, None]
+        return dists.abs().argmin(dim=0).view(sigma.shape)
+
+    def idx_to_sigma(self, idx):
+        return self._table(idx)[idx]
+
+    def possibly_quantize_sigma(self, sigma):
+        return self.idx_to_sigma(self.sigma_to_idx(sigma))
+
+    def possibly_quantize_c_noise(self, c_noise):
+        return self.sigma_to_idx(c_noise) if self.quantize_c_noise else c_noise
+
+
+# ------------------------------------------------------------------------------------------
+# guiders
+# ------------------------------------------------------------------------------------------
+class NoDynamicThresholding:
+    def __call__(self, uncond, cond, scale):
+        # u + scale * (c - u) on the device: y = (1-scale)*u + scale*c  (sampling_utils.py:7-9)
+        u, c = uncond.float().contiguous(), cond.float().contiguous()
+        return ops.axpby(u, c, 1.0 - float(scale), float(scale))
+
+
+class VanillaCFG:
+    """guiders.py:8-40"""
+
+    _CAT_KEYS = ("vector", "crossattn", "concat", "cond_feat")
+
+    def __init__(self, scale, dyn_thresh_config=None):
+        self.scale = scale
+        self.scale_schedule = lambda sigma: scale
+        self.dyn_thresh = instantiate_from_config(default(dyn_thresh_config, {
+            "target": "sgm.modules.diffusionmodules.sampling_utils.NoDynamicThresholding"}))
+
+    def __call__(self, x, sigma):
+        x_u, x_c = x.chunk(2)
+        return self.dyn_thresh(x_u, x_c, self.scale_schedule(sigma))
+
+    def prepare_inputs(self, x, s, c, uc):
+        c_out = dict()
+        for k in c:
+            if k in self._CAT_KEYS:
+                c_out[k] = torch.cat((uc[k], c[k]), 0)          # uc FIRST (guiders.py:63)
+            else:
+                assert c[k] == uc[k]
+                c_out[k] = c[k]
+        return torch.cat([x] * 2), torch.cat([s] * 2), c_out
+
+
+class VanillaCFGTV2V(VanillaCFG):
+    """guiders.py:56-67: control_hint (and interpolate_*) are batch-doubled too."""
+
+    _CAT_KEYS = ("vector", "crossattn", "concat", "cond_feat", "control_hint", "interpolate_first", "interpolate_last",
+                 "interpolate_first_last")
+
+
+class IdentityGuider:
+    def __call__(self, x, sigma):
+        return x
+
+    def prepare_inputs(self, x, s, c, uc):
+        return x, s, {k: c[k] for k in c}
+
+
+# ------------------------------------------------------------------------------------------
+# samplers
+# ------------------------------------------------------------------------------------------
+def get_ancestral_step(sigma_from, sigma_to, eta=1.0):
+    """sampling_utils.py:27-36"""
+    if not eta:
+        return sigma_to, 0.0
+    sigma_up = torch.minimum(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+    return sigma_down, sigma_up
+
+
+def to_neg_log_sigma(sigma):
+    return sigma.log().neg()
+
+
+def to_sigma(neg_log_sigma):
+    return neg_log_sigma.neg().exp()
+
+
+class BaseDiffusionSampler:
+    """sampling.py:24-77.  `device` names where the latent lives; sigma scalars stay on the host."""
+
+    def __init__(self, discretization_config, num_steps=None, guider_config=None, verbose=False, device="cuda"):
+        self.num_steps = num_steps
+        self.discretization = instantiate_from_config(discretization_config)
+        self.guider = instantiate_from_config(default(guider_config, DEFAULT_GUIDER))
+        self.verbose = verbose
+        self.device = device
+
+    def prepare_sampling_loop(self, x, cond, uc=None, num_steps=None):
+        sigmas = self.discretization(self.num_steps if num_steps is None else num_steps, device="cpu")
+        uc = default(uc, cond)
+        # x *= sqrt(1 + sigma_0^2), in place like the reference (sampling.py:50)
+        k = float(torch.sqrt(1.0 + sigmas[0] ** 2.0))
+        xf = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+        ops.axpby(xf, xf, k, 0.0, out=xf)
+        num_sigmas = len(sigmas)
+        s_in = torch.ones([x.shape[0]], dtype=torch.float32, device="cpu")          # host
+        return xf, s_in, sigmas, num_sigmas, cond, uc
+
+    def denoise(self, x, denoiser, sigma, cond, uc):
+        denoised = denoiser(*self.guider.prepare_inputs(x, sigma, cond, uc))
+        return self.guider(denoised, sigma)
+
+    def get_sigma_gen(self, num_sigmas):
+        gen = range(num_sigmas - 1)
+        if self.verbose:
+            print("#" * 30, " Sampling setting ", "#" * 30)
+            print(f"Sampler: {self.__class__.__name__}")
+            print(f"Discretization: {self.discretization.__class__.__name__}")
+            print(f"Guider: {self.guider.__class__.__name__}")
+            try:
+                from tqdm import tqdm
+                gen = tqdm(gen, total=num_sigmas, desc=f"Sampling with {self.__class__.__name__} for {num_sigmas} steps")
+            except ImportError:      # pragma: no cover
+                pass
+        return gen
+
+
+class SingleStepDiffusionSampler(BaseDiffusionSampler):
+    def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc, *args, **kwargs):
+        raise NotImplementedError
+
+    def euler_step(self, x, d, dt):
+        return x + dt * d
+
+
+class AncestralSampler(SingleStepDiffusionSampler):
+    """sampling.py:168-205"""
+
+    def __init__(self, eta=1.0, s_noise=1.0, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.eta = eta
+        self.s_noise = s_noise
+        self.noise_sampler = lambda x: torch.randn_like(x)
+
+    def ancestral_euler_step(self, x, denoised, sigma, sigma_down):
+        # x + (x - denoised)/sigma * (sigma_down - sigma) == (1 + r) x - r denoised,  r = (sigma_down - sigma)/sigma
+        r = float(((sigma_down - sigma) / sigma)[0])
+        return ops.axpby(x, denoised, 1.0 + r, -r)
+
+    def ancestral_step(self, x, sigma, next_sigma, sigma_up):
+        noise = self.noise_sampler(x)              # drawn on every step, including the last (sampling.py:182-188)
+        if float(next_sigma[0]) > 0.0:
+            return ops.axpby(x, noise.float().contiguous(), 1.0, self.s_noise * float(sigma_up[0]))
+        return x
+
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None):
+        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        for i in self.get_sigma_gen(num_sigmas):
+            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc)
+        return x
+
+
+class EulerAncestralSampler(AncestralSampler):
+    def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc):
+        sigma_down, sigma_up = get_ancestral_step(sigma, next_sigma, eta=self.eta)
+        denoised = self.denoise(x, denoiser, sigma, cond, uc)
+        x = self.ancestral_euler_step(x, denoised, sigma, sigma_down)
+        return self.ancestral_step(x, sigma, next_sigma, sigma_up)
+
+
+class DPMPP2SAncestralSampler(AncestralSampler):
+    """sampling.py:370-407.  All batch entries share one sigma (s_in * sigma_i), as in the reference's
+    only call site; the per-step scalars are computed on the host in the reference's op order."""
+
+    def get_variables(self, sigma, sigma_down):
+        t, t_next = [to_neg_log_sigma(s) for s in (sigma, sigma_down)]
+        h = t_next - t
+        s = t + 0.5 * h
+        return h, s, t, t_next
+
+    def get_mult(self, h, s, t, t_next):
+        mult1 = to_sigma(s) / to_sigma(t)
+        mult2 = (-0.5 * h).expm1()
+        mult3 = to_sigma(t_next) / to_sigma(t)
+        mult4 = (-h).expm1()
+        return mult1, mult2, mult3, mult4
+
+    def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc=None, **kwargs):
+        sigma_down, sigma_up = get_ancestral_step(sigma, next_sigma, eta=self.eta)
+        denoised = self.denoise(x, denoiser, sigma, cond, uc)
+        if torch.sum(sigma_down) < 1e-14:
+            # save a network evaluation if all noise levels are 0 (host check, no device sync)
+            x = self.ancestral_euler_step(x, denoised, sigma, sigma_down)
+        else:
+            h, s, t, t_next = self.get_variables(sigma, sigma_down)
+            m1, m2, m3, m4 = [float(m[0]) for m in self.get_mult(h, s, t, t_next)]
+            x2 = ops.axpby(x, denoised, m1, -m2)
+            denoised2 = self.denoise(x2, denoiser, to_sigma(s), cond, uc)
+            # sigma_down > 0 here, so the reference's torch.where picks x_dpmpp2s
+            x = ops.axpby(x, denoised2, m3, -m4)
+        return self.ancestral_step(x, sigma, next_sigma, sigma_up)

@@ -156,6 +156,12 @@ int ccedit_silu(const void* x, void* y, int64_t n, void* stream);
 /* timestep_embedding (diffusionmodules/util.py:244-268): out bf16 [n][ld], [cos | sin], dim even */
 int ccedit_timestep_embedding(const int64_t* t, void* out, int32_t n, int32_t dim, int32_t ld, void* stream);
 
+/* p = softmax(s * scale) row-wise, fp32 in -> bf16 out, columns [cols, cols_pad) zero-filled.
+ * The single-head d=512 attention of the VAE mid block (model.py:180-195) is evaluated as
+ * GEMM (q k^T) -> this -> GEMM (p v); cols_pad <= 8192. */
+int ccedit_softmax_rows(const float* s, void* p, int64_t rows, int32_t cols, int32_t cols_pad, int64_t lds,
+                        int64_t ldp, float scale, void* stream);
+
 /* Sampler / guider / denoiser elementwise math on the fp32 latent (417,792 elements at 17x64x96):
  *   ccedit_cfg_denoise : den = x + (-sigma) * (eps_u + scale*(eps_c - eps_u))        [denoiser.py:40 with
  *                        c_skip=1, c_out=-sigma; guiders.py:25-29]   eps = fp32 [2][n]
