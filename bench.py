@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: UNet denoising steps/s on synthetic 17x512x768 clips (BASELINE.json metric).
+
+One "step" = one network evaluation of the TV2V hot path on the CFG-doubled batch
+(OpenAIWrapperControlLDM3DTV2V.forward: hint remap -> ControlNet2D on 34 frames -> pseudo-3D UNet ->
+eps), B=2 (uncond+cond), T=17 keyframes, latent 64x96, context 77x768, hint 3x512x768 per frame —
+77.68 TFLOP algorithmic.  The DPMPP2SAncestral sampler calls exactly this 59 times per
+30-step clip; `--clip` additionally times one whole clip (sampler loop + AutoencoderKL decode) and adds
+frames/s to the JSON line.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Multi-GPU (round 1): BASELINE.json config 5 — N independent clips, one per GPU ("replicas only", no
+data-path collective); value = N x per-GPU steps/s measured with a barrier on both sides and the MAX
+time over ranks.  Frame-sharded single-clip execution (config 4) is the next multi-GPU row.
+
+Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_STEP = 77.68e12          # SURVEY.md §8d, measured from the reference modules on the meta device
+MFMA_PEAK_TFLOPS = 2500.0         # MI355X dense bf16 (MI355X_MICROARCH.md)
+T, H, W, L, CTX = 17, 64, 96, 77, 768
+
+
+def synth_inputs(device, seed=42, b=1):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(b, 4, T, H, W, generator=g)
+    cross_c = torch.randn(b, L, CTX, generator=g)
+    cross_uc = torch.randn(b, L, CTX, generator=g)
+    low = torch.rand(b, 1, T, H // 4, W // 4, generator=g)
+    hint = torch.nn.functional.interpolate(low, size=(T, 8 * H, 8 * W), mode="trilinear", align_corners=False)
+    hint = (hint * 2 - 1).repeat(1, 3, 1, 1, 1).contiguous()
+    return x.to(device), cross_c.to(device), cross_uc.to(device), hint.to(device)
+
+
+def build_model(device):
+    from ccedit_amd.sgm_compat import build_network
+    from ccedit_amd.utils.synth import fill_module_
+    w = build_network(device)                      # full-size TV2V network, parameters created on the GPU
+    fill_module_(w, prefix="model.")               # name-keyed synthetic weights (device generator)
+    w.diffusion_model.pack(device)
+    return w
+
+
+def cpu_baseline(wrapper):
+    """Oracle (CPU fp32 restatement, `kind: port`) on a bounded sample of the same workload: the same
+    full-width network and weights on a crop — B=2 (CFG), T=2 keyframes, latent 16x24 — timed on the host
+    cores; converted to steps/s through the FLOPs ATen actually executed (FlopCounterMode)."""
+    from oracle import ccedit_oracle as O
+    from torch.utils.flop_counter import FlopCounterMode
+    threads = min(os.cpu_count() or 1, 32)        # ATen's CPU kernels stop scaling (and collapse) far below 256 threads
+    torch.set_num_threads(threads)
+    sd = {"model." + k: v.detach().float().cpu() for k, v in wrapper.state_dict().items()}
+    g = torch.Generator().manual_seed(7)
+    tt, hh, ww = 2, 16, 24
+    x = torch.randn(2, 4, tt, hh, ww, generator=g)
+    c = dict(crossattn=torch.randn(2, L, CTX, generator=g), control_hint=torch.rand(2, 3, tt, 8 * hh, 8 * ww, generator=g) * 2 - 1)
+    t = torch.tensor([601, 601], dtype=torch.int64)
+    with torch.no_grad():
+        with FlopCounterMode(display=False) as fc:
+            t0 = time.time()
+            O.network_forward(sd, O.NetConfig(), x, t, c)
+            dt = time.time() - t0
+    flops = float(fc.get_total_flops())
+    return dict(value=(flops / dt) / FLOP_PER_STEP, unit="UNet steps/s (FLOP-equivalent)", cores=threads,
+                kind="port", seconds=round(dt, 2), cpu_tflops=round(flops / dt / 1e12, 3),
+                sample=f"oracle network_forward, full-width weights, B=2 T={tt} latent {hh}x{ww}: {flops/1e12:.2f} TFLOP in {dt:.1f}s; "
+                       f"steps/s = CPU FLOP/s / 77.68 TFLOP")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clip", action="store_true", help="also time one full 30-step clip + VAE decode (frames/s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from ccedit_amd import hip, ops
+    hip.lib()                                       # fail loudly if the HIP library is missing
+    torch.set_grad_enabled(False)
+    wrapper = build_model(device)
+    x, cross_c, cross_uc, hint = synth_inputs(device, seed=42 + rank)
+    x2 = torch.cat([x, x]).contiguous()             # CFG-doubled batch, uc first (guiders.py:63)
+    cond = dict(crossattn=torch.cat([cross_uc, cross_c]).contiguous(), control_hint=torch.cat([hint, hint]).contiguous())
+    tstep = torch.tensor([601, 601], dtype=torch.int64, device=device)
+
+    def step():
+        return wrapper(x2, tstep, cond)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all()
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.steps / dt
+
+    # ---- roofline of the dominant kernel family, measured live with HIP events (one extra step) ----
+    roof = None
+    extra = {}
+    if rank == 0:
+        ops.PROFILE = ops.LaunchProfile()
+        step()
+        prof = ops.PROFILE.summary()
+        ops.PROFILE = None
+        g = prof["tap_gemm"]
+        ach = g["flops"] / (g["total_ms"] * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel="tap_gemm_kernel", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None, launches=g["launches"],
+                    avg_launch_us=round(g["avg_us"], 2), algorithmic_flops_per_step=g["flops"])
+        a = prof.get("attention")
+        if a:
+            extra["attention"] = dict(tflops=round(a["flops"] / (a["total_ms"] * 1e-3) / 1e12, 1), launches=a["launches"],
+                                      total_ms=round(a["total_ms"], 2), algorithmic_flops_per_step=a["flops"])
+        extra["gemm_total_ms"] = round(g["total_ms"], 2)
+        extra["step_tflops"] = round(FLOP_PER_STEP / (ms_per_step * 1e-3) / 1e12, 1)
+        extra["step_frac_of_mfma_peak"] = round(FLOP_PER_STEP / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+
+    clip = None
+    if args.clip and rank == 0:
+        clip = time_clip(wrapper, device)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(wrapper)
+
+    if rank == 0:
+        line = {
+            "metric": "UNet denoising steps/s (TV2V 17x512x768, bf16, CFG-doubled batch)", "value": round(value, 4),
+            "unit": "UNet steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (seeded latent/context/depth hint; name-keyed random-init weights)",
+            "config": {"workload": "TV2V depth-midas, 17x512x768, one network evaluation = ControlNet2D + pseudo-3D UNet on "
+                                   "B=2 (cfg 7.5 uncond+cond) x T=17 frames, latent 64x96, 77x768 text context; "
+                                   "77.68 TFLOP/step; a 30-step DPMPP2SAncestral clip = 59 such steps + VAE decode",
+                       "parallelism": "1 clip per GPU (replicas, no collective)" if world > 1 else "single GPU",
+                       "hint_stem": "recomputed every step"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        if clip:
+            line["clip"] = clip
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def time_clip(wrapper, device, num_steps=30, scale=7.5):
+    """One full clip: DPMPP2SAncestral (30 steps = 59 evaluations) + AutoencoderKL decode -> frames/s."""
+    from ccedit_amd.config import instantiate_from_config
+    from ccedit_amd.sgm_compat import build_vae
+    from ccedit_amd.utils.synth import fill_module_
+    from ccedit_amd import ops
+    vae = build_vae(device)
+    fill_module_(vae, prefix="first_stage_model.")
+    vae.pack(device)
+    dd = "sgm.modules.diffusionmodules."
+    denoiser = instantiate_from_config(dict(target=dd + "denoiser.DiscreteDenoiser", params=dict(
+        num_idx=1000, weighting_config=dict(target=dd + "denoiser_weighting.EpsWeighting"),
+        scaling_config=dict(target=dd + "denoiser_scaling.EpsScaling"),
+        discretization_config=dict(target=dd + "discretizer.LegacyDDPMDiscretization"))))
+    sampler = instantiate_from_config(dict(target=dd + "sampling.DPMPP2SAncestralSampler", params=dict(
+        num_steps=num_steps, eta=1.0, s_noise=1.0, discretization_config=dict(target=dd + "discretizer.LegacyDDPMDiscretization"),
+        guider_config=dict(target=dd + "guiders.VanillaCFGTV2V", params=dict(scale=scale)))))
+    x, cross_c, cross_uc, hint = synth_inputs(device, seed=43)
+    c = dict(crossattn=cross_c, control_hint=hint)
+    uc = dict(crossattn=cross_uc, control_hint=hint.clone())
+    evals = [0]
+
+    def network(xx, tt, cond):
+        evals[0] += 1
+        return wrapper(xx, tt, cond)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    z = sampler(lambda inp, sig, cc: denoiser(network, inp, sig, cc), x.clone(), c, uc=uc)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    zs = ops.axpby(z.contiguous(), z.contiguous(), 1.0 / 0.18215, 0.0)
+    frames = vae.decode(zs)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    assert frames.shape == (1, 3, T, 8 * H, 8 * W)
+    return dict(sampler_s=round(t1 - t0, 3), vae_decode_s=round(t2 - t1, 3), evaluations=evals[0],
+                frames_per_s=round(T / (t2 - t0), 3), finite=bool(torch.isfinite(frames).all()))
+
+
+if __name__ == "__main__":
+    main()

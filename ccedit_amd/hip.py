@@ -9,6 +9,9 @@ import ctypes as C
 import os
 from typing import Optional
 
+import torch  # noqa: F401  -- must be imported BEFORE the library is loaded: torch bundles its own libamdhip64 and
+#                              both sides have to share ONE HIP runtime (device state, streams, allocations).
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libccedit_hip.so")
 

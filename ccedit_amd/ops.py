@@ -19,6 +19,29 @@ from .packing import PackedWeight
 BF16 = torch.bfloat16
 
 
+class LaunchProfile:
+    """Optional per-launch HIP-event timing of the dominant kernel families (used by bench.py only).
+    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = {}          # family -> list of (start_event, end_event, algorithmic_flops, algorithmic_bytes)
+
+    def add(self, family, e0, e1, flops, nbytes):
+        self.records.setdefault(family, []).append((e0, e1, flops, nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fam, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _, _ in recs]
+            out[fam] = dict(launches=len(recs), total_ms=sum(ms), avg_us=1e3 * sum(ms) / max(len(ms), 1),
+                            flops=sum(r[2] for r in recs), bytes=sum(r[3] for r in recs))
+        return out
+
+
+PROFILE: Optional[LaunchProfile] = None
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -67,6 +90,13 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
     d.bias = _ptr(pw.bias) if use_bias else None
     d.group_bias = _ptr(group_bias)
     d.res1, d.res2, d.out = _ptr(res1), _ptr(res2), out.data_ptr()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        hip.check(hip.lib().ccedit_gemm(C.byref(d), _stream()), "ccedit_gemm")
+        e1.record()
+        PROFILE.add("tap_gemm", e0, e1, pw.flops_per_row * m, 0.0)
+        return out
     hip.check(hip.lib().ccedit_gemm(C.byref(d), _stream()), "ccedit_gemm")
     return out
 
@@ -158,6 +188,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, d: 
     a.kv_div, a.kv_inner = kv_div, kv_inner
     a.kv_outer_rows, a.kv_inner_rows, a.kv_seq_rows = (lk if kv_outer_rows is None else kv_outer_rows), kv_inner_rows, kv_seq_rows
     a.scale = float(d) ** -0.5
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        hip.check(hip.lib().ccedit_attention(C.byref(a), _stream()), "ccedit_attention")
+        e1.record()
+        PROFILE.add("attention", e0, e1, 4.0 * batches * heads * lq * lk * d, 0.0)
+        return out
     hip.check(hip.lib().ccedit_attention(C.byref(a), _stream()), "ccedit_attention")
     return out
 

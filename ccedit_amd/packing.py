@@ -33,6 +33,7 @@ class PackedWeight:
     kpad: int
     ksize: int = 1
     geglu: bool = False
+    flops_per_row: float = 0.0      # algorithmic 2*O*I*taps (unpadded) per output row
 
     def to(self, device):
         self.w = self.w.to(device)
@@ -86,7 +87,7 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
     if b is not None:
         bb = torch.zeros(n, dtype=torch.float32, device=dev)
         bb[:o] = b.to(dev)
-    return PackedWeight(buf, bb, n, (o // 2) if geglu else o, cin, taps, kpad, ksize, geglu)
+    return PackedWeight(buf, bb, n, (o // 2) if geglu else o, cin, taps, kpad, ksize, geglu, 2.0 * o * i * taps)
 
 
 def pack_concat(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optional[torch.Tensor]]] = None,
