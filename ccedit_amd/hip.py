@@ -28,7 +28,7 @@ class CcGemmDesc(C.Structure):
         ("stride", C.c_int32), ("pad", C.c_int32), ("ksize", C.c_int32), ("upsample", C.c_int32),
         ("T", C.c_int32), ("HW", C.c_int32), ("lda", C.c_int32), ("lda2", C.c_int32), ("ldc", C.c_int32),
         ("Kpad", C.c_int32), ("act", C.c_int32), ("out_f32", C.c_int32), ("group_rows", C.c_int32),
-        ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("tile", C.c_int32),
+        ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("tile", C.c_int32), ("korder", C.c_int32), ("reserved0", C.c_int32),
         ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
         ("group_bias", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p),
     ]

@@ -86,6 +86,7 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
     d.ldr1 = res1.stride(0) if res1 is not None else 0
     d.ldr2 = res2.stride(0) if res2 is not None else 0
     d.tile = tile
+    d.korder = pw.korder
     d.A, d.A2, d.W = a2d.data_ptr(), _ptr(a2), pw.w.data_ptr()
     d.bias = _ptr(pw.bias) if use_bias else None
     d.group_bias = _ptr(group_bias)

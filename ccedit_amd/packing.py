@@ -34,6 +34,7 @@ class PackedWeight:
     ksize: int = 1
     geglu: bool = False
     flops_per_row: float = 0.0      # algorithmic 2*O*I*taps (unpadded) per output row
+    korder: int = 0                 # 0: K = [tap][Cin];  1: K = [Cin/64][tap][64]
 
     def to(self, device):
         self.w = self.w.to(device)
@@ -82,12 +83,15 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
     buf = torch.zeros(opad, kpad, dtype=torch.bfloat16, device=dev)
     tmp = torch.zeros(o, taps, cin, dtype=torch.float32, device=w3.device)
     tmp[:, :, :i] = w3
+    korder = 1 if (taps > 1 and cin % 64 == 0) else 0
+    if korder:      # taps of one 64-channel chunk adjacent in K (see gemm.hip: L2 reuse across the 3x3 taps)
+        tmp = tmp.reshape(o, taps, cin // 64, 64).permute(0, 2, 1, 3).contiguous()
     buf[:o, : taps * cin] = tmp.reshape(o, taps * cin).to(torch.bfloat16).to(dev)
     bb = None
     if b is not None:
         bb = torch.zeros(n, dtype=torch.float32, device=dev)
         bb[:o] = b.to(dev)
-    return PackedWeight(buf, bb, n, (o // 2) if geglu else o, cin, taps, kpad, ksize, geglu, 2.0 * o * i * taps)
+    return PackedWeight(buf, bb, n, (o // 2) if geglu else o, cin, taps, kpad, ksize, geglu, 2.0 * o * i * taps, korder)
 
 
 def pack_concat(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optional[torch.Tensor]]] = None,

@@ -82,6 +82,8 @@ typedef struct CcGemmDesc {
     int32_t group_rows;   /* rows per group_bias row (T*H*W for the timestep-embedding add); 0 = unused */
     int32_t ldr1, ldr2;   /* residual row strides */
     int32_t tile;         /* 0 = auto, 1 = 128ch x 128pix, 2 = 64ch x 256pix */
+    int32_t korder;       /* weight K order: 0 = [tap][Cin]; 1 = [Cin/64][tap][64] (needs Cin % 64 == 0) */
+    int32_t reserved0;
     const void* A;        /* bf16 [rows][lda] */
     const void* A2;       /* optional second source */
     const void* W;        /* bf16 [ceil(N,128)][Kpad] */

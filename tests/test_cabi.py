@@ -35,7 +35,7 @@ def test_binding_matches_header(libpath):
     from ccedit_amd import hip
     assert sorted(hip.EXPORTS) == _declared()
     # descriptor layouts: sizes the C side was compiled with (kept in sync by hand; a mismatch shows up here)
-    assert ctypes.sizeof(hip.CcGemmDesc) == 8 + 25 * 4 + 4 + 8 * 8
+    assert ctypes.sizeof(hip.CcGemmDesc) == 8 + 27 * 4 + 4 + 8 * 8
     assert ctypes.sizeof(hip.CcAttnDesc) % 8 == 0
 
 

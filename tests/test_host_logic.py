@@ -111,6 +111,11 @@ def test_packing_layouts():
     assert pw.w[1, 4 * 8 + 2].float().item() == w[1, 2, 1, 1].item()
     assert pw.w[0, 3].item() == 0 and pw.w[2].abs().sum().item() == 0
     assert pw.bias.tolist() == [1.0, 2.0, 0.0, 0.0]
+    wk = torch.randn(3, 128, 3, 3)
+    pk = pack_weight(wk)
+    assert pk.korder == 1 and pk.kpad == 9 * 128
+    # chunk-major: K index = chunk*(9*64) + tap*64 + c
+    assert pk.w[2, 1 * 576 + 5 * 64 + 7].float().item() == wk[2, 64 + 7, 1, 2].to(torch.bfloat16).float().item()
     w1 = torch.randn(5, 16, 3)
     p1 = pack_weight(w1)
     assert torch.equal(p1.w[:5, 16:32].float(), w1[:, :, 1].to(torch.bfloat16).float())

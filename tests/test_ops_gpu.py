@@ -47,7 +47,7 @@ def _nchw(y_nhwc):
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (300, 320, 320), (77, 960, 768), (1000, 4, 320), (257, 1280, 2560),
                                    (64, 640, 40)])
-@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
 def test_linear(m, n, k, tile):
     _dev()
     from ccedit_amd import ops
@@ -111,16 +111,17 @@ def test_geglu():
     _close(y, a * F.gelu(g), what="GEGLU")
 
 
+@pytest.mark.parametrize("tile", [0, 3])
 @pytest.mark.parametrize("cin,cout,h,w,stride", [(320, 320, 16, 24, 1), (64, 128, 9, 7, 1), (320, 320, 16, 24, 2),
                                                   (8, 320, 16, 24, 1), (16, 32, 32, 48, 2), (640, 4, 8, 12, 1)])
-def test_conv3x3(cin, cout, h, w, stride):
+def test_conv3x3(cin, cout, h, w, stride, tile):
     _dev()
     from ccedit_amd import ops
     from ccedit_amd.packing import pack_weight
     n = 3
     x = _rnd(n, cin, h, w, seed=1)
     wt, b = _rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), _rnd(cout, seed=3)
-    y = ops.conv2d(_nhwc(x), pack_weight(wt, b).to("cuda"), stride=stride)
+    y = ops.conv2d(_nhwc(x), pack_weight(wt, b).to("cuda"), stride=stride, tile=tile)
     ref = F.conv2d(x, wt, b, stride=stride, padding=1)
     _close(_nchw(y)[:, :cout], ref, what=f"conv3x3 {cin}->{cout} s{stride}")
 
@@ -146,7 +147,7 @@ def test_conv3x3_upsample_and_concat():
     n, c, h, w = 2, 64, 8, 12
     x = _rnd(n, c, h, w, seed=1)
     wt, b = _rnd(96, c, 3, 3, seed=2, scale=(9 * c) ** -0.5), _rnd(96, seed=3)
-    y = ops.conv2d(_nhwc(x), pack_weight(wt, b).to("cuda"), upsample=True)
+    y = ops.conv2d(_nhwc(x), pack_weight(wt, b).to("cuda"), upsample=True, tile=3)
     ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, b, padding=1)
     _close(_nchw(y), ref, what="upsample2x + conv3x3")
     x2 = _rnd(n, 32, h, w, seed=4)
@@ -169,7 +170,7 @@ def test_conv1x1_and_temporal():
     xp = x.reshape(b_, t, c, h, w).permute(0, 3, 4, 2, 1).reshape(b_ * h * w, c, t)
     ref = F.conv1d(xp, wt, bt, padding=1).reshape(b_, h, w, c, t).permute(0, 4, 3, 1, 2).reshape(b_ * t, c, h, w)
     res = _rnd(b_ * t, c, h, w, seed=6)
-    y = ops.conv_temporal(_nhwc(x), t, pack_weight(wt, bt).to("cuda"), res1=_nhwc(res).reshape(-1, c))
+    y = ops.conv_temporal(_nhwc(x), t, pack_weight(wt, bt).to("cuda"), res1=_nhwc(res).reshape(-1, c), tile=3)
     _close(_nchw(y), ref + res, what="conv1d k3 over T + residual")
     wk1 = _rnd(c, c, 1, seed=7, scale=c ** -0.5)
     y = ops.conv_temporal(_nhwc(x), t, pack_weight(wk1, bt).to("cuda"))

@@ -88,7 +88,7 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["conv", "linear", "temporal", "attn", "norm"]
     N = 34
     if "conv" in which:
-        for tile in (1, 2):
+        for tile in (1, 2, 3):
             bench_conv(N, 64, 96, 320, 320, tile=tile, name="L0")
         bench_conv(N, 32, 48, 640, 640, name="L1")
         bench_conv(N, 16, 24, 1280, 1280, name="L2")
@@ -97,7 +97,7 @@ if __name__ == "__main__":
         bench_conv(N, 64, 96, 320, 320, stride=2, name="down")
     if "linear" in which:
         M = N * 6144
-        for tile in (1, 2):
+        for tile in (1, 2, 3):
             bench_linear(M, 320, 960, tile=tile, name="qkv L0")
         bench_linear(M, 320, 320, name="to_out L0")
         bench_linear(M, 320, 2560, geglu=True, name="ff.proj L0")
