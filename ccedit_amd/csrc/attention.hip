@@ -33,12 +33,20 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p, int second_off) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
+// amdgpu_waves_per_eu(2, 8): with a 1-wave lower bound hipcc parks part of the S^T / O^T accumulators in AGPRs and
+// pays ~150 v_accvgpr_read/write per KV tile to run the softmax on them (the kernel is VALU-bound: 20 VALU per
+// MFMA measured); with >= 2 waves/EU it keeps everything in arch VGPRs (0 moves).
 template <int D, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(const CcAttnDesc a) {
-    constexpr int DK = (D + 15) / 16 * 16;    // K tile width (elements)
-    constexpr int DV = (D + 31) / 32 * 32;    // V tile width
-    constexpr int KS = DK / 16;               // QK^T k-steps
-    constexpr int NT = DV / 32;               // O^T row tiles
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8))) void attn_kernel(const CcAttnDesc a) {
+    constexpr int KS = (D + 15) / 16;         // QK^T k-steps
+    constexpr int NT = (D + 31) / 32;         // O^T row tiles
+    // LDS row widths.  For d <= 128 rows are padded to a power of two so that an XOR swizzle of the 16-byte
+    // granule index makes the K fragment reads (ds_read_b128, rows 96/160 B apart otherwise: 2-way) and the V
+    // transpose reads (ds_read_b64_tr_b16: rows r and r+2 on the same banks) conflict-free; the pad granules
+    // are DMA'd from the zero page.  d = 160 keeps the compact, unswizzled image (LDS capacity).
+    constexpr bool SWZ = (D <= 128);
+    constexpr int DK = SWZ ? (D <= 64 ? 64 : 128) : KS * 16;     // K tile width (elements)
+    constexpr int DV = SWZ ? (D <= 64 ? 64 : 128) : NT * 32;     // V tile width
     constexpr int GK = DK / 8, GV = DV / 8;   // 16-byte granules per tile row
     constexpr int KB = 64 * DK * 2, VB = 64 * DV * 2;
     constexpr int NTHR = NW * 64;
@@ -76,29 +84,51 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const CcAttnDesc a) {
         }
     }
 
-    auto stage = [&](int j, int buf) {
-        // K tile
+    // ---- DMA plan: every thread owns fixed (row, granule) slots of the K and V tiles; only the tile index moves,
+    //      so the source pointers are computed once and advanced by a constant per KV tile ----
+    constexpr int ITK = (64 * GK + NTHR - 1) / NTHR, ITV = (64 * GV + NTHR - 1) / NTHR;
+    const bf16* kp[ITK];
+    const bf16* vp[ITV];
+    int krw[ITK], vrw[ITV];            // tile row of the slot, or -1 when the slot is a pad granule / out of range
 #pragma unroll
-        for (int it = 0; it < (64 * GK + NTHR - 1) / NTHR; ++it) {
-            const int idx = it * NTHR + tid;
-            if (idx < 64 * GK) {
-                const int row = idx / GK, g = idx - row * GK;
-                const int kv = j * 64 + row;
-                const bf16* src = zp;
-                if (kv < a.Lk && g * 8 < D) src = K + (size_t)(kvbase + (int64_t)kv * a.kv_seq_rows) * a.ldk + g * 8;
+    for (int it = 0; it < ITK; ++it) {
+        const int idx = it * NTHR + tid;
+        const int row = idx / GK;
+        int g = idx - row * GK;
+        if (SWZ) g ^= (GK == 8) ? ((row >> 1) & 7) : (row & 15);      // LDS slot -> source granule
+        const bool use = (idx < 64 * GK) && (g * 8 < D);               // pad granules are never DMA'd
+        krw[it] = use ? row : -1;
+        kp[it] = K + (size_t)(kvbase + (int64_t)row * a.kv_seq_rows) * a.ldk + g * 8;
+    }
+#pragma unroll
+    for (int it = 0; it < ITV; ++it) {
+        const int idx = it * NTHR + tid;
+        const int row = idx / GV;
+        int g = idx - row * GV;
+        if (SWZ) g ^= ((row >> 1) & 1) << 2;                           // rows r, r+2 -> different bank halves
+        const bool use = (idx < 64 * GV) && (g * 8 < D);
+        vrw[it] = use ? row : -1;
+        vp[it] = V + (size_t)(kvbase + (int64_t)row * a.kv_seq_rows) * a.ldv + g * 8;
+    }
+    const int64_t kstep = 64 * a.kv_seq_rows * (int64_t)a.ldk, vstep = 64 * a.kv_seq_rows * (int64_t)a.ldv;
+
+    auto stage = [&](int j, int buf) {
+        const int rows_left = a.Lk - j * 64;        // rows >= rows_left of this tile come from the zero page
+#pragma unroll
+        for (int it = 0; it < ITK; ++it) {
+            if (krw[it] >= 0) {
+                const bf16* src = (krw[it] < rows_left) ? kp[it] : zp;
                 glds16(src, sK + buf * KB + (it * NTHR + wave * 64) * 16);
             }
+            kp[it] += kstep;
         }
 #pragma unroll
-        for (int it = 0; it < (64 * GV + NTHR - 1) / NTHR; ++it) {
-            const int idx = it * NTHR + tid;
-            if (idx < 64 * GV) {
-                const int row = idx / GV, g = idx - row * GV;
-                const int kv = j * 64 + row;
-                const bf16* src = zp;
-                if (kv < a.Lk && g * 8 < D) src = V + (size_t)(kvbase + (int64_t)kv * a.kv_seq_rows) * a.ldv + g * 8;
+        for (int it = 0; it < ITV; ++it) {
+            if (vrw[it] >= 0) {
+                const bf16* src = (vrw[it] < rows_left) ? vp[it] : zp;
                 glds16(src, sV + buf * VB + (it * NTHR + wave * 64) * 16);
             }
+            vp[it] += vstep;
         }
     };
 
@@ -115,6 +145,28 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const CcAttnDesc a) {
     const int i16 = lane & 15, dvhalf = (lane >> 4) & 1;
     const int ntiles = (a.Lk + 63) / 64;
 
+    // zero, once, the K pad granules that the last QK^T k-step reads (columns [D, 16*KS)) in both ring slots
+    if constexpr (KS * 2 > (D + 7) / 8) {
+        constexpr int NPAD = KS * 2 - (D + 7) / 8;
+        for (int idx = tid; idx < 2 * 64 * NPAD; idx += NTHR) {
+            const int b = idx / (64 * NPAD), rem = idx - b * 64 * NPAD;
+            const int row = rem / NPAD, g = (D + 7) / 8 + (rem - row * NPAD);
+            const int slot = SWZ ? (g ^ ((GK == 8) ? ((row >> 1) & 7) : (row & 15))) : g;
+            *(u32x4*)(sK + b * KB + row * (DK * 2) + slot * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    // When d is not a multiple of 32 the last O^T tile has unused rows: put a column of ones at V[:, D] (written
+    // once, never overwritten by the DMA) and the PV MFMA delivers the softmax denominator sum_kv p in O^T row D
+    // for free — no per-element row-sum adds in the (VALU-bound) softmax.
+    constexpr bool MFMA_ROWSUM = (D % 32 != 0);
+    if constexpr (MFMA_ROWSUM) {
+        for (int idx = tid; idx < 2 * 64; idx += NTHR) {
+            const int b = idx >> 6, row = idx & 63;
+            const int g = D / 8;
+            const int slot = SWZ ? (g ^ (((row >> 1) & 1) << 2)) : g;
+            *(u32x4*)(sV + b * VB + row * (DV * 2) + slot * 16) = u32x4{0x00003F80u, 0u, 0u, 0u};   // bf16 {1,0,0,...}
+        }
+    }
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -130,46 +182,58 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const CcAttnDesc a) {
         for (int t2 = 0; t2 < 2; ++t2) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[t2][r] = 0.f;
-            const char* kr = kb + (t2 * 32 + krow_l) * (DK * 2) + hi * 16;
+            const int krow = t2 * 32 + krow_l;
+            const char* kr = kb + krow * (DK * 2);
+            const int ksw = SWZ ? ((GK == 8) ? ((krow >> 1) & 7) : (krow & 15)) : 0;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(kr + ks * 32);
+                const bf16x8 kf = *(const bf16x8*)(kr + (((ks * 2 + hi) ^ ksw) << 4));
                 s[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t2], 0, 0, 0);
             }
         }
         // ---- online softmax (this lane: query q0 + l31, kv = 64 j + 32 t2 + 16 (r>>3) + 8 hi + (r&7)) ----
-        const bool tail = (j * 64 + 64 > a.Lk);
-        float mt = -INFINITY;
+        // The running max is kept in raw-score units; p = exp2(s*sc - m*sc) is one FMA + one v_exp_f32 per
+        // element (raw hardware exp2: arguments are <= 0, flush-to-zero of tiny results is what we want).
+        if (j * 64 + 64 > a.Lk) {          // wave-uniform: only the last KV tile has masked columns
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
+            for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = s[t2][r] * sc;
-                if (tail) {
+                for (int r = 0; r < 16; ++r) {
                     const int kv = j * 64 + 32 * t2 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (kv >= a.Lk) v = -INFINITY;
+                    if (kv >= a.Lk) s[t2][r] = -INFINITY;
                 }
-                s[t2][r] = v;
-                mt = fmaxf(mt, v);
-            }
+        }
+        float mt = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
+        // rescale only when some row's max actually moved (exact: alpha == 1 otherwise); wave-uniform branch
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+            l_run *= alpha;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+            m_run = m_new;
+        }
+        const float msc = -m_run * sc;
         float psum = 0.f;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s[t2][r] - m_new);
-                s[t2][r] = pv;
-                psum += pv;
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 e = {s[t2][r], s[t2][r + 1]};
+                e = __builtin_elementwise_fma(e, f32x2{sc, sc}, f32x2{msc, msc});      // v_pk_fma_f32
+                const float p0 = __builtin_amdgcn_exp2f(e[0]), p1 = __builtin_amdgcn_exp2f(e[1]);
+                s[t2][r] = p0;
+                s[t2][r + 1] = p1;
+                if constexpr (!MFMA_ROWSUM) psum += p0 + p1;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+        if constexpr (!MFMA_ROWSUM) l_run += psum;
 
         // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -177,10 +241,12 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const CcAttnDesc a) {
             bf16x8 pf;
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[e] = f2bf(s[sp >> 1][8 * (sp & 1) + e]);
-            const char* vr = vb + (16 * sp + 8 * hi + (i16 >> 2)) * (DV * 2) + (dvhalf * 16 + (i16 & 3) * 4) * 2;
+            const int vrow = 16 * sp + 8 * hi + (i16 >> 2);                 // rows vrow and vrow + 4: same swizzle bit
+            const char* vr = vb + vrow * (DV * 2) + (dvhalf * 16 + (i16 & 3) * 4) * 2;
+            const int vsw = SWZ ? (((vrow >> 1) & 1) << 6) : 0;              // granule bit 2 == byte bit 6
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const bf16x8 vf = tr_pair(vr + n * 64, 4 * DV * 2);
+                const bf16x8 vf = tr_pair(vr + ((n * 64) ^ vsw), 4 * DV * 2);
                 o[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[n], 0, 0, 0);
             }
         }
@@ -190,7 +256,13 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const CcAttnDesc a) {
     }
 
     // ---- normalise and store: lane holds O^T[dv = 32 n + (r&3) + 8 (r>>2) + 4 hi][q = l31] ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if constexpr (MFMA_ROWSUM) {
+        // O^T row D lives in register (D%32/8)*4 of tile D/32 on the hi = 0 lanes
+        l_tot = __shfl(o[D / 32][((D % 32) / 8) * 4], l31, 64);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv = 1.0f / l_tot;
     const int qi = q0 + l31;
     if (qi < a.Lq) {
@@ -211,7 +283,9 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const CcAttnDesc a) {
 
 template <int D, int NW>
 int launch_attn(const CcAttnDesc& a, hipStream_t s) {
-    constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
+    constexpr bool SWZ = (D <= 128);
+    constexpr int DK = SWZ ? (D <= 64 ? 64 : 128) : (D + 15) / 16 * 16;
+    constexpr int DV = SWZ ? (D <= 64 ? 64 : 128) : (D + 31) / 32 * 32;
     constexpr int lds = 2 * 64 * DK * 2 + 2 * 64 * DV * 2;
     static bool attr_set = false;
     if (!attr_set) {
