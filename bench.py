@@ -58,7 +58,7 @@ def build_model(device):
 
 def cpu_baseline(wrapper):
     """Oracle (CPU fp32 restatement, `kind: port`) on a bounded sample of the same workload: the same
-    full-width network and weights on a crop — B=2 (CFG), T=2 keyframes, latent 16x24 — timed on the host
+    full-width network and weights on a crop — B=2 (CFG), T=4 keyframes, latent 32x48 — timed on the host
     cores; converted to steps/s through the FLOPs ATen actually executed (FlopCounterMode)."""
     from oracle import ccedit_oracle as O
     from torch.utils.flop_counter import FlopCounterMode
@@ -66,7 +66,7 @@ def cpu_baseline(wrapper):
     torch.set_num_threads(threads)
     sd = {"model." + k: v.detach().float().cpu() for k, v in wrapper.state_dict().items()}
     g = torch.Generator().manual_seed(7)
-    tt, hh, ww = 2, 16, 24
+    tt, hh, ww = 4, 32, 48
     x = torch.randn(2, 4, tt, hh, ww, generator=g)
     c = dict(crossattn=torch.randn(2, L, CTX, generator=g), control_hint=torch.rand(2, 3, tt, 8 * hh, 8 * ww, generator=g) * 2 - 1)
     t = torch.tensor([601, 601], dtype=torch.int64)
@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clip", action="store_true", help="also time one full 30-step clip + VAE decode (frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print per-shape GEMM / attention time of one step to stderr")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,6 +147,10 @@ def main():
         ops.PROFILE = ops.LaunchProfile()
         step()
         prof = ops.PROFILE.summary()
+        if args.breakdown:
+            for fam in ("tap_gemm", "attention"):
+                for shape, n, ms, tf in ops.PROFILE.by_shape(fam)[:40]:
+                    print(f"{fam:9s} {str(shape):60s} x{n:3d} {ms:8.3f} ms {tf:7.1f} TF/s", file=sys.stderr)
         ops.PROFILE = None
         g = prof["tap_gemm"]
         ach = g["flops"] / (g["total_ms"] * 1e-3) / 1e12

@@ -26,14 +26,23 @@ class LaunchProfile:
     def __init__(self):
         self.records = {}          # family -> list of (start_event, end_event, algorithmic_flops, algorithmic_bytes)
 
-    def add(self, family, e0, e1, flops, nbytes):
-        self.records.setdefault(family, []).append((e0, e1, flops, nbytes))
+    def add(self, family, e0, e1, flops, nbytes, shape=None):
+        self.records.setdefault(family, []).append((e0, e1, flops, nbytes, shape))
+
+    def by_shape(self, family):
+        """{shape: (launches, total_ms, tflops)} sorted by time."""
+        torch.cuda.synchronize()
+        acc = {}
+        for a, b, fl, _, shape in self.records.get(family, []):
+            n, ms, f = acc.get(shape, (0, 0.0, 0.0))
+            acc[shape] = (n + 1, ms + a.elapsed_time(b), f + fl)
+        return sorted(((k, n, ms, f / (ms * 1e-3) / 1e12) for k, (n, ms, f) in acc.items()), key=lambda r: -r[2])
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for fam, recs in self.records.items():
-            ms = [a.elapsed_time(b) for a, b, _, _ in recs]
+            ms = [r[0].elapsed_time(r[1]) for r in recs]
             out[fam] = dict(launches=len(recs), total_ms=sum(ms), avg_us=1e3 * sum(ms) / max(len(ms), 1),
                             flops=sum(r[2] for r in recs), bytes=sum(r[3] for r in recs))
         return out
@@ -96,7 +105,9 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
         e0.record()
         hip.check(hip.lib().ccedit_gemm(C.byref(d), _stream()), "ccedit_gemm")
         e1.record()
-        PROFILE.add("tap_gemm", e0, e1, pw.flops_per_row * m, 0.0)
+        PROFILE.add("tap_gemm", e0, e1, pw.flops_per_row * m, 0.0,
+                    (("lin", "conv", "temp")[mode] + ("+up" if upsample else ""), m, pw.n, pw.taps * pw.cin, stride,
+                     int(res1 is not None) + int(res2 is not None), d.act))
         return out
     hip.check(hip.lib().ccedit_gemm(C.byref(d), _stream()), "ccedit_gemm")
     return out
@@ -194,7 +205,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, d: 
         e0.record()
         hip.check(hip.lib().ccedit_attention(C.byref(a), _stream()), "ccedit_attention")
         e1.record()
-        PROFILE.add("attention", e0, e1, 4.0 * batches * heads * lq * lk * d, 0.0)
+        PROFILE.add("attention", e0, e1, 4.0 * batches * heads * lq * lk * d, 0.0, (batches, heads, d, lq, lk))
         return out
     hip.check(hip.lib().ccedit_attention(C.byref(a), _stream()), "ccedit_attention")
     return out
