@@ -462,10 +462,9 @@ class ControlNet2D(UNetModel):
             h = ops.conv2d(h, cv.pw, stride=cv.stride, act=0 if last else ACT_SILU)
         return h
 
-    def run(self, x_nhwc, hint_nhwc, timesteps, ctx2d, ctx_len, geo: Geometry) -> List[torch.Tensor]:
-        """x_nhwc (B*T, h, w, 8) bf16, hint_nhwc (B*T, 8h, 8w, 8) bf16 already remapped -> 13 residuals."""
+    def run(self, x_nhwc, guided, timesteps, ctx2d, ctx_len, geo: Geometry) -> List[torch.Tensor]:
+        """x_nhwc (B*T, h, w, 8) bf16, guided = hint_stem(remapped hint) (B*T, h, w, C) -> 13 residuals."""
         emb_silu = self._emb_silu(timesteps)
-        guided = self.hint_stem(hint_nhwc)
         outs = []
         h = x_nhwc
         for i, (block, zc) in enumerate(zip(self.input_blocks, self.zero_convs)):
@@ -484,8 +483,8 @@ class ControlNet2D(UNetModel):
         b, _, t, _, _ = x.shape
         geo = Geometry(b, t)
         ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
-        res = self.run(ops.ncthw_to_nhwc(x.float().contiguous(), 8), ops.ncthw_to_nhwc(hint.float().contiguous(), 8),
-                       timesteps, ctx2d, context.shape[1], geo)
+        guided = self.hint_stem(ops.ncthw_to_nhwc(hint.float().contiguous(), 8))
+        res = self.run(ops.ncthw_to_nhwc(x.float().contiguous(), 8), guided, timesteps, ctx2d, context.shape[1], geo)
         return [ops.nhwc_to_ncthw(r, b, t, r.shape[-1]) for r in res]
 
 
@@ -560,8 +559,25 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     """wrappers.py:155-207: hint remap -> ControlNet -> UNet.  Stays in the channels-last layout between
     the two networks; only x (4 ch) and the eps output (4 ch) cross the (B, C, T, H, W) boundary."""
 
-    hint_cache_key = None
-    _hint_cache = None
+    # The hint stem (8 convs at up to 512x768, 0.77 TFLOP) depends only on control_hint, which is constant over
+    # the 59 evaluations of a clip; the reference recomputes it every time.  With cache_hint_stem=True the
+    # result is kept while the SAME hint tensor (storage, shape, version) is passed again — results are
+    # unchanged.  bench.py's per-step metric runs with the cache OFF (every step does the full work).
+    cache_hint_stem = True
+    _hint_key = None
+    _hint_val = None
+
+    def _guided_hint(self, hint5d: torch.Tensor):
+        net = self.diffusion_model.controlnet
+        key = (hint5d.data_ptr(), tuple(hint5d.shape), hint5d._version, hint5d.dtype)
+        if self.cache_hint_stem and key == self._hint_key and self._hint_val is not None:
+            return self._hint_val
+        # control_hint in [-1,1] -> 1 - (h+1)/2 (wrappers.py:160-162), fused into the layout change
+        hint8 = ops.ncthw_to_nhwc(hint5d.float().contiguous(), 8, scale=-0.5, shift=0.5)
+        g = net.hint_stem(hint8)
+        if self.cache_hint_stem:
+            self._hint_key, self._hint_val = key, g
+        return g
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, c: Dict[str, torch.Tensor], **kwargs) -> torch.Tensor:
         if c.get("concat") is not None and c["concat"].numel():
@@ -574,8 +590,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         context = c["crossattn"]
         ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
         x8 = ops.ncthw_to_nhwc(x.float().contiguous(), 8)
-        # control_hint in [-1,1] -> 1 - (h+1)/2 (wrappers.py:160-162), fused into the layout change
-        hint8 = ops.ncthw_to_nhwc(c["control_hint"].float().contiguous(), 8, scale=-0.5, shift=0.5)
-        control = net.controlnet.run(x8, hint8, t, ctx2d, context.shape[1], geo)
+        guided = self._guided_hint(c["control_hint"])
+        control = net.controlnet.run(x8, guided, t, ctx2d, context.shape[1], geo)
         eps = net.run(x8, t, ctx2d, context.shape[1], control, geo)
         return ops.nhwc_to_ncthw(eps, b, nt, net.out_channels)

@@ -192,6 +192,7 @@ class VanillaCFG:
 
     def __init__(self, scale, dyn_thresh_config=None):
         self.scale = scale
+        self._cat_cache = {}
         self.scale_schedule = lambda sigma: scale
         self.dyn_thresh = instantiate_from_config(default(dyn_thresh_config, {
             "target": "sgm.modules.diffusionmodules.sampling_utils.NoDynamicThresholding"}))
@@ -204,7 +205,14 @@ class VanillaCFG:
         c_out = dict()
         for k in c:
             if k in self._CAT_KEYS:
-                c_out[k] = torch.cat((uc[k], c[k]), 0)          # uc FIRST (guiders.py:63)
+                # uc FIRST (guiders.py:63).  The conditioning tensors do not change during a clip: the
+                # concatenation (160 MB for the 17x512x768 hint) is built once per (uc[k], c[k]) pair.
+                key = (k, uc[k].data_ptr(), c[k].data_ptr(), uc[k]._version, c[k]._version, tuple(c[k].shape))
+                hit = self._cat_cache.get(k)
+                if hit is None or hit[0] != key:
+                    hit = (key, torch.cat((uc[k], c[k]), 0))
+                    self._cat_cache[k] = hit
+                c_out[k] = hit[1]
             else:
                 assert c[k] == uc[k]
                 c_out[k] = c[k]
