@@ -43,12 +43,12 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int STAGES, int MODE>
+template <int WM, int WN, int TI, int TJ, int STAGES, int MODE>
 __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc d) {
     constexpr int NT = WM * WN * 64;         // threads per block
     constexpr int RPI = NT / 8;              // tile rows staged per issue (8 lanes x 16 B per 128-byte row)
-    constexpr int BMC = WM * 64;             // channels per block
-    constexpr int BNP = WN * 64;             // pixels per block
+    constexpr int BMC = WM * TI * 32;        // channels per block (each wave: TI x TJ MFMA tiles of 32 x 32)
+    constexpr int BNP = WN * TJ * 32;        // pixels per block
     constexpr int A_ISSUES = BMC / RPI;
     constexpr int B_ISSUES = BNP / RPI;
     constexpr int LPS = A_ISSUES + B_ISSUES; // DMA instructions per thread per stage
@@ -193,31 +193,36 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
     const int l31 = lane & 31;
     const int hi = lane >> 5;
     const int sw = (l31 >> 1) & 7;
-    const char* fa = sA + (wm * 64 + l31) * kRowBytes;
-    const char* fb = sB + (wn * 64 + l31) * kRowBytes;
+    const char* fa = sA + (wm * TI * 32 + l31) * kRowBytes;
+    const char* fb = sB + (wn * TJ * 32 + l31) * kRowBytes;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     auto compute = [&](int buf) {
         const char* pa = fa + buf * A_BYTES;
         const char* pb = fb + buf * B_BYTES;
+        // Fragments are read per k-step and the compiler interleaves the next step's ds_read_b128 with the MFMAs.
+        // (Measured alternative: issuing all 16 reads of the K tile up front behind a sched_barrier lifts the
+        // DMA-free ceiling 877 -> 922 TF/s but costs 46 VGPRs and is 5 % SLOWER in the network: 160 vs 152 ms/step.)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int off = ((ks * 2 + hi) ^ sw) << 4;
-            bf16x8 a0 = *(const bf16x8*)(pa + off);
-            bf16x8 a1 = *(const bf16x8*)(pa + 32 * kRowBytes + off);
-            bf16x8 b0 = *(const bf16x8*)(pb + off);
-            bf16x8 b1 = *(const bf16x8*)(pb + 32 * kRowBytes + off);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            bf16x8 af[TI], bfr[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8*)(pa + i * 32 * kRowBytes + off);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8*)(pb + j * 32 * kRowBytes + off);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -264,23 +269,34 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
     // each pixel row contiguously (bias / timestep-embedding / activation / residual reads use the same
     // coalesced pattern).
     constexpr int EROW = BMC * 4 + 16;        // +16 B: the ds_write_b128 of 8 consecutive lanes cover all banks
-    __syncthreads();                          // every wave has finished reading the operand tiles
+    constexpr int LDS_MAIN = STAGES * (A_BYTES + B_BYTES);
+    constexpr int FULL_EPI = BNP * EROW;
+    // the 128x128 shape allocates 3.5 KB more than its operand ring so that the whole tile is staged at once
+    constexpr int LDS_TOTAL = (FULL_EPI > LDS_MAIN && FULL_EPI <= 70 * 1024) ? FULL_EPI : LDS_MAIN;
+    constexpr int WPIX = TJ * 32;             // pixels per wave column
+    constexpr int ECH = (LDS_TOTAL / EROW / WPIX) * WPIX < BNP ? (LDS_TOTAL / EROW / WPIX) * WPIX : BNP;   // pixels per chunk
+    static_assert(ECH >= WPIX && BNP % ECH == 0, "epilogue chunking");
     char* const sE = smem;
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v = {acc[ti][tj][q * 4 + 0], acc[ti][tj][q * 4 + 1], acc[ti][tj][q * 4 + 2], acc[ti][tj][q * 4 + 3]};
-                *(f32x4*)(sE + (wn * 64 + tj * 32 + l31) * EROW + (wm * 64 + ti * 32 + q * 8 + hi * 4) * 4) = v;
-            }
-    __syncthreads();
-
     const float* __restrict__ bias = d.bias;
     const float* __restrict__ gbias = d.group_bias;
     const bf16* __restrict__ r1 = (const bf16*)d.res1;
     const bf16* __restrict__ r2 = (const bf16*)d.res2;
+  for (int ec = 0; ec < BNP / ECH; ++ec) {
+    __syncthreads();                          // operand tiles (or the previous chunk) are no longer being read
+    if (wn * WPIX >= ec * ECH && wn * WPIX < (ec + 1) * ECH) {
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[ti][tj][q * 4 + 0], acc[ti][tj][q * 4 + 1], acc[ti][tj][q * 4 + 2], acc[ti][tj][q * 4 + 3]};
+                    *(f32x4*)(sE + (wn * WPIX - ec * ECH + tj * 32 + l31) * EROW + (wm * TI * 32 + ti * 32 + q * 8 + hi * 4) * 4) = v;
+                }
+    }
+    __syncthreads();
+    const int64_t cpix0 = pix0 + ec * ECH;
+
     if (d.act == CCEDIT_ACT_GEGLU) {
         constexpr int CPR = BMC / 16;                    // 16 packed rows = 8 value + 8 gate channels
         const int g = tid % CPR, r0 = tid / CPR;
@@ -292,8 +308,8 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
                 bx[e] = bias ? bias[rx + e] : 0.f;
                 bg[e] = bias ? bias[rx + 8 + e] : 0.f;
             }
-            for (int row = r0; row < BNP; row += NT / CPR) {
-                const int64_t m = pix0 + row;
+            for (int row = r0; row < ECH; row += NT / CPR) {
+                const int64_t m = cpix0 + row;
                 if (m >= d.M) break;
                 const char* src = sE + row * EROW + g * 64;
                 const f32x4 x0 = *(const f32x4*)(src), x1 = *(const f32x4*)(src + 16);
@@ -316,8 +332,8 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
             float bv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) bv[e] = (bias && (full || e < 4)) ? bias[cb + e] : 0.f;
-            for (int row = r0; row < BNP; row += NT / CPR) {
-                const int64_t m = pix0 + row;
+            for (int row = r0; row < ECH; row += NT / CPR) {
+                const int64_t m = cpix0 + row;
                 if (m >= d.M) break;
                 const char* src = sE + row * EROW + g * 32;
                 const f32x4 a0 = *(const f32x4*)(src), a1 = *(const f32x4*)(src + 16);
@@ -375,17 +391,19 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
             }
         }
     }
+  }   // epilogue chunks
 }
 
-template <int WM, int WN, int STAGES, int MODE>
+template <int WM, int WN, int TI, int TJ, int STAGES, int MODE>
 int launch(const CcGemmDesc& d, hipStream_t s) {
-    constexpr int BMC = WM * 64, BNP = WN * 64;
+    constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
     constexpr int lds_main = STAGES * (BMC + BNP) * kRowBytes;
-    constexpr int lds_epi = BNP * (BMC * 4 + 16);
-    constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
+    constexpr int full_epi = BNP * (BMC * 4 + 16);
+    constexpr int lds = (full_epi > lds_main && full_epi <= 70 * 1024) ? full_epi : lds_main;   // == LDS_TOTAL in the kernel
+    static_assert(lds >= (TJ * 32) * (BMC * 4 + 16), "at least one wave column per epilogue chunk");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)tap_gemm_kernel<WM, WN, STAGES, MODE>,
+        hipError_t e = hipFuncSetAttribute((const void*)tap_gemm_kernel<WM, WN, TI, TJ, STAGES, MODE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             cc_set_error("hipFuncSetAttribute(tap_gemm): %s", hipGetErrorString(e));
@@ -400,15 +418,17 @@ int launch(const CcGemmDesc& d, hipStream_t s) {
         return CCEDIT_EUNSUPPORTED;
     }
     dim3 grid((unsigned)nblk);
-    hipLaunchKernelGGL((tap_gemm_kernel<WM, WN, STAGES, MODE>), grid, dim3(WM * WN * 64), lds, s, d);
+    hipLaunchKernelGGL((tap_gemm_kernel<WM, WN, TI, TJ, STAGES, MODE>), grid, dim3(WM * WN * 64), lds, s, d);
     return cc_launch_status("tap_gemm_kernel");
 }
 
 template <int MODE>
 int launch_tile(const CcGemmDesc& d, int tile, hipStream_t s) {
-    if (tile == 3) return launch<2, 4, 3, MODE>(d, s);
-    if (tile == 2) return launch<1, 4, 2, MODE>(d, s);
-    return launch<2, 2, 2, MODE>(d, s);
+    if (tile == 5) return launch<2, 4, 2, 4, 2, MODE>(d, s);      // 128ch x 512pix, 8 waves of 64ch x 128pix
+    if (tile == 4) return launch<2, 4, 4, 2, 2, MODE>(d, s);      // 256ch x 256pix, 8 waves of 128ch x 64pix
+    if (tile == 3) return launch<2, 4, 2, 2, 3, MODE>(d, s);
+    if (tile == 2) return launch<1, 4, 2, 2, 2, MODE>(d, s);
+    return launch<2, 2, 2, 2, 2, MODE>(d, s);
 }
 
 }  // namespace
@@ -450,11 +470,12 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int tile = d.tile;
     if (tile == 0) {
-        // measured on MI355X over the network's contraction shapes (tools/tile_sweep.py):
-        //   Cout multiple of 64 but not 128 (320, 960): the 64ch x 256pix shape avoids 17 % padded MFMA work, and
-        //     wins for the 3x3 / temporal gathers and for short K; the 128x128 shape wins for long plain K;
-        //   very large M with Cout % 128 == 0 and long K: the 8-wave 128ch x 256pix 3-stage shape;
-        //   everything else: 128ch x 128pix, two workgroups per CU.
+        // Chosen from IN-NETWORK timings (bench.py --breakdown), where operands arrive cold from HBM; the isolated
+        // sweep (tools/tile_sweep.py, operands hot in the 256 MB Infinity Cache) over-rates the wide 8-wave shapes
+        // (t4 = 256ch x 256pix, t5 = 128ch x 512pix: up to 1064 TF/s isolated, but slower than t1/t2 in the network):
+        //   Cout multiple of 64 but not 128 (320, 960): 64ch x 256pix (t2) for gathers and short K, else 128x128 (t1)
+        //   very large M with Cout % 128 == 0 and long K: 128ch x 256pix 3-stage (t3)
+        //   everything else: 128ch x 128pix, two workgroups per CU (t1)
         const int w128 = (d.N + 127) / 128 * 128, w64 = (d.N + 63) / 64 * 64;
         if (w64 < w128) tile = (d.taps > 1 || d.Kpad <= 512) ? 2 : 1;
         else if (d.M >= 150000 && d.Kpad >= 2048) tile = 3;

@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the library is loaded: to
 #                              both sides have to share ONE HIP runtime (device state, streams, allocations).
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libccedit_hip.so")
+LIB_PATH = os.environ.get("CCEDIT_HIP_LIB") or os.path.join(_HERE, "libccedit_hip.so")
 
 ABI_VERSION = 1
 

@@ -4,7 +4,7 @@ The state-dict contract keeps the reference's key names and ten
 a one-time, load-time transformation into what `ccedit_gemm` consumes:
 
     W_packed[Opad][Kpad]   bf16,  K index = tap * Cin_pad + c   (K contiguous),
-    Opad = ceil(N, 128), Cin_pad = ceil(Cin, 8), Kpad = ceil(taps * Cin_pad, 64), zero padded.
+    Opad = ceil(N, 256), Cin_pad = ceil(Cin, 8), Kpad = ceil(taps * Cin_pad, 64), zero padded.
 
 Tap order: Conv2d tap = ky * kw + kx (source pixel (oy*s + ky - pad, ox*s + kx - pad));
 Conv1d-over-T tap = k (source frame t + k - K//2).  GEGLU projections are row-interleaved in blocks
@@ -77,7 +77,7 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
             b = b[perm]
     cin = _ceil(i, 8)
     n = _ceil(o, 4)
-    opad = _ceil(n, 128)
+    opad = _ceil(n, 256)            # the widest GEMM block shape covers 256 output channels
     kpad = _ceil(taps * cin, 64)
     dev = device if device is not None else w3.device
     buf = torch.zeros(opad, kpad, dtype=torch.bfloat16, device=dev)

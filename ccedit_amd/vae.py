@@ -69,13 +69,13 @@ class AttnBlock(nn.Module):
         L = h * w
         lp = _ceil(L, 64)
         a = ops.groupnorm_spatial(x, self.norm.g, self.norm.b, GN_EPS, False)
-        a2 = torch.zeros((n * L + 128, c), dtype=torch.bfloat16, device=x.device)      # +128 zero rows: operand padding
+        a2 = torch.zeros((n * L + 256, c), dtype=torch.bfloat16, device=x.device)      # +256 zero rows: operand padding
         a2[: n * L].copy_(a.view(-1, c))
         q = ops.linear(a2[: n * L], self.q.pw)
-        k = torch.zeros((n * L + 128, c), dtype=torch.bfloat16, device=x.device)
+        k = torch.zeros((n * L + 256, c), dtype=torch.bfloat16, device=x.device)
         ops.linear(a2[: n * L], self.k.pw, out=k[: n * L])
         o = torch.empty((n * L, c), dtype=torch.bfloat16, device=x.device)
-        vt = torch.zeros((_ceil(c, 128), lp), dtype=torch.bfloat16, device=x.device)
+        vt = torch.zeros((_ceil(c, 256), lp), dtype=torch.bfloat16, device=x.device)
         for f in range(n):
             kf = PackedWeight(k[f * L:], None, _ceil(L, 4), L, c, 1, c)
             s = ops.linear(q[f * L:(f + 1) * L], kf, out_f32=True)                       # [L, L] fp32 scores

@@ -86,7 +86,7 @@ typedef struct CcGemmDesc {
     int32_t reserved0;
     const void* A;        /* bf16 [rows][lda] */
     const void* A2;       /* optional second source */
-    const void* W;        /* bf16 [ceil(N,128)][Kpad] */
+    const void* W;        /* bf16 [ceil(N,256)][Kpad] (rows zero-padded to the widest block shape) */
     const float* bias;    /* [N] in packed row order, or null */
     const float* group_bias; /* [M/group_rows][N] fp32 or null  (ResBlock: h + emb_out, openaimodel.py:762) */
     const void* res1;     /* bf16 residuals added after the activation, or null */

@@ -106,7 +106,7 @@ def test_packing_layouts():
     from ccedit_amd.packing import pack_concat, pack_weight
     w = torch.arange(2 * 3 * 9, dtype=torch.float32).reshape(2, 3, 3, 3)
     pw = pack_weight(w, torch.tensor([1.0, 2.0]))
-    assert pw.w.shape == (128, 128) and pw.cin == 8 and pw.taps == 9 and pw.kpad == 128 and pw.n == 4
+    assert pw.w.shape == (256, 128) and pw.cin == 8 and pw.taps == 9 and pw.kpad == 128 and pw.n == 4
     # K index = tap*Cin_pad + c ; tap = ky*3+kx
     assert pw.w[1, 4 * 8 + 2].float().item() == w[1, 2, 1, 1].item()
     assert pw.w[0, 3].item() == 0 and pw.w[2].abs().sum().item() == 0
