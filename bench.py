@@ -32,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOP_PER_STEP = 77.68e12          # SURVEY.md §8d, measured from the reference modules on the meta device
+FLOP_PER_STEP_TVI2V = 110.31e12   # BASELINE.json config 3 (controlnet_img + anchor cross-frame attention)
 MFMA_PEAK_TFLOPS = 2500.0         # MI355X dense bf16 (MI355X_MICROARCH.md)
 T, H, W, L, CTX = 17, 64, 96, 77, 768
 
@@ -47,10 +48,10 @@ def synth_inputs(device, seed=42, b=1):
     return x.to(device), cross_c.to(device), cross_uc.to(device), hint.to(device)
 
 
-def build_model(device):
+def build_model(device, tvi2v=False):
     from ccedit_amd.sgm_compat import build_network
     from ccedit_amd.utils.synth import fill_module_
-    w = build_network(device)                      # full-size TV2V network, parameters created on the GPU
+    w = build_network(device, crossframe=tvi2v)    # full-size network, parameters created on the GPU
     fill_module_(w, prefix="model.")               # name-keyed synthetic weights (device generator)
     w.diffusion_model.pack(device)
     w.cache_hint_stem = False                      # the per-step metric recomputes the hint stem every step
@@ -90,6 +91,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clip", action="store_true", help="also time one full 30-step clip + VAE decode (frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["tv2v", "tvi2v"], default="tv2v",
+                    help="tv2v = BASELINE.json config 2 (the headline metric); tvi2v = config 3 (ref-frame cfca network)")
     ap.add_argument("--breakdown", action="store_true", help="print per-shape GEMM / attention time of one step to stderr")
     args = ap.parse_args()
 
@@ -110,10 +113,15 @@ def main():
     from ccedit_amd import hip, ops
     hip.lib()                                       # fail loudly if the HIP library is missing
     torch.set_grad_enabled(False)
-    wrapper = build_model(device)
+    tvi2v = args.workload == "tvi2v"
+    flop_per_step = FLOP_PER_STEP_TVI2V if tvi2v else FLOP_PER_STEP
+    wrapper = build_model(device, tvi2v)
     x, cross_c, cross_uc, hint = synth_inputs(device, seed=42 + rank)
     x2 = torch.cat([x, x]).contiguous()             # CFG-doubled batch, uc first (guiders.py:63)
     cond = dict(crossattn=torch.cat([cross_uc, cross_c]).contiguous(), control_hint=torch.cat([hint, hint]).contiguous())
+    if tvi2v:
+        cf = (torch.randn(1, 4, H, W, generator=torch.Generator().manual_seed(7 + rank)) * 0.18215).to(device)
+        cond["cond_feat"] = torch.cat([cf, cf]).contiguous()
     tstep = torch.tensor([601, 601], dtype=torch.int64, device=device)
 
     def step():
@@ -163,15 +171,15 @@ def main():
             extra["attention"] = dict(tflops=round(a["flops"] / (a["total_ms"] * 1e-3) / 1e12, 1), launches=a["launches"],
                                       total_ms=round(a["total_ms"], 2), algorithmic_flops_per_step=a["flops"])
         extra["gemm_total_ms"] = round(g["total_ms"], 2)
-        extra["step_tflops"] = round(FLOP_PER_STEP / (ms_per_step * 1e-3) / 1e12, 1)
-        extra["step_frac_of_mfma_peak"] = round(FLOP_PER_STEP / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+        extra["step_tflops"] = round(flop_per_step / (ms_per_step * 1e-3) / 1e12, 1)
+        extra["step_frac_of_mfma_peak"] = round(flop_per_step / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
 
     clip = None
     if args.clip and rank == 0:
         clip = time_clip(wrapper, device)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not tvi2v:
         cpu = cpu_baseline(wrapper)
 
     if rank == 0:
@@ -180,9 +188,12 @@ def main():
             "unit": "UNet steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (seeded latent/context/depth hint; name-keyed random-init weights)",
-            "config": {"workload": "TV2V depth-midas, 17x512x768, one network evaluation = ControlNet2D + pseudo-3D UNet on "
-                                   "B=2 (cfg 7.5 uncond+cond) x T=17 frames, latent 64x96, 77x768 text context; "
-                                   "77.68 TFLOP/step; a 30-step DPMPP2SAncestral clip = 59 such steps + VAE decode",
+            "config": {"workload": ("TVI2V ref-frame (cfca) + depth, 17x512x768, one network evaluation = ControlNet2D + controlnet_img + "
+                                    "pseudo-3D UNet with anchor cross-frame attention on B=2 x T=17 frames; 110.31 TFLOP/step"
+                                    if tvi2v else
+                                    "TV2V depth-midas, 17x512x768, one network evaluation = ControlNet2D + pseudo-3D UNet on "
+                                    "B=2 (cfg 7.5 uncond+cond) x T=17 frames, latent 64x96, 77x768 text context; "
+                                    "77.68 TFLOP/step; a 30-step DPMPP2SAncestral clip = 59 such steps + VAE decode"),
                        "parallelism": "1 clip per GPU (replicas, no collective)" if world > 1 else "single GPU",
                        "hint_stem": "recomputed every step"},
             "roofline": roof, "cpu_baseline": cpu,

@@ -111,9 +111,39 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
         vp[it] = V + (size_t)(kvbase + (int64_t)row * a.kv_seq_rows) * a.ldv + g * 8;
     }
     const int64_t kstep = 64 * a.kv_seq_rows * (int64_t)a.ldk, vstep = 64 * a.kv_seq_rows * (int64_t)a.ldv;
+    // optional leading segment (anchor-frame keys): its rows are addressed from another kv batch
+    int64_t seg1base = 0;
+    if (a.seg1_len > 0) {
+        const int sb = (batch / a.seg1_div) * a.seg1_mul + a.seg1_add;
+        seg1base = (int64_t)(sb / a.kv_inner) * a.kv_outer_rows + (int64_t)(sb % a.kv_inner) * a.kv_inner_rows;
+    }
 
     auto stage = [&](int j, int buf) {
         const int rows_left = a.Lk - j * 64;        // rows >= rows_left of this tile come from the zero page
+        if (a.seg1_len > 0) {
+            // two-segment keys: recompute the row address per slot (the running pointers assume one segment)
+#pragma unroll
+            for (int it = 0; it < ITK; ++it) {
+                if (krw[it] >= 0) {
+                    const int kv = j * 64 + krw[it];
+                    const int64_t r = (kv < a.seg1_len) ? seg1base + (int64_t)kv * a.kv_seq_rows
+                                                        : kvbase + (int64_t)(kv - a.seg1_len) * a.kv_seq_rows;
+                    const bf16* src = (kv < a.Lk) ? kp[it] + (r - kvbase - (int64_t)krw[it] * a.kv_seq_rows) * a.ldk : zp;
+                    glds16(src, sK + buf * KB + (it * NTHR + wave * 64) * 16);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < ITV; ++it) {
+                if (vrw[it] >= 0) {
+                    const int kv = j * 64 + vrw[it];
+                    const int64_t r = (kv < a.seg1_len) ? seg1base + (int64_t)kv * a.kv_seq_rows
+                                                        : kvbase + (int64_t)(kv - a.seg1_len) * a.kv_seq_rows;
+                    const bf16* src = (kv < a.Lk) ? vp[it] + (r - kvbase - (int64_t)vrw[it] * a.kv_seq_rows) * a.ldv : zp;
+                    glds16(src, sV + buf * VB + (it * NTHR + wave * 64) * 16);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < ITK; ++it) {
             if (krw[it] >= 0) {
@@ -317,6 +347,7 @@ extern "C" int ccedit_attention(const CcAttnDesc* desc, void* stream) {
     CC_CHECK_ARG(a.heads > 0 && a.batches > 0 && a.Lq > 0 && a.Lk > 0 && a.q_inner > 0 && a.kv_inner > 0 && a.kv_div > 0,
                  "ccedit_attention: bad sizes");
     CC_UNSUPPORTED(a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4, "ccedit_attention: row strides must be multiples of 8");
+    CC_CHECK_ARG(a.seg1_len >= 0 && a.seg1_len <= a.Lk && (a.seg1_len == 0 || a.seg1_div > 0), "ccedit_attention: bad leading segment");
     CC_UNSUPPORTED(a.heads > 65535 || (int64_t)a.batches * ((a.Lq + 31) / 32) > 2147483647LL, "ccedit_attention: grid too large");
     hipStream_t s = (hipStream_t)stream;
     switch (a.d) {

@@ -42,6 +42,7 @@ class CcAttnDesc(C.Structure):
         ("q_inner", C.c_int32), ("q_outer_rows", C.c_int64), ("q_inner_rows", C.c_int64), ("q_seq_rows", C.c_int64),
         ("kv_div", C.c_int32), ("kv_inner", C.c_int32), ("kv_outer_rows", C.c_int64), ("kv_inner_rows", C.c_int64),
         ("kv_seq_rows", C.c_int64), ("scale", C.c_float),
+        ("seg1_len", C.c_int32), ("seg1_div", C.c_int32), ("seg1_mul", C.c_int32), ("seg1_add", C.c_int32),
     ]
 
 

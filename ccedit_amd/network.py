@@ -120,6 +120,25 @@ class BasicTransformerSingleLayerBlock(nn.Module):
         self.ff = FeedForward(dim)
         self.norm1, self.norm2 = Norm(dim, 1e-5), Norm(dim, 1e-5)
 
+    def run_frames(self, tok, frames: int, hw: int, anchor_t: Optional[int] = None, frames_per_clip: int = 1):
+        """Per-frame attention with K/V from the un-normalised tokens.  anchor_t is None: plain self-attention
+        (controlnet_img's SpatialTransformer, disable_text_ca).  Otherwise the keys are
+        [tokens of frame anchor_t of the same clip ; own tokens] — SpatialTransformer3DCA 'center_self'."""
+        a = self.attn1
+        c = a.inner
+        n1 = ops.layernorm(tok, self.norm1.g, self.norm1.b)
+        q = ops.linear(n1, a.to_q.pw)
+        kv = ops.linear(tok, a.kv)
+        if anchor_t is None:
+            o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=frames, lq=hw, lk=hw)
+        else:
+            o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=frames, lq=hw, lk=2 * hw,
+                              kv_outer_rows=hw, seg1_len=hw, seg1_div=frames_per_clip, seg1_mul=frames_per_clip,
+                              seg1_add=anchor_t)
+        tok = ops.linear(o, a.to_out[0].pw, res1=tok)
+        n2 = ops.layernorm(tok, self.norm2.g, self.norm2.b)
+        return self.ff.run(n2, tok)
+
     def run_temporal(self, tok, geo: Geometry, hw: int):
         a = self.attn1
         c = a.inner
@@ -140,19 +159,26 @@ class SpatialTransformer(nn.Module):
 
     def __init__(self, in_channels, n_heads, d_head, depth=1, context_dim=None, **kw):
         super().__init__()
-        if depth != 1 or kw.get("use_linear", False) or kw.get("disable_self_attn", False) or kw.get("disable_text_ca", False):
-            raise NotImplementedError("SpatialTransformer: only depth=1, conv projections, text cross-attn")
+        if depth != 1 or kw.get("use_linear", False) or kw.get("disable_self_attn", False):
+            raise NotImplementedError("SpatialTransformer: only depth=1, conv projections")
         inner = n_heads * d_head
+        self.disable_text_ca = bool(kw.get("disable_text_ca", False))
         self.norm = Norm(in_channels, GN_EPS_ATTN)
         self.proj_in = Conv(in_channels, inner, 1)
-        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, n_heads, d_head, context_dim)])
+        if self.disable_text_ca:      # attention.py:820-838: single-layer block, called as block(x, context=x)
+            self.transformer_blocks = nn.ModuleList([BasicTransformerSingleLayerBlock(inner, n_heads, d_head)])
+        else:
+            self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, n_heads, d_head, context_dim)])
         self.proj_out = Conv(inner, in_channels, 1)
 
     def run_spatial(self, x, ctx2d, ctx_len, frames_per_clip):
         n, h, w, c = x.shape
         a = ops.groupnorm_spatial(x, self.norm.g, self.norm.b, self.norm.eps, False)
         tok = ops.linear(a.view(-1, c), self.proj_in.pw)
-        tok = self.transformer_blocks[0].run(tok, n, h * w, ctx2d, ctx_len, frames_per_clip)
+        if self.disable_text_ca:
+            tok = self.transformer_blocks[0].run_frames(tok, n, h * w)
+        else:
+            tok = self.transformer_blocks[0].run(tok, n, h * w, ctx2d, ctx_len, frames_per_clip)
         y = ops.linear(tok, self.proj_out.pw, res1=x.view(-1, c))
         return y.view(n, h, w, c)
 
@@ -182,6 +208,34 @@ class SpatialTransformer3D(SpatialTransformer):
         tok = ops.linear(a.view(-1, c), self.proj_in_temporal.pw)
         tok = self.transformer_blocks_temporal[0].run_temporal(tok, geo, h * w)
         z = ops.linear(tok, self.proj_out_temporal.pw, res1=y.view(-1, c))
+        return z.view(n, h, w, c)
+
+
+class SpatialTransformer3DCA(SpatialTransformer3D):
+    """attention.py:1211-1350 (TVI2V): after the 3-D transformer, a cross-frame attention in which every frame
+    attends to [centre-frame tokens ; own tokens] (ST3DCA_ca_type='center_self').  The anchor keys are rows of the
+    same K/V matrix (frame T//2 of the clip): the attention kernel reads them as a leading KV segment, nothing
+    is concatenated or repeated in memory."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, context_dim=None, **kw):
+        ca_type = kw.pop("ST3DCA_ca_type", "center")
+        if ca_type != "center_self":
+            raise NotImplementedError(f"ST3DCA_ca_type={ca_type!r}: the shipped TVI2V config uses 'center_self'")
+        super().__init__(in_channels, n_heads, d_head, depth, context_dim, **kw)
+        inner = n_heads * d_head
+        self.norm_temporal_ca = Norm(in_channels, GN_EPS_ATTN)
+        self.proj_in_temporal_ca = Conv(in_channels, inner, 1)
+        self.transformer_blocks_temporal_ca = nn.ModuleList([BasicTransformerSingleLayerBlock(inner, n_heads, d_head)])
+        self.proj_out_temporal_ca = Conv(inner, in_channels, 1)
+
+    def run(self, x, geo, ctx2d, ctx_len):
+        y = super().run(x, geo, ctx2d, ctx_len)
+        n, h, w, c = y.shape
+        nc = self.norm_temporal_ca
+        a = ops.groupnorm_spatial(y, nc.g, nc.b, nc.eps, False)
+        tok = ops.linear(a.view(-1, c), self.proj_in_temporal_ca.pw)
+        tok = self.transformer_blocks_temporal_ca[0].run_frames(tok, n, h * w, anchor_t=geo.t // 2, frames_per_clip=geo.t)
+        z = ops.linear(tok, self.proj_out_temporal_ca.pw, res1=y.view(-1, c))
         return z.view(n, h, w, c)
 
 
@@ -312,8 +366,7 @@ class TimestepEmbedSequential(nn.Sequential):
 _UNSUPPORTED_DEFAULTS = dict(dropout=0, conv_resample=True, dims=2, num_classes=None, use_scale_shift_norm=False,
                              resblock_updown=False, use_linear_in_transformer=False, disable_self_attentions=None,
                              num_attention_blocks=None, disable_middle_self_attn=False, adm_in_channels=None,
-                             transformer_depth_middle=None, n_embed=None, num_head_channels=-1,
-                             enable_attention3d_crossframe=False, disable_text_ca=False)
+                             transformer_depth_middle=None, n_embed=None, num_head_channels=-1)
 
 
 def _check_supported(kw: dict, who: str):
@@ -350,8 +403,15 @@ class UNetModel(nn.Module):
         self.use_checkpoint = use_checkpoint
         res_cls = ResBlock3D if self.THREE_D else ResBlock
         down_cls = Downsample3D if self.THREE_D else Downsample
-        tkw = dict(disable_temporal_text_ca=kw.get("disable_temporal_text_ca", False)) if self.THREE_D else {}
-        st_cls = SpatialTransformer3D if self.THREE_D else SpatialTransformer
+        if self.THREE_D:
+            tkw = dict(disable_temporal_text_ca=kw.get("disable_temporal_text_ca", False))
+            st_cls = SpatialTransformer3D
+            if kw.get("enable_attention3d_crossframe", False):
+                st_cls = SpatialTransformer3DCA
+                tkw["ST3DCA_ca_type"] = kw.get("ST3DCA_ca_type", "center")
+        else:
+            tkw = dict(disable_text_ca=kw.get("disable_text_ca", False))
+            st_cls = SpatialTransformer
 
         def make_st(ch):
             return st_cls(ch, num_heads, ch // num_heads, depth=1, context_dim=context_dim, **tkw)
@@ -427,18 +487,24 @@ class ControlNet2D(UNetModel):
     """Per-frame SD-1.5 encoder copy + hint stem + 13 zero convs (controlmodel.py:195-317)."""
 
     def __init__(self, hint_channels, control_scales, no_add_x=False, set_input_hint_block_as_identity=False, *args, **kw):
-        if no_add_x or set_input_hint_block_as_identity:
-            raise NotImplementedError("controlnet_img variant (TVI2V) is a later scope row")
+        if no_add_x != set_input_hint_block_as_identity:
+            raise NotImplementedError("no_add_x and set_input_hint_block_as_identity are only supported together "
+                                      "(the shipped controlnet_img config)")
         kw["out_channels"] = kw["in_channels"]
         super().__init__(*args, build_decoder=False, **kw)
         self.control_scales = float(control_scales)
+        self.no_add_x = bool(no_add_x)
+        self.set_input_hint_block_as_identity = bool(set_input_hint_block_as_identity)
         mc = self.model_channels
-        mods, cin = [], hint_channels
-        for cout, stride in _HINT_PLAN:
-            mods += [Conv(cin, cout, 3, stride=stride), Slot()]
-            cin = cout
-        mods.append(Conv(cin, mc, 3))
-        self.input_hint_block = TimestepEmbedSequential(*mods)
+        if self.set_input_hint_block_as_identity:
+            self.input_hint_block = TimestepEmbedSequential(Slot())          # nn.Identity(): no parameters
+        else:
+            mods, cin = [], hint_channels
+            for cout, stride in _HINT_PLAN:
+                mods += [Conv(cin, cout, 3, stride=stride), Slot()]
+                cin = cout
+            mods.append(Conv(cin, mc, 3))
+            self.input_hint_block = TimestepEmbedSequential(*mods)
         self.zero_convs = nn.ModuleList([TimestepEmbedSequential(Conv(mc, mc, 1))])
         ch = mc
         for level, mult in enumerate(self.channel_mult):
@@ -463,12 +529,16 @@ class ControlNet2D(UNetModel):
         return h
 
     def run(self, x_nhwc, guided, timesteps, ctx2d, ctx_len, geo: Geometry) -> List[torch.Tensor]:
-        """x_nhwc (B*T, h, w, 8) bf16, guided = hint_stem(remapped hint) (B*T, h, w, C) -> 13 residuals."""
+        """x_nhwc (B*T, h, w, 8) bf16, guided = hint_stem(remapped hint) (B*T, h, w, C) -> 13 residuals.
+        controlnet_img (no_add_x + identity hint block): x_nhwc is ignored and `guided` is the 8-channel-padded
+        reference latent; the first block's output is input_blocks[0](guided) (controlmodel.py:283-299)."""
         emb_silu = self._emb_silu(timesteps)
         outs = []
         h = x_nhwc
         for i, (block, zc) in enumerate(zip(self.input_blocks, self.zero_convs)):
-            if i == 0:
+            if i == 0 and self.no_add_x:
+                h = ops.conv2d(guided, block[0].pw)
+            elif i == 0:
                 h = ops.conv2d(h, block[0].pw, res1=guided.view(-1, guided.shape[-1]))     # h = conv(x); h += guided_hint
             else:
                 h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
@@ -480,6 +550,12 @@ class ControlNet2D(UNetModel):
     def forward(self, x, hint, timesteps=None, context=None, y=None, **kwargs):
         """Reference signature (controlmodel.py:252): 5-D fp32 tensors in, list of 13 (b c t h w) out."""
         assert y is None, "must specify y if and only if the model is class-conditional"
+        if x.dim() == 4:       # controlnet_img: (B, C, h, w) reference latent as hint -> 13 x (B, C, h, w)
+            if not self.no_add_x:
+                raise NotImplementedError("4-D input is only used by the controlnet_img variant")
+            b = x.shape[0]
+            res = self.run(None, ops.ncthw_to_nhwc(hint.float()[:, :, None].contiguous(), 8), timesteps, None, 0, Geometry(b, 1))
+            return [ops.nhwc_to_ncthw(r, b, 1, r.shape[-1])[:, :, 0] for r in res]
         b, _, t, _, _ = x.shape
         geo = Geometry(b, t)
         ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
@@ -492,15 +568,30 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
     """controlmodel.py:320-553 (TV2V): pseudo-3D UNet that sums ControlNet residuals into its skips."""
 
     def __init__(self, controlnet_config, *args, **kw):
-        if kw.get("controlnet_img_config") is not None or kw.get("crossframe_type") is not None:
-            raise NotImplementedError("controlnet_img / crossframe (TVI2V) is a later scope row")
+        if kw.get("crossframe_type") is not None:
+            raise NotImplementedError("crossframe_type='reference' (attention hooks) is commented out in the shipped configs")
+        controlnet_img_config = kw.pop("controlnet_img_config", None)
         super().__init__(*args, **kw)
         from .config import instantiate_from_config
         self.controlnet = instantiate_from_config(controlnet_config)
+        if controlnet_img_config is not None:
+            self.controlnet_img = instantiate_from_config(controlnet_img_config)
 
-    def run(self, x_nhwc, timesteps, ctx2d, ctx_len, control: List[torch.Tensor], geo: Geometry):
-        """x_nhwc (B*T, h, w, 8) bf16; control = 13 NHWC residuals (consumed) -> eps (B*T, h, w, out) fp32."""
+    def run(self, x_nhwc, timesteps, ctx2d, ctx_len, control: List[torch.Tensor], geo: Geometry,
+            img_control: Optional[List[torch.Tensor]] = None):
+        """x_nhwc (B*T, h, w, 8) bf16; control = 13 NHWC residuals (consumed); img_control = 13 (B, h, w, C)
+        residuals added in place to the centre frame T//2 of every clip (controlmodel.py:529-535)
+        -> eps (B*T, h, w, out) fp32."""
         emb_silu = self._emb_silu(timesteps)
+
+        def add_center(hh):
+            if img_control is not None:
+                ic = img_control.pop(0)
+                for b in range(geo.b):
+                    fr = hh[b * geo.t + geo.t // 2]
+                    ops.add(fr, ic[b], out=fr)
+            return hh
+
         hs = []
         h = x_nhwc
         for i, block in enumerate(self.input_blocks):
@@ -509,8 +600,8 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
                 h = ops.conv_temporal(s, geo.t, self.input_blocks_temporal[0].pw, res1=s.view(-1, s.shape[-1]))
             else:
                 h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
-            hs.append(h)
-        h = self.middle_block.run(h, emb_silu, geo, ctx2d, ctx_len)
+            hs.append(add_center(h))
+        h = add_center(self.middle_block.run(h, emb_silu, geo, ctx2d, ctx_len))
         h = ops.add(h, control.pop())
         for block in self.output_blocks:
             h = ops.cat_add(h, hs.pop(), control.pop())          # cat([h, hs.pop() + control.pop()], dim=1)
@@ -530,14 +621,18 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
                 **kwargs):
         """Reference signature (controlmodel.py:471-481); `control` (5-D fp32 list) is consumed."""
         assert y is None, "must specify y if and only if the model is class-conditional"
-        if img_control is not None or only_mid_control or control is None:
-            raise NotImplementedError("img_control / only_mid_control / control=None")
+        if only_mid_control or control is None:
+            raise NotImplementedError("only_mid_control / control=None")
         b, _, t, _, _ = x.shape
         geo = Geometry(b, t)
         ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
         ctrl = [ops.ncthw_to_nhwc(c.float().contiguous(), c.shape[1]) for c in control]
         del control[:]
-        eps = self.run(ops.ncthw_to_nhwc(x.float().contiguous(), 8), timesteps, ctx2d, context.shape[1], ctrl, geo)
+        ictrl = None
+        if img_control is not None:      # 13 x (B, C, h, w) -> (B, h, w, C)
+            ictrl = [ops.ncthw_to_nhwc(c.float()[:, :, None].contiguous(), c.shape[1]) for c in img_control]
+            del img_control[:]
+        eps = self.run(ops.ncthw_to_nhwc(x.float().contiguous(), 8), timesteps, ctx2d, context.shape[1], ctrl, geo, ictrl)
         return ops.nhwc_to_ncthw(eps, b, t, self.out_channels)
 
 
@@ -582,8 +677,6 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     def forward(self, x: torch.Tensor, t: torch.Tensor, c: Dict[str, torch.Tensor], **kwargs) -> torch.Tensor:
         if c.get("concat") is not None and c["concat"].numel():
             raise NotImplementedError("'concat' conditioning is not used by the TV2V configs")
-        if c.get("cond_feat") is not None:
-            raise NotImplementedError("cond_feat (TVI2V) is a later scope row")
         net = self.diffusion_model
         b, _, nt, _, _ = x.shape
         geo = Geometry(b, nt)
@@ -592,5 +685,10 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         x8 = ops.ncthw_to_nhwc(x.float().contiguous(), 8)
         guided = self._guided_hint(c["control_hint"])
         control = net.controlnet.run(x8, guided, t, ctx2d, context.shape[1], geo)
-        eps = net.run(x8, t, ctx2d, context.shape[1], control, geo)
+        img_control = None
+        cond_feat = c.get("cond_feat", None)
+        if cond_feat is not None:        # TVI2V (wrappers.py:176-190): controlnet_img on the reference latent
+            cf8 = ops.ncthw_to_nhwc(cond_feat.float()[:, :, None].contiguous(), 8)
+            img_control = net.controlnet_img.run(None, cf8, t, None, 0, Geometry(b, 1))
+        eps = net.run(x8, t, ctx2d, context.shape[1], control, geo, img_control)
         return ops.nhwc_to_ncthw(eps, b, nt, net.out_channels)

@@ -186,7 +186,8 @@ def layernorm(x2d: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, d: int, *, batches: int, lq: int, lk: int,
               q_inner: int = 1, q_outer_rows: Optional[int] = None, q_inner_rows: int = 0, q_seq_rows: int = 1,
               kv_div: int = 1, kv_inner: int = 1, kv_outer_rows: Optional[int] = None, kv_inner_rows: int = 0,
-              kv_seq_rows: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              kv_seq_rows: int = 1, out: Optional[torch.Tensor] = None,
+              seg1_len: int = 0, seg1_div: int = 1, seg1_mul: int = 0, seg1_add: int = 0) -> torch.Tensor:
     """q/k/v: 2-D row-major views [rows, >= heads*d] (may be column slices of a fused buffer)."""
     for tns in (q, k, v):
         assert tns.dtype == BF16 and tns.is_cuda and tns.stride(-1) == 1
@@ -200,6 +201,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, d: 
     a.kv_div, a.kv_inner = kv_div, kv_inner
     a.kv_outer_rows, a.kv_inner_rows, a.kv_seq_rows = (lk if kv_outer_rows is None else kv_outer_rows), kv_inner_rows, kv_seq_rows
     a.scale = float(d) ** -0.5
+    a.seg1_len, a.seg1_div, a.seg1_mul, a.seg1_add = seg1_len, seg1_div, seg1_mul, seg1_add
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

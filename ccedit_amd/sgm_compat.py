@@ -12,15 +12,21 @@ from .vae import AutoencoderKLInferenceWrapper
 
 def network_params(model_channels=320, num_heads=8, context_dim=768, in_channels=4, out_channels=4,
                    attention_resolutions=(4, 2, 1), num_res_blocks=2, channel_mult=(1, 2, 4, 4), hint_channels=3,
-                   control_scales=1.0, **ignored) -> dict:
+                   control_scales=1.0, crossframe=False, **ignored) -> dict:
     """network_config.params of configs/inference_ccedit/keyframe_no2ndca_depthmidas.yaml:25-56."""
     common = dict(use_checkpoint=False, in_channels=in_channels, model_channels=model_channels,
                   attention_resolutions=list(attention_resolutions), num_res_blocks=num_res_blocks,
                   channel_mult=list(channel_mult), num_heads=num_heads, use_spatial_transformer=True,
                   transformer_depth=1, context_dim=context_dim, legacy=False)
     cn = dict(common, hint_channels=hint_channels, control_scales=control_scales)
-    return dict(common, out_channels=out_channels, disable_temporal_text_ca=True,
-                controlnet_config=dict(target="sgm.modules.diffusionmodules.controlmodel.ControlNet2D", params=cn))
+    p = dict(common, out_channels=out_channels, disable_temporal_text_ca=True,
+             controlnet_config=dict(target="sgm.modules.diffusionmodules.controlmodel.ControlNet2D", params=cn))
+    if crossframe:       # TVI2V: keyframe_ref_cp_no2ndca_add_cfca_depthzoe.yaml:32-90
+        p.update(enable_attention3d_crossframe=True, ST3DCA_ca_type="center_self",
+                 controlnet_img_config=dict(target="sgm.modules.diffusionmodules.controlmodel.ControlNet2D",
+                                            params=dict(cn, no_add_x=True, set_input_hint_block_as_identity=True,
+                                                        disable_text_ca=True)))
+    return p
 
 
 def build_network(device="cpu", **cfg) -> OpenAIWrapperControlLDM3DTV2V:

@@ -134,6 +134,10 @@ typedef struct CcAttnDesc {
     int32_t kv_div;                   /* kv batch = batch / kv_div (text K/V shared across frames) */
     int32_t kv_inner; int64_t kv_outer_rows, kv_inner_rows, kv_seq_rows;
     float scale;                      /* d^-0.5 */
+    /* optional leading KV segment (anchor-frame keys of SpatialTransformer3DCA, attention.py:1324-1336:
+     * context = cat([anchor tokens, x tokens])): keys [0, seg1_len) come from the kv batch
+     * (batch / seg1_div) * seg1_mul + seg1_add, keys [seg1_len, Lk) from the regular kv batch.  0 = unused. */
+    int32_t seg1_len, seg1_div, seg1_mul, seg1_add;
 } CcAttnDesc;
 
 int ccedit_attention(const CcAttnDesc* desc, void* stream);

@@ -56,6 +56,8 @@ class NetConfig:
     context_dim: int = 768
     hint_channels: int = 3
     control_scales: float = 1.0
+    # TVI2V (keyframe_ref_cp_no2ndca_add_cfca_depthzoe.yaml:32-90): anchor cross-frame attention + controlnet_img
+    crossframe: bool = False
 
 
 @dataclass
@@ -264,6 +266,60 @@ def spatial_transformer3d(sd: SD, p: str, x5, context, heads: int):
     return _pix_to_5d(xp + y, b, h, w)
 
 
+def spatial_transformer2d_selfonly(sd: SD, p: str, x, heads: int):
+    """SpatialTransformer with disable_text_ca=True (attention.py:820-838, 880-881): one
+    BasicTransformerSingleLayerBlock called as block(x, context=x)."""
+    b, c, h, w = x.shape
+    y = _conv2d(sd, p + ".proj_in", _gn(sd, p + ".norm", x, GN_EPS_ATTN))
+    tok = y.flatten(2).transpose(1, 2)
+    tok = single_block(sd, p + ".transformer_blocks.0", tok, tok, heads)
+    y = tok.transpose(1, 2).reshape(b, c, h, w)
+    return _conv2d(sd, p + ".proj_out", y) + x
+
+
+def spatial_transformer3dca(sd: SD, p: str, x5, context, heads: int):
+    """SpatialTransformer3DCA.forward, ST3DCA_ca_type='center_self' (attention.py:1302-1350): after the 3D
+    transformer, every frame attends to [tokens of the centre frame T//2 ; its own tokens] (un-normalised K/V)."""
+    x5 = spatial_transformer3d(sd, p, x5, context, heads)
+    b, c, t, h, w = x5.shape
+    x = _to_frames(x5)
+    y = _conv2d(sd, p + ".proj_in_temporal_ca", _gn(sd, p + ".norm_temporal_ca", x, GN_EPS_ATTN))
+    tok = y.flatten(2).transpose(1, 2)                                   # (bt, hw, c)
+    anchor = tok.reshape(b, t, h * w, c)[:, t // 2].repeat_interleave(t, dim=0)
+    ctx = torch.cat([anchor, tok], dim=1)
+    tok = single_block(sd, p + ".transformer_blocks_temporal_ca.0", tok, ctx, heads)
+    y = _conv2d(sd, p + ".proj_out_temporal_ca", tok.transpose(1, 2).reshape(b * t, c, h, w)) + x
+    return y.reshape(b, t, c, h, w).permute(0, 2, 1, 3, 4).contiguous()
+
+
+def controlnet2d_img_forward(sd: SD, p: str, cfg: NetConfig, hint4, t, trace=None):
+    """ControlNet2D.forward of `controlnet_img` (controlmodel.py:252-317 with no_add_x=True,
+    set_input_hint_block_as_identity=True, disable_text_ca=True) on the 4-D reference latent `cond_feat`:
+    the noisy x is ignored, the first block's output IS input_blocks[0](hint)."""
+    emb = time_embed(sd, p + ".time_embed", t, cfg.model_channels)
+    inputs, _, _ = unet_topology(cfg)
+    heads = cfg.num_heads
+    outs = []
+    h = None
+    for i, spec in enumerate(inputs):
+        bp = f"{p}.input_blocks.{i}"
+        if spec.kind == "conv_in":
+            h = _conv2d(sd, bp + ".0", hint4, padding=1)
+        elif spec.kind == "res":
+            h = resblock2d(sd, bp + ".0", h, emb)
+            if spec.attn:
+                h = spatial_transformer2d_selfonly(sd, bp + ".1", h, heads)
+        else:
+            h = _conv2d(sd, bp + ".0.op", h, stride=2, padding=1)
+        outs.append(_conv2d(sd, f"{p}.zero_convs.{i}.0", h) * cfg.control_scales)
+    mp = p + ".middle_block"
+    h = resblock2d(sd, mp + ".0", h, emb)
+    h = spatial_transformer2d_selfonly(sd, mp + ".1", h, heads)
+    h = resblock2d(sd, mp + ".2", h, emb)
+    outs.append(_conv2d(sd, p + ".middle_block_out.0", h) * cfg.control_scales)
+    return outs
+
+
 # ----------------------------------------------------------------------------------------
 # ControlNet2D
 # ----------------------------------------------------------------------------------------
@@ -322,9 +378,21 @@ def controlnet2d_forward(sd: SD, p: str, cfg: NetConfig, x5, hint5, t, context, 
 # ----------------------------------------------------------------------------------------
 # pseudo-3D UNet
 # ----------------------------------------------------------------------------------------
-def unet3d_forward(sd: SD, p: str, cfg: NetConfig, x5, t, context, control: List[torch.Tensor], trace=None):
-    """ControlledUNetModel3DTV2V.forward (controlmodel.py:471-550), TV2V (no img_control)."""
+def unet3d_forward(sd: SD, p: str, cfg: NetConfig, x5, t, context, control: List[torch.Tensor], trace=None,
+                   img_control: Optional[List[torch.Tensor]] = None):
+    """ControlledUNetModel3DTV2V.forward (controlmodel.py:471-550).  img_control (TVI2V): 13 (B,C,h,w) residuals
+    added IN PLACE to the centre frame after every input block and after the middle block (:529-535)."""
     control = list(control)
+    img_control = None if img_control is None else list(img_control)
+    st3d = spatial_transformer3dca if cfg.crossframe else spatial_transformer3d
+
+    def add_center(hh):
+        if img_control is None:
+            return hh
+        hh = hh.clone()
+        hh[:, :, hh.shape[2] // 2] += img_control.pop(0)
+        return hh
+
     emb = time_embed(sd, p + ".time_embed", t, cfg.model_channels)
     inputs, _, outputs = unet_topology(cfg)
     heads = cfg.num_heads
@@ -338,17 +406,19 @@ def unet3d_forward(sd: SD, p: str, cfg: NetConfig, x5, t, context, control: List
         elif spec.kind == "res":
             h = resblock3d(sd, bp + ".0", h, emb)
             if spec.attn:
-                h = spatial_transformer3d(sd, bp + ".1", h, context, heads)
+                h = st3d(sd, bp + ".1", h, context, heads)
         else:   # Downsample3D (openaimodel.py:388-394)
             h = stf(h, lambda x: _conv2d(sd, bp + ".0.op", x, stride=2, padding=1),
                     lambda x: _conv1d(sd, bp + ".0.conv_temporal", x, padding=1))
+        h = add_center(h)
         hs.append(h)
         if trace is not None:
             trace[bp] = h
     mp = p + ".middle_block"
     h = resblock3d(sd, mp + ".0", h, emb)
-    h = spatial_transformer3d(sd, mp + ".1", h, context, heads)
+    h = st3d(sd, mp + ".1", h, context, heads)
     h = resblock3d(sd, mp + ".2", h, emb)
+    h = add_center(h)
     h = h + control.pop()
     if trace is not None:
         trace[mp] = h
@@ -358,7 +428,7 @@ def unet3d_forward(sd: SD, p: str, cfg: NetConfig, x5, t, context, control: List
         h = resblock3d(sd, bp + ".0", h, emb)
         j = 1
         if spec.attn:
-            h = spatial_transformer3d(sd, f"{bp}.{j}", h, context, heads)
+            h = st3d(sd, f"{bp}.{j}", h, context, heads)
             j += 1
         if spec.up:   # Upsample3D (openaimodel.py:254-263): nearest x(1,2,2) then conv3x3 + conv1d
             up = F.interpolate(h, scale_factor=(1, 2, 2), mode="nearest")
@@ -375,7 +445,10 @@ def network_forward(sd: SD, cfg: NetConfig, x5, t, c: Dict[str, torch.Tensor],
     """OpenAIWrapperControlLDM3DTV2V.forward (wrappers.py:156-207)."""
     hint = 1.0 - (c["control_hint"] + 1.0) / 2.0
     control = controlnet2d_forward(sd, p + ".controlnet", cfg, x5, hint, t, c["crossattn"], trace)
-    return unet3d_forward(sd, p, cfg, x5, t, c["crossattn"], control, trace)
+    img_control = None
+    if c.get("cond_feat") is not None:      # TVI2V: controlnet_img on the reference latent (wrappers.py:176-190)
+        img_control = controlnet2d_img_forward(sd, p + ".controlnet_img", cfg, c["cond_feat"], t, trace)
+    return unet3d_forward(sd, p, cfg, x5, t, c["crossattn"], control, trace, img_control)
 
 
 # ----------------------------------------------------------------------------------------

@@ -1,2 +1,2 @@
 from ccedit_amd.network import (BasicTransformerBlock, BasicTransformerSingleLayerBlock, CrossAttention,  # noqa: F401
-                                FeedForward, SpatialTransformer, SpatialTransformer3D)
+                                FeedForward, SpatialTransformer, SpatialTransformer3D, SpatialTransformer3DCA)

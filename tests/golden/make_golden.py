@@ -13,6 +13,8 @@ synthetic weights of ccedit_amd/utils/synth.py, runs them on CPU in fp32 and wri
   sampler_g160.npz    a 5-step DPMPP2SAncestral + CFG 7.5 trajectory with injected noise:
                       timestep-index trace, per-step latent digests, final latent
   vae_g32.npz         AutoencoderKL decode at a reduced ddconfig: latent in, frames digest out
+  net_tvi2v_g160.npz  one TVI2V network evaluation (controlnet_img on cond_feat + SpatialTransformer3DCA
+                      anchor cross-frame attention) + keys_tvi2v_g160.json (state-dict keys/shapes)
 
 A digest of a tensor = (shape, mean, std, abs-max, 256 evenly spaced samples) — enough to pin a
 restatement while keeping every fixture well under 1 MB.
@@ -68,11 +70,22 @@ def net_params(mc, heads, ctx):
                 controlnet_config=dict(target="sgm.modules.diffusionmodules.controlmodel.ControlNet2D", params=cn))
 
 
-def build_ref_network(mc, heads, ctx, device="cpu"):
+def tvi2v_params(mc, heads, ctx):
+    """network_config.params of keyframe_ref_cp_no2ndca_add_cfca_depthzoe.yaml:32-90 at reduced width."""
+    p = net_params(mc, heads, ctx)
+    cn = dict(p["controlnet_config"]["params"])
+    p.update(enable_attention3d_crossframe=True, ST3DCA_ca_type="center_self",
+             controlnet_img_config=dict(target="sgm.modules.diffusionmodules.controlmodel.ControlNet2D",
+                                        params=dict(cn, no_add_x=True, set_input_hint_block_as_identity=True,
+                                                    disable_text_ca=True)))
+    return p
+
+
+def build_ref_network(mc, heads, ctx, device="cpu", tvi2v=False):
     cm = _refshim.ref("sgm.modules.diffusionmodules.controlmodel")
     wr = _refshim.ref("sgm.modules.diffusionmodules.wrappers")
     with torch.device(device):
-        net = cm.ControlledUNetModel3DTV2V(**net_params(mc, heads, ctx))
+        net = cm.ControlledUNetModel3DTV2V(**(tvi2v_params if tvi2v else net_params)(mc, heads, ctx))
     return wr.OpenAIWrapperControlLDM3DTV2V(net)
 
 
@@ -187,6 +200,30 @@ def gen_net():
     return wrapper
 
 
+def gen_net_tvi2v():
+    """One TVI2V network evaluation (controlnet_img + anchor cross-frame attention) at the G160 width."""
+    mc, heads, ctx = G160["model_channels"], G160["num_heads"], G160["context_dim"]
+    S = G160_SHAPE
+    wrapper = build_ref_network(mc, heads, ctx, tvi2v=True).eval()
+    fill_module_(wrapper, prefix="model.")
+    x, cross_c, cross_uc, hint = synth_inputs(2468, S["B"], S["T"], S["H"], S["W"], S["L"], ctx)
+    g = torch.Generator().manual_seed(97)
+    cond_feat = torch.randn(S["B"], 4, S["H"], S["W"], generator=g) * 0.18215
+    x2 = torch.cat([x, x])
+    t = torch.tensor([401, 401], dtype=torch.int64)
+    c = dict(crossattn=torch.cat([cross_uc, cross_c]), control_hint=torch.cat([hint, hint]),
+             cond_feat=torch.cat([cond_feat, cond_feat]))
+    eps = wrapper(x2, t, c)
+    keys = {"model." + k: list(v.shape) for k, v in wrapper.state_dict().items()}
+    with open(os.path.join(HERE, "keys_tvi2v_g160.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    out = dict(x=x.numpy(), cross_c=cross_c.numpy(), cross_uc=cross_uc.numpy(), hint1=hint[:, :1].numpy(),
+               cond_feat=cond_feat.numpy(), t=t.numpy(), eps=eps.numpy())
+    np.savez_compressed(os.path.join(HERE, "net_tvi2v_g160.npz"), **out)
+    print("net_tvi2v_g160.npz eps", tuple(eps.shape), "rms", eps.pow(2).mean().sqrt().item(), "keys", len(keys),
+          "size", os.path.getsize(os.path.join(HERE, "net_tvi2v_g160.npz")))
+
+
 def gen_sampler(wrapper, den):
     sp = _refshim.ref("sgm.modules.diffusionmodules.sampling")
     mc, heads, ctx = G160["model_channels"], G160["num_heads"], G160["context_dim"]
@@ -256,3 +293,4 @@ if __name__ == "__main__":
     wrapper = gen_net()
     gen_sampler(wrapper, den)
     gen_vae()
+    gen_net_tvi2v()

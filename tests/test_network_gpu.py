@@ -183,3 +183,23 @@ def test_full_width_network_vs_oracle():
     r = _rel(eps, ref)
     print(f"full-width network eval rel rms err vs oracle: {r:.4f}")
     assert r < NET_TOL
+
+
+def test_tvi2v_network_eval_vs_reference_golden(golden_dir):
+    """BASELINE.json config 3 path: controlnet_img (cond_feat) + anchor cross-frame attention (two-segment KV)."""
+    _need_gpu()
+    from ccedit_amd.sgm_compat import build_network
+    from ccedit_amd.utils.synth import fill_module_
+    z = np.load(os.path.join(golden_dir, "net_tvi2v_g160.npz"))
+    w = build_network("cpu", crossframe=True, **G160)
+    fill_module_(w, prefix="model.")
+    w.diffusion_model.pack("cuda")
+    x = torch.from_numpy(z["x"])
+    hint = torch.from_numpy(z["hint1"]).repeat(1, 3, 1, 1, 1)
+    cf = torch.from_numpy(z["cond_feat"])
+    c = dict(crossattn=torch.cat([torch.from_numpy(z["cross_uc"]), torch.from_numpy(z["cross_c"])]).cuda(),
+             control_hint=torch.cat([hint, hint]).cuda(), cond_feat=torch.cat([cf, cf]).cuda())
+    eps = w(torch.cat([x, x]).cuda(), torch.from_numpy(z["t"]).cuda(), c)
+    r = _rel(eps, torch.from_numpy(z["eps"]))
+    print(f"TVI2V network eval rel rms err vs reference golden: {r:.4f}")
+    assert torch.isfinite(eps).all() and r < NET_TOL

@@ -327,3 +327,21 @@ def test_layout_and_elementwise():
     _close(den, du + 7.5 * (dc - du), rel=1e-6, abs_=1e-5, what="cfg_denoise")
     z = torch.randn(1000)
     _close(ops.axpby(x32.cuda(), z.cuda(), 0.3, -1.7), 0.3 * x32 - 1.7 * z, rel=1e-6, abs_=1e-5, what="axpby")
+
+
+def test_attention_anchor_segment():
+    """Two-segment keys of SpatialTransformer3DCA: [tokens of the clip's centre frame ; own tokens]."""
+    _dev()
+    from ccedit_amd import ops
+    heads, d, t, clips, hw = 4, 40, 3, 2, 96        # hw = 96: the segment boundary is not a multiple of the KV tile
+    c = heads * d
+    n = clips * t
+    q = _rnd(n, hw, c, seed=1)
+    kv = _rnd(n, hw, 2 * c, seed=2)
+    kvd = kv.reshape(-1, 2 * c).to(BF).cuda()
+    o = ops.attention(q.reshape(-1, c).to(BF).cuda(), kvd[:, :c], kvd[:, c:], heads, d, batches=n, lq=hw, lk=2 * hw,
+                      kv_outer_rows=hw, seg1_len=hw, seg1_div=t, seg1_mul=t, seg1_add=t // 2)
+    anchor = kv.reshape(clips, t, hw, 2 * c)[:, t // 2].repeat_interleave(t, 0)
+    ctx = torch.cat([anchor, kv], dim=1)
+    _close(o.reshape(n, hw, c), _sdpa_ref(q, ctx[..., :c], ctx[..., c:], heads), rel=2.0 ** -6, abs_=4e-3,
+           what="anchor + self attention")

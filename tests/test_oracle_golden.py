@@ -134,3 +134,25 @@ def test_vae_decode_matches_reference(golden_dir):
     ref = torch.from_numpy(z["dec"])
     rel = (dec - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()
     assert rel < 1e-4, f"vae decode rel rms err {rel}"
+
+
+def test_tvi2v_network_eval_matches_reference(golden_dir):
+    """TVI2V branch (BASELINE.json config 3): controlnet_img on `cond_feat` + SpatialTransformer3DCA
+    anchor cross-frame attention, against the reference's own output."""
+    from ccedit_amd.sgm_compat import build_network_spec
+    z = np.load(os.path.join(golden_dir, "net_tvi2v_g160.npz"))
+    cfg = O.NetConfig(model_channels=160, num_heads=4, context_dim=128, crossframe=True)
+    spec = build_network_spec(dict(model_channels=160, num_heads=4, context_dim=128, crossframe=True))
+    with open(os.path.join(golden_dir, "keys_tvi2v_g160.json")) as f:
+        ref_keys = json.load(f)
+    assert {k: list(s) for k, s in spec} == ref_keys                  # 2129 tensors, reference names and shapes
+    sd = synth_state_dict(spec)
+    x = torch.from_numpy(z["x"])
+    hint = torch.from_numpy(z["hint1"]).repeat(1, 3, 1, 1, 1)
+    cf = torch.from_numpy(z["cond_feat"])
+    c = dict(crossattn=torch.cat([torch.from_numpy(z["cross_uc"]), torch.from_numpy(z["cross_c"])]),
+             control_hint=torch.cat([hint, hint]), cond_feat=torch.cat([cf, cf]))
+    eps = O.network_forward(sd, cfg, torch.cat([x, x]), torch.from_numpy(z["t"]), c)
+    ref = torch.from_numpy(z["eps"])
+    rel = (eps - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()
+    assert rel < 1e-4, f"TVI2V eps rel rms err {rel}"
