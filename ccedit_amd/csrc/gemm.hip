@@ -34,7 +34,6 @@ namespace {
 
 __device__ __attribute__((aligned(64))) char g_zero_page[64];
 
-constexpr int kRowBytes = 128;   // 64 bf16 per tile row
 
 enum { M_LINEAR = 0, M_CONV = 1, M_TEMPORAL = 2, M_CONV_UP = 3 };
 
@@ -43,10 +42,14 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int TI, int TJ, int STAGES, int MODE>
+template <int WM, int WN, int TI, int TJ, int STAGES, int BKE, int MODE>
 __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc d) {
+    static_assert(BKE == 64 || BKE == 32, "K tile");
+    constexpr int kRowBytes = BKE * 2;       // one K tile row of one tile row in LDS (128 or 64 bytes)
+    constexpr int GPR = BKE / 8;             // 16-byte granules per tile row (8 or 4)
+    constexpr int KSTEPS = BKE / 16;         // MFMA k-steps per K tile
     constexpr int NT = WM * WN * 64;         // threads per block
-    constexpr int RPI = NT / 8;              // tile rows staged per issue (8 lanes x 16 B per 128-byte row)
+    constexpr int RPI = NT / GPR;            // tile rows staged per DMA issue (GPR lanes x 16 B per row)
     constexpr int BMC = WM * TI * 32;        // channels per block (each wave: TI x TJ MFMA tiles of 32 x 32)
     constexpr int BNP = WN * TJ * 32;        // pixels per block
     constexpr int A_ISSUES = BMC / RPI;
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
     constexpr int LPS = A_ISSUES + B_ISSUES; // DMA instructions per thread per stage
     constexpr int A_BYTES = BMC * kRowBytes;
     constexpr int B_BYTES = BNP * kRowBytes;
-    static_assert(RPI % 16 == 0 && BMC % RPI == 0 && BNP % RPI == 0, "tile / thread-count mismatch");
+    static_assert(RPI % 32 == 0 && BMC % RPI == 0 && BNP % RPI == 0, "tile / thread-count mismatch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sA = smem;                         // [STAGES][A_BYTES]
     char* const sB = smem + STAGES * A_BYTES;      // [STAGES][B_BYTES]
@@ -79,12 +82,15 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
     const int ch0 = (int)(local % ct_n) * BMC;
 
     // ---- staging coordinates: thread -> (row rsub + RPI*i, LDS slot p) ----
-    const int p = tid & 7;
-    const int rsub = tid >> 3;
-    const int gcol = p ^ ((rsub >> 1) & 7);    // source granule held in slot p of this row
+    // LDS slot p of row r holds source granule p ^ f(r): f(r) = (r>>1)&7 for 128-byte rows (2 rows per 256-byte
+    // bank row), (r>>2)&3 for 64-byte rows (4 rows per bank row) — both make the 16-lane ds_read_b128 groups of
+    // the 32x32x16 fragment pattern hit 16 distinct 16-byte slots.
+    const int p = tid & (GPR - 1);
+    const int rsub = tid / GPR;
+    const int gcol = p ^ (GPR == 8 ? ((rsub >> 1) & 7) : ((rsub >> 2) & 3));
     const int gpt = d.Cin >> 3;                // 16-byte granules per tap
     const int gtot = d.taps * gpt;
-    const int nk = d.Kpad / 64;
+    const int nk = d.Kpad / BKE;
 
     const bf16* __restrict__ Ap = (const bf16*)d.A;
     const bf16* __restrict__ A2p = (const bf16*)d.A2;
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
     // were fetched one K tile earlier (L2 resident) instead of lines last touched Cin/64 tiles ago.
     int s_tap = gcol / gpt;
     int s_cg = gcol - s_tap * gpt;
+    int s_half = 0;                            // BKE == 32: which half of the 64-channel chunk (korder 1)
     if (d.korder) {
         s_tap = 0;
         s_cg = gcol;
@@ -132,11 +139,11 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
         // weights: always in range (rows and K are zero-padded by the packer)
 #pragma unroll
         for (int i = 0; i < A_ISSUES; ++i) {
-            const bf16* src = Wp + (size_t)(ch0 + i * RPI + rsub) * d.Kpad + kt * 64 + gcol * 8;
+            const bf16* src = Wp + (size_t)(ch0 + i * RPI + rsub) * d.Kpad + kt * BKE + gcol * 8;
             glds16(src, sA + buf * A_BYTES + i * (RPI * kRowBytes) + wave * 1024);
         }
         // activations: gather (branch-free address select)
-        const bool kvalid = d.korder ? true : (kt * 8 + gcol) < gtot;
+        const bool kvalid = d.korder ? true : (kt * GPR + gcol) < gtot;
         const int c0 = s_cg * 8;
         const bool second = c0 >= d.Cin1;
         const bf16* sp = second ? A2p : Ap;
@@ -174,14 +181,23 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
             src = (v & kvalid) ? src : zp;
             glds16(src, sB + buf * B_BYTES + i * (RPI * kRowBytes) + wave * 1024);
         }
-        // advance to the next K tile (+8 granules)
+        // advance to the next K tile (+GPR granules)
         if (d.korder) {
-            if (++s_tap == d.taps) {
-                s_tap = 0;
-                s_cg += 8;
+            if (GPR == 4 && s_half == 0) {         // second 32-channel half of the same (chunk, tap)
+                s_half = 1;
+                s_cg += 4;
+            } else {
+                if (GPR == 4) {
+                    s_half = 0;
+                    s_cg -= 4;
+                }
+                if (++s_tap == d.taps) {
+                    s_tap = 0;
+                    s_cg += 8;
+                }
             }
         } else {
-            s_cg += 8;
+            s_cg += GPR;
             while (s_cg >= gpt) {
                 s_cg -= gpt;
                 ++s_tap;
@@ -192,7 +208,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
     // ---- fragment read coordinates ----
     const int l31 = lane & 31;
     const int hi = lane >> 5;
-    const int sw = (l31 >> 1) & 7;
+    const int sw = GPR == 8 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
     const char* fa = sA + (wm * TI * 32 + l31) * kRowBytes;
     const char* fb = sB + (wn * TJ * 32 + l31) * kRowBytes;
 
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
         // (Measured alternative: issuing all 16 reads of the K tile up front behind a sched_barrier lifts the
         // DMA-free ceiling 877 -> 922 TF/s but costs 46 VGPRs and is 5 % SLOWER in the network: 160 vs 152 ms/step.)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KSTEPS; ++ks) {
             const int off = ((ks * 2 + hi) ^ sw) << 4;
             bf16x8 af[TI], bfr[TJ];
 #pragma unroll
@@ -242,24 +258,27 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
         }
         compute(cur);
     } else {
-        // 3-deep ring, one workgroup per CU: tiles t+1 and t+2 are in flight while tile t is consumed.  The DMA
-        // queue is drained only down to the newest stage (counted vmcnt), and the barrier is a bare s_barrier so
-        // the loads stay in flight across it.
-        static_assert(STAGES == 3, "ring depth");
-        stage(0, 0);
-        if (nk > 1) stage(1, 1);
+        // STAGES-deep ring, one workgroup per CU: tiles t+1 .. t+STAGES-1 are in flight while tile t is consumed.
+        // The DMA queue is drained only down to the newer stages (counted vmcnt) and the barrier is a bare
+        // s_barrier, so the loads stay in flight across it.
+        static_assert(STAGES == 3 || STAGES == 4, "ring depth");
+#pragma unroll
+        for (int st = 0; st < STAGES - 1; ++st)
+            if (st < nk) stage(st, st);
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) wait_vmcnt<LPS>();
+            const int newer = nk - 1 - kt;         // stages issued after tile kt that may stay in flight
+            if (newer >= STAGES - 2) wait_vmcnt<LPS*(STAGES - 2)>();
+            else if (newer == 1) wait_vmcnt<LPS>();
             else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();          // tile kt landed for every wave; buffer (kt+2)%3 is free again
-            if (kt + 2 < nk) {
-                int nb = cur + 2;
-                if (nb >= 3) nb -= 3;
-                stage(kt + 2, nb);
+            __builtin_amdgcn_s_barrier();          // tile kt landed for every wave; the oldest buffer is free again
+            if (kt + STAGES - 1 < nk) {
+                int nb = cur + STAGES - 1;
+                if (nb >= STAGES) nb -= STAGES;
+                stage(kt + STAGES - 1, nb);
             }
             compute(cur);
-            if (++cur == 3) cur = 0;
+            if (++cur == STAGES) cur = 0;
         }
     }
 
@@ -394,16 +413,16 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
   }   // epilogue chunks
 }
 
-template <int WM, int WN, int TI, int TJ, int STAGES, int MODE>
+template <int WM, int WN, int TI, int TJ, int STAGES, int BKE, int MODE>
 int launch(const CcGemmDesc& d, hipStream_t s) {
     constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
-    constexpr int lds_main = STAGES * (BMC + BNP) * kRowBytes;
+    constexpr int lds_main = STAGES * (BMC + BNP) * BKE * 2;
     constexpr int full_epi = BNP * (BMC * 4 + 16);
     constexpr int lds = (full_epi > lds_main && full_epi <= 70 * 1024) ? full_epi : lds_main;   // == LDS_TOTAL in the kernel
     static_assert(lds >= (TJ * 32) * (BMC * 4 + 16), "at least one wave column per epilogue chunk");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)tap_gemm_kernel<WM, WN, TI, TJ, STAGES, MODE>,
+        hipError_t e = hipFuncSetAttribute((const void*)tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             cc_set_error("hipFuncSetAttribute(tap_gemm): %s", hipGetErrorString(e));
@@ -418,17 +437,19 @@ int launch(const CcGemmDesc& d, hipStream_t s) {
         return CCEDIT_EUNSUPPORTED;
     }
     dim3 grid((unsigned)nblk);
-    hipLaunchKernelGGL((tap_gemm_kernel<WM, WN, TI, TJ, STAGES, MODE>), grid, dim3(WM * WN * 64), lds, s, d);
+    hipLaunchKernelGGL((tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>), grid, dim3(WM * WN * 64), lds, s, d);
     return cc_launch_status("tap_gemm_kernel");
 }
 
 template <int MODE>
 int launch_tile(const CcGemmDesc& d, int tile, hipStream_t s) {
-    if (tile == 5) return launch<2, 4, 2, 4, 2, MODE>(d, s);      // 128ch x 512pix, 8 waves of 64ch x 128pix
-    if (tile == 4) return launch<2, 4, 4, 2, 2, MODE>(d, s);      // 256ch x 256pix, 8 waves of 128ch x 64pix
-    if (tile == 3) return launch<2, 4, 2, 2, 3, MODE>(d, s);
-    if (tile == 2) return launch<1, 4, 2, 2, 2, MODE>(d, s);
-    return launch<2, 2, 2, 2, 2, MODE>(d, s);
+    if (tile == 7) return launch<2, 4, 2, 4, 2, 64, MODE>(d, s);  // 128ch x 512pix, 2 stages of K=64
+    if (tile == 6) return launch<2, 4, 4, 2, 2, 64, MODE>(d, s);  // 256ch x 256pix, 2 stages of K=64
+    if (tile == 5) return launch<2, 4, 2, 4, 4, 32, MODE>(d, s);  // 128ch x 512pix, 8 waves of 64ch x 128pix, 4 stages of K=32
+    if (tile == 4) return launch<2, 4, 4, 2, 4, 32, MODE>(d, s);  // 256ch x 256pix, 8 waves of 128ch x 64pix, 4 stages of K=32
+    if (tile == 3) return launch<2, 4, 2, 2, 3, 64, MODE>(d, s);
+    if (tile == 2) return launch<1, 4, 2, 2, 2, 64, MODE>(d, s);
+    return launch<2, 2, 2, 2, 2, 64, MODE>(d, s);
 }
 
 }  // namespace
@@ -472,7 +493,8 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     if (tile == 0) {
         // Chosen from IN-NETWORK timings (bench.py --breakdown), where operands arrive cold from HBM; the isolated
         // sweep (tools/tile_sweep.py, operands hot in the 256 MB Infinity Cache) over-rates the wide 8-wave shapes
-        // (t4 = 256ch x 256pix, t5 = 128ch x 512pix: up to 1064 TF/s isolated, but slower than t1/t2 in the network):
+        // (t4/t6 = 256ch x 256pix, t5/t7 = 128ch x 512pix, 2-stage K=64 or 4-stage K=32 rings: up to 1064 TF/s isolated,
+        // but every policy that routes network layers to them measured 1-6 % slower per step than this one):
         //   Cout multiple of 64 but not 128 (320, 960): 64ch x 256pix (t2) for gathers and short K, else 128x128 (t1)
         //   very large M with Cout % 128 == 0 and long K: 128ch x 256pix 3-stage (t3)
         //   everything else: 128ch x 128pix, two workgroups per CU (t1)
