@@ -91,8 +91,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clip", action="store_true", help="also time one full 30-step clip + VAE decode (frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-frames", action="store_true",
+                    help="N>1: BASELINE.json config 4 — ONE clip, its T=17 keyframes sharded over the ranks (halo p2p, "
+                         "statistics all-reduce, RCCL all-gather of K/V at temporal attention); default N>1 mode is "
+                         "config 5 (one clip per GPU, no collective)")
     ap.add_argument("--workload", choices=["tv2v", "tvi2v"], default="tv2v",
                     help="tv2v = BASELINE.json config 2 (the headline metric); tvi2v = config 3 (ref-frame cfca network)")
+    ap.add_argument("--no-profile-step", action="store_true", help="skip the extra HIP-event profiled step (PMC runs)")
+    ap.add_argument("--dump-shapes", type=str, default="", help="write the GEMM launch shape sequence of one step (json)")
     ap.add_argument("--breakdown", action="store_true", help="print per-shape GEMM / attention time of one step to stderr")
     args = ap.parse_args()
 
@@ -116,7 +122,11 @@ def main():
     tvi2v = args.workload == "tvi2v"
     flop_per_step = FLOP_PER_STEP_TVI2V if tvi2v else FLOP_PER_STEP
     wrapper = build_model(device, tvi2v)
-    x, cross_c, cross_uc, hint = synth_inputs(device, seed=42 + rank)
+    shard = args.shard_frames and world > 1
+    x, cross_c, cross_uc, hint = synth_inputs(device, seed=42 + (0 if shard else rank))
+    if shard:
+        from ccedit_amd.parallel import FrameShard
+        wrapper.frame_shard = FrameShard(T)
     x2 = torch.cat([x, x]).contiguous()             # CFG-doubled batch, uc first (guiders.py:63)
     cond = dict(crossattn=torch.cat([cross_uc, cross_c]).contiguous(), control_hint=torch.cat([hint, hint]).contiguous())
     if tvi2v:
@@ -147,12 +157,19 @@ def main():
         dt = float(tt.item())
     assert torch.isfinite(out).all()
     ms_per_step = dt / args.steps * 1e3
-    value = world * args.steps / dt
+    value = (1 if shard else world) * args.steps / dt
 
     # ---- roofline of the dominant kernel family, measured live with HIP events (one extra step) ----
     roof = None
     extra = {}
-    if rank == 0:
+    if rank == 0 and args.dump_shapes:
+        ops.PROFILE = ops.LaunchProfile()
+        step()
+        torch.cuda.synchronize()
+        with open(args.dump_shapes, "w") as f:
+            json.dump([list(map(str, r[4])) + [r[2]] for r in ops.PROFILE.records["tap_gemm"]], f)
+        ops.PROFILE = None
+    if rank == 0 and not args.no_profile_step:
         ops.PROFILE = ops.LaunchProfile()
         step()
         prof = ops.PROFILE.summary()
@@ -186,7 +203,8 @@ def main():
         line = {
             "metric": "UNet denoising steps/s (TV2V 17x512x768, bf16, CFG-doubled batch)", "value": round(value, 4),
             "unit": "UNet steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if shard else "weak",
+            "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (seeded latent/context/depth hint; name-keyed random-init weights)",
             "config": {"workload": ("TVI2V ref-frame (cfca) + depth, 17x512x768, one network evaluation = ControlNet2D + controlnet_img + "
                                     "pseudo-3D UNet with anchor cross-frame attention on B=2 x T=17 frames; 110.31 TFLOP/step"
@@ -194,7 +212,9 @@ def main():
                                     "TV2V depth-midas, 17x512x768, one network evaluation = ControlNet2D + pseudo-3D UNet on "
                                     "B=2 (cfg 7.5 uncond+cond) x T=17 frames, latent 64x96, 77x768 text context; "
                                     "77.68 TFLOP/step; a 30-step DPMPP2SAncestral clip = 59 such steps + VAE decode"),
-                       "parallelism": "1 clip per GPU (replicas, no collective)" if world > 1 else "single GPU",
+                       "parallelism": ("one clip, T=17 keyframes sharded over the ranks (halo p2p + stats all-reduce + K/V "
+                                       "all-gather)" if shard else
+                                       "1 clip per GPU (replicas, no collective)" if world > 1 else "single GPU"),
                        "hint_stem": "recomputed every step"},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -58,10 +58,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int head = blockIdx.y;
+    // XCD-aware 1-D block order (speed only): workgroup b runs on XCD b % 8, so all query tiles of one
+    // (batch, head) group are given to ONE XCD back to back — its K/V (0.98 MB at 6144 x 40) then stays in that
+    // XCD's 4 MB L2 instead of being fetched from HBM through all 8 L2s (measured: 9.6 GB fetched per launch).
     const int qtiles = (a.Lq + NW * 32 - 1) / (NW * 32);
-    const int batch = blockIdx.x / qtiles;
-    const int q0 = (blockIdx.x - batch * qtiles) * (NW * 32) + wave * 32;
+    const int xcd = blockIdx.x & 7;
+    const int local = blockIdx.x >> 3;
+    const int grp = (local / qtiles) * 8 + xcd;            // (batch, head) group
+    if (grp >= a.batches * a.heads) return;
+    const int batch = grp / a.heads;
+    const int head = grp - batch * a.heads;
+    const int q0 = (local % qtiles) * (NW * 32) + wave * 32;
 
     const bf16* zp = (const bf16*)g_attn_zero_page;
     const int64_t qbase = (int64_t)(batch / a.q_inner) * a.q_outer_rows + (int64_t)(batch % a.q_inner) * a.q_inner_rows;
@@ -327,7 +334,8 @@ int launch_attn(const CcAttnDesc& a, hipStream_t s) {
         attr_set = true;
     }
     const int64_t qtiles = (a.Lq + NW * 32 - 1) / (NW * 32);
-    dim3 grid((unsigned)(qtiles * a.batches), a.heads);
+    const int64_t groups = ((int64_t)a.batches * a.heads + 7) / 8 * 8;
+    dim3 grid((unsigned)(qtiles * groups));
     hipLaunchKernelGGL((attn_kernel<D, NW>), grid, dim3(NW * 64), lds, s, a);
     return cc_launch_status("attn_kernel");
 }
@@ -348,7 +356,7 @@ extern "C" int ccedit_attention(const CcAttnDesc* desc, void* stream) {
                  "ccedit_attention: bad sizes");
     CC_UNSUPPORTED(a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4, "ccedit_attention: row strides must be multiples of 8");
     CC_CHECK_ARG(a.seg1_len >= 0 && a.seg1_len <= a.Lk && (a.seg1_len == 0 || a.seg1_div > 0), "ccedit_attention: bad leading segment");
-    CC_UNSUPPORTED(a.heads > 65535 || (int64_t)a.batches * ((a.Lq + 31) / 32) > 2147483647LL, "ccedit_attention: grid too large");
+    CC_UNSUPPORTED(((int64_t)a.batches * a.heads + 8) * ((a.Lq + 31) / 32) > 2147483647LL, "ccedit_attention: grid too large");
     hipStream_t s = (hipStream_t)stream;
     switch (a.d) {
         case 8: return dispatch_nw<8>(a, s);

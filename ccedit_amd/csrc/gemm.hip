@@ -113,8 +113,9 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
             rrow[i] = (MODE == M_CONV) ? n * d.Hin * d.Win + ra[i] * d.Win + rb[i] : n * d.Hin * d.Win;
         } else if constexpr (MODE == M_TEMPORAL) {
             const int frame = (int)(m / d.HW);
-            rrow[i] = (int)m;
-            ra[i] = ok ? frame % d.T : -100000;
+            const int b = frame / d.T, tl = frame - b * d.T;
+            rrow[i] = (b * d.Tsrc + tl + d.tsrc_off) * d.HW + (int)(m - (int64_t)frame * d.HW);   // row in the (halo-extended) source
+            ra[i] = ok ? d.t0 + tl : -100000;                                                      // global keyframe index
             rb[i] = 0;
         } else {
             rrow[i] = (int)m;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
                 v = ((unsigned)iy < (unsigned)(2 * d.Hin)) & ((unsigned)ix < (unsigned)(2 * d.Win));
                 row = rrow[i] + (iy >> 1) * d.Win + (ix >> 1);
             } else if constexpr (MODE == M_TEMPORAL) {
-                v = (unsigned)(ra[i] + dy) < (unsigned)d.T;
+                v = (unsigned)(ra[i] + dy) < (unsigned)d.Tglob;
                 row = rrow[i] + delta;
             } else {
                 v = ra[i] >= 0;
@@ -480,6 +481,15 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     } else if (d.mode == CCEDIT_GEMM_TEMPORAL) {
         CC_CHECK_ARG(d.T > 0 && d.HW > 0 && d.M % ((int64_t)d.T * d.HW) == 0, "ccedit_gemm: bad temporal geometry");
         CC_CHECK_ARG(d.taps % 2 == 1, "ccedit_gemm: temporal taps must be odd");
+        if (d.Tsrc == 0) {          // unsharded clip
+            d.Tsrc = d.T;
+            d.tsrc_off = 0;
+            d.t0 = 0;
+            d.Tglob = d.T;
+        }
+        CC_CHECK_ARG(d.Tsrc >= d.T + d.tsrc_off && d.tsrc_off >= 0 && d.t0 >= 0 && d.t0 + d.T <= d.Tglob,
+                     "ccedit_gemm: bad frame-shard geometry");
+        CC_UNSUPPORTED((int64_t)(d.M / ((int64_t)d.T * d.HW)) * d.Tsrc * d.HW >= (1LL << 31), "ccedit_gemm: source too large");
     } else {
         CC_CHECK_ARG(d.mode == CCEDIT_GEMM_LINEAR && d.taps == 1, "ccedit_gemm: bad mode/taps");
     }

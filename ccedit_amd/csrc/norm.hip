@@ -221,6 +221,116 @@ __global__ __launch_bounds__(256) void gn_temporal_kernel(const bf16* __restrict
     }
 }
 
+// Two-phase form for frame-sharded clips: local partial statistics, (all-reduce by the caller), apply.
+__global__ __launch_bounds__(256) void gn_temporal_stats_kernel(const bf16* __restrict__ x, float* __restrict__ stats, int B,
+                                                                int T, int hw, int C) {
+    __shared__ float s_sum[4][32], s_sq[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wp = (int64_t)blockIdx.x * 4 + wave;
+    const bool active = wp < (int64_t)B * hw;
+    const int b = active ? (int)(wp / hw) : 0;
+    const int pix = active ? (int)(wp - (int64_t)b * hw) : 0;
+    const int G8 = C >> 3, cpg = C >> 5;
+    if (lane < 32) {
+        s_sum[wave][lane] = 0.f;
+        s_sq[wave][lane] = 0.f;
+    }
+    __syncthreads();
+    if (active) {
+        const size_t fstride = (size_t)hw * C;
+        const bf16* xb = x + ((size_t)b * T * hw + pix) * C;
+        float sum[kGtCols][8], sq[kGtCols][8];
+#pragma unroll
+        for (int k = 0; k < kGtCols; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum[k][e] = sq[k][e] = 0.f;
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int k = 0; k < kGtCols; ++k) {
+                const int gc = lane + 64 * k;
+                if (gc < G8) {
+                    const bf16x8 v = *(const bf16x8*)(xb + t * fstride + gc * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = bf2f(v[e]);
+                        sum[k][e] += f;
+                        sq[k][e] += f * f;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kGtCols; ++k) {
+            const int gc = lane + 64 * k;
+            if (gc < G8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int g = (gc * 8 + e) / cpg;
+                    atomicAdd(&s_sum[wave][g], sum[k][e]);
+                    atomicAdd(&s_sq[wave][g], sq[k][e]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (active && lane < 32) {
+        stats[(wp * 32 + lane) * 2 + 0] = s_sum[wave][lane];
+        stats[(wp * 32 + lane) * 2 + 1] = s_sq[wave][lane];
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_temporal_apply_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ stats, int B, int T, int hw, int C,
+                                                                float count, float eps, int silu, int dst_frames, int dst_off) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wp = (int64_t)blockIdx.x * 4 + wave;
+    if (wp >= (int64_t)B * hw) return;
+    const int b = (int)(wp / hw);
+    const int pix = (int)(wp - (int64_t)b * hw);
+    const int G8 = C >> 3, cpg = C >> 5;
+    const float inv_n = 1.0f / count;
+    float a[kGtCols][8], bb[kGtCols][8];
+#pragma unroll
+    for (int k = 0; k < kGtCols; ++k) {
+        const int gc = lane + 64 * k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[k][e] = 0.f;
+            bb[k][e] = 0.f;
+            if (gc < G8) {
+                const int c = gc * 8 + e;
+                const int g = c / cpg;
+                const float mean = stats[(wp * 32 + g) * 2] * inv_n;
+                const float var = fmaxf(stats[(wp * 32 + g) * 2 + 1] * inv_n - mean * mean, 0.f);
+                const float rstd = rsqrtf(var + eps);
+                a[k][e] = rstd * gamma[c];
+                bb[k][e] = beta[c] - mean * a[k][e];
+            }
+        }
+    }
+    const size_t fstride = (size_t)hw * C;
+    const bf16* xb = x + ((size_t)b * T * hw + pix) * C;
+    bf16* yb = y + (((size_t)b * dst_frames + dst_off) * hw + pix) * C;
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int k = 0; k < kGtCols; ++k) {
+            const int gc = lane + 64 * k;
+            if (gc < G8) {
+                const bf16x8 v = *(const bf16x8*)(xb + t * fstride + gc * 8);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = bf2f(v[e]) * a[k][e] + bb[k][e];
+                    if (silu) f = silu_f(f);
+                    o[e] = f2bf(f);
+                }
+                *(bf16x8*)(yb + t * fstride + gc * 8) = o;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // LayerNorm over C: one wave per row, two-pass in registers
 // ------------------------------------------------------------------------------------------
@@ -311,6 +421,29 @@ extern "C" int ccedit_groupnorm_temporal(const void* x, void* y, const float* ga
     hipLaunchKernelGGL(gn_temporal_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, gamma, beta,
                        B, T, hw, C, eps, silu);
     return cc_launch_status("groupnorm_temporal");
+}
+
+extern "C" int ccedit_groupnorm_temporal_stats(const void* x, float* stats, int32_t B, int32_t T, int32_t hw, int32_t C,
+                                               void* stream) {
+    CC_CHECK_ARG(x && stats && B > 0 && T > 0 && hw > 0 && C > 0, "ccedit_groupnorm_temporal_stats: bad args");
+    CC_UNSUPPORTED(C % 32 != 0 || C > kGtCols * 512, "ccedit_groupnorm_temporal_stats: C=%d", C);
+    const int64_t waves = (int64_t)B * hw;
+    hipLaunchKernelGGL(gn_temporal_stats_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, stats, B, T, hw, C);
+    return cc_launch_status("groupnorm_temporal_stats");
+}
+
+extern "C" int ccedit_groupnorm_temporal_apply(const void* x, void* y, const float* gamma, const float* beta,
+                                               const float* stats, int32_t B, int32_t T, int32_t hw, int32_t C, float count,
+                                               float eps, int32_t silu, int32_t dst_frames, int32_t dst_off, void* stream) {
+    CC_CHECK_ARG(x && y && gamma && beta && stats && B > 0 && T > 0 && hw > 0 && C > 0 && count > 0,
+                 "ccedit_groupnorm_temporal_apply: bad args");
+    CC_CHECK_ARG(dst_frames >= T + dst_off && dst_off >= 0, "ccedit_groupnorm_temporal_apply: bad destination geometry");
+    CC_UNSUPPORTED(C % 32 != 0 || C > kGtCols * 512, "ccedit_groupnorm_temporal_apply: C=%d", C);
+    const int64_t waves = (int64_t)B * hw;
+    hipLaunchKernelGGL(gn_temporal_apply_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, (bf16*)y, gamma, beta, stats, B, T, hw, C, count, eps, silu, dst_frames, dst_off);
+    return cc_launch_status("groupnorm_temporal_apply");
 }
 
 extern "C" int ccedit_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t C,

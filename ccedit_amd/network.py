@@ -34,10 +34,56 @@ GN_EPS_ATTN = 1e-6    # reference: Normalize()                               att
 
 
 class Geometry:
-    """Clip geometry travelling with the activations: B clips x T frames."""
+    """Clip geometry travelling with the activations: B clips x T frames.  With `shard` (parallel.FrameShard) the
+    activations hold only this rank's t = shard.t_local keyframes of every clip; temporal ops then exchange halos /
+    statistics / K-V rows with the other ranks (see temporal_gn / temporal_conv3 / run_temporal)."""
 
-    def __init__(self, b: int, t: int):
-        self.b, self.t = b, t
+    def __init__(self, b: int, t: int, shard=None):
+        self.b, self.t, self.shard = b, t, shard
+
+
+def temporal_gn(x, norm: "Norm", geo: Geometry, silu: bool, ext: bool = False):
+    """GroupNorm over (C/32 x T) per pixel (+SiLU).  ext=True (sharded only): return the halo-extended buffer
+    (B*(t+2), H, W, C) with the normalised local frames in the middle, ready for temporal_conv3."""
+    sh = geo.shard
+    if sh is None:
+        return ops.groupnorm_temporal(x, geo.b, geo.t, norm.g, norm.b, norm.eps, silu)
+    st = ops.groupnorm_temporal_stats(x, geo.b, geo.t)
+    sh.allreduce(st)                       # sum / sumsq over the ranks holding the other keyframes
+    if not ext:
+        return ops.groupnorm_temporal_apply(x, st, geo.b, geo.t, sh.t_glob, norm.g, norm.b, norm.eps, silu)
+    n, h, w, c = x.shape
+    buf = torch.empty((geo.b * (geo.t + 2), h, w, c), dtype=x.dtype, device=x.device)
+    ops.groupnorm_temporal_apply(x, st, geo.b, geo.t, sh.t_glob, norm.g, norm.b, norm.eps, silu, out=buf,
+                                 dst_frames=geo.t + 2, dst_off=1)
+    return buf
+
+
+def _fill_halos(buf, geo: Geometry):
+    """Exchange the boundary frames of a halo-extended buffer with the neighbour ranks (in place)."""
+    sh = geo.shard
+    v = buf.view(geo.b, geo.t + 2, *buf.shape[1:])
+    prev, nxt = sh.halo(v[:, 1].contiguous(), v[:, geo.t].contiguous())
+    if prev is not None:
+        v[:, 0].copy_(prev)
+    if nxt is not None:
+        v[:, geo.t + 1].copy_(nxt)
+    return buf
+
+
+def temporal_conv3(a, pw, geo: Geometry, a_is_ext: bool = False, **kw):
+    """Conv1d k=3 over T.  Sharded: `a` is (or is copied into) the halo-extended buffer, one frame is exchanged
+    with each neighbour rank, and the GEMM gathers through the extended source (zeros outside the clip)."""
+    sh = geo.shard
+    if sh is None:
+        return ops.conv_temporal(a, geo.t, pw, **kw)
+    if not a_is_ext:
+        n, h, w, c = a.shape
+        buf = torch.empty((geo.b * (geo.t + 2), h, w, c), dtype=a.dtype, device=a.device)
+        buf.view(geo.b, geo.t + 2, h, w, c)[:, 1:geo.t + 1].copy_(a.view(geo.b, geo.t, h, w, c))
+        a = buf
+    _fill_halos(a, geo)
+    return ops.conv_temporal_sharded(a, geo.b, geo.t, sh.t0, sh.t_glob, pw, **kw)
 
 
 def _seq(*mods) -> nn.Sequential:
@@ -145,10 +191,13 @@ class BasicTransformerSingleLayerBlock(nn.Module):
         n1 = ops.layernorm(tok, self.norm1.g, self.norm1.b)
         q = ops.linear(n1, a.to_q.pw)
         kv = ops.linear(tok, a.kv)
-        t = geo.t
-        o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=geo.b * hw, lq=t, lk=t,
+        t = tk = geo.t
+        if geo.shard is not None:      # all-gather the K/V rows of the other ranks' keyframes (RCCL over xGMI)
+            kv = geo.shard.gather_frames(kv.view(geo.b * t, hw, 2 * c), geo.b).view(-1, 2 * c)
+            tk = geo.shard.t_glob
+        o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=geo.b * hw, lq=t, lk=tk,
                           q_inner=hw, q_outer_rows=t * hw, q_inner_rows=1, q_seq_rows=hw,
-                          kv_inner=hw, kv_outer_rows=t * hw, kv_inner_rows=1, kv_seq_rows=hw)
+                          kv_inner=hw, kv_outer_rows=tk * hw, kv_inner_rows=1, kv_seq_rows=hw)
         tok = ops.linear(o, a.to_out[0].pw, res1=tok)
         n2 = ops.layernorm(tok, self.norm2.g, self.norm2.b)
         return self.ff.run(n2, tok)
@@ -203,8 +252,7 @@ class SpatialTransformer3D(SpatialTransformer):
     def run(self, x, geo, ctx2d, ctx_len):
         y = self.run_spatial(x, ctx2d, ctx_len, geo.t)
         n, h, w, c = y.shape
-        nt = self.norm_temporal
-        a = ops.groupnorm_temporal(y, geo.b, geo.t, nt.g, nt.b, nt.eps, False)
+        a = temporal_gn(y, self.norm_temporal, geo, False)
         tok = ops.linear(a.view(-1, c), self.proj_in_temporal.pw)
         tok = self.transformer_blocks_temporal[0].run_temporal(tok, geo, h * w)
         z = ops.linear(tok, self.proj_out_temporal.pw, res1=y.view(-1, c))
@@ -229,6 +277,8 @@ class SpatialTransformer3DCA(SpatialTransformer3D):
         self.proj_out_temporal_ca = Conv(inner, in_channels, 1)
 
     def run(self, x, geo, ctx2d, ctx_len):
+        if geo.shard is not None:
+            raise NotImplementedError("frame sharding of the TVI2V anchor attention (broadcast of the centre frame)")
         y = super().run(x, geo, ctx2d, ctx_len)
         n, h, w, c = y.shape
         nc = self.norm_temporal_ca
@@ -289,23 +339,23 @@ class ResBlock3D(nn.Module):
         a = ops.groupnorm_spatial(x, gn.g, gn.b, gn.eps, True)
         s = ops.conv2d(a, self.in_layers[2].pw)
         co = s.shape[-1]
-        gn = self.in_layers_temporal[0]
-        at = ops.groupnorm_temporal(s, geo.b, geo.t, gn.g, gn.b, gn.eps, True)
+        sharded = geo.shard is not None
+        at = temporal_gn(s, self.in_layers_temporal[0], geo, True, ext=sharded)
         e = ops.linear(emb_silu, self.emb_layers[1].pw, out_f32=True)
         # stf output (s + conv_t) and the `+ emb_out` of openaimodel.py:762 in one epilogue
-        hid = ops.conv_temporal(at, geo.t, self.in_layers_temporal[2].pw, res1=s.view(-1, co), group_bias=e,
-                                group_rows=geo.t * h * w)
+        hid = temporal_conv3(at, self.in_layers_temporal[2].pw, geo, a_is_ext=sharded, res1=s.view(-1, co), group_bias=e,
+                             group_rows=geo.t * h * w)
         gn = self.out_layers[0]
         a = ops.groupnorm_spatial(hid, gn.g, gn.b, gn.eps, True)
         s2 = ops.conv2d(a, self.out_layers[3].pw)
-        gn = self.out_layers_temporal[0]
-        at = ops.groupnorm_temporal(s2, geo.b, geo.t, gn.g, gn.b, gn.eps, True)
+        at = temporal_gn(s2, self.out_layers_temporal[0], geo, True, ext=sharded)
         if isinstance(self.skip_connection, Slot):
             skip = x
         else:
             k = ops.conv2d(x, self.skip_connection.pw)
             skip = ops.conv_temporal(k, geo.t, self.skip_connection_temporal.pw, res1=k.view(-1, co))
-        return ops.conv_temporal(at, geo.t, self.out_layers_temporal[3].pw, res1=s2.view(-1, co), res2=skip.view(-1, co))
+        return temporal_conv3(at, self.out_layers_temporal[3].pw, geo, a_is_ext=sharded, res1=s2.view(-1, co),
+                              res2=skip.view(-1, co))
 
 
 class Downsample(nn.Module):
@@ -329,7 +379,7 @@ class Downsample3D(nn.Module):
 
     def run(self, x, geo):
         s = ops.conv2d(x, self.op.pw, stride=2)
-        return ops.conv_temporal(s, geo.t, self.conv_temporal.pw, res1=s.view(-1, s.shape[-1]))
+        return temporal_conv3(s, self.conv_temporal.pw, geo, res1=s.view(-1, s.shape[-1]))
 
 
 class Upsample3D(nn.Module):
@@ -343,7 +393,7 @@ class Upsample3D(nn.Module):
 
     def run(self, x, geo):
         s = ops.conv2d(x, self.conv.pw, upsample=True)
-        return ops.conv_temporal(s, geo.t, self.conv_temporal.pw, res1=s.view(-1, s.shape[-1]))
+        return temporal_conv3(s, self.conv_temporal.pw, geo, res1=s.view(-1, s.shape[-1]))
 
 
 class TimestepEmbedSequential(nn.Sequential):
@@ -597,7 +647,7 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
         for i, block in enumerate(self.input_blocks):
             if i == 0:
                 s = ops.conv2d(h, block[0].pw)
-                h = ops.conv_temporal(s, geo.t, self.input_blocks_temporal[0].pw, res1=s.view(-1, s.shape[-1]))
+                h = temporal_conv3(s, self.input_blocks_temporal[0].pw, geo, res1=s.view(-1, s.shape[-1]))
             else:
                 h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
             hs.append(add_center(h))
@@ -614,7 +664,7 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
         s = torch.zeros((n * hh * ww, ocp), dtype=torch.bfloat16, device=a.device)
         ops.conv2d(a, self.out[2].pw, out=s[:, : self.out[2].pw.n])
         at = ops.silu(s)
-        eps = ops.conv_temporal(at.view(n, hh, ww, ocp), geo.t, self.out_temporal[1].pw, res1=s, out_f32=True)
+        eps = temporal_conv3(at.view(n, hh, ww, ocp), self.out_temporal[1].pw, geo, res1=s, out_f32=True)
         return eps
 
     def forward(self, x, timesteps=None, context=None, y=None, control=None, img_control=None, only_mid_control=False,
@@ -661,6 +711,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     cache_hint_stem = True
     _hint_key = None
     _hint_val = None
+    frame_shard = None          # parallel.FrameShard: split the T keyframes of each clip over the ranks (config 4)
 
     def _guided_hint(self, hint5d: torch.Tensor):
         net = self.diffusion_model.controlnet
@@ -679,11 +730,24 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             raise NotImplementedError("'concat' conditioning is not used by the TV2V configs")
         net = self.diffusion_model
         b, _, nt, _, _ = x.shape
-        geo = Geometry(b, nt)
+        sh = self.frame_shard
+        hint5 = c["control_hint"]
+        if sh is not None:             # keep this rank's keyframes of every clip; everything spatial is frame-local
+            if sh.t_glob != nt:
+                raise ValueError(f"frame shard built for T={sh.t_glob}, got T={nt}")
+            x = x[:, :, sh.t0:sh.t1]
+            hint5 = hint5[:, :, sh.t0:sh.t1]
+            if not hasattr(self, "_hint_slices"):
+                self._hint_slices = {}
+            hk = (c["control_hint"].data_ptr(), c["control_hint"]._version, sh.t0, sh.t1)
+            if hk not in self._hint_slices:          # a stable tensor object so the hint-stem cache can hit
+                self._hint_slices = {hk: hint5.contiguous()}
+            hint5 = self._hint_slices[hk]
+        geo = Geometry(b, x.shape[2], sh)
         context = c["crossattn"]
         ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
         x8 = ops.ncthw_to_nhwc(x.float().contiguous(), 8)
-        guided = self._guided_hint(c["control_hint"])
+        guided = self._guided_hint(hint5)
         control = net.controlnet.run(x8, guided, t, ctx2d, context.shape[1], geo)
         img_control = None
         cond_feat = c.get("cond_feat", None)
@@ -691,4 +755,6 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             cf8 = ops.ncthw_to_nhwc(cond_feat.float()[:, :, None].contiguous(), 8)
             img_control = net.controlnet_img.run(None, cf8, t, None, 0, Geometry(b, 1))
         eps = net.run(x8, t, ctx2d, context.shape[1], control, geo, img_control)
+        if sh is not None:             # all ranks get the full (B, C, T, h, w) prediction (1.6 MB at 17x64x96)
+            eps = sh.gather_frames(eps, b)
         return ops.nhwc_to_ncthw(eps, b, nt, net.out_channels)

@@ -66,7 +66,8 @@ def _chk_act(t: torch.Tensor, name: str):
 
 def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Optional[int] = None,
          hin: int = 0, win: int = 0, hout: int = 0, wout: int = 0, stride: int = 1, pad: int = 0, upsample: bool = False,
-         t: int = 0, hw: int = 0, a2: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+         t: int = 0, hw: int = 0, tsrc: int = 0, tsrc_off: int = 0, t0: int = 0, tglob: int = 0,
+         a2: Optional[torch.Tensor] = None, act: int = ACT_NONE,
          group_bias: Optional[torch.Tensor] = None, group_rows: int = 0,
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, out_f32: bool = False, use_bias: bool = True, tile: int = 0) -> torch.Tensor:
@@ -88,6 +89,7 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
     d.Hin, d.Win, d.Hout, d.Wout = hin, win, hout, wout
     d.stride, d.pad, d.ksize, d.upsample = stride, pad, pw.ksize, int(upsample)
     d.T, d.HW = t, hw
+    d.Tsrc, d.tsrc_off, d.t0, d.Tglob = tsrc, tsrc_off, t0, tglob
     d.lda, d.lda2, d.ldc, d.Kpad = lda, (a2.stride(0) if a2 is not None else 0), out.stride(0), pw.kpad
     d.act = ACT_GEGLU if pw.geglu else act
     d.out_f32 = int(out.dtype == torch.float32)
@@ -142,6 +144,17 @@ def conv_temporal(x: torch.Tensor, t: int, pw: PackedWeight, **kw) -> torch.Tens
     return out.view(n, h, w, out.shape[-1])
 
 
+def conv_temporal_sharded(x_ext: torch.Tensor, b: int, t_local: int, t0: int, t_glob: int, pw: PackedWeight, **kw) -> torch.Tensor:
+    """Conv1d (k3) over T for a frame shard.  x_ext: (B*(t_local+2), H, W, C) = per clip [halo from the previous
+    rank | t_local local frames | halo from the next rank] (halo contents are ignored where they fall outside the
+    clip); local frame 0 is global keyframe t0 of t_glob.  Returns (B*t_local, H, W, Cout)."""
+    n, h, w, c = x_ext.shape
+    assert n == b * (t_local + 2) and pw.taps == 3
+    out = gemm(x_ext.reshape(-1, c), pw, mode=GEMM_TEMPORAL, m=b * t_local * h * w, t=t_local, hw=h * w,
+               tsrc=t_local + 2, tsrc_off=1, t0=t0, tglob=t_glob, **kw)
+    return out.view(b * t_local, h, w, out.shape[-1])
+
+
 # ------------------------------------------------------------------------------------------
 _ws_cache = {}
 
@@ -172,6 +185,32 @@ def groupnorm_temporal(x: torch.Tensor, b: int, t: int, gamma, beta, eps: float,
     y = torch.empty_like(x)
     hip.check(hip.lib().ccedit_groupnorm_temporal(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                   b, t, h * w, c, eps, int(silu), _stream()), "ccedit_groupnorm_temporal")
+    return y
+
+
+def groupnorm_temporal_stats(x: torch.Tensor, b: int, t: int) -> torch.Tensor:
+    """Partial (sum, sumsq) per (clip, pixel, group) over the local frames: fp32 (b*hw, 32, 2)."""
+    _chk_act(x, "groupnorm_temporal_stats")
+    n, h, w, c = x.shape
+    assert n == b * t
+    st = torch.empty((b * h * w, 32, 2), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().ccedit_groupnorm_temporal_stats(x.data_ptr(), st.data_ptr(), b, t, h * w, c, _stream()),
+              "ccedit_groupnorm_temporal_stats")
+    return st
+
+
+def groupnorm_temporal_apply(x: torch.Tensor, stats: torch.Tensor, b: int, t: int, t_glob: int, gamma, beta, eps: float,
+                             silu: bool, out: Optional[torch.Tensor] = None, dst_frames: int = 0, dst_off: int = 0):
+    """Apply with (all-reduced) statistics over t_glob frames; optionally write into a halo-extended buffer."""
+    _chk_act(x, "groupnorm_temporal_apply")
+    n, h, w, c = x.shape
+    y = torch.empty_like(x) if out is None else out
+    if dst_frames == 0:
+        dst_frames, dst_off = t, 0
+    hip.check(hip.lib().ccedit_groupnorm_temporal_apply(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                        stats.data_ptr(), b, t, h * w, c, float((c // 32) * t_glob), eps,
+                                                        int(silu), dst_frames, dst_off, _stream()),
+              "ccedit_groupnorm_temporal_apply")
     return y
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCEDIT_ABI_VERSION 1
+#define CCEDIT_ABI_VERSION 2
 
 #define CCEDIT_OK 0
 #define CCEDIT_EINVAL (-1)       /* null pointer / bad size */
@@ -84,6 +84,10 @@ typedef struct CcGemmDesc {
     int32_t tile;         /* 0 = auto, 1 = 128ch x 128pix, 2 = 64ch x 256pix */
     int32_t korder;       /* weight K order: 0 = [tap][Cin]; 1 = [Cin/64][tap][64] (needs Cin % 64 == 0) */
     int32_t reserved0;
+    /* TEMPORAL with the T keyframes of a clip sharded over ranks (0 = unsharded): the source holds Tsrc frames
+     * per clip — tsrc_off halo frames received from the previous rank, the T local frames, then the next rank's —
+     * and local frame 0 is global keyframe t0 of Tglob; taps outside [0, Tglob) read zeros (Conv1d padding). */
+    int32_t Tsrc, tsrc_off, t0, Tglob;
     const void* A;        /* bf16 [rows][lda] */
     const void* A2;       /* optional second source */
     const void* W;        /* bf16 [ceil(N,256)][Kpad] (rows zero-padded to the widest block shape) */
@@ -111,6 +115,16 @@ int ccedit_groupnorm_spatial(const void* x, void* y, const float* gamma, const f
 int ccedit_groupnorm_temporal(const void* x, void* y, const float* gamma, const float* beta,
                               int32_t B, int32_t T, int32_t hw, int32_t C, float eps, int32_t silu,
                               void* stream);
+/* The same normalisation in two phases for frame-sharded clips: per-(clip, pixel, group) partial sum / sum-of-
+ * squares over the LOCAL frames (stats: float[B*hw*32*2], fully overwritten), all-reduced by the caller across the
+ * ranks that hold the other frames, then applied with count = (C/32) * T_global.  The output may be written into
+ * a halo-extended buffer: frame t of clip b goes to frame index b*dst_frames + t + dst_off. */
+int ccedit_groupnorm_temporal_stats(const void* x, float* stats, int32_t B, int32_t T, int32_t hw, int32_t C,
+                                    void* stream);
+int ccedit_groupnorm_temporal_apply(const void* x, void* y, const float* gamma, const float* beta,
+                                    const float* stats, int32_t B, int32_t T, int32_t hw, int32_t C,
+                                    float count, float eps, int32_t silu, int32_t dst_frames, int32_t dst_off,
+                                    void* stream);
 /* LayerNorm over C (eps 1e-5) — attention.py:667-669, 755-756. x,y: [rows][C] */
 int ccedit_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows,
                      int32_t C, float eps, void* stream);

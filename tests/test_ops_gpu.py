@@ -345,3 +345,48 @@ def test_attention_anchor_segment():
     ctx = torch.cat([anchor, kv], dim=1)
     _close(o.reshape(n, hw, c), _sdpa_ref(q, ctx[..., :c], ctx[..., c:], heads), rel=2.0 ** -6, abs_=4e-3,
            what="anchor + self attention")
+
+
+def test_temporal_ops_frame_sharded_equal_unsharded():
+    """The frame-shard forms (halo-extended temporal conv, two-phase temporal GroupNorm) reproduce the unsharded
+    kernels when the shards are stitched by hand (no communication involved)."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    b, t, c, h, w = 2, 5, 64, 4, 6
+    bounds = [(0, 2), (2, 3), (3, 5)]
+    x = _rnd(b * t, c, h, w, seed=1)
+    xn = _nhwc(x)                                                   # (b*t, h, w, c)
+    g, be = (_rnd(c, seed=2) * 0.1 + 1).cuda(), (_rnd(c, seed=3) * 0.1).cuda()
+    wt, bt = _rnd(c, c, 3, seed=4, scale=(3 * c) ** -0.5), _rnd(c, seed=5)
+    pw = pack_weight(wt, bt).to("cuda")
+    res = _nhwc(_rnd(b * t, c, h, w, seed=6))
+    ref_gn = ops.groupnorm_temporal(xn, b, t, g, be, 1e-5, True)
+    ref_cv = ops.conv_temporal(ref_gn, t, pw, res1=res.view(-1, c))
+    x5 = xn.view(b, t, h, w, c)
+    # two-phase GN: partial stats per shard, summed ("all-reduce"), applied per shard
+    stats = sum(ops.groupnorm_temporal_stats(x5[:, lo:hi].contiguous().view(-1, h, w, c), b, hi - lo) for lo, hi in bounds)
+    gn_parts = [ops.groupnorm_temporal_apply(x5[:, lo:hi].contiguous().view(-1, h, w, c), stats, b, hi - lo, t, g, be, 1e-5, True)
+                for lo, hi in bounds]
+    gn_full = torch.cat([p.view(b, -1, h, w, c) for p in gn_parts], dim=1)
+    _close(gn_full.reshape(b * t, h, w, c), ref_gn, rel=2.0 ** -8, abs_=1e-3, what="two-phase temporal GroupNorm")
+    # halo-extended conv per shard
+    outs = []
+    r5 = res.view(b, t, h, w, c)
+    for lo, hi in bounds:
+        tl = hi - lo
+        ext = torch.full((b, tl + 2, h, w, c), 7.0, dtype=BF, device="cuda")          # poison: must be ignored at clip ends
+        ext[:, 1:tl + 1] = gn_full[:, lo:hi]
+        if lo > 0:
+            ext[:, 0] = gn_full[:, lo - 1]
+        if hi < t:
+            ext[:, tl + 1] = gn_full[:, hi]
+        o = ops.conv_temporal_sharded(ext.view(-1, h, w, c), b, tl, lo, t, pw, res1=r5[:, lo:hi].contiguous().view(-1, c))
+        outs.append(o.view(b, tl, h, w, c))
+    _close(torch.cat(outs, dim=1).reshape(b * t, h, w, c), ref_cv, rel=2.0 ** -8, abs_=1e-3, what="halo-extended temporal conv")
+    # GN apply writing straight into the halo-extended buffer
+    lo, hi = bounds[0]
+    ext = torch.zeros((b * (hi - lo + 2), h, w, c), dtype=BF, device="cuda")
+    ops.groupnorm_temporal_apply(x5[:, lo:hi].contiguous().view(-1, h, w, c), stats, b, hi - lo, t, g, be, 1e-5, True, out=ext,
+                                 dst_frames=hi - lo + 2, dst_off=1)
+    _close(ext.view(b, hi - lo + 2, h, w, c)[:, 1:hi - lo + 1], gn_full[:, lo:hi], rel=0, abs_=0, what="GN apply into ext buffer")

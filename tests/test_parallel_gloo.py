@@ -63,3 +63,49 @@ def test_frame_shard_plan():
     assert sharding_efficiency(34, 8) == pytest.approx(0.85)
     assert sharding_efficiency(17, 8) == pytest.approx(17 / 24)
     assert sharding_efficiency(17, 2) == pytest.approx(17 / 18)
+
+
+def _shard_worker(rank, world, port, t_glob, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ccedit_amd.parallel import FrameShard
+    sh = FrameShard(t_glob)
+    b, hw, c = 2, 5, 4
+    # global tensor: value encodes (clip, frame); every rank holds its own keyframes of every clip
+    full = (torch.arange(b)[:, None] * 100 + torch.arange(t_glob)[None, :]).float()[:, :, None, None].expand(b, t_glob, hw, c)
+    local = full[:, sh.t0:sh.t1].contiguous()
+    prev, nxt = sh.halo(local[:, 0].contiguous(), local[:, -1].contiguous())
+    ok = True
+    if sh.t0 > 0:
+        ok &= torch.equal(prev, full[:, sh.t0 - 1])
+    else:
+        ok &= prev is None
+    if sh.t1 < t_glob:
+        ok &= torch.equal(nxt, full[:, sh.t1])
+    else:
+        ok &= nxt is None
+    g = sh.gather_frames(local.reshape(b * sh.t_local, hw, c), b)
+    ok &= torch.equal(g.reshape(b, t_glob, hw, c), full)
+    st = local.sum(dim=1)                      # partial statistic over the local frames
+    sh.allreduce(st)
+    ok &= torch.allclose(st, full.sum(dim=1))
+    q.put((rank, bool(ok), sh.t0, sh.t1))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world,t_glob", [(2, 17), (3, 5)])
+def test_frame_shard_primitives_gloo(world, t_glob):
+    """halo exchange / statistics all-reduce / K-V all-gather of the frame-sharded mode, uneven shards included."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, t_glob, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert res[0][2] == 0 and res[-1][3] == t_glob and all(res[i][3] == res[i + 1][2] for i in range(world - 1))
