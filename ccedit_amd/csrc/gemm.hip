@@ -292,8 +292,9 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
     constexpr int LDS_MAIN = STAGES * (A_BYTES + B_BYTES);
     constexpr int FULL_EPI = BNP * EROW;
     // the 128x128 shape allocates 3.5 KB more than its operand ring so that the whole tile is staged at once
-    constexpr int LDS_TOTAL = (FULL_EPI > LDS_MAIN && FULL_EPI <= 70 * 1024) ? FULL_EPI : LDS_MAIN;
     constexpr int WPIX = TJ * 32;             // pixels per wave column
+    constexpr int ONE_COL = WPIX * EROW;      // the epilogue needs room for at least one wave column
+    constexpr int LDS_TOTAL = (FULL_EPI > LDS_MAIN && FULL_EPI <= 70 * 1024) ? FULL_EPI : (LDS_MAIN > ONE_COL ? LDS_MAIN : ONE_COL);
     constexpr int ECH = (LDS_TOTAL / EROW / WPIX) * WPIX < BNP ? (LDS_TOTAL / EROW / WPIX) * WPIX : BNP;   // pixels per chunk
     static_assert(ECH >= WPIX && BNP % ECH == 0, "epilogue chunking");
     char* const sE = smem;
@@ -419,8 +420,8 @@ int launch(const CcGemmDesc& d, hipStream_t s) {
     constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
     constexpr int lds_main = STAGES * (BMC + BNP) * BKE * 2;
     constexpr int full_epi = BNP * (BMC * 4 + 16);
-    constexpr int lds = (full_epi > lds_main && full_epi <= 70 * 1024) ? full_epi : lds_main;   // == LDS_TOTAL in the kernel
-    static_assert(lds >= (TJ * 32) * (BMC * 4 + 16), "at least one wave column per epilogue chunk");
+    constexpr int one_col = (TJ * 32) * (BMC * 4 + 16);
+    constexpr int lds = (full_epi > lds_main && full_epi <= 70 * 1024) ? full_epi : (lds_main > one_col ? lds_main : one_col);   // == LDS_TOTAL
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>,
@@ -444,8 +445,6 @@ int launch(const CcGemmDesc& d, hipStream_t s) {
 
 template <int MODE>
 int launch_tile(const CcGemmDesc& d, int tile, hipStream_t s) {
-    if (tile == 7) return launch<2, 4, 2, 4, 2, 64, MODE>(d, s);  // 128ch x 512pix, 2 stages of K=64
-    if (tile == 6) return launch<2, 4, 4, 2, 2, 64, MODE>(d, s);  // 256ch x 256pix, 2 stages of K=64
     if (tile == 5) return launch<2, 4, 2, 4, 4, 32, MODE>(d, s);  // 128ch x 512pix, 8 waves of 64ch x 128pix, 4 stages of K=32
     if (tile == 4) return launch<2, 4, 4, 2, 4, 32, MODE>(d, s);  // 256ch x 256pix, 8 waves of 128ch x 64pix, 4 stages of K=32
     if (tile == 3) return launch<2, 4, 2, 2, 3, 64, MODE>(d, s);
@@ -503,8 +502,9 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     if (tile == 0) {
         // Chosen from IN-NETWORK timings (bench.py --breakdown), where operands arrive cold from HBM; the isolated
         // sweep (tools/tile_sweep.py, operands hot in the 256 MB Infinity Cache) over-rates the wide 8-wave shapes
-        // (t4/t6 = 256ch x 256pix, t5/t7 = 128ch x 512pix, 2-stage K=64 or 4-stage K=32 rings: up to 1064 TF/s isolated,
-        // but every policy that routes network layers to them measured 1-6 % slower per step than this one):
+        // (t4 = 256ch x 256pix, t5 = 128ch x 512pix, 8 waves with 8 MFMA tiles each, 4-stage K=32 rings — also tried
+        // as 2-stage K=64 rings and as 4-wave / 2-workgroup-per-CU 128ch x 256pix shapes: up to 1064 TF/s isolated,
+        // but every policy that routes network layers to them measured 1-8 % slower per step than this one):
         //   Cout multiple of 64 but not 128 (320, 960): 64ch x 256pix (t2) for gathers and short K, else 128x128 (t1)
         //   very large M with Cout % 128 == 0 and long K: 128ch x 256pix 3-stage (t3)
         //   everything else: 128ch x 128pix, two workgroups per CU (t1)

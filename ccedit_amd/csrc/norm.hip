@@ -17,7 +17,7 @@ constexpr int kGnWaves = 4;
 constexpr int kGnPixPerBlock = 64;
 
 __global__ __launch_bounds__(256) void gn_spatial_stats_kernel(const bf16* __restrict__ x, float* __restrict__ stats,
-                                                               int hw, int C) {
+                                                               int hw, int C, int pix_per_block) {
     __shared__ float s_sum[32], s_sq[32];
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -32,8 +32,8 @@ __global__ __launch_bounds__(256) void gn_spatial_stats_kernel(const bf16* __res
     for (int k = 0; k < kMaxCols; ++k)
 #pragma unroll
         for (int e = 0; e < 8; ++e) sum[k][e] = sq[k][e] = 0.f;
-    const int p0 = blockIdx.x * kGnPixPerBlock;
-    const int p1 = min(p0 + kGnPixPerBlock, hw);
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(p0 + pix_per_block, hw);
     const bf16* xf = x + (size_t)frame * hw * C;
     for (int pix = p0 + wave; pix < p1; pix += kGnWaves) {
         const bf16* row = xf + (size_t)pix * C;
@@ -404,7 +404,12 @@ extern "C" int ccedit_groupnorm_spatial(const void* x, void* y, const float* gam
         return (int)e;
     }
     dim3 grid((hw + kGnPixPerBlock - 1) / kGnPixPerBlock, frames);
-    hipLaunchKernelGGL(gn_spatial_stats_kernel, grid, dim3(256), 0, s, (const bf16*)x, stats_ws, hw, C);
+    // the per-block reduction tail (LDS + global atomics) costs about as much as reading 16 pixel rows per wave:
+    // give a stats block 256 pixels when the frame is large enough to still fill the chip
+    int spb = 256;
+    while (spb > kGnPixPerBlock && (int64_t)((hw + spb - 1) / spb) * frames < 512) spb >>= 1;
+    dim3 sgrid((hw + spb - 1) / spb, frames);
+    hipLaunchKernelGGL(gn_spatial_stats_kernel, sgrid, dim3(256), 0, s, (const bf16*)x, stats_ws, hw, C, spb);
     hipLaunchKernelGGL(gn_spatial_apply_kernel, grid, dim3(256), 0, s, (const bf16*)x, (bf16*)y, stats_ws, gamma, beta, hw,
                        C, eps, silu);
     return cc_launch_status("groupnorm_spatial");

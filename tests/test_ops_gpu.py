@@ -47,7 +47,7 @@ def _nchw(y_nhwc):
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (300, 320, 320), (77, 960, 768), (1000, 4, 320), (257, 1280, 2560),
                                    (64, 640, 40)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 def test_linear(m, n, k, tile):
     _dev()
     from ccedit_amd import ops
@@ -111,7 +111,7 @@ def test_geglu():
     _close(y, a * F.gelu(g), what="GEGLU")
 
 
-@pytest.mark.parametrize("tile", [0, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [0, 3, 4, 5])
 @pytest.mark.parametrize("cin,cout,h,w,stride", [(320, 320, 16, 24, 1), (64, 128, 9, 7, 1), (320, 320, 16, 24, 2),
                                                   (8, 320, 16, 24, 1), (16, 32, 32, 48, 2), (640, 4, 8, 12, 1)])
 def test_conv3x3(cin, cout, h, w, stride, tile):

@@ -16,7 +16,7 @@ def conv(name, h, w, cin, cout, stride=1, up=False):
     ho, wo = (2 * h, 2 * w) if up else (h // stride, w // stride)
     fl = 2.0 * N * ho * wo * cout * cin * 9
     r = []
-    for tile in (1, 2, 3, 4, 5, 6, 7):
+    for tile in (1, 2, 3, 4, 5):
         t = timeit(lambda: ops.conv2d(x, pw, stride=stride, upsample=up, tile=tile), iters=5, warm=2)
         r.append(fl / t / 1e12)
     print(f"{name:34s} M={N*ho*wo:7d} K={9*cin:6d} N={cout:5d}  " + "  ".join(f"t{i+1}:{v:6.0f}" for i, v in enumerate(r)), flush=True)
@@ -26,7 +26,7 @@ def lin(name, m, k, n, geglu=False):
     pw = pack_weight(torch.randn(n, k) * k ** -0.5, torch.randn(n), geglu=geglu).to(dev)
     fl = 2.0 * m * k * n
     r = []
-    for tile in (1, 2, 3, 4, 5, 6, 7):
+    for tile in (1, 2, 3, 4, 5):
         t = timeit(lambda: ops.linear(x, pw, tile=tile), iters=5, warm=2)
         r.append(fl / t / 1e12)
     print(f"{name:34s} M={m:7d} K={k:6d} N={n:5d}  " + "  ".join(f"t{i+1}:{v:6.0f}" for i, v in enumerate(r)), flush=True)
@@ -36,7 +36,7 @@ def temp(name, h, w, c):
     pw = pack_weight(torch.randn(c, c, 3) * (3 * c) ** -0.5, torch.randn(c)).to(dev)
     fl = 2.0 * N * h * w * c * c * 3
     r = []
-    for tile in (1, 2, 3, 4, 5, 6, 7):
+    for tile in (1, 2, 3, 4, 5):
         t = timeit(lambda: ops.conv_temporal(x, 17, pw, tile=tile), iters=5, warm=2)
         r.append(fl / t / 1e12)
     print(f"{name:34s} M={N*h*w:7d} K={3*c:6d} N={c:5d}  " + "  ".join(f"t{i+1}:{v:6.0f}" for i, v in enumerate(r)), flush=True)
