@@ -69,6 +69,69 @@ __global__ void cat_add_kernel(const bf16* __restrict__ a, const bf16* __restric
     }
 }
 
+// The same concatenation, one wave per pixel row, also accumulating the GroupNorm(32, C1+C2) statistics of the
+// tensor it writes (the decoder's in_layers.0 reads them instead of re-reading the tensor): lane l owns granules
+// l, l+64, ... of the row; block-level reduction in LDS, then 64 global atomics per block.
+constexpr int kCatCols = 5;       // C1 + C2 <= 2560
+__global__ __launch_bounds__(256) void cat_add_gn_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b,
+                                                         const bf16* __restrict__ c, bf16* __restrict__ out,
+                                                         float* __restrict__ stats, int hw, int C1, int C2,
+                                                         int pix_per_block) {
+    __shared__ float sS[64];
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g1 = C1 >> 3, gt = (C1 + C2) >> 3, cpg = (C1 + C2) >> 5;
+    if (threadIdx.x < 64) sS[threadIdx.x] = 0.f;
+    __syncthreads();
+    float sum[kCatCols][8], sq[kCatCols][8];
+#pragma unroll
+    for (int k = 0; k < kCatCols; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[k][e] = sq[k][e] = 0.f;
+    const int p1 = min((int)(blockIdx.x + 1) * pix_per_block, hw);
+    for (int pix = blockIdx.x * pix_per_block + wave; pix < p1; pix += 4) {
+        const int64_t row = (int64_t)frame * hw + pix;
+#pragma unroll
+        for (int k = 0; k < kCatCols; ++k) {
+            const int g = lane + 64 * k;
+            if (g < gt) {
+                bf16x8 v;
+                if (g < g1) {
+                    v = *(const bf16x8*)(a + row * C1 + g * 8);
+                } else {
+                    v = *(const bf16x8*)(b + row * C2 + (g - g1) * 8);
+                    if (c) {
+                        const bf16x8 w = *(const bf16x8*)(c + row * C2 + (g - g1) * 8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(w[e]));
+                    }
+                }
+                *(bf16x8*)(out + row * (C1 + C2) + g * 8) = v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = bf2f(v[e]);
+                    sum[k][e] += f;
+                    sq[k][e] += f * f;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kCatCols; ++k) {
+        const int g = lane + 64 * k;
+        if (g < gt) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int grp = (g * 8 + e) / cpg;
+                atomicAdd(&sS[grp * 2], sum[k][e]);
+                atomicAdd(&sS[grp * 2 + 1], sq[k][e]);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) atomicAdd(&stats[frame * 64 + threadIdx.x], sS[threadIdx.x]);
+}
+
 __global__ void add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ y, int64_t n8) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const bf16x8 u = *(const bf16x8*)(a + i * 8), w = *(const bf16x8*)(b + i * 8);
@@ -189,6 +252,18 @@ extern "C" int ccedit_cat_add(const void* a, const void* b, const void* c, void*
     hipLaunchKernelGGL(cat_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)a,
                        (const bf16*)b, (const bf16*)c, (bf16*)out, rows, C1, C2);
     return cc_launch_status("cat_add");
+}
+
+extern "C" int ccedit_cat_add_gn(const void* a, const void* b, const void* c, void* out, float* stats, int32_t frames,
+                                 int32_t hw, int32_t C1, int32_t C2, void* stream) {
+    CC_CHECK_ARG(a && b && out && stats && frames > 0 && hw > 0, "ccedit_cat_add_gn: bad args");
+    CC_UNSUPPORTED(C1 % 8 || C2 % 8 || (C1 + C2) % 32 || C1 + C2 > kCatCols * 512,
+                   "ccedit_cat_add_gn: C1=%d C2=%d (multiples of 8, sum a multiple of 32 and <= %d)", C1, C2, kCatCols * 512);
+    int ppb = 256;
+    while (ppb > 32 && (int64_t)((hw + ppb - 1) / ppb) * frames < 1024) ppb >>= 1;
+    hipLaunchKernelGGL(cat_add_gn_kernel, dim3((hw + ppb - 1) / ppb, frames), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)a, (const bf16*)b, (const bf16*)c, (bf16*)out, stats, hw, C1, C2, ppb);
+    return cc_launch_status("cat_add_gn");
 }
 
 extern "C" int ccedit_add(const void* a, const void* b, void* y, int64_t n, void* stream) {

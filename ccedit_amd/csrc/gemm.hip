@@ -302,6 +302,9 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
     const float* __restrict__ gbias = d.group_bias;
     const bf16* __restrict__ r1 = (const bf16*)d.res1;
     const bf16* __restrict__ r2 = (const bf16*)d.res2;
+    float gs[8], gq[8];                       // GroupNorm statistics of this thread's 8 output channels (gn_stats)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
   for (int ec = 0; ec < BNP / ECH; ++ec) {
     __syncthreads();                          // operand tiles (or the previous chunk) are no longer being read
     if (wn * WPIX >= ec * ECH && wn * WPIX < (ec + 1) * ECH) {
@@ -390,6 +393,14 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
                         *(bf16x8*)((bf16*)d.out + (size_t)m * d.ldc + cb) = o;
+                        if (d.gn_stats) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float f = bf2f(o[e]);      // statistics of what the consumer will read
+                                gs[e] += f;
+                                gq[e] += f * f;
+                            }
+                        }
                     }
                 } else {
                     if (r1) {
@@ -413,6 +424,47 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
         }
     }
   }   // epilogue chunks
+
+    // ---- fused GroupNorm(32) statistics: thread -> lanes sharing the channel granule -> LDS -> global atomics ----
+    if (d.gn_stats) {
+        constexpr int CPR = BMC / 8;
+        float* const sS = (float*)smem;           // [32 groups][sum, sumsq]
+        __syncthreads();                          // the last chunk's staging area has been consumed
+        if (tid < 64) sS[tid] = 0.f;
+        __syncthreads();
+        const int cb = ch0 + (tid % CPR) * 8;
+        const int cpg = d.N >> 5;                 // >= 8: eight aligned channels span at most two groups
+        const int g0 = cb / cpg;
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool first = (cb + e) < (g0 + 1) * cpg;
+            s0 += first ? gs[e] : 0.f;
+            q0 += first ? gq[e] : 0.f;
+            s1 += first ? 0.f : gs[e];
+            q1 += first ? 0.f : gq[e];
+        }
+#pragma unroll
+        for (int off = CPR; off < 64; off <<= 1) {
+            s0 += __shfl_xor(s0, off);
+            q0 += __shfl_xor(q0, off);
+            s1 += __shfl_xor(s1, off);
+            q1 += __shfl_xor(q1, off);
+        }
+        if ((tid & 63) < CPR && cb < d.N) {
+            atomicAdd(&sS[g0 * 2], s0);
+            atomicAdd(&sS[g0 * 2 + 1], q0);
+            if (g0 < 31) {
+                atomicAdd(&sS[g0 * 2 + 2], s1);
+                atomicAdd(&sS[g0 * 2 + 3], q1);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const float v = sS[tid];
+            if (v != 0.f) atomicAdd(d.gn_stats + (size_t)(pix0 / d.gn_rows) * 64 + tid, v);
+        }
+    }
 }
 
 template <int WM, int WN, int TI, int TJ, int STAGES, int BKE, int MODE>
@@ -497,6 +549,14 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
                        "ccedit_gemm: GEGLU epilogue needs N%%16==0 and no residual/group bias/f32 out");
     }
     if (d.group_bias) CC_CHECK_ARG(d.group_rows > 0, "ccedit_gemm: group_bias without group_rows");
+    if (d.gn_stats) {
+        CC_CHECK_ARG(d.gn_rows > 0 && d.gn_rows % 128 == 0 && d.M % d.gn_rows == 0,
+                     "ccedit_gemm: gn_stats needs gn_rows %% 128 == 0 dividing M (gn_rows=%d)", d.gn_rows);
+        CC_CHECK_ARG(d.gn_rows % 256 == 0 || d.tile <= 1,
+                     "ccedit_gemm: gn_rows=%d is not a multiple of 256: only the 128-pixel block shape (tile 1) applies", d.gn_rows);
+        CC_UNSUPPORTED(d.N % 32 != 0 || d.N < 256 || d.out_f32 || d.act == CCEDIT_ACT_GEGLU,
+                       "ccedit_gemm: gn_stats needs N%%32==0, N>=256, bf16 output, no GEGLU (N=%d)", d.N);
+    }
     hipStream_t s = (hipStream_t)stream;
     int tile = d.tile;
     if (tile == 0) {
@@ -512,6 +572,7 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         if (w64 < w128) tile = (d.taps > 1 || d.Kpad <= 512) ? 2 : 1;
         else if (d.M >= 150000 && d.Kpad >= 2048) tile = 3;
         else tile = 1;
+        if (d.gn_stats && d.gn_rows % 256 != 0) tile = 1;     // a block must not straddle two frames
     }
     const int mode = d.mode == CCEDIT_GEMM_CONV2D ? (d.upsample ? M_CONV_UP : M_CONV)
                                                   : (d.mode == CCEDIT_GEMM_TEMPORAL ? M_TEMPORAL : M_LINEAR);

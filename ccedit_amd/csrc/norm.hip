@@ -415,6 +415,19 @@ extern "C" int ccedit_groupnorm_spatial(const void* x, void* y, const float* gam
     return cc_launch_status("groupnorm_spatial");
 }
 
+extern "C" int ccedit_groupnorm_spatial_apply(const void* x, void* y, const float* gamma, const float* beta,
+                                              const float* stats, int32_t frames, int32_t hw, int32_t C, float eps,
+                                              int32_t silu, void* stream) {
+    CC_CHECK_ARG(x && y && gamma && beta && stats, "ccedit_groupnorm_spatial_apply: null pointer");
+    CC_CHECK_ARG(frames > 0 && hw > 0 && C > 0, "ccedit_groupnorm_spatial_apply: bad sizes");
+    CC_UNSUPPORTED(C % 32 != 0 || C > kMaxCols * 512, "ccedit_groupnorm_spatial_apply: C=%d (need C%%32==0, C<=%d)", C,
+                   kMaxCols * 512);
+    dim3 grid((hw + kGnPixPerBlock - 1) / kGnPixPerBlock, frames);
+    hipLaunchKernelGGL(gn_spatial_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, stats,
+                       gamma, beta, hw, C, eps, silu);
+    return cc_launch_status("groupnorm_spatial_apply");
+}
+
 extern "C" int ccedit_groupnorm_temporal(const void* x, void* y, const float* gamma, const float* beta, int32_t B,
                                          int32_t T, int32_t hw, int32_t C, float eps, int32_t silu, void* stream) {
     CC_CHECK_ARG(x && y && gamma && beta, "ccedit_groupnorm_temporal: null pointer");

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the library is loaded: to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCEDIT_HIP_LIB") or os.path.join(_HERE, "libccedit_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 GEMM_LINEAR, GEMM_CONV2D, GEMM_TEMPORAL = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
@@ -28,10 +28,11 @@ class CcGemmDesc(C.Structure):
         ("stride", C.c_int32), ("pad", C.c_int32), ("ksize", C.c_int32), ("upsample", C.c_int32),
         ("T", C.c_int32), ("HW", C.c_int32), ("lda", C.c_int32), ("lda2", C.c_int32), ("ldc", C.c_int32),
         ("Kpad", C.c_int32), ("act", C.c_int32), ("out_f32", C.c_int32), ("group_rows", C.c_int32),
-        ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("tile", C.c_int32), ("korder", C.c_int32), ("reserved0", C.c_int32),
+        ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("tile", C.c_int32), ("korder", C.c_int32), ("gn_rows", C.c_int32),
         ("Tsrc", C.c_int32), ("tsrc_off", C.c_int32), ("t0", C.c_int32), ("Tglob", C.c_int32),
         ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
         ("group_bias", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p),
+        ("gn_stats", C.c_void_p),
     ]
 
 
@@ -60,6 +61,8 @@ _SIGS = {
     "ccedit_gemm": (C.c_int, [C.POINTER(CcGemmDesc), C.c_void_p]),
     "ccedit_groupnorm_spatial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "ccedit_groupnorm_spatial_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                 C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ccedit_groupnorm_temporal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ccedit_groupnorm_temporal_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -75,6 +78,8 @@ _SIGS = {
                                        C.c_int32, C.c_int32, C.c_void_p]),
     "ccedit_cat_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                  C.c_void_p]),
+    "ccedit_cat_add_gn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_void_p]),
     "ccedit_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ccedit_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ccedit_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

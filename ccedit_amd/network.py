@@ -220,7 +220,7 @@ class SpatialTransformer(nn.Module):
             self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, n_heads, d_head, context_dim)])
         self.proj_out = Conv(inner, in_channels, 1)
 
-    def run_spatial(self, x, ctx2d, ctx_len, frames_per_clip):
+    def run_spatial(self, x, ctx2d, ctx_len, frames_per_clip, gn: bool = False):
         n, h, w, c = x.shape
         a = ops.groupnorm_spatial(x, self.norm.g, self.norm.b, self.norm.eps, False)
         tok = ops.linear(a.view(-1, c), self.proj_in.pw)
@@ -228,11 +228,11 @@ class SpatialTransformer(nn.Module):
             tok = self.transformer_blocks[0].run_frames(tok, n, h * w)
         else:
             tok = self.transformer_blocks[0].run(tok, n, h * w, ctx2d, ctx_len, frames_per_clip)
-        y = ops.linear(tok, self.proj_out.pw, res1=x.view(-1, c))
-        return y.view(n, h, w, c)
+        y = ops.linear(tok, self.proj_out.pw, res1=x.view(-1, c), gn_rows=h * w if gn else 0)
+        return ops.carry_gn_stats(y, y.view(n, h, w, c))
 
     def run(self, x, geo, ctx2d, ctx_len):
-        return self.run_spatial(x, ctx2d, ctx_len, geo.t)
+        return self.run_spatial(x, ctx2d, ctx_len, geo.t, gn=True)      # the next block opens with a GroupNorm
 
 
 class SpatialTransformer3D(SpatialTransformer):
@@ -255,8 +255,8 @@ class SpatialTransformer3D(SpatialTransformer):
         a = temporal_gn(y, self.norm_temporal, geo, False)
         tok = ops.linear(a.view(-1, c), self.proj_in_temporal.pw)
         tok = self.transformer_blocks_temporal[0].run_temporal(tok, geo, h * w)
-        z = ops.linear(tok, self.proj_out_temporal.pw, res1=y.view(-1, c))
-        return z.view(n, h, w, c)
+        z = ops.linear(tok, self.proj_out_temporal.pw, res1=y.view(-1, c), gn_rows=h * w)
+        return ops.carry_gn_stats(z, z.view(n, h, w, c))
 
 
 class SpatialTransformer3DCA(SpatialTransformer3D):
@@ -285,8 +285,8 @@ class SpatialTransformer3DCA(SpatialTransformer3D):
         a = ops.groupnorm_spatial(y, nc.g, nc.b, nc.eps, False)
         tok = ops.linear(a.view(-1, c), self.proj_in_temporal_ca.pw)
         tok = self.transformer_blocks_temporal_ca[0].run_frames(tok, n, h * w, anchor_t=geo.t // 2, frames_per_clip=geo.t)
-        z = ops.linear(tok, self.proj_out_temporal_ca.pw, res1=y.view(-1, c))
-        return z.view(n, h, w, c)
+        z = ops.linear(tok, self.proj_out_temporal_ca.pw, res1=y.view(-1, c), gn_rows=h * w)
+        return ops.carry_gn_stats(z, z.view(n, h, w, c))
 
 
 # ------------------------------------------------------------------------------------------
@@ -307,11 +307,11 @@ class ResBlock(nn.Module):
         gn = self.in_layers[0]
         a = ops.groupnorm_spatial(x, gn.g, gn.b, gn.eps, True)
         e = ops.linear(emb_silu, self.emb_layers[1].pw, out_f32=True)              # (B, Cout) fp32
-        hid = ops.conv2d(a, self.in_layers[2].pw, group_bias=e, group_rows=geo.t * h * w)
+        hid = ops.conv2d(a, self.in_layers[2].pw, group_bias=e, group_rows=geo.t * h * w, gn=True)
         gn = self.out_layers[0]
         a = ops.groupnorm_spatial(hid, gn.g, gn.b, gn.eps, True)
         skip = x if isinstance(self.skip_connection, Slot) else ops.conv2d(x, self.skip_connection.pw)
-        return ops.conv2d(a, self.out_layers[3].pw, res1=skip.view(-1, skip.shape[-1]))
+        return ops.conv2d(a, self.out_layers[3].pw, res1=skip.view(-1, skip.shape[-1]), gn=True)
 
 
 class ResBlock3D(nn.Module):
@@ -344,7 +344,7 @@ class ResBlock3D(nn.Module):
         e = ops.linear(emb_silu, self.emb_layers[1].pw, out_f32=True)
         # stf output (s + conv_t) and the `+ emb_out` of openaimodel.py:762 in one epilogue
         hid = temporal_conv3(at, self.in_layers_temporal[2].pw, geo, a_is_ext=sharded, res1=s.view(-1, co), group_bias=e,
-                             group_rows=geo.t * h * w)
+                             group_rows=geo.t * h * w, gn=True)
         gn = self.out_layers[0]
         a = ops.groupnorm_spatial(hid, gn.g, gn.b, gn.eps, True)
         s2 = ops.conv2d(a, self.out_layers[3].pw)
@@ -355,7 +355,7 @@ class ResBlock3D(nn.Module):
             k = ops.conv2d(x, self.skip_connection.pw)
             skip = ops.conv_temporal(k, geo.t, self.skip_connection_temporal.pw, res1=k.view(-1, co))
         return temporal_conv3(at, self.out_layers_temporal[3].pw, geo, a_is_ext=sharded, res1=s2.view(-1, co),
-                              res2=skip.view(-1, co))
+                              res2=skip.view(-1, co), gn=True)
 
 
 class Downsample(nn.Module):
@@ -366,7 +366,7 @@ class Downsample(nn.Module):
         self.op = Conv(channels, channels, 3, stride=2)
 
     def run(self, x, geo):
-        return ops.conv2d(x, self.op.pw, stride=2)
+        return ops.conv2d(x, self.op.pw, stride=2, gn=True)
 
 
 class Downsample3D(nn.Module):
@@ -379,7 +379,7 @@ class Downsample3D(nn.Module):
 
     def run(self, x, geo):
         s = ops.conv2d(x, self.op.pw, stride=2)
-        return temporal_conv3(s, self.conv_temporal.pw, geo, res1=s.view(-1, s.shape[-1]))
+        return temporal_conv3(s, self.conv_temporal.pw, geo, res1=s.view(-1, s.shape[-1]), gn=True)
 
 
 class Upsample3D(nn.Module):
@@ -640,6 +640,8 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
                 for b in range(geo.b):
                     fr = hh[b * geo.t + geo.t // 2]
                     ops.add(fr, ic[b], out=fr)
+                if hasattr(hh, "_gn_stats"):
+                    del hh._gn_stats                             # modified in place: the producer's statistics are stale
             return hh
 
         hs = []
@@ -654,7 +656,7 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
         h = add_center(self.middle_block.run(h, emb_silu, geo, ctx2d, ctx_len))
         h = ops.add(h, control.pop())
         for block in self.output_blocks:
-            h = ops.cat_add(h, hs.pop(), control.pop())          # cat([h, hs.pop() + control.pop()], dim=1)
+            h = ops.cat_add(h, hs.pop(), control.pop(), gn=True)          # cat([h, hs.pop() + control.pop()], dim=1)
             h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
         gn = self.out[0]
         a = ops.groupnorm_spatial(h, gn.g, gn.b, gn.eps, True)

@@ -8,6 +8,7 @@ N = B*T frames, equivalently a row-major [N*H*W][C] matrix.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -70,8 +71,13 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
          a2: Optional[torch.Tensor] = None, act: int = ACT_NONE,
          group_bias: Optional[torch.Tensor] = None, group_rows: int = 0,
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
-         out: Optional[torch.Tensor] = None, out_f32: bool = False, use_bias: bool = True, tile: int = 0) -> torch.Tensor:
-    """out[m, :] = epilogue(sum_taps W . A[src(m, tap)]).  a2d: [rows, lda] bf16 (last dim contiguous)."""
+         out: Optional[torch.Tensor] = None, out_f32: bool = False, use_bias: bool = True, tile: int = 0,
+         gn_rows: int = 0) -> torch.Tensor:
+    """out[m, :] = epilogue(sum_taps W . A[src(m, tap)]).  a2d: [rows, lda] bf16 (last dim contiguous).
+
+    gn_rows > 0 (= H*W of the output frames) asks the epilogue to also accumulate the GroupNorm(32) statistics of
+    the output; they travel with the returned tensor (`gn_stats_of`) and `groupnorm_spatial` then skips its own
+    statistics pass.  Silently not fused when the shape does not qualify (see include/ccedit_hip.h)."""
     assert a2d.dtype == BF16 and a2d.is_cuda and a2d.stride(-1) == 1
     lda = a2d.stride(0)
     cin1 = a2d.shape[1]
@@ -102,6 +108,12 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
     d.bias = _ptr(pw.bias) if use_bias else None
     d.group_bias = _ptr(group_bias)
     d.res1, d.res2, d.out = _ptr(res1), _ptr(res2), out.data_ptr()
+    stats = None
+    if (gn_rows > 0 and FUSE_GN_STATS and gn_rows % 128 == 0 and m % gn_rows == 0 and pw.n % 32 == 0 and pw.n >= 256
+            and not pw.geglu and out.dtype == BF16 and out.shape[1] == pw.n and out.is_contiguous()):
+        stats = torch.zeros((m // gn_rows, 32, 2), dtype=torch.float32, device=out.device)
+        d.gn_rows, d.gn_stats = gn_rows, stats.data_ptr()
+        out._gn_stats = (stats, gn_rows)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -120,8 +132,9 @@ def linear(x2d, pw, **kw):
 
 
 def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, upsample: bool = False,
-           x2: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
-    """x: (N, H, W, C) -> (N, Hout, Wout, Cout); 3x3 (pad 1) or 1x1 (pad 0) by the packed kernel size."""
+           x2: Optional[torch.Tensor] = None, gn: bool = False, **kw) -> torch.Tensor:
+    """x: (N, H, W, C) -> (N, Hout, Wout, Cout); 3x3 (pad 1) or 1x1 (pad 0) by the packed kernel size.
+    gn=True: the output feeds a spatial GroupNorm — accumulate its statistics in the epilogue."""
     n, h, w, c = x.shape
     if pw.ksize == 1:
         pad = 0
@@ -130,29 +143,30 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, ups
     wout = (wv + 2 * pad - pw.ksize) // stride + 1
     a2 = None if x2 is None else x2.reshape(-1, x2.shape[-1])
     out = gemm(x.reshape(-1, c), pw, mode=GEMM_CONV2D, m=n * hout * wout, hin=h, win=w, hout=hout, wout=wout,
-               stride=stride, pad=pad, upsample=upsample, a2=a2, **kw)
-    return out.view(n, hout, wout, out.shape[-1])
+               stride=stride, pad=pad, upsample=upsample, a2=a2, gn_rows=hout * wout if gn else 0, **kw)
+    return carry_gn_stats(out, out.view(n, hout, wout, out.shape[-1]))
 
 
-def conv_temporal(x: torch.Tensor, t: int, pw: PackedWeight, **kw) -> torch.Tensor:
+def conv_temporal(x: torch.Tensor, t: int, pw: PackedWeight, gn: bool = False, **kw) -> torch.Tensor:
     """Conv1d over the T frames of each clip; x: (B*T, H, W, C)."""
     n, h, w, c = x.shape
     if pw.taps == 1:
-        out = gemm(x.reshape(-1, c), pw, mode=GEMM_LINEAR, **kw)
+        out = gemm(x.reshape(-1, c), pw, mode=GEMM_LINEAR, gn_rows=h * w if gn else 0, **kw)
     else:
-        out = gemm(x.reshape(-1, c), pw, mode=GEMM_TEMPORAL, t=t, hw=h * w, **kw)
-    return out.view(n, h, w, out.shape[-1])
+        out = gemm(x.reshape(-1, c), pw, mode=GEMM_TEMPORAL, t=t, hw=h * w, gn_rows=h * w if gn else 0, **kw)
+    return carry_gn_stats(out, out.view(n, h, w, out.shape[-1]))
 
 
-def conv_temporal_sharded(x_ext: torch.Tensor, b: int, t_local: int, t0: int, t_glob: int, pw: PackedWeight, **kw) -> torch.Tensor:
+def conv_temporal_sharded(x_ext: torch.Tensor, b: int, t_local: int, t0: int, t_glob: int, pw: PackedWeight,
+                          gn: bool = False, **kw) -> torch.Tensor:
     """Conv1d (k3) over T for a frame shard.  x_ext: (B*(t_local+2), H, W, C) = per clip [halo from the previous
     rank | t_local local frames | halo from the next rank] (halo contents are ignored where they fall outside the
     clip); local frame 0 is global keyframe t0 of t_glob.  Returns (B*t_local, H, W, Cout)."""
     n, h, w, c = x_ext.shape
     assert n == b * (t_local + 2) and pw.taps == 3
     out = gemm(x_ext.reshape(-1, c), pw, mode=GEMM_TEMPORAL, m=b * t_local * h * w, t=t_local, hw=h * w,
-               tsrc=t_local + 2, tsrc_off=1, t0=t0, tglob=t_glob, **kw)
-    return out.view(b * t_local, h, w, out.shape[-1])
+               tsrc=t_local + 2, tsrc_off=1, t0=t0, tglob=t_glob, gn_rows=h * w if gn else 0, **kw)
+    return carry_gn_stats(out, out.view(b * t_local, h, w, out.shape[-1]))
 
 
 # ------------------------------------------------------------------------------------------
@@ -168,10 +182,34 @@ def _stats_ws(frames: int, device) -> torch.Tensor:
     return ws
 
 
+FUSE_GN_STATS = os.environ.get("CCEDIT_FUSE_GN_STATS", "1") != "0"      # 0: always the two-pass GroupNorm
+
+
+def gn_stats_of(x: torch.Tensor, hw: int):
+    """Statistics a producing GEMM left on `x` (None if it did not)."""
+    st = getattr(x, "_gn_stats", None)
+    return st[0] if st is not None and st[1] == hw else None
+
+
+def carry_gn_stats(src: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
+    """`view` is a reshape of `src` (same memory): keep the producer's statistics attached."""
+    st = getattr(src, "_gn_stats", None)
+    if st is not None:
+        view._gn_stats = st
+    return view
+
+
 def groupnorm_spatial(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, silu: bool) -> torch.Tensor:
     _chk_act(x, "groupnorm_spatial")
     n, h, w, c = x.shape
     y = torch.empty_like(x)
+    st = gn_stats_of(x, h * w)
+    if st is not None:
+        assert st.shape[0] == n
+        hip.check(hip.lib().ccedit_groupnorm_spatial_apply(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                           st.data_ptr(), n, h * w, c, eps, int(silu), _stream()),
+                  "ccedit_groupnorm_spatial_apply")
+        return y
     hip.check(hip.lib().ccedit_groupnorm_spatial(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                  _stats_ws(n, x.device).data_ptr(), n, h * w, c, eps, int(silu), _stream()),
               "ccedit_groupnorm_spatial")
@@ -274,11 +312,19 @@ def nhwc_to_ncthw(x: torch.Tensor, b: int, t: int, c: int) -> torch.Tensor:
     return y
 
 
-def cat_add(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor]) -> torch.Tensor:
-    """(..., C1) ++ ((..., C2) + (..., C2)) along channels."""
+def cat_add(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor], gn: bool = False) -> torch.Tensor:
+    """(..., C1) ++ ((..., C2) + (..., C2)) along channels.  gn=True (4-D NHWC input): also accumulate the
+    GroupNorm(32) statistics of the result for the `groupnorm_spatial` that follows."""
     _chk_act(a, "cat_add.a"), _chk_act(b, "cat_add.b")
     c1, c2 = a.shape[-1], b.shape[-1]
     out = torch.empty((*a.shape[:-1], c1 + c2), dtype=BF16, device=a.device)
+    if gn and FUSE_GN_STATS and a.dim() == 4 and (c1 + c2) % 32 == 0 and c1 + c2 <= 2560:
+        n, hw = a.shape[0], a.shape[1] * a.shape[2]
+        stats = torch.zeros((n, 32, 2), dtype=torch.float32, device=a.device)
+        hip.check(hip.lib().ccedit_cat_add_gn(a.data_ptr(), b.data_ptr(), _ptr(c), out.data_ptr(), stats.data_ptr(), n, hw,
+                                              c1, c2, _stream()), "ccedit_cat_add_gn")
+        out._gn_stats = (stats, hw)
+        return out
     hip.check(hip.lib().ccedit_cat_add(a.data_ptr(), b.data_ptr(), _ptr(c), out.data_ptr(), a.numel() // c1, c1, c2,
                                        _stream()), "ccedit_cat_add")
     return out

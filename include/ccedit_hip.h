@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCEDIT_ABI_VERSION 2
+#define CCEDIT_ABI_VERSION 3
 
 #define CCEDIT_OK 0
 #define CCEDIT_EINVAL (-1)       /* null pointer / bad size */
@@ -83,7 +83,8 @@ typedef struct CcGemmDesc {
     int32_t ldr1, ldr2;   /* residual row strides */
     int32_t tile;         /* 0 = auto, 1 = 128ch x 128pix, 2 = 64ch x 256pix */
     int32_t korder;       /* weight K order: 0 = [tap][Cin]; 1 = [Cin/64][tap][64] (needs Cin % 64 == 0) */
-    int32_t reserved0;
+    int32_t gn_rows;      /* with gn_stats: output rows per frame (H*W), a multiple of 128 dividing M (not a
+                           * multiple of 256: block shape 1 is used); else 0 */
     /* TEMPORAL with the T keyframes of a clip sharded over ranks (0 = unsharded): the source holds Tsrc frames
      * per clip — tsrc_off halo frames received from the previous rank, the T local frames, then the next rank's —
      * and local frame 0 is global keyframe t0 of Tglob; taps outside [0, Tglob) read zeros (Conv1d padding). */
@@ -96,6 +97,11 @@ typedef struct CcGemmDesc {
     const void* res1;     /* bf16 residuals added after the activation, or null */
     const void* res2;
     void* out;            /* bf16 (or fp32) [M][ldc]; GEGLU writes N/2 columns */
+    /* optional: GroupNorm(32, N) statistics of the tensor being written, accumulated in the epilogue so that the
+     * following normalisation (openaimodel.py:441-444, 479-482; attention.py:153-156) does not re-read it:
+     * float[M/gn_rows][32][2] (sum, sum of squares of the bf16-rounded outputs), ZEROED BY THE CALLER, added to
+     * atomically.  Needs N % 32 == 0, N >= 256, bf16 output, no GEGLU.  Consumed by ccedit_groupnorm_spatial_apply. */
+    float* gn_stats;
 } CcGemmDesc;
 
 int ccedit_gemm(const CcGemmDesc* desc, void* stream);
@@ -109,6 +115,11 @@ int ccedit_gemm(const CcGemmDesc* desc, void* stream);
 int ccedit_groupnorm_spatial(const void* x, void* y, const float* gamma, const float* beta,
                              float* stats_ws, int32_t frames, int32_t hw, int32_t C, float eps,
                              int32_t silu, void* stream);
+/* The apply half alone, for statistics that a producer already accumulated (CcGemmDesc.gn_stats):
+ * stats: float[frames][32][2] = (sum, sum of squares) over the C/32 x hw elements of each group. */
+int ccedit_groupnorm_spatial_apply(const void* x, void* y, const float* gamma, const float* beta,
+                                   const float* stats, int32_t frames, int32_t hw, int32_t C, float eps,
+                                   int32_t silu, void* stream);
 /* GroupNorm(32, C) over (C/32 x T) per pixel — the normalization() / norm_temporal applied to the
  * '(b h w) c t' view (openaimodel.py:617-619, 674-676; attention.py:1085, 1176).
  * x: [B*T][hw][C]; one statistics group = T frames x C/32 channels at one pixel. */
@@ -169,6 +180,11 @@ int ccedit_nhwc_to_ncthw(const void* x, int32_t x_is_f32, int32_t ld, float* y, 
 /* out[:, :C1] = a ; out[:, C1:C1+C2] = b + c   (cat([h, hs.pop() + control.pop()]), controlmodel.py:543) */
 int ccedit_cat_add(const void* a, const void* b, const void* c, void* out, int64_t rows, int32_t C1,
                    int32_t C2, void* stream);
+/* The same, additionally accumulating the GroupNorm(32, C1+C2) statistics of `out` ([frames][hw][C1+C2]) into
+ * stats = float[frames][32][2] (sum, sum of squares; ZEROED BY THE CALLER) for ccedit_groupnorm_spatial_apply —
+ * the decoder ResBlock's in_layers.0 (openaimodel.py:441-444) then does not re-read the concatenation. */
+int ccedit_cat_add_gn(const void* a, const void* b, const void* c, void* out, float* stats, int32_t frames,
+                      int32_t hw, int32_t C1, int32_t C2, void* stream);
 /* y = a + b (bf16), n elements — `h = h + control.pop()` (controlmodel.py:537), `h += guided_hint` (:300) */
 int ccedit_add(const void* a, const void* b, void* y, int64_t n, void* stream);
 /* y = silu(x), bf16 elementwise (out_temporal's leading nn.SiLU, openaimodel.py:1627-1632) */

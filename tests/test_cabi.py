@@ -28,14 +28,14 @@ def test_header_symbols_exported(libpath):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ccedit_hip.h but not exported"
     lib.ccedit_abi_version.restype = ctypes.c_int
-    assert lib.ccedit_abi_version() == 2
+    assert lib.ccedit_abi_version() == 3
 
 
 def test_binding_matches_header(libpath):
     from ccedit_amd import hip
     assert sorted(hip.EXPORTS) == _declared()
     # descriptor layouts: sizes the C side was compiled with (kept in sync by hand; a mismatch shows up here)
-    assert ctypes.sizeof(hip.CcGemmDesc) == 8 + 31 * 4 + 4 + 8 * 8
+    assert ctypes.sizeof(hip.CcGemmDesc) == 8 + 31 * 4 + 4 + 9 * 8
     assert ctypes.sizeof(hip.CcAttnDesc) % 8 == 0
 
 

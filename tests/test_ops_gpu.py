@@ -156,6 +156,66 @@ def test_conv3x3_upsample_and_concat():
     _close(_nchw(y), F.conv2d(torch.cat([x, x2], 1), wt2, b, padding=1), what="dual-source conv3x3")
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cout", [320, 640, 256])
+def test_gemm_fused_groupnorm_statistics(tile, cout):
+    """CcGemmDesc.gn_stats: the epilogue's (sum, sum of squares) per (frame, group) must equal the statistics of
+    the bf16 tensor it wrote, and GroupNorm through them must equal the two-pass GroupNorm."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    n, cin, h, w = 3, 64, 16, 32                         # 512 pixels per frame (multiple of 256)
+    x = _rnd(n, cin, h, w, seed=1)
+    wt, b = _rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), _rnd(cout, seed=3)
+    res = _rnd(n, cout, h, w, seed=4)
+    gb = _rnd(n, cout, seed=5)
+    y = ops.conv2d(_nhwc(x), pack_weight(wt, b).to("cuda"), res1=_nhwc(res).view(-1, cout), group_bias=gb.cuda(),
+                   group_rows=h * w, gn=True, tile=tile)
+    st = ops.gn_stats_of(y, h * w)
+    assert st is not None and st.shape == (n, 32, 2)
+    yf = y.float().view(n, h * w, 32, cout // 32)
+    ref_sum, ref_sq = yf.sum(dim=(1, 3)), (yf * yf).sum(dim=(1, 3))
+    assert torch.allclose(st[..., 0], ref_sum, rtol=1e-4, atol=1e-2), (st[..., 0] - ref_sum).abs().max()
+    assert torch.allclose(st[..., 1], ref_sq, rtol=1e-4, atol=1e-2), (st[..., 1] - ref_sq).abs().max()
+    g, be = (_rnd(cout, seed=6) * 0.1 + 1).cuda(), (_rnd(cout, seed=7) * 0.1).cuda()
+    fused = ops.groupnorm_spatial(y, g, be, 1e-5, True)
+    two_pass = ops.groupnorm_spatial(y.clone(), g, be, 1e-5, True)
+    _close(fused, two_pass.float(), rel=2.0 ** -8, what="GN through fused statistics")
+    # linear (1x1) and temporal producers; shapes that do not qualify silently fall back
+    tok = _rnd(n * h * w, 128, seed=8)
+    z = ops.linear(tok.to(BF).cuda(), pack_weight(_rnd(cout, 128, seed=9, scale=128 ** -0.5)).to("cuda"),
+                   gn_rows=h * w, tile=tile)
+    zf = z.float().view(n, h * w, 32, cout // 32)
+    assert torch.allclose(ops.gn_stats_of(z, h * w)[..., 0], zf.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+    wt3 = _rnd(cout, 128, 3, seed=10, scale=384 ** -0.5)
+    zt = ops.conv_temporal(tok.to(BF).cuda().view(n, h, w, 128), n, pack_weight(wt3).to("cuda"), gn=True, tile=tile)
+    ztf = zt.float().view(n, h * w, 32, cout // 32)
+    assert torch.allclose(ops.gn_stats_of(zt, h * w)[..., 1], (ztf * ztf).sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+    small = ops.conv2d(_nhwc(_rnd(2, cin, 8, 8, seed=11)), pack_weight(wt, b).to("cuda"), gn=True)
+    assert ops.gn_stats_of(small, 64) is None
+    if tile <= 1:            # 384 pixels per frame (the 16x24 latent level): only the 128-pixel block shape qualifies
+        x3 = _rnd(2, cin, 16, 24, seed=12)
+        y3 = ops.conv2d(_nhwc(x3), pack_weight(wt, b).to("cuda"), gn=True, tile=tile)
+        y3f = y3.float().view(2, 384, 32, cout // 32)
+        assert torch.allclose(ops.gn_stats_of(y3, 384)[..., 0], y3f.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+
+
+def test_cat_add_fused_groupnorm_statistics():
+    _dev()
+    from ccedit_amd import ops
+    n, h, w, c1, c2 = 3, 12, 9, 640, 320
+    a, bb, cc = _rnd(n, h, w, c1, seed=1), _rnd(n, h, w, c2, seed=2), _rnd(n, h, w, c2, seed=3)
+    o = ops.cat_add(a.to(BF).cuda(), bb.to(BF).cuda(), cc.to(BF).cuda(), gn=True)
+    plain = ops.cat_add(a.to(BF).cuda(), bb.to(BF).cuda(), cc.to(BF).cuda())
+    assert torch.equal(o, plain)
+    st = ops.gn_stats_of(o, h * w)
+    of = o.float().view(n, h * w, 32, (c1 + c2) // 32)
+    assert torch.allclose(st[..., 0], of.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[..., 1], (of * of).sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+    o2 = ops.cat_add(a.to(BF).cuda(), bb.to(BF).cuda(), None, gn=True)
+    assert torch.equal(o2, torch.cat([a.to(BF), bb.to(BF)], -1).cuda())
+
+
 def test_conv1x1_and_temporal():
     _dev()
     from ccedit_amd import ops
