@@ -16,6 +16,14 @@ constexpr int kMaxCols = 5;    // C <= 2560
 constexpr int kGnWaves = 4;
 constexpr int kGnPixPerBlock = 64;
 
+// pixels per 4-wave block: 64 for large frames, down to 4 (one row per wave) so that the small latent levels
+// (8x12 pixels x 34 frames) still put a few thousand workgroups on the 256 CUs
+inline int gn_pix_per_block(int hw, int frames, int lo, int64_t want_blocks) {
+    int ppb = kGnPixPerBlock;
+    while (ppb > lo && (int64_t)((hw + ppb - 1) / ppb) * frames < want_blocks) ppb >>= 1;
+    return ppb;
+}
+
 __global__ __launch_bounds__(256) void gn_spatial_stats_kernel(const bf16* __restrict__ x, float* __restrict__ stats,
                                                                int hw, int C, int pix_per_block) {
     __shared__ float s_sum[32], s_sq[32];
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(256) void gn_spatial_apply_kernel(const bf16* __res
                                                                const float* __restrict__ stats,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int hw, int C, float eps,
-                                                               int silu) {
+                                                               int silu, int pix_per_block) {
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int G8 = C >> 3, cpg = C >> 5;
@@ -98,8 +106,8 @@ __global__ __launch_bounds__(256) void gn_spatial_apply_kernel(const bf16* __res
             }
         }
     }
-    const int p0 = blockIdx.x * kGnPixPerBlock;
-    const int p1 = min(p0 + kGnPixPerBlock, hw);
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(p0 + pix_per_block, hw);
     const bf16* xf = x + (size_t)frame * hw * C;
     bf16* yf = y + (size_t)frame * hw * C;
     for (int pix = p0 + wave; pix < p1; pix += kGnWaves) {
@@ -219,6 +227,88 @@ __global__ __launch_bounds__(256) void gn_temporal_kernel(const bf16* __restrict
             }
         }
     }
+}
+
+// Single-sweep form for short clips (T <= kGtCacheT): a wave owns one (clip, pixel, channel slice) — a slice is a
+// whole number of groups, at most 512 channels — keeps its T rows in registers between the statistics and the
+// normalisation, and issues all T loads back to back.  The launch has only B*H*W*slices waves, each touching T
+// rows one frame apart, so it is bound by load latency: memory-level parallelism per wave and the number of
+// waves are what count (the 16x24 / 8x12 levels have 768 / 192 pixels).
+constexpr int kGtCacheT = 20;
+
+__global__ __launch_bounds__(256) void gn_temporal_cached_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int B, int T, int hw,
+                                                                 int C, int nsl, float eps, int silu) {
+    __shared__ float s_sum[4][32], s_sq[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;     // ((b, pixel), slice)
+    const bool active = wid < (int64_t)B * hw * nsl;
+    const int64_t wp = active ? wid / nsl : 0;
+    const int sl = active ? (int)(wid - wp * nsl) : 0;
+    const int b = (int)(wp / hw);
+    const int pix = (int)(wp - (int64_t)b * hw);
+    const int cpg = C >> 5, slg = (C >> 3) / nsl;            // granules per slice (<= 64)
+    const int gc = sl * slg + lane;                          // this lane's granule of the row
+    const bool lane_on = active && lane < slg;
+    if (lane < 32) {
+        s_sum[wave][lane] = 0.f;
+        s_sq[wave][lane] = 0.f;
+    }
+    __syncthreads();
+    const size_t fstride = (size_t)hw * C;
+    const bf16* xb = x + ((size_t)b * T * hw + pix) * C + gc * 8;
+    bf16* yb = y + ((size_t)b * T * hw + pix) * C + gc * 8;
+    bf16x8 cache[kGtCacheT];
+    if (lane_on) {
+#pragma unroll
+        for (int t = 0; t < kGtCacheT; ++t)
+            if (t < T) cache[t] = *(const bf16x8*)(xb + t * fstride);
+        float sum[8], sq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] = sq[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < kGtCacheT; ++t)
+            if (t < T) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = bf2f(cache[t][e]);
+                    sum[e] += f;
+                    sq[e] += f * f;
+                }
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (gc * 8 + e) / cpg;
+            atomicAdd(&s_sum[wave][g], sum[e]);
+            atomicAdd(&s_sq[wave][g], sq[e]);
+        }
+    }
+    __syncthreads();
+    if (!lane_on) return;
+    const float inv_n = 1.0f / ((float)cpg * (float)T);
+    float a[8], bb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = gc * 8 + e;
+        const int g = c / cpg;
+        const float mean = s_sum[wave][g] * inv_n;
+        const float var = fmaxf(s_sq[wave][g] * inv_n - mean * mean, 0.f);
+        a[e] = rsqrtf(var + eps) * gamma[c];
+        bb[e] = beta[c] - mean * a[e];
+    }
+#pragma unroll
+    for (int t = 0; t < kGtCacheT; ++t)
+        if (t < T) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = bf2f(cache[t][e]) * a[e] + bb[e];
+                if (silu) f = silu_f(f);
+                o[e] = f2bf(f);
+            }
+            *(bf16x8*)(yb + t * fstride) = o;
+        }
 }
 
 // Two-phase form for frame-sharded clips: local partial statistics, (all-reduce by the caller), apply.
@@ -403,15 +493,16 @@ extern "C" int ccedit_groupnorm_spatial(const void* x, void* y, const float* gam
         cc_set_error("groupnorm_spatial memset: %s", hipGetErrorString(e));
         return (int)e;
     }
-    dim3 grid((hw + kGnPixPerBlock - 1) / kGnPixPerBlock, frames);
+    const int apb = gn_pix_per_block(hw, frames, 4, 2048);
+    dim3 grid((hw + apb - 1) / apb, frames);
     // the per-block reduction tail (LDS + global atomics) costs about as much as reading 16 pixel rows per wave:
     // give a stats block 256 pixels when the frame is large enough to still fill the chip
     int spb = 256;
-    while (spb > kGnPixPerBlock && (int64_t)((hw + spb - 1) / spb) * frames < 512) spb >>= 1;
+    while (spb > 16 && (int64_t)((hw + spb - 1) / spb) * frames < 512) spb >>= 1;
     dim3 sgrid((hw + spb - 1) / spb, frames);
     hipLaunchKernelGGL(gn_spatial_stats_kernel, sgrid, dim3(256), 0, s, (const bf16*)x, stats_ws, hw, C, spb);
     hipLaunchKernelGGL(gn_spatial_apply_kernel, grid, dim3(256), 0, s, (const bf16*)x, (bf16*)y, stats_ws, gamma, beta, hw,
-                       C, eps, silu);
+                       C, eps, silu, apb);
     return cc_launch_status("groupnorm_spatial");
 }
 
@@ -422,9 +513,10 @@ extern "C" int ccedit_groupnorm_spatial_apply(const void* x, void* y, const floa
     CC_CHECK_ARG(frames > 0 && hw > 0 && C > 0, "ccedit_groupnorm_spatial_apply: bad sizes");
     CC_UNSUPPORTED(C % 32 != 0 || C > kMaxCols * 512, "ccedit_groupnorm_spatial_apply: C=%d (need C%%32==0, C<=%d)", C,
                    kMaxCols * 512);
-    dim3 grid((hw + kGnPixPerBlock - 1) / kGnPixPerBlock, frames);
+    const int apb = gn_pix_per_block(hw, frames, 4, 2048);
+    dim3 grid((hw + apb - 1) / apb, frames);
     hipLaunchKernelGGL(gn_spatial_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, stats,
-                       gamma, beta, hw, C, eps, silu);
+                       gamma, beta, hw, C, eps, silu, apb);
     return cc_launch_status("groupnorm_spatial_apply");
 }
 
@@ -436,8 +528,16 @@ extern "C" int ccedit_groupnorm_temporal(const void* x, void* y, const float* ga
                    kGtCols * 512);
     const int64_t waves = (int64_t)B * hw;
     dim3 grid((unsigned)((waves + 3) / 4));
-    hipLaunchKernelGGL(gn_temporal_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, gamma, beta,
-                       B, T, hw, C, eps, silu);
+    int nsl = 1;                                   // channel slices: whole groups, at most 512 channels each
+    while (nsl < 32 && C / nsl > 512) nsl <<= 1;
+    if (T <= kGtCacheT && (C >> 3) % nsl == 0) {
+        const int64_t nw = waves * nsl;
+        hipLaunchKernelGGL(gn_temporal_cached_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16*)x, (bf16*)y, gamma, beta, B, T, hw, C, nsl, eps, silu);
+    } else {
+        hipLaunchKernelGGL(gn_temporal_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, gamma,
+                           beta, B, T, hw, C, eps, silu);
+    }
     return cc_launch_status("groupnorm_temporal");
 }
 
