@@ -60,7 +60,7 @@ def build_model(device, tvi2v=False):
 
 def cpu_baseline(wrapper):
     """Oracle (CPU fp32 restatement, `kind: port`) on a bounded sample of the same workload: the same
-    full-width network and weights on a crop — B=2 (CFG), T=4 keyframes, latent 32x48 — timed on the host
+    full-width network and weights on a crop — B=2 (CFG), T=6 keyframes, latent 32x48 — timed on the host
     cores; converted to steps/s through the FLOPs ATen actually executed (FlopCounterMode)."""
     from oracle import ccedit_oracle as O
     from torch.utils.flop_counter import FlopCounterMode
@@ -68,7 +68,7 @@ def cpu_baseline(wrapper):
     torch.set_num_threads(threads)
     sd = {"model." + k: v.detach().float().cpu() for k, v in wrapper.state_dict().items()}
     g = torch.Generator().manual_seed(7)
-    tt, hh, ww = 4, 32, 48
+    tt, hh, ww = 6, 32, 48
     x = torch.randn(2, 4, tt, hh, ww, generator=g)
     c = dict(crossattn=torch.randn(2, L, CTX, generator=g), control_hint=torch.rand(2, 3, tt, 8 * hh, 8 * ww, generator=g) * 2 - 1)
     t = torch.tensor([601, 601], dtype=torch.int64)
@@ -183,6 +183,17 @@ def main():
         roof = dict(bound="mfma", kernel="tap_gemm_kernel", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None, launches=g["launches"],
                     avg_launch_us=round(g["avg_us"], 2), algorithmic_flops_per_step=g["flops"])
+        # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 PMC passes of this
+        # same workload (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH x2 per
+        # MI355X_MICROARCH.md), averaged per tap_gemm launch like `achieved`.
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if not tvi2v and os.path.exists(pmc):
+            with open(pmc) as f:
+                tg = json.load(f).get("tap_gemm")
+            if tg and tg["launches"]:
+                roof["traffic"] = round((tg["fetch_bytes_x2"] + tg["write_bytes"]) / tg["launches"])
+                roof["traffic_unit"] = "HBM bytes per tap_gemm launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)"
+                roof["algorithmic_bytes_per_launch"] = round(g["bytes"] / g["launches"])
         a = prof.get("attention")
         if a:
             extra["attention"] = dict(tflops=round(a["flops"] / (a["total_ms"] * 1e-3) / 1e12, 1), launches=a["launches"],
@@ -201,7 +212,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "UNet denoising steps/s (TV2V 17x512x768, bf16, CFG-doubled batch)", "value": round(value, 4),
+            "metric": f"UNet denoising steps/s ({'TVI2V' if tvi2v else 'TV2V'} 17x512x768, bf16, CFG-doubled batch)", "value": round(value, 4),
             "unit": "UNet steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if shard else "weak",
             "vs_baseline": None,

@@ -29,6 +29,8 @@
 //   * epilogue: accumulators -> LDS (fp32) -> 16-byte-per-lane row-contiguous stores with bias,
 //     timestep-embedding row bias, SiLU / GEGLU and up to two residual reads fused.
 #include "common.h"
+#include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -76,10 +78,21 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
     const int64_t bid = blockIdx.x;
     const int xcd = (int)(bid & 7);
     const int64_t local = bid >> 3;
-    const int64_t pt = xcd * pt_per_xcd + local / ct_n;
+    // Within an XCD the channel tiles are walked in groups of Q = d.cgroup (host-chosen, see launch()): the ~64
+    // workgroups resident on the XCD's 32 CUs then cover (64/Q pixel tiles) x (Q channel tiles), so a weight tile
+    // that does not fit in the 4 MB L2 is shared by 64/Q concurrently running workgroups instead of being
+    // re-fetched by every one of them.  Q = ct_n (weights L2-resident) degenerates to "all channel tiles of one
+    // pixel tile back to back".
+    const int Q = d.cgroup > 0 ? d.cgroup : ct_n;
+    const int64_t gsz = pt_per_xcd * Q;
+    const int cg = (int)(local / gsz);
+    const int64_t rr = local - cg * gsz;
+    const int qn = min(Q, ct_n - cg * Q);
+    const int64_t pl = rr / qn;
+    const int64_t pt = xcd * pt_per_xcd + pl;
     if (pt >= pt_n) return;
     const int64_t pix0 = pt * BNP;
-    const int ch0 = (int)(local % ct_n) * BMC;
+    const int ch0 = (cg * Q + (int)(rr - pl * qn)) * BMC;
 
     // ---- staging coordinates: thread -> (row rsub + RPI*i, LDS slot p) ----
     // LDS slot p of row r holds source granule p ^ f(r): f(r) = (r>>1)&7 for 128-byte rows (2 rows per 256-byte
@@ -491,7 +504,25 @@ int launch(const CcGemmDesc& d, hipStream_t s) {
         return CCEDIT_EUNSUPPORTED;
     }
     dim3 grid((unsigned)nblk);
-    hipLaunchKernelGGL((tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>), grid, dim3(WM * WN * 64), lds, s, d);
+    // Channel-tile group width (see the block-order comment in the kernel).  Weights that fit in an XCD's L2 are
+    // fetched once whatever the order; otherwise, with C workgroups resident per XCD as (C/Q pixel tiles) x (Q
+    // channel tiles), the fabric traffic per workgroup is  wtile * Q/C + atile / Q, minimal at Q = sqrt(C*atile/wtile)
+    // (atile shrinks by the tap re-use of a 3x3 / temporal gather).
+    CcGemmDesc dd = d;
+    dd.cgroup = 0;
+    static const int cg_env = getenv("CCEDIT_CGROUP") ? atoi(getenv("CCEDIT_CGROUP")) : -1;    // tuning: -1 auto, 0 off, n fixed
+    const double wbytes = (double)ct_n * BMC * d.Kpad * 2.0;
+    if (cg_env != 0 && ct_n > 4 && wbytes > 3.0 * 1024 * 1024) {
+        const double resident = (lds <= 80 * 1024 ? 2.0 : 1.0) * 32.0;
+        const double a_over_w = (double)BNP / ((double)BMC * d.taps);
+        int q = cg_env > 0 ? cg_env : (int)(sqrt(resident * a_over_w) + 0.5);
+        q = q < 2 ? 2 : q;
+        if (q < ct_n) {
+            const int ng = (int)((ct_n + q - 1) / q);
+            dd.cgroup = (int)((ct_n + ng - 1) / ng);
+        }
+    }
+    hipLaunchKernelGGL((tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>), grid, dim3(WM * WN * 64), lds, s, dd);
     return cc_launch_status("tap_gemm_kernel");
 }
 

@@ -119,7 +119,10 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
         e0.record()
         hip.check(hip.lib().ccedit_gemm(C.byref(d), _stream()), "ccedit_gemm")
         e1.record()
-        PROFILE.add("tap_gemm", e0, e1, pw.flops_per_row * m, 0.0,
+        nres = int(res1 is not None) + int(res2 is not None)
+        alg_bytes = (a2d.shape[0] * cin1 * 2 + (a2.shape[0] * a2.shape[1] * 2 if a2 is not None else 0)      # sources, once
+                     + m * out.shape[1] * out.element_size() + nres * m * pw.n * 2 + pw.n * pw.kpad * 2)   # out, residuals, W
+        PROFILE.add("tap_gemm", e0, e1, pw.flops_per_row * m, float(alg_bytes),
                     (("lin", "conv", "temp")[mode] + ("+up" if upsample else ""), m, pw.n, pw.taps * pw.cin, stride,
                      int(res1 is not None) + int(res2 is not None), d.act))
         return out

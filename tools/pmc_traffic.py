@@ -21,6 +21,10 @@ for k in sorted(set(f) | set(w)):
     if k != "torch/setup": tf += fb; tw += wb
     print(f"{k:20s} {f[k][0]:8d} {fb:10.2f} {2*fb:11.2f} {wb:10.2f}")
 print(f"{'TOTAL (ours)':20s} {'':8s} {tf:10.2f} {2*tf:11.2f} {tw:10.2f}")
+if os.environ.get("PMC_JSON"):
+    import json as _json
+    _json.dump({k: {"launches": f[k][0], "fetch_bytes_x2": 2 * f[k][1] * 1024, "write_bytes": w[k][1] * 1024}
+                for k in sorted(set(f) | set(w))}, open(os.environ["PMC_JSON"], "w"), indent=1)
 
 # optional per-shape table for tap_gemm: argv[3] = shapes json dumped by bench.py --dump-shapes (same launch order)
 if len(sys.argv) > 3:
