@@ -159,6 +159,21 @@ __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, bf16* _
     }
 }
 
+// DiagonalGaussianDistribution.sample (distributions.py:24-41) on the channels-last moments of the VAE encoder:
+// out[n][c][p] = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise[n][c][p]),  moments row = [mean(zc) | logvar(zc)]
+__global__ void gaussian_sample_kernel(const float* __restrict__ mom, const float* __restrict__ noise,
+                                       float* __restrict__ out, int64_t total, int zc, int hw, int ldm, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t nc = i / hw;                   // (frame, channel) of the NCHW output element
+        const int p = (int)(i - nc * hw);
+        const int64_t n = nc / zc;
+        const int c = (int)(nc - n * zc);
+        const float* row = mom + (n * hw + p) * ldm;
+        const float logvar = fminf(fmaxf(row[zc + c], -30.0f), 20.0f);
+        out[i] = scale * (row[c] + expf(0.5f * logvar) * noise[i]);
+    }
+}
+
 __global__ void cfg_denoise_kernel(const float* __restrict__ x, const float* __restrict__ eps2, float* __restrict__ den,
                                    int64_t n, float sigma, float scale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -285,6 +300,16 @@ extern "C" int ccedit_timestep_embedding(const int64_t* t, void* out, int32_t n,
     CC_UNSUPPORTED(dim % 2, "ccedit_timestep_embedding: odd dim");
     hipLaunchKernelGGL(timestep_embedding_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, t, (bf16*)out, n, dim, ld);
     return cc_launch_status("timestep_embedding");
+}
+
+extern "C" int ccedit_gaussian_sample(const float* moments, const float* noise, float* out, int64_t frames, int32_t zc,
+                                      int32_t hw, int32_t ldm, float scale, void* stream) {
+    CC_CHECK_ARG(moments && noise && out && frames > 0 && zc > 0 && hw > 0 && ldm >= 2 * zc,
+                 "ccedit_gaussian_sample: bad args");
+    const int64_t total = frames * zc * hw;
+    hipLaunchKernelGGL(gaussian_sample_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, moments, noise,
+                       out, total, zc, hw, ldm, scale);
+    return cc_launch_status("gaussian_sample");
 }
 
 extern "C" int ccedit_cfg_denoise(const float* x, const float* eps2, float* den, int64_t n, float sigma, float scale,

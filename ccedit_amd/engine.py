@@ -38,9 +38,19 @@ class VideoDiffusionEngineTV2V(nn.Module):
         self.first_stage_model = instantiate_from_config(first_stage_config).eval()
         self.scale_factor = scale_factor
         self.disable_first_stage_autocast = disable_first_stage_autocast
+        self.setup_vaeembedder()
         self.use_ema = False
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path)
+
+    def setup_vaeembedder(self) -> None:
+        """diffusion.py:375-385: the TVI2V `VAEEmbedder` shares the engine's first stage (not a sub-module of it)."""
+        for e in (self.conditioner.embedders if self.conditioner is not None else []):
+            if e.__class__.__name__ == "VAEEmbedder":
+                e.__dict__["first_stage_model"] = self.first_stage_model        # plain attribute: no second registration
+                e.disable_first_stage_autocast = self.disable_first_stage_autocast
+                e.scale_factor = self.scale_factor
+                e.freeze()
 
     # -- weights -------------------------------------------------------------------------------
     def init_from_ckpt(self, path: str) -> None:
@@ -78,6 +88,9 @@ class VideoDiffusionEngineTV2V(nn.Module):
         return self.first_stage_model.decode(zs)
 
     @torch.no_grad()
-    def encode_first_stage(self, x):
-        z = self.first_stage_model.encode(x)
-        return self.scale_factor * z
+    def encode_first_stage(self, x, noise=None):
+        """diffusion.py:158-163: scale_factor * first_stage_model.encode(x) (a posterior SAMPLE; `noise` overrides the
+        reference's CPU-generator draw for reproducible tests)."""
+        from . import ops
+        z = self.first_stage_model.encode(x, noise=noise)
+        return ops.axpby(z, z, float(self.scale_factor), 0.0)

@@ -731,7 +731,12 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         if c.get("concat") is not None and c["concat"].numel():
             raise NotImplementedError("'concat' conditioning is not used by the TV2V configs")
         net = self.diffusion_model
-        b, _, nt, _, _ = x.shape
+        b, _, nt, lh, lw = x.shape
+        if lh % 8 or lw % 8:
+            raise ValueError(f"latent {lh}x{lw}: frame sizes must be multiples of 64 pixels (three stride-2 levels whose "
+                             f"skips are concatenated with the 2x-upsampled decoder tensors, controlmodel.py:539-543)")
+        if tuple(c["control_hint"].shape[-2:]) != (8 * lh, 8 * lw):
+            raise ValueError(f"control_hint {tuple(c['control_hint'].shape)} does not match latent {lh}x{lw} (x8)")
         sh = self.frame_shard
         hint5 = c["control_hint"]
         if sh is not None:             # keep this rank's keyframes of every clip; everything spatial is frame-local

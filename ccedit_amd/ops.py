@@ -135,7 +135,7 @@ def linear(x2d, pw, **kw):
 
 
 def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, upsample: bool = False,
-           x2: Optional[torch.Tensor] = None, gn: bool = False, **kw) -> torch.Tensor:
+           x2: Optional[torch.Tensor] = None, gn: bool = False, out_hw: Optional[tuple] = None, **kw) -> torch.Tensor:
     """x: (N, H, W, C) -> (N, Hout, Wout, Cout); 3x3 (pad 1) or 1x1 (pad 0) by the packed kernel size.
     gn=True: the output feeds a spatial GroupNorm — accumulate its statistics in the epilogue."""
     n, h, w, c = x.shape
@@ -144,6 +144,8 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, ups
     hv, wv = (2 * h, 2 * w) if upsample else (h, w)
     hout = (hv + 2 * pad - pw.ksize) // stride + 1
     wout = (wv + 2 * pad - pw.ksize) // stride + 1
+    if out_hw is not None:          # asymmetric padding (VAE Downsample, model.py:74-93: pad right/bottom only, conv pad 0):
+        hout, wout = out_hw         # taps that fall outside the source read zeros, so only the output size changes
     a2 = None if x2 is None else x2.reshape(-1, x2.shape[-1])
     out = gemm(x.reshape(-1, c), pw, mode=GEMM_CONV2D, m=n * hout * wout, hin=h, win=w, hout=hout, wout=wout,
                stride=stride, pad=pad, upsample=upsample, a2=a2, gn_rows=hout * wout if gn else 0, **kw)
@@ -319,6 +321,10 @@ def cat_add(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor], gn: boo
     """(..., C1) ++ ((..., C2) + (..., C2)) along channels.  gn=True (4-D NHWC input): also accumulate the
     GroupNorm(32) statistics of the result for the `groupnorm_spatial` that follows."""
     _chk_act(a, "cat_add.a"), _chk_act(b, "cat_add.b")
+    if a.shape[:-1] != b.shape[:-1] or (c is not None and c.shape != b.shape):
+        raise ValueError(f"cat_add: mismatched shapes {tuple(a.shape)}, {tuple(b.shape)}"
+                         + (f", {tuple(c.shape)}" if c is not None else "")
+                         + " (frame sizes must be multiples of 64 pixels so that the UNet's 3 down/up levels agree)")
     c1, c2 = a.shape[-1], b.shape[-1]
     out = torch.empty((*a.shape[:-1], c1 + c2), dtype=BF16, device=a.device)
     if gn and FUSE_GN_STATS and a.dim() == 4 and (c1 + c2) % 32 == 0 and c1 + c2 <= 2560:
@@ -352,6 +358,17 @@ def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     out = torch.empty((t.shape[0], dim), dtype=BF16, device=t.device)
     hip.check(hip.lib().ccedit_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], dim, dim, _stream()),
               "ccedit_timestep_embedding")
+    return out
+
+
+def gaussian_sample(moments: torch.Tensor, noise: torch.Tensor, zc: int, scale: float = 1.0) -> torch.Tensor:
+    """moments: fp32 [frames*hw, >=2*zc] channels-last rows [mean | logvar]; noise: fp32 (frames, zc, h, w)."""
+    assert moments.dtype == torch.float32 and noise.dtype == torch.float32 and noise.is_contiguous() and moments.stride(-1) == 1
+    n, c, h, w = noise.shape
+    assert c == zc and moments.shape[0] == n * h * w
+    out = torch.empty_like(noise)
+    hip.check(hip.lib().ccedit_gaussian_sample(moments.data_ptr(), noise.data_ptr(), out.data_ptr(), n, zc, h * w,
+                                               moments.stride(0), scale, _stream()), "ccedit_gaussian_sample")
     return out
 
 

@@ -94,6 +94,22 @@ class LegacyDDPMDiscretization(Discretization):
 # ------------------------------------------------------------------------------------------
 # denoiser
 # ------------------------------------------------------------------------------------------
+class Img2ImgDiscretizationWrapper:
+    """scripts/demo/streamlit_helpers.py:212-233 (SDEdit): wraps a discretizer and keeps only the
+    max(int(strength * len), 1) smallest sigmas (the tail of the descending schedule, trailing zero included)."""
+
+    def __init__(self, discretization, strength: float = 1.0):
+        self.discretization = discretization
+        self.strength = strength
+        assert 0.0 <= self.strength <= 1.0
+
+    def __call__(self, *args, **kwargs):
+        sigmas = self.discretization(*args, **kwargs)
+        sigmas = torch.flip(sigmas, (0,))
+        sigmas = sigmas[: max(int(self.strength * len(sigmas)), 1)]
+        return torch.flip(sigmas, (0,))
+
+
 class EpsWeighting:
     def __call__(self, sigma):
         return sigma ** -2.0

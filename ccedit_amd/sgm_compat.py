@@ -54,3 +54,24 @@ def build_network_spec(cfg: dict, prefix: str = "model.") -> List[Tuple[str, Tup
 def build_vae_spec(cfg: dict, prefix: str = "first_stage_model.") -> List[Tuple[str, Tuple[int, ...]]]:
     v = build_vae("meta", **cfg)
     return [(prefix + k, tuple(t.shape)) for k, t in v.state_dict().items()]
+
+
+def engine_config(crossframe: bool = False, vae_ch: int = 128, **net_cfg) -> dict:
+    """The `model:` section of the reference's inference yamls as a dict (keyframe_no2ndca_depthmidas.yaml, or with
+    crossframe=True keyframe_ref_cp_no2ndca_add_cfca_depthzoe.yaml), optionally at reduced width for tests."""
+    dd = "sgm.modules.diffusionmodules."
+    emb = [dict(is_trainable=False, input_key="txt", ucg_rate=0.5, target="sgm.modules.encoders.modules.FrozenCLIPEmbedder"),
+           dict(is_trainable=False, input_key="control_hint",
+                target="sgm.modules.encoders.modules." + ("DepthZoeEncoder" if crossframe else "DepthMidasEncoder"))]
+    if crossframe:
+        emb.append(dict(is_trainable=False, input_key="cond_img", ucg_rate=0.0, target="sgm.modules.encoders.modules.VAEEmbedder"))
+    return dict(target="sgm.models.diffusion.VideoDiffusionEngineTV2V", params=dict(
+        use_ema=False, scale_factor=0.18215, disable_first_stage_autocast=True, log_keys=["txt"], freeze_model="spatial",
+        denoiser_config=dict(target=dd + "denoiser.DiscreteDenoiser", params=dict(
+            num_idx=1000, weighting_config=dict(target=dd + "denoiser_weighting.EpsWeighting"),
+            scaling_config=dict(target=dd + "denoiser_scaling.EpsScaling"),
+            discretization_config=dict(target=dd + "discretizer.LegacyDDPMDiscretization"))),
+        network_config=dict(target=dd + "controlmodel.ControlledUNetModel3DTV2V",
+                            params=network_params(crossframe=crossframe, **net_cfg)),
+        conditioner_config=dict(target="sgm.modules.GeneralConditioner", params=dict(emb_models=emb)),
+        first_stage_config=dict(target="sgm.models.autoencoder.AutoencoderKLInferenceWrapper", params=vae_params(ch=vae_ch))))

@@ -1,4 +1,4 @@
-"""AutoencoderKL decode (SD-1.5 KL-VAE) on the HIP kernels.
+"""AutoencoderKL (SD-1.5 KL-VAE) decode and encode on the HIP kernels.
 
 Reference: sgm/models/autoencoder.py:283-343 (AutoencoderKL, AutoencoderKLInferenceWrapper),
 sgm/modules/diffusionmodules/model.py:94-151 (ResnetBlock), 161-201 (AttnBlock), 56-71 (Upsample),
@@ -6,8 +6,11 @@ sgm/modules/diffusionmodules/model.py:94-151 (ResnetBlock), 161-201 (AttnBlock),
 The reference runs the VAE in fp32 (autocast disabled); here it runs in bf16 storage with fp32
 accumulation / statistics like the rest of the path — the tolerance is stated in the tests.
 
-Scope: `decode` (on the hot path).  `encode` parameters are held so checkpoints load and round-trip,
-but running the encoder is a "next" row and raises NotImplementedError.
+`decode` is on the hot path (once per clip).  `encode` (Encoder model.py:498-614, asymmetric
+Downsample :74-93, DiagonalGaussianDistribution.sample distributions.py:24-41) serves the `--prior_coefficient_x`
+noise prior, SDEdit and the TVI2V `VAEEmbedder` (`cond_feat`); it re-uses the same conv / GroupNorm / attention
+kernels.  The posterior noise is drawn exactly as the reference draws it — `torch.randn(mean.shape)` on the CPU
+global generator — so a seeded script consumes the RNG stream identically.
 """
 from __future__ import annotations
 
@@ -142,11 +145,28 @@ class Decoder(nn.Module):
         return ops.conv2d(a, self.conv_out.pw, out_f32=True)
 
 
-class _EncoderParams(nn.Module):
-    """Encoder parameters with the reference's keys (model.py:498-614) so checkpoints round-trip."""
+class Downsample(nn.Module):
+    """model.py:74-93 (with_conv): F.pad(x, (0,1,0,1)) then Conv2d 3x3 stride 2 padding 0.  The conv kernel reads
+    zeros for taps outside the source, so the pad is just pad=0 with the output size of the padded input."""
 
-    def __init__(self, *, ch, ch_mult, num_res_blocks, in_channels, z_channels, double_z=True, **ignored):
+    def __init__(self, c: int):
         super().__init__()
+        self.conv = Conv(c, c, 3, stride=2)
+
+    def run(self, x):
+        n, h, w, _ = x.shape
+        return ops.conv2d(x, self.conv.pw, stride=2, pad=0, out_hw=((h + 1 - 3) // 2 + 1, (w + 1 - 3) // 2 + 1))
+
+
+class Encoder(nn.Module):
+    """model.py:498-614; parameter names are the reference's (`encoder.down.1.block.0.norm1.weight`, ...)."""
+
+    def __init__(self, *, ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions=(), in_channels, z_channels,
+                 double_z=True, **ignored):
+        super().__init__()
+        if len(attn_resolutions) != 0:
+            raise NotImplementedError("attention inside down-levels is not used by the SD-1.5 VAE config")
+        self.ch_mult, self.num_res_blocks = list(ch_mult), num_res_blocks
         self.conv_in = Conv(in_channels, ch, 3)
         in_mult = (1,) + tuple(ch_mult)
         self.down = nn.ModuleList()
@@ -162,8 +182,7 @@ class _EncoderParams(nn.Module):
             down.block = block
             down.attn = nn.ModuleList()
             if i_level != len(ch_mult) - 1:
-                down.downsample = nn.Module()
-                down.downsample.conv = Conv(block_in, block_in, 3, stride=2)
+                down.downsample = Downsample(block_in)
             self.down.append(down)
         self.mid = nn.Module()
         self.mid.block_1 = ResnetBlock(block_in, block_in)
@@ -172,13 +191,31 @@ class _EncoderParams(nn.Module):
         self.norm_out = Norm(block_in, GN_EPS)
         self.conv_out = Conv(block_in, 2 * z_channels if double_z else z_channels, 3)
 
+    def run(self, x8):
+        """x8: (N, H, W, 8) bf16 frames (3 real channels) -> (N*H/8*W/8, >=2*z) bf16 pre-quant moments."""
+        h = ops.conv2d(x8, self.conv_in.pw)
+        for lvl in range(len(self.ch_mult)):
+            for i in range(self.num_res_blocks):
+                h = self.down[lvl].block[i].run(h)
+            if lvl != len(self.ch_mult) - 1:
+                h = self.down[lvl].downsample.run(h)
+        h = self.mid.block_1.run(h)
+        h = self.mid.attn_1.run(h)
+        h = self.mid.block_2.run(h)
+        a = ops.groupnorm_spatial(h, self.norm_out.g, self.norm_out.b, GN_EPS, True)
+        n, hh, ww, _ = a.shape
+        co = self.conv_out.pw
+        out = torch.zeros((n * hh * ww, (co.n + 7) // 8 * 8), dtype=torch.bfloat16, device=a.device)
+        ops.conv2d(a, co, out=out[:, : co.n])
+        return out.view(n, hh, ww, out.shape[1])
+
 
 class AutoencoderKL(nn.Module):
     def __init__(self, embed_dim: int, ddconfig=None, lossconfig=None, ckpt_path=None, monitor=None, **ignored):
         super().__init__()
         assert ddconfig["double_z"]
         dd = dict(ddconfig)
-        self.encoder = _EncoderParams(**dd)
+        self.encoder = Encoder(**dd)
         self.decoder = Decoder(**dd)
         self.quant_conv = Conv(2 * dd["z_channels"], 2 * embed_dim, 1)
         self.post_quant_conv = Conv(embed_dim, dd["z_channels"], 1)
@@ -195,8 +232,15 @@ class AutoencoderKL(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
-    def encode(self, x):
-        raise NotImplementedError("VAE encode is a 'next' scope row (SURVEY.md §8f): not on the TV2V hot path")
+    def _encode_frames(self, x8, noise=None):
+        """x8: (N, H, W, 8) bf16 frames -> posterior sample (N, z, H/8, W/8) fp32 (autoencoder.py:306-314 + .sample())."""
+        pre = self.encoder.run(x8)                                       # (N, h, w, 8) bf16: conv_out
+        n, h, w, c = pre.shape
+        mom = ops.conv2d(pre, self.quant_conv.pw, out_f32=True)          # 1x1, fp32 [mean | logvar]
+        zc = self.quant_conv.pw.n // 2
+        if noise is None:
+            noise = torch.randn(n, zc, h, w)                             # CPU global generator, like distributions.py:37-41
+        return ops.gaussian_sample(mom.view(n * h * w, -1), noise.to(device=pre.device, dtype=torch.float32).contiguous(), zc)
 
     def _decode_frames(self, z8):
         """z8: (N, h, w, 8) bf16 latent frames (4 real channels) -> (N, 8h, 8w, 4) fp32 (3 real channels)."""
@@ -209,6 +253,21 @@ class AutoencoderKL(nn.Module):
 
 class AutoencoderKLInferenceWrapper(AutoencoderKL):
     """autoencoder.py:322-343: accepts 4-D (N,C,H,W) or 5-D (B,C,T,H,W) latents."""
+
+    def encode(self, x, noise=None):
+        """autoencoder.py:323-332: (N,3,H,W) or (B,3,T,H,W) frames in [-1,1] -> posterior SAMPLE of the same rank
+        (unscaled; encode_first_stage applies scale_factor).  `noise` (N or B*T, z, H/8, W/8) overrides the draw."""
+        if not self._packed:
+            raise RuntimeError("call .pack() after loading weights")
+        is_video = x.dim() == 5
+        x5 = x if is_video else x[:, :, None]
+        b, c, t, h, w = x5.shape
+        if h % 8 or w % 8:
+            raise ValueError(f"frame size {h}x{w} must be a multiple of 8")
+        z = self._encode_frames(ops.ncthw_to_nhwc(x5.float().contiguous(), 8), noise)     # (b*t, zc, h/8, w/8)
+        if is_video:
+            return z.view(b, t, *z.shape[1:]).permute(0, 2, 1, 3, 4).contiguous()
+        return z
 
     def decode(self, z, **decoder_kwargs):
         if not self._packed:

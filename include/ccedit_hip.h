@@ -199,6 +199,14 @@ int ccedit_timestep_embedding(const int64_t* t, void* out, int32_t n, int32_t di
 int ccedit_softmax_rows(const float* s, void* p, int64_t rows, int32_t cols, int32_t cols_pad, int64_t lds,
                         int64_t ldp, float scale, void* stream);
 
+/* Posterior sample of the KL-VAE encoder (DiagonalGaussianDistribution.sample, distributions.py:24-41, called from
+ * AutoencoderKLInferenceWrapper.encode, autoencoder.py:323-332): moments = fp32 [frames*hw][ldm] channels-last rows
+ * [mean(zc) | logvar(zc)] (quant_conv output); noise, out = fp32 (frames, zc, h, w);
+ * out = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise).  The caller supplies the noise (the reference
+ * draws it with torch.randn on the CPU global generator). */
+int ccedit_gaussian_sample(const float* moments, const float* noise, float* out, int64_t frames, int32_t zc,
+                           int32_t hw, int32_t ldm, float scale, void* stream);
+
 /* Sampler / guider / denoiser elementwise math on the fp32 latent (417,792 elements at 17x64x96):
  *   ccedit_cfg_denoise : den = x + (-sigma) * (eps_u + scale*(eps_c - eps_u))        [denoiser.py:40 with
  *                        c_skip=1, c_out=-sigma; guiders.py:25-29]   eps = fp32 [2][n]

@@ -621,3 +621,57 @@ def vae_decode(sd: SD, p: str, cfg: VAEConfig, z, scale_factor: float = 0.18215)
             x = _conv2d(sd, f"{d}.up.{lvl}.upsample.conv", x, padding=1)
     x = _conv2d(sd, d + ".conv_out", F.silu(_gn(sd, d + ".norm_out", x, GN_EPS_ATTN)), padding=1)
     return x.reshape(b, t, x.shape[1], x.shape[2], x.shape[3]).permute(0, 2, 1, 3, 4).contiguous()
+
+
+def vae_encode_moments(sd: SD, p: str, cfg: VAEConfig, x4):
+    """AutoencoderKL.encode up to the moments (autoencoder.py:306-314): Encoder.forward (model.py:587-614) and
+    quant_conv.  x4: (n, 3, H, W) in [-1, 1] -> (n, 2*z_channels, H/8, W/8) = [mean | logvar].
+    Downsample (model.py:74-93): zero pad right/bottom by one, conv3x3 stride 2 without padding."""
+    e = p + ".encoder"
+    h = _conv2d(sd, e + ".conv_in", x4, padding=1)
+    nres = len(cfg.ch_mult)
+    for lvl in range(nres):
+        for i in range(cfg.num_res_blocks):
+            h = _vae_resblock(sd, f"{e}.down.{lvl}.block.{i}", h)
+        if lvl != nres - 1:
+            h = _conv2d(sd, f"{e}.down.{lvl}.downsample.conv", F.pad(h, (0, 1, 0, 1)), stride=2)
+    h = _vae_resblock(sd, e + ".mid.block_1", h)
+    h = _vae_attn(sd, e + ".mid.attn_1", h)
+    h = _vae_resblock(sd, e + ".mid.block_2", h)
+    h = _conv2d(sd, e + ".conv_out", F.silu(_gn(sd, e + ".norm_out", h, GN_EPS_ATTN)), padding=1)
+    return _conv2d(sd, p + ".quant_conv", h)
+
+
+def gaussian_sample(moments, noise):
+    """DiagonalGaussianDistribution.__init__ / .sample (distributions.py:24-41): logvar clamped to [-30, 20],
+    x = mean + exp(0.5 logvar) * noise.  The reference draws `noise = torch.randn(mean.shape)` from the CPU
+    global generator; here it is an explicit argument."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    return mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise
+
+
+def vae_encode(sd: SD, p: str, cfg: VAEConfig, x, noise, scale_factor: float = 0.18215):
+    """encode_first_stage (diffusion.py:158-163) -> AutoencoderKLInferenceWrapper.encode (autoencoder.py:323-332):
+    4-D (n c h w) or 5-D (b c t h w) frames in, posterior sample * scale_factor out (same rank).  `noise` has
+    the shape the reference draws: (n or b*t, z_channels, h/8, w/8)."""
+    video = x.dim() == 5
+    x4 = _to_frames(x) if video else x
+    z = gaussian_sample(vae_encode_moments(sd, p, cfg, x4), noise)
+    if video:
+        b, t = x.shape[0], x.shape[2]
+        z = z.reshape(b, t, *z.shape[1:]).permute(0, 2, 1, 3, 4).contiguous()
+    return scale_factor * z
+
+
+def img2img_sigmas(sigmas: torch.Tensor, strength: float) -> torch.Tensor:
+    """Img2ImgDiscretizationWrapper.__call__ (scripts/demo/streamlit_helpers.py:212-233): keep the
+    max(int(strength * len), 1) smallest sigmas (the tail of the descending schedule, trailing 0 included)."""
+    s = torch.flip(sigmas, (0,))
+    s = s[: max(int(strength * len(s)), 1)]
+    return torch.flip(s, (0,))
+
+
+def sdedit_noised_latent(z, noise, sigmas):
+    """sampling_tv2v.py:439-448: noised_z = (z + noise * sigma0) / sqrt(1 + sigma0^2) (DDPM-like scaling)."""
+    s0 = sigmas[0]
+    return (z + noise * s0) / torch.sqrt(1.0 + s0 ** 2.0)

@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
 """TV2V sampling entry point on the MI355X path — counterpart of the reference's
-scripts/sampling/sampling_tv2v.py (same flag names for the hot-path options; core loop = its lines 333-470).
+scripts/sampling/sampling_tv2v.py (same flag names for the options on the path; core loop = its lines 333-470,
+including the `--prior_coefficient_x` noise prior and the `--sdedit_denoise_strength` branch).
 
-Conditioning producers (CLIP text encoder, MiDaS depth) are outside this build (weights unavailable offline,
-SURVEY.md §2 row 14): pass precomputed tensors with --cond_path (a .pt/.safetensors holding `crossattn`,
-`crossattn_uc` (1,77,768) and `control_hint` (1,3,T,H,W) in [-1,1]) or use --synthetic for seeded random
-conditioning of the right shapes (benchmarks / smoke runs).  Outputs: `<save_path>/result/sample_XXXX.npy`
-(frames in [0,1], (T,H,W,3)) + `log_info.json` with the resume-skip list, like the reference.
+Conditioning producers (CLIP text encoder, MiDaS depth, video decoding) are outside this build (weights / codecs
+unavailable offline): pass precomputed tensors with --cond_path — a .pt/.safetensors holding
+`crossattn`, `crossattn_uc` (1,77,768), `control_hint` (1,3,T,H,W) in [-1,1] and, for the prior / SDEdit options,
+`keyframes` (1,3,T,H,W) in [-1,1] — or use --synthetic for seeded random tensors of the right shapes.  They enter
+through `model.conditioner.get_unconditional_conditioning` exactly like the reference's batch dicts.
+Outputs: `<save_path>/result/sample_XXXX.npy` (frames in [0,1], (T,H,W,3)) + `log_info.json` resume-skip list.
 """
 from __future__ import annotations
 
 import argparse
-import json
 import os
 import sys
 import time
@@ -22,9 +23,10 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+GUIDER = "sgm.modules.diffusionmodules.guiders.VanillaCFGTV2V"
 
-def parse():
-    p = argparse.ArgumentParser()
+
+def add_common_args(p: argparse.ArgumentParser) -> None:
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--config_path", type=str, default="")
     p.add_argument("--ckpt_path", type=str, default="")
@@ -42,35 +44,20 @@ def parse():
     p.add_argument("--sampler_name", type=str, default="DPMPP2SAncestralSampler")
     p.add_argument("--discretization_name", type=str, default="LegacyDDPMDiscretization")
     p.add_argument("--cfg_scale", type=float, default=7.5)
+    p.add_argument("--prior_coefficient_x", type=float, default=0.0)
+    p.add_argument("--prior_coefficient_noise", type=float, default=1.0)
+    p.add_argument("--sdedit_denoise_strength", type=float, default=0.0)
     p.add_argument("--num_samples", type=int, default=1)
     p.add_argument("--disable_check_repeat", action="store_true")
-    return p.parse_args()
 
 
-def init_sampling(name: str, steps: int, scale: float, discretization: str):
-    """scripts/sampling/util.py:385-556 reduced to the samplers of the hot path (eta=1, s_noise=1, VanillaCFGTV2V)."""
-    from ccedit_amd.config import instantiate_from_config
-    dd = "sgm.modules.diffusionmodules."
-    if name not in ("DPMPP2SAncestralSampler", "EulerAncestralSampler"):
-        raise NotImplementedError(f"sampler {name}: only the ancestral samplers of the hot path are built")
-    return instantiate_from_config(dict(target=dd + "sampling." + name, params=dict(
-        num_steps=steps, eta=1.0, s_noise=1.0, verbose=True,
-        discretization_config=dict(target=dd + "discretizer." + discretization),
-        guider_config=dict(target=dd + "guiders.VanillaCFGTV2V", params=dict(scale=scale)))))
-
-
-def main():
-    args = parse()
-    torch.manual_seed(args.seed)
-    torch.set_grad_enabled(False)
-    from ccedit_amd.config import instantiate_from_config, load_config
+def build_model(args):
     from ccedit_amd.utils.synth import fill_module_
+    from scripts.sampling.util import create_model
     if not args.config_path:
         raise SystemExit("--config_path is required (e.g. configs/inference_ccedit/keyframe_no2ndca_depthmidas.yaml)")
-    cfg = load_config(args.config_path)
     dev = torch.device("cuda")
-    with torch.device(dev):
-        model = instantiate_from_config(cfg.model)
+    model = create_model(args.config_path, dev)
     if args.ckpt_path:
         model.init_from_ckpt(args.ckpt_path)
     elif args.synthetic:
@@ -78,43 +65,85 @@ def main():
         fill_module_(model.first_stage_model, prefix="first_stage_model.")
     else:
         raise SystemExit("need --ckpt_path or --synthetic")
+    if args.vae_path:
+        model.first_stage_model.load_state_dict(torch.load(args.vae_path, map_location="cpu")["state_dict"], strict=False)
     model.pack(dev)
+    args.context_dim = model.model.diffusion_model.context_dim     # 768 for the shipped configs
+    return model, dev
 
+
+def conditioning_tensors(args, g: torch.Generator, need_frames: bool, need_ref: bool = False):
+    from scripts.sampling.util import load_conditioning
+    T = args.num_keyframes
+    if args.cond_path:
+        cond = load_conditioning(args.cond_path)
+    else:
+        cond = dict(crossattn=torch.randn(1, 77, args.context_dim, generator=g),
+                    crossattn_uc=torch.randn(1, 77, args.context_dim, generator=g),
+                    control_hint=(torch.rand(1, 1, T, args.H, args.W, generator=g) * 2 - 1).repeat(1, 3, 1, 1, 1))
+        if need_frames:
+            cond["keyframes"] = torch.rand(1, 3, T, args.H, args.W, generator=g) * 2 - 1
+        if need_ref:
+            cond["cond_img"] = torch.rand(1, 3, args.H, args.W, generator=g) * 2 - 1
+    for k in (["keyframes"] if need_frames else []) + (["cond_img"] if need_ref else []):
+        if k not in cond:
+            raise SystemExit(f"--cond_path must hold `{k}` for the requested options")
+    return cond
+
+
+def sample_one(args, model, dev, c, uc, randn, keyframes=None, ref=None, prior_type="video"):
+    """sampling_tv2v.py:361-470 for one clip."""
+    from scripts.sampling.util import init_sampling, prior_latent, sdedit_start
+
+    def denoiser(inp, sigma, cc):
+        return model.denoiser(model.model, inp, sigma, cc)
+
+    if args.sdedit_denoise_strength == 0.0:
+        if args.prior_coefficient_x != 0.0:
+            randn = prior_latent(model, randn, args.prior_coefficient_x, args.prior_coefficient_noise, keyframes, ref, prior_type)
+        sampler = init_sampling(sample_steps=args.sample_steps, sampler_name=args.sampler_name,
+                                discretization_name=args.discretization_name, guider_config_target=GUIDER,
+                                cfg_scale=args.cfg_scale)
+        samples = sampler(denoiser, randn, c, uc=uc)
+    else:
+        assert 0.0 < args.sdedit_denoise_strength <= 1.0, "sdedit_denoise_strength should be in (0, 1]"
+        assert args.prior_coefficient_x == 0, "prior_coefficient_x should be 0 when using sdedit_denoise_strength"
+        sampler = init_sampling(sample_steps=args.sample_steps, sampler_name=args.sampler_name,
+                                discretization_name=args.discretization_name, guider_config_target=GUIDER,
+                                cfg_scale=args.cfg_scale, img2img_strength=args.sdedit_denoise_strength)
+        samples = sampler(denoiser, sdedit_start(model, sampler, keyframes), cond=c, uc=uc)
+    return model.decode_first_stage(samples)
+
+
+def main():
+    p = argparse.ArgumentParser()
+    add_common_args(p)
+    args = p.parse_args()
+    torch.manual_seed(args.seed)
+    torch.set_grad_enabled(False)
+    from scripts.sampling.util import ResumeLog, save_frames
+    model, dev = build_model(args)
     T, h, w = args.num_keyframes, args.H // 8, args.W // 8
     g = torch.Generator().manual_seed(args.seed)
-    if args.cond_path:
-        if args.cond_path.endswith(".safetensors"):
-            from safetensors.torch import load_file
-            cond = load_file(args.cond_path)
-        else:
-            cond = torch.load(args.cond_path, map_location="cpu")
-        cross_c, cross_uc, hint = cond["crossattn"], cond["crossattn_uc"], cond["control_hint"]
-    else:
-        cross_c, cross_uc = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
-        hint = (torch.rand(1, 1, T, args.H, args.W, generator=g) * 2 - 1).repeat(1, 3, 1, 1, 1)
-    c = dict(crossattn=cross_c.to(dev), control_hint=hint.to(dev))
-    uc = dict(crossattn=cross_uc.to(dev), control_hint=hint.clone().to(dev))     # uc keeps the SAME hint (:339-344)
-
-    os.makedirs(os.path.join(args.save_path, "result"), exist_ok=True)
-    log_path = os.path.join(args.save_path, "log_info.json")
-    log = json.load(open(log_path)) if os.path.exists(log_path) else {"done": []}
+    need_frames = args.prior_coefficient_x != 0.0 or args.sdedit_denoise_strength != 0.0
+    cond = conditioning_tensors(args, g, need_frames)
+    hint = cond["control_hint"].to(dev)
+    batch = {"txt": cond["crossattn"].to(dev), "control_hint": hint}
+    batch_uc = {"txt": cond["crossattn_uc"].to(dev), "control_hint": hint.clone()}      # uc keeps the SAME hint (:339-344)
+    c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=batch_uc)
+    keyframes = cond["keyframes"].to(dev) if need_frames else None
+    log = ResumeLog(args.save_path)
     for i in range(args.num_samples):
         tag = f"sample_{i:04d}"
-        if tag in log["done"] and not args.disable_check_repeat:
+        if log.done(tag) and not args.disable_check_repeat:
             continue
-        randn = torch.randn(1, 4, T, h, w, generator=g).to(dev)                   # CPU generator, like :363
-        sampler = init_sampling(args.sampler_name, args.sample_steps, args.cfg_scale, args.discretization_name)
+        randn = torch.randn(1, 4, T, h, w, generator=g).to(dev)                           # CPU generator, like :363
         t0 = time.time()
-        z = sampler(lambda inp, sigma, cc: model.denoiser(model.model, inp, sigma, cc), randn, c, uc=uc)
-        x = model.decode_first_stage(z)
+        x = sample_one(args, model, dev, c, uc, randn, keyframes=keyframes)
         torch.cuda.synchronize()
-        x = torch.clamp((x + 1.0) / 2.0, 0.0, 1.0)                               # :473-475
-        frames = x[0].permute(1, 2, 3, 0).cpu().numpy()
-        import numpy as np
-        np.save(os.path.join(args.save_path, "result", tag + ".npy"), frames)
+        save_frames(args.save_path, tag, x)
         print(f"{tag}: {T} frames {args.H}x{args.W} in {time.time() - t0:.2f}s")
-        log["done"].append(tag)
-        json.dump(log, open(log_path, "w"))
+        log.add(tag)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""TVI2V (reference-frame) sampling entry point — counterpart of the reference's
+scripts/sampling/sampling_tv2v_ref.py: everything of sampling_tv2v.py plus the edited centre frame `cond_img`
+((1,3,H,W) in [-1,1]; VAE-encoded to `cond_feat` by the conditioner's VAEEmbedder and, on the network side, fed to
+controlnet_img and the anchor cross-frame attention) and `--prior_type {video, ref, video_ref}` for the noise prior
+(sampling_tv2v_ref.py:415-437).  Config: configs/inference_ccedit/keyframe_ref_cp_no2ndca_add_cfca_depthzoe.yaml.
+`--cond_path` additionally holds `cond_img`.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from scripts.sampling.sampling_tv2v import add_common_args, build_model, conditioning_tensors, sample_one  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    add_common_args(p)
+    p.add_argument("--prior_type", type=str, default="ref", choices=["video", "ref", "video_ref"])
+    args = p.parse_args()
+    torch.manual_seed(args.seed)
+    torch.set_grad_enabled(False)
+    from scripts.sampling.util import ResumeLog, save_frames
+    model, dev = build_model(args)
+    T, h, w = args.num_keyframes, args.H // 8, args.W // 8
+    g = torch.Generator().manual_seed(args.seed)
+    need_frames = (args.prior_coefficient_x != 0.0 and args.prior_type != "ref") or args.sdedit_denoise_strength != 0.0
+    cond = conditioning_tensors(args, g, need_frames, need_ref=True)
+    hint, ref = cond["control_hint"].to(dev), cond["cond_img"].to(dev)
+    batch = {"txt": cond["crossattn"].to(dev), "control_hint": hint, "cond_img": ref}
+    batch_uc = {"txt": cond["crossattn_uc"].to(dev), "control_hint": hint.clone(), "cond_img": ref.clone()}
+    c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=batch_uc)     # two VAE encodes (two RNG draws)
+    keyframes = cond["keyframes"].to(dev) if need_frames else None
+    log = ResumeLog(args.save_path)
+    for i in range(args.num_samples):
+        tag = f"sample_{i:04d}"
+        if log.done(tag) and not args.disable_check_repeat:
+            continue
+        randn = torch.randn(1, 4, T, h, w, generator=g).to(dev)
+        t0 = time.time()
+        x = sample_one(args, model, dev, c, uc, randn, keyframes=keyframes, ref=ref, prior_type=args.prior_type)
+        torch.cuda.synchronize()
+        save_frames(args.save_path, tag, x)
+        print(f"{tag}: {T} frames {args.H}x{args.W} in {time.time() - t0:.2f}s")
+        log.add(tag)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,11 +1,17 @@
-"""Conditioner contract (reference: sgm/modules/encoders/modules.py:84-204).
+"""Conditioner (reference: sgm/modules/encoders/modules.py:84-204, 982-1023).
 
-The embedders themselves (HF CLIP ViT-L/14 text encoder, MiDaS / ZoeDepth annotators from the un-vendored
-ControlNet-v1-1 repo) run once per clip OUTSIDE the denoising loop and need weights that are not
-available offline; they are out of scope for this build.  What the hot
-path needs is the dict contract: batch keys `txt` / `control_hint` / `cond_img` -> conditioning keys
-`crossattn` (B,77,768) / `control_hint` (B,3,T,H,W) / `cond_feat`.  `GeneralConditioner` keeps that
-routing and accepts *precomputed* tensors: batch["crossattn"] may carry the text embedding directly.
+`GeneralConditioner` keeps the reference's routing exactly — embedders instantiated from their `target`
+strings, `input_key` -> output key rules (`cond_img` -> `cond_feat`, `control_hint` -> `control_hint`, otherwise by
+rank: 2 `vector`, 3 `crossattn`, 4/5 `concat`), concatenation of repeated keys, `force_zero_embeddings`, and
+`get_unconditional_conditioning`.
+
+Embedders:
+  * `VAEEmbedder` (TVI2V `cond_img` -> `cond_feat`) is real: it runs the engine's first-stage encoder on the HIP
+    kernels.
+  * `FrozenCLIPEmbedder`, `DepthMidasEncoder`, `DepthZoeEncoder` need weights / an un-vendored third-party repo that
+    do not exist offline; they run once per clip outside the denoising loop.  Here they are
+    *pass-through* embedders: they accept an already computed tensor for their input key (text embedding
+    (B,77,768) / depth hint (B,3,T,H,W) in [-1,1]) and raise with a clear message when handed raw text or video.
 """
 from __future__ import annotations
 
@@ -14,38 +20,143 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from ccedit_amd.config import instantiate_from_config
 
-class _Unavailable(nn.Module):
-    def __init__(self, target: str, input_key: str):
+
+class AbstractEmbModel(nn.Module):
+    """encoders/modules.py:44-81: carries is_trainable / ucg_rate / input_key set by the conditioner."""
+
+    def __init__(self):
         super().__init__()
-        self.target, self.input_key = target, input_key
+        self.is_trainable = False
+        self.ucg_rate = 0.0
+        self.input_key: Optional[str] = None
+        self.legacy_ucg_val = None
 
-    def forward(self, *a, **k):
+
+class _Precomputed(AbstractEmbModel):
+    """An embedder whose network is outside this build: passes a precomputed tensor through."""
+    what = "embedding"
+    rank = 3
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+
+    def forward(self, x):
+        if torch.is_tensor(x) and x.dim() == self.rank:
+            return x
         raise NotImplementedError(
-            f"embedder {self.target} is outside the hot path of this build and its weights are not available offline; "
-            f"pass a precomputed tensor for its output key instead (see GeneralConditioner docstring)")
+            f"{self.__class__.__name__}: its network/weights are not part of this build (they are not available "
+            f"offline and run once per clip outside the denoising loop); pass the precomputed {self.what} tensor "
+            f"as batch[{self.input_key!r}]")
+
+    def encode(self, x):
+        return self(x)
+
+
+class FrozenCLIPEmbedder(_Precomputed):
+    """encoders/modules.py:358-420 (HF openai/clip-vit-large-patch14 text encoder): (B, 77, 768)."""
+    what = "CLIP text embedding (B,77,768)"
+    rank = 3
+
+
+class DepthMidasEncoder(_Precomputed):
+    """encoders/modules.py:1346-1392: MiDaS depth of every keyframe, min-max normalised to [-1,1], 3 channels."""
+    what = "depth hint (B,3,T,H,W) in [-1,1]"
+    rank = 5
+
+
+class DepthZoeEncoder(DepthMidasEncoder):
+    """encoders/modules.py:1289-1342 (ZoeDepth, percentile normalisation)."""
+
+
+class VAEEmbedder(AbstractEmbModel):
+    """encoders/modules.py:982-1023: cond_feat = scale_factor * first_stage_model.encode(cond_img).  The engine
+    attaches first_stage_model / scale_factor (diffusion.py:375-385, `setup_vaeembedder`)."""
+
+    def __init__(self, down_blur_factor=1, *args, **kwargs):
+        super().__init__()
+        assert down_blur_factor >= 1, "down_blur_factor must be >= 1"
+        if down_blur_factor != 1:
+            raise NotImplementedError("VAEEmbedder.down_blur_factor > 1 (bilinear blur) is not used by the shipped configs")
+        self.down_blur_factor = down_blur_factor
+
+    def freeze(self):
+        self.eval()
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        assert "first_stage_model" in self.__dict__, "first_stage_model not defined"
+        assert hasattr(self, "scale_factor"), "scale_factor not defined"
+        from ccedit_amd import ops
+        z = self.__dict__["first_stage_model"].encode(x)
+        return ops.axpby(z, z, float(self.scale_factor), 0.0)
+
+    def encode(self, x):
+        return self(x)
 
 
 class GeneralConditioner(nn.Module):
-    OUTPUT_KEY = {"txt": "crossattn", "control_hint": "control_hint", "cond_img": "cond_feat"}
+    OUTPUT_DIM2KEYS = {2: "vector", 3: "crossattn", 4: "concat", 5: "concat"}
+    KEY2CATDIM = {"vector": 1, "crossattn": 2, "concat": 1}
+    _KEYED = {"cond_img": "cond_feat", "interpolate_first": "interpolate_first", "interpolate_last": "interpolate_last",
+              "interpolate_first_last": "interpolate_first_last", "control_hint": "control_hint"}
 
     def __init__(self, emb_models: Optional[List[dict]] = None):
         super().__init__()
-        self.embedders = nn.ModuleList([_Unavailable(e.get("target", "?"), e.get("input_key", "?")) for e in (emb_models or [])])
-
-    def forward(self, batch: Dict, force_zero_embeddings=None) -> Dict[str, torch.Tensor]:
-        out = {}
-        for e in self.embedders:
-            okey = self.OUTPUT_KEY.get(e.input_key, e.input_key)
-            if okey in batch and torch.is_tensor(batch[okey]):
-                out[okey] = batch[okey]
-            elif e.input_key in batch and torch.is_tensor(batch[e.input_key]):
-                out[okey] = batch[e.input_key]
+        embedders = []
+        for embconfig in (emb_models or []):
+            embedder = instantiate_from_config(embconfig)
+            assert isinstance(embedder, AbstractEmbModel), \
+                f"embedder model {embedder.__class__.__name__} has to inherit from AbstractEmbModel"
+            embedder.is_trainable = embconfig.get("is_trainable", False)
+            embedder.ucg_rate = embconfig.get("ucg_rate", 0.0)
+            if "input_key" in embconfig:
+                embedder.input_key = embconfig["input_key"]
+            elif "input_keys" in embconfig:
+                embedder.input_keys = embconfig["input_keys"]
             else:
-                e()
-        return out
+                raise KeyError(f"need either 'input_key' or 'input_keys' for embedder {embedder.__class__.__name__}")
+            embedder.legacy_ucg_val = embconfig.get("legacy_ucg_value", None)
+            if embedder.legacy_ucg_val is not None:
+                raise NotImplementedError("legacy_ucg_value is a training-time feature")
+            embedders.append(embedder.eval())
+        self.embedders = nn.ModuleList(embedders)
+
+    @torch.no_grad()
+    def forward(self, batch: Dict, force_zero_embeddings: Optional[List] = None) -> Dict[str, torch.Tensor]:
+        output: Dict[str, torch.Tensor] = {}
+        force_zero_embeddings = force_zero_embeddings or []
+        for embedder in self.embedders:
+            if getattr(embedder, "input_key", None) is not None:
+                emb_out = embedder(batch[embedder.input_key])
+            else:
+                emb_out = embedder(*[batch[k] for k in embedder.input_keys])
+            assert isinstance(emb_out, (torch.Tensor, list, tuple)), \
+                f"encoder outputs must be tensors or a sequence, but got {type(emb_out)}"
+            if not isinstance(emb_out, (list, tuple)):
+                emb_out = [emb_out]
+            for emb in emb_out:
+                key = getattr(embedder, "input_key", None)
+                out_key = self._KEYED.get(key) or self.OUTPUT_DIM2KEYS[emb.dim()]
+                if embedder.ucg_rate > 0.0:
+                    raise NotImplementedError("ucg_rate > 0 is training-time conditioning dropout")
+                if key in force_zero_embeddings:
+                    emb = torch.zeros_like(emb)
+                if out_key in output:
+                    output[out_key] = torch.cat((output[out_key], emb), self.KEY2CATDIM[out_key])
+                else:
+                    output[out_key] = emb
+        return output
 
     def get_unconditional_conditioning(self, batch_c, batch_uc=None, force_uc_zero_embeddings=None) -> Tuple[Dict, Dict]:
+        force_uc_zero_embeddings = force_uc_zero_embeddings or []
+        rates = [e.ucg_rate for e in self.embedders]
+        for e in self.embedders:
+            e.ucg_rate = 0.0
         c = self(batch_c)
-        uc = self(batch_c if batch_uc is None else batch_uc)
+        uc = self(batch_c if batch_uc is None else batch_uc, force_uc_zero_embeddings)
+        for e, r in zip(self.embedders, rates):
+            e.ucg_rate = r
         return c, uc

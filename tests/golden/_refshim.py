@@ -81,3 +81,16 @@ def ref(modname: str):
     """Import a reference module, e.g. ref('sgm.modules.diffusionmodules.controlmodel')."""
     install()
     return importlib.import_module(modname)
+
+
+def ref_class_from_file(relpath: str, classname: str):
+    """Evaluate ONE class definition of a reference file whose module cannot be imported (its top-level imports
+    are unavailable here), e.g. Img2ImgDiscretizationWrapper in scripts/demo/streamlit_helpers.py (imports
+    streamlit).  The class is compiled from the reference file in place, at golden-generation time only."""
+    import ast
+    src = open(f"{REF_ROOT}/{relpath}").read()
+    tree = ast.parse(src)
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == classname)
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), f"{REF_ROOT}/{relpath}", "exec"), ns)
+    return ns[classname]

@@ -16,6 +16,10 @@ synthetic weights of ccedit_amd/utils/synth.py, runs them on CPU in fp32 and wri
   net_tvi2v_g160.npz  one TVI2V network evaluation (controlnet_img on cond_feat + SpatialTransformer3DCA
                       anchor cross-frame attention) + keys_tvi2v_g160.json (state-dict keys/shapes)
 
+  vae_enc_g32.npz     AutoencoderKLInferenceWrapper.encode at the same reduced ddconfig: 5-D frames and a 4-D reference
+                      image in, moments digests + the posterior samples out (the CPU global-generator noise the
+                      reference drew is recorded); Img2ImgDiscretizationWrapper sigma tables (SDEdit)
+
 A digest of a tensor = (shape, mean, std, abs-max, 256 evenly spaced samples) — enough to pin a
 restatement while keeping every fixture well under 1 MB.
 """
@@ -286,7 +290,50 @@ def gen_vae():
           "size", os.path.getsize(os.path.join(HERE, "vae_g32.npz")))
 
 
+def gen_vae_encode():
+    import contextlib
+    import io
+    ae = _refshim.ref("sgm.models.autoencoder")
+    vae = ae.AutoencoderKLInferenceWrapper(
+        embed_dim=4, monitor="val/rec_loss", lossconfig=dict(target="torch.nn.Identity"),
+        ddconfig=dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=32,
+                      ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)).eval()
+    fill_module_(vae, prefix="first_stage_model.")
+    g = torch.Generator().manual_seed(778)
+    # smooth-ish frames in [-1, 1]: low-resolution noise upsampled, plus a little pixel noise
+    base = torch.nn.functional.interpolate(torch.rand(3, 3, 8, 12, generator=g), size=(64, 96), mode="bilinear")
+    frames = ((base + 0.1 * torch.rand(3, 3, 64, 96, generator=g)).clamp(0, 1) * 2 - 1)
+    x5 = frames.permute(1, 0, 2, 3)[None].contiguous()            # (1, 3, T=3, 64, 96)
+    out = dict(x5=x5.numpy().astype(np.float16))                  # fp16 storage is exact enough for an input: re-read as fp32
+    x5 = torch.from_numpy(out["x5"].astype(np.float32))
+    # the reference draws the posterior noise with torch.randn(mean.shape) from the CPU global generator
+    torch.manual_seed(4242)
+    noise5 = torch.randn(3, 4, 8, 12)
+    torch.manual_seed(4242)
+    z5 = vae.encode(x5)                                           # (1, 4, 3, 8, 12), unscaled posterior sample
+    mom5 = ae.AutoencoderKL.encode(vae, x5[0].permute(1, 0, 2, 3)).parameters      # (3, 8, 8, 12) = [mean | logvar]
+    ref_img = x5[:, :, 1]                                         # (1, 3, 64, 96): the VAEEmbedder / prior_type='ref' input
+    torch.manual_seed(99)
+    noise4 = torch.randn(1, 4, 8, 12)
+    torch.manual_seed(99)
+    z4 = vae.encode(ref_img)
+    out.update(noise5=noise5.numpy(), z5=z5.numpy(), moments5=mom5.numpy(), noise4=noise4.numpy(), z4=z4.numpy())
+    # SDEdit sigma pruning (scripts/demo/streamlit_helpers.py:212-233) around the reference's own discretization
+    disc_mod = _refshim.ref("sgm.modules.diffusionmodules.discretizer")
+    Wrap = _refshim.ref_class_from_file("scripts/demo/streamlit_helpers.py", "Img2ImgDiscretizationWrapper")
+    for n, strength in ((30, 0.6), (5, 0.5), (50, 1.0), (30, 0.01)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            sig = Wrap(disc_mod.LegacyDDPMDiscretization(), strength=strength)(n, device="cpu")
+        out[f"img2img_sigmas_{n}_{strength}"] = sig.numpy()
+    np.savez_compressed(os.path.join(HERE, "vae_enc_g32.npz"), **out)
+    print("vae_enc_g32.npz z5 rms", z5.pow(2).mean().sqrt().item(), "logvar range",
+          mom5[:, 4:].min().item(), mom5[:, 4:].max().item(), "size", os.path.getsize(os.path.join(HERE, "vae_enc_g32.npz")))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "vae_encode":          # add this fixture without regenerating the others
+        gen_vae_encode()
+        sys.exit(0)
     torch.manual_seed(0)
     den = gen_sigmas()
     gen_keys()
@@ -294,3 +341,4 @@ if __name__ == "__main__":
     gen_sampler(wrapper, den)
     gen_vae()
     gen_net_tvi2v()
+    gen_vae_encode()

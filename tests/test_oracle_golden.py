@@ -136,6 +136,39 @@ def test_vae_decode_matches_reference(golden_dir):
     assert rel < 1e-4, f"vae decode rel rms err {rel}"
 
 
+def test_vae_encode_matches_reference(golden_dir):
+    """Encoder + quant_conv moments, the posterior sample with the noise the reference drew from
+    the CPU global generator, 5-D video and 4-D reference-image inputs."""
+    from ccedit_amd.sgm_compat import build_vae_spec
+    z = np.load(os.path.join(golden_dir, "vae_enc_g32.npz"))
+    vcfg = O.VAEConfig(ch=32)
+    sd = synth_state_dict(build_vae_spec(vcfg.__dict__))
+    x5 = torch.from_numpy(z["x5"].astype(np.float32))
+    mom = O.vae_encode_moments(sd, "first_stage_model", vcfg, x5[0].permute(1, 0, 2, 3))
+    ref = torch.from_numpy(z["moments5"])
+    assert ((mom - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) < 1e-4
+    z5 = O.vae_encode(sd, "first_stage_model", vcfg, x5, torch.from_numpy(z["noise5"]), scale_factor=1.0)
+    ref = torch.from_numpy(z["z5"])
+    assert z5.shape == ref.shape == (1, 4, 3, 8, 12)
+    assert ((z5 - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) < 1e-4
+    z4 = O.vae_encode(sd, "first_stage_model", vcfg, x5[:, :, 1], torch.from_numpy(z["noise4"]), scale_factor=1.0)
+    ref = torch.from_numpy(z["z4"])
+    assert z4.shape == ref.shape == (1, 4, 8, 12)
+    assert ((z4 - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) < 1e-4
+    # the noise really is what torch.randn(mean.shape) yields after the recorded seeding (RNG-consumption contract)
+    torch.manual_seed(4242)
+    assert torch.equal(torch.randn(3, 4, 8, 12), torch.from_numpy(z["noise5"]))
+
+
+def test_img2img_sigma_pruning_bit_exact(golden_dir):
+    """SDEdit: Img2ImgDiscretizationWrapper around LegacyDDPMDiscretization (streamlit_helpers.py:212-233)."""
+    z = np.load(os.path.join(golden_dir, "vae_enc_g32.npz"))
+    for n, strength in ((30, 0.6), (5, 0.5), (50, 1.0), (30, 0.01)):
+        got = O.img2img_sigmas(O.sampler_sigmas(n), strength).numpy()
+        ref = z[f"img2img_sigmas_{n}_{strength}"]
+        assert got.dtype == ref.dtype == np.float32 and np.array_equal(got, ref), (n, strength)
+
+
 def test_tvi2v_network_eval_matches_reference(golden_dir):
     """TVI2V branch (BASELINE.json config 3): controlnet_img on `cond_feat` + SpatialTransformer3DCA
     anchor cross-frame attention, against the reference's own output."""
