@@ -240,6 +240,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
                     if (kv >= a.Lk) s[t2][r] = -INFINITY;
                 }
         }
+        if (a.causal && j * 64 + 63 > q0) {   // wave-uniform: the tile reaches past this wave's first query
+            const int qi_c = q0 + l31;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = j * 64 + 32 * t2 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    if (kv > qi_c) s[t2][r] = -INFINITY;
+                }
+        }
         float mt = s[0][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
@@ -356,6 +366,7 @@ extern "C" int ccedit_attention(const CcAttnDesc* desc, void* stream) {
                  "ccedit_attention: bad sizes");
     CC_UNSUPPORTED(a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4, "ccedit_attention: row strides must be multiples of 8");
     CC_CHECK_ARG(a.seg1_len >= 0 && a.seg1_len <= a.Lk && (a.seg1_len == 0 || a.seg1_div > 0), "ccedit_attention: bad leading segment");
+    CC_CHECK_ARG(!a.causal || (a.Lq == a.Lk && a.seg1_len == 0), "ccedit_attention: causal needs Lq == Lk and no leading segment");
     CC_UNSUPPORTED(((int64_t)a.batches * a.heads + 8) * ((a.Lq + 31) / 32) > 2147483647LL, "ccedit_attention: grid too large");
     hipStream_t s = (hipStream_t)stream;
     switch (a.d) {

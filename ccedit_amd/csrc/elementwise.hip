@@ -159,6 +159,26 @@ __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, bf16* _
     }
 }
 
+// out[row] = tok[ids[row]] + pos[row % L], 8 channels per thread (fp32 tables -> bf16 activations)
+__global__ void embedding_lookup_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
+                                        const float* __restrict__ pos, bf16* __restrict__ out, int64_t rows, int L, int C,
+                                        int vocab) {
+    const int g8 = C >> 3;
+    const int64_t total = rows * g8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / g8;
+        const int g = (int)(i - row * g8);
+        int64_t id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const float* t = tok + id * C + g * 8;
+        const float* p = pos + (row % L) * C + g * 8;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(t[e] + p[e]);
+        *(bf16x8*)(out + row * C + g * 8) = o;
+    }
+}
+
 // DiagonalGaussianDistribution.sample (distributions.py:24-41) on the channels-last moments of the VAE encoder:
 // out[n][c][p] = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise[n][c][p]),  moments row = [mean(zc) | logvar(zc)]
 __global__ void gaussian_sample_kernel(const float* __restrict__ mom, const float* __restrict__ noise,
@@ -300,6 +320,15 @@ extern "C" int ccedit_timestep_embedding(const int64_t* t, void* out, int32_t n,
     CC_UNSUPPORTED(dim % 2, "ccedit_timestep_embedding: odd dim");
     hipLaunchKernelGGL(timestep_embedding_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, t, (bf16*)out, n, dim, ld);
     return cc_launch_status("timestep_embedding");
+}
+
+extern "C" int ccedit_embedding_lookup(const int64_t* ids, const float* tok, const float* pos, void* out, int64_t rows,
+                                       int32_t L, int32_t C, int32_t vocab, void* stream) {
+    CC_CHECK_ARG(ids && tok && pos && out && rows > 0 && L > 0 && vocab > 0, "ccedit_embedding_lookup: bad args");
+    CC_UNSUPPORTED(C % 8 != 0, "ccedit_embedding_lookup: C=%d must be a multiple of 8", C);
+    hipLaunchKernelGGL(embedding_lookup_kernel, dim3(grid_for(rows * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream, ids,
+                       tok, pos, (bf16*)out, rows, L, C, vocab);
+    return cc_launch_status("embedding_lookup");
 }
 
 extern "C" int ccedit_gaussian_sample(const float* moments, const float* noise, float* out, int64_t frames, int32_t zc,

@@ -385,6 +385,9 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
                 if (d.act == CCEDIT_ACT_SILU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                } else if (d.act == CCEDIT_ACT_QUICK_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
                 }
                 if (full) {
                     if (r1) {

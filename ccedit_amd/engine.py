@@ -71,6 +71,9 @@ class VideoDiffusionEngineTV2V(nn.Module):
         device = torch.device("cuda") if device is None else torch.device(device)
         self.model.diffusion_model.pack(device)
         self.first_stage_model.pack(device)
+        for e in (self.conditioner.embedders if self.conditioner is not None else []):
+            if hasattr(e, "pack"):
+                e.pack(device)                       # FrozenCLIPEmbedder: the text transformer's kernel operands
         self.denoiser.to(device)
         return self
 

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("CCEDIT_HIP_LIB") or os.path.join(_HERE, "libccedit_hi
 ABI_VERSION = 3
 
 GEMM_LINEAR, GEMM_CONV2D, GEMM_TEMPORAL = 0, 1, 2
-ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 
 
 class CcGemmDesc(C.Structure):
@@ -45,6 +45,7 @@ class CcAttnDesc(C.Structure):
         ("kv_div", C.c_int32), ("kv_inner", C.c_int32), ("kv_outer_rows", C.c_int64), ("kv_inner_rows", C.c_int64),
         ("kv_seq_rows", C.c_int64), ("scale", C.c_float),
         ("seg1_len", C.c_int32), ("seg1_div", C.c_int32), ("seg1_mul", C.c_int32), ("seg1_add", C.c_int32),
+        ("causal", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -85,6 +86,8 @@ _SIGS = {
     "ccedit_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ccedit_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                                       C.c_float, C.c_void_p]),
+    "ccedit_embedding_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_void_p]),
     "ccedit_gaussian_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_float, C.c_void_p]),
     "ccedit_cfg_denoise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]),

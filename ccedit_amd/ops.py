@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 from . import hip
-from .hip import ACT_GEGLU, ACT_NONE, ACT_SILU, CcAttnDesc, CcGemmDesc, GEMM_CONV2D, GEMM_LINEAR, GEMM_TEMPORAL
+from .hip import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, CcAttnDesc, CcGemmDesc, GEMM_CONV2D, GEMM_LINEAR, GEMM_TEMPORAL
 from .packing import PackedWeight
 
 BF16 = torch.bfloat16
@@ -269,7 +269,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, d: 
               q_inner: int = 1, q_outer_rows: Optional[int] = None, q_inner_rows: int = 0, q_seq_rows: int = 1,
               kv_div: int = 1, kv_inner: int = 1, kv_outer_rows: Optional[int] = None, kv_inner_rows: int = 0,
               kv_seq_rows: int = 1, out: Optional[torch.Tensor] = None,
-              seg1_len: int = 0, seg1_div: int = 1, seg1_mul: int = 0, seg1_add: int = 0) -> torch.Tensor:
+              seg1_len: int = 0, seg1_div: int = 1, seg1_mul: int = 0, seg1_add: int = 0, causal: bool = False) -> torch.Tensor:
     """q/k/v: 2-D row-major views [rows, >= heads*d] (may be column slices of a fused buffer)."""
     for tns in (q, k, v):
         assert tns.dtype == BF16 and tns.is_cuda and tns.stride(-1) == 1
@@ -284,6 +284,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, d: 
     a.kv_outer_rows, a.kv_inner_rows, a.kv_seq_rows = (lk if kv_outer_rows is None else kv_outer_rows), kv_inner_rows, kv_seq_rows
     a.scale = float(d) ** -0.5
     a.seg1_len, a.seg1_div, a.seg1_mul, a.seg1_add = seg1_len, seg1_div, seg1_mul, seg1_add
+    a.causal = int(causal)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -358,6 +359,19 @@ def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     out = torch.empty((t.shape[0], dim), dtype=BF16, device=t.device)
     hip.check(hip.lib().ccedit_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], dim, dim, _stream()),
               "ccedit_timestep_embedding")
+    return out
+
+
+def embedding_lookup(ids: torch.Tensor, tok: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    """ids int64 (B, L) -> bf16 [B*L, C] = tok[ids] + pos (CLIP text embeddings)."""
+    assert ids.dtype == torch.int64 and ids.is_cuda and ids.is_contiguous() and tok.dtype == pos.dtype == torch.float32
+    b, l = ids.shape
+    assert pos.shape[0] == l and tok.shape[1] == pos.shape[1]
+    if int(ids.min()) < 0 or int(ids.max()) >= tok.shape[0]:
+        raise ValueError(f"token id outside [0, {tok.shape[0]})")
+    out = torch.empty((b * l, tok.shape[1]), dtype=BF16, device=ids.device)
+    hip.check(hip.lib().ccedit_embedding_lookup(ids.data_ptr(), tok.data_ptr(), pos.data_ptr(), out.data_ptr(), b * l, l,
+                                                tok.shape[1], tok.shape[0], _stream()), "ccedit_embedding_lookup")
     return out
 
 

@@ -60,7 +60,8 @@ int ccedit_device_info(char* name, int name_len);
  * of controlmodel.py:539-543 without materialising it.
  * ------------------------------------------------------------------------------------------ */
 enum { CCEDIT_GEMM_LINEAR = 0, CCEDIT_GEMM_CONV2D = 1, CCEDIT_GEMM_TEMPORAL = 2 };
-enum { CCEDIT_ACT_NONE = 0, CCEDIT_ACT_SILU = 1, CCEDIT_ACT_GEGLU = 2 };
+enum { CCEDIT_ACT_NONE = 0, CCEDIT_ACT_SILU = 1, CCEDIT_ACT_GEGLU = 2,
+       CCEDIT_ACT_QUICK_GELU = 3 /* x * sigmoid(1.702 x): the CLIP text MLP (FrozenCLIPEmbedder, encoders/modules.py:358-420) */ };
 
 typedef struct CcGemmDesc {
     int64_t M;            /* output rows: pixels (B*T*Hout*Wout) or tokens */
@@ -164,6 +165,8 @@ typedef struct CcAttnDesc {
      * context = cat([anchor tokens, x tokens])): keys [0, seg1_len) come from the kv batch
      * (batch / seg1_div) * seg1_mul + seg1_add, keys [seg1_len, Lk) from the regular kv batch.  0 = unused. */
     int32_t seg1_len, seg1_div, seg1_mul, seg1_add;
+    int32_t causal;       /* 1: key j is visible to query i only if j <= i (CLIP text encoder); Lq == Lk, no segment */
+    int32_t reserved1;
 } CcAttnDesc;
 
 int ccedit_attention(const CcAttnDesc* desc, void* stream);
@@ -198,6 +201,12 @@ int ccedit_timestep_embedding(const int64_t* t, void* out, int32_t n, int32_t di
  * GEMM (q k^T) -> this -> GEMM (p v); cols_pad <= 8192. */
 int ccedit_softmax_rows(const float* s, void* p, int64_t rows, int32_t cols, int32_t cols_pad, int64_t lds,
                         int64_t ldp, float scale, void* stream);
+
+/* Token + position embedding lookup of the CLIP text encoder (transformers CLIPTextEmbeddings, called from
+ * FrozenCLIPEmbedder.forward, encoders/modules.py:393-413): out[b*L + i] = tok[ids[b*L + i]] + pos[i]  (bf16 out).
+ * ids: int64 [rows]; tok: fp32 [vocab][C]; pos: fp32 [L][C].  ids are clamped to [0, vocab): validate on the host. */
+int ccedit_embedding_lookup(const int64_t* ids, const float* tok, const float* pos, void* out, int64_t rows, int32_t L,
+                            int32_t C, int32_t vocab, void* stream);
 
 /* Posterior sample of the KL-VAE encoder (DiagonalGaussianDistribution.sample, distributions.py:24-41, called from
  * AutoencoderKLInferenceWrapper.encode, autoencoder.py:323-332): moments = fp32 [frames*hw][ldm] channels-last rows

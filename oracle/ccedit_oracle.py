@@ -675,3 +675,42 @@ def sdedit_noised_latent(z, noise, sigmas):
     """sampling_tv2v.py:439-448: noised_z = (z + noise * sigma0) / sqrt(1 + sigma0^2) (DDPM-like scaling)."""
     s0 = sigmas[0]
     return (z + noise * s0) / torch.sqrt(1.0 + s0 ** 2.0)
+
+
+# ------------------------------------------------------------------------------------------
+# CLIP text encoder (SURVEY.md §8f-2)
+# ------------------------------------------------------------------------------------------
+@dataclass
+class CLIPTextConfig:
+    """openai/clip-vit-large-patch14 text tower (FrozenCLIPEmbedder default `version`, encoders/modules.py:365)."""
+    vocab_size: int = 49408
+    hidden: int = 768
+    intermediate: int = 3072
+    layers: int = 12
+    heads: int = 12
+    max_len: int = 77
+    eps: float = 1e-5
+
+
+def clip_text_forward(sd: SD, p: str, cfg: CLIPTextConfig, tokens: torch.Tensor) -> torch.Tensor:
+    """`FrozenCLIPEmbedder.forward` with layer="last" (encoders/modules.py:393-413) = last_hidden_state of
+    HF `CLIPTextModel`.  The algorithm is a third-party dependency absent from /root/reference — transformers==4.19.1
+    (requirements.txt:34), `modeling_clip.py: CLIPTextTransformer.forward`: token + learned position embeddings;
+    `layers` x pre-LN blocks [LayerNorm -> causal multi-head self-attention (q scaled by d^-0.5) -> residual ->
+    LayerNorm -> fc1 -> quick_gelu (x sigmoid(1.702 x)) -> fc2 -> residual]; final LayerNorm.  Pinned against the
+    transformers installed in the authoring container (tests/golden/make_golden.py: gen_clip).
+    `p` is the prefix of `text_model.` (e.g. "conditioner.embedders.0.transformer.text_model"); tokens int64 (B, L)."""
+    b, l = tokens.shape
+    x = sd[p + ".embeddings.token_embedding.weight"][tokens] + sd[p + ".embeddings.position_embedding.weight"][:l]
+    mask = torch.full((l, l), float("-inf")).triu(1)
+    d = cfg.hidden // cfg.heads
+    for i in range(cfg.layers):
+        q = f"{p}.encoder.layers.{i}"
+        h = F.layer_norm(x, (cfg.hidden,), sd[q + ".layer_norm1.weight"], sd[q + ".layer_norm1.bias"], cfg.eps)
+        qq, kk, vv = (_linear(sd, f"{q}.self_attn.{n}_proj", h).view(b, l, cfg.heads, d).transpose(1, 2) for n in "qkv")
+        a = torch.softmax((qq * d ** -0.5) @ kk.transpose(-1, -2) + mask, dim=-1) @ vv
+        x = x + _linear(sd, q + ".self_attn.out_proj", a.transpose(1, 2).reshape(b, l, cfg.hidden))
+        h = F.layer_norm(x, (cfg.hidden,), sd[q + ".layer_norm2.weight"], sd[q + ".layer_norm2.bias"], cfg.eps)
+        h = _linear(sd, q + ".mlp.fc1", h)
+        x = x + _linear(sd, q + ".mlp.fc2", h * torch.sigmoid(1.702 * h))
+    return F.layer_norm(x, (cfg.hidden,), sd[p + ".final_layer_norm.weight"], sd[p + ".final_layer_norm.bias"], cfg.eps)

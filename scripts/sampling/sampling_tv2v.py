@@ -5,7 +5,7 @@ including the `--prior_coefficient_x` noise prior and the `--sdedit_denoise_stre
 
 Conditioning producers (CLIP text encoder, MiDaS depth, video decoding) are outside this build (weights / codecs
 unavailable offline): pass precomputed tensors with --cond_path — a .pt/.safetensors holding
-`crossattn`, `crossattn_uc` (1,77,768), `control_hint` (1,3,T,H,W) in [-1,1] and, for the prior / SDEdit options,
+`tokens`, `tokens_uc` (1,77) int64 CLIP token ids (or precomputed `crossattn`, `crossattn_uc` (1,77,768)), `control_hint` (1,3,T,H,W) in [-1,1] and, for the prior / SDEdit options,
 `keyframes` (1,3,T,H,W) in [-1,1] — or use --synthetic for seeded random tensors of the right shapes.  They enter
 through `model.conditioner.get_unconditional_conditioning` exactly like the reference's batch dicts.
 Outputs: `<save_path>/result/sample_XXXX.npy` (frames in [0,1], (T,H,W,3)) + `log_info.json` resume-skip list.
@@ -63,6 +63,7 @@ def build_model(args):
     elif args.synthetic:
         fill_module_(model.model, prefix="model.")
         fill_module_(model.first_stage_model, prefix="first_stage_model.")
+        fill_module_(model.conditioner, prefix="conditioner.")
     else:
         raise SystemExit("need --ckpt_path or --synthetic")
     if args.vae_path:
@@ -78,8 +79,12 @@ def conditioning_tensors(args, g: torch.Generator, need_frames: bool, need_ref: 
     if args.cond_path:
         cond = load_conditioning(args.cond_path)
     else:
-        cond = dict(crossattn=torch.randn(1, 77, args.context_dim, generator=g),
-                    crossattn_uc=torch.randn(1, 77, args.context_dim, generator=g),
+        if args.context_dim == 768:      # shipped configs: seeded random token ids through the CLIP text encoder
+            text = dict(tokens=torch.randint(0, 49406, (1, 77), generator=g), tokens_uc=torch.randint(0, 49406, (1, 77), generator=g))
+        else:                            # reduced test configs: a precomputed embedding of the network's context width
+            text = dict(crossattn=torch.randn(1, 77, args.context_dim, generator=g),
+                        crossattn_uc=torch.randn(1, 77, args.context_dim, generator=g))
+        cond = dict(**text,
                     control_hint=(torch.rand(1, 1, T, args.H, args.W, generator=g) * 2 - 1).repeat(1, 3, 1, 1, 1))
         if need_frames:
             cond["keyframes"] = torch.rand(1, 3, T, args.H, args.W, generator=g) * 2 - 1
@@ -89,6 +94,14 @@ def conditioning_tensors(args, g: torch.Generator, need_frames: bool, need_ref: 
         if k not in cond:
             raise SystemExit(f"--cond_path must hold `{k}` for the requested options")
     return cond
+
+
+def text_inputs(cond, dev):
+    """batch['txt'] for prompt / negative prompt: token ids (`tokens`, `tokens_uc`: (1,77) int64 -> CLIP text encoder
+    on the GPU) or precomputed embeddings (`crossattn`, `crossattn_uc`)."""
+    if "tokens" in cond:
+        return cond["tokens"].to(dev), cond["tokens_uc"].to(dev)
+    return cond["crossattn"].to(dev), cond["crossattn_uc"].to(dev)
 
 
 def sample_one(args, model, dev, c, uc, randn, keyframes=None, ref=None, prior_type="video"):
@@ -128,8 +141,9 @@ def main():
     need_frames = args.prior_coefficient_x != 0.0 or args.sdedit_denoise_strength != 0.0
     cond = conditioning_tensors(args, g, need_frames)
     hint = cond["control_hint"].to(dev)
-    batch = {"txt": cond["crossattn"].to(dev), "control_hint": hint}
-    batch_uc = {"txt": cond["crossattn_uc"].to(dev), "control_hint": hint.clone()}      # uc keeps the SAME hint (:339-344)
+    txt, txt_uc = text_inputs(cond, dev)
+    batch = {"txt": txt, "control_hint": hint}
+    batch_uc = {"txt": txt_uc, "control_hint": hint.clone()}                              # uc keeps the SAME hint (:339-344)
     c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=batch_uc)
     keyframes = cond["keyframes"].to(dev) if need_frames else None
     log = ResumeLog(args.save_path)

@@ -19,7 +19,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from scripts.sampling.sampling_tv2v import add_common_args, build_model, conditioning_tensors, sample_one  # noqa: E402
+from scripts.sampling.sampling_tv2v import add_common_args, build_model, conditioning_tensors, sample_one, text_inputs  # noqa: E402
 
 
 def main():
@@ -36,8 +36,9 @@ def main():
     need_frames = (args.prior_coefficient_x != 0.0 and args.prior_type != "ref") or args.sdedit_denoise_strength != 0.0
     cond = conditioning_tensors(args, g, need_frames, need_ref=True)
     hint, ref = cond["control_hint"].to(dev), cond["cond_img"].to(dev)
-    batch = {"txt": cond["crossattn"].to(dev), "control_hint": hint, "cond_img": ref}
-    batch_uc = {"txt": cond["crossattn_uc"].to(dev), "control_hint": hint.clone(), "cond_img": ref.clone()}
+    txt, txt_uc = text_inputs(cond, dev)
+    batch = {"txt": txt, "control_hint": hint, "cond_img": ref}
+    batch_uc = {"txt": txt_uc, "control_hint": hint.clone(), "cond_img": ref.clone()}
     c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=batch_uc)     # two VAE encodes (two RNG draws)
     keyframes = cond["keyframes"].to(dev) if need_frames else None
     log = ResumeLog(args.save_path)

@@ -8,10 +8,13 @@ rank: 2 `vector`, 3 `crossattn`, 4/5 `concat`), concatenation of repeated keys, 
 Embedders:
   * `VAEEmbedder` (TVI2V `cond_img` -> `cond_feat`) is real: it runs the engine's first-stage encoder on the HIP
     kernels.
-  * `FrozenCLIPEmbedder`, `DepthMidasEncoder`, `DepthZoeEncoder` need weights / an un-vendored third-party repo that
-    do not exist offline; they run once per clip outside the denoising loop.  Here they are
-    *pass-through* embedders: they accept an already computed tensor for their input key (text embedding
-    (B,77,768) / depth hint (B,3,T,H,W) in [-1,1]) and raise with a clear message when handed raw text or video.
+  * `FrozenCLIPEmbedder` (`txt` -> `crossattn`) is real: the CLIP ViT-L/14 text transformer runs on the HIP kernels
+    (ccedit_amd/clip.py) with the checkpoint's parameter names.  It takes token ids (B,77) int64,
+    raw strings when the HF tokenizer files are available locally, or an already computed (B,77,768) embedding.
+  * `DepthMidasEncoder`, `DepthZoeEncoder` need an un-vendored third-party repo and weights that do not exist
+    offline; they run once per clip outside the denoising loop.  Here they are *pass-through*
+    embedders: they accept the already computed depth hint (B,3,T,H,W) in [-1,1] and raise with a clear message when
+    handed raw video.
 """
 from __future__ import annotations
 
@@ -54,10 +57,59 @@ class _Precomputed(AbstractEmbModel):
         return self(x)
 
 
-class FrozenCLIPEmbedder(_Precomputed):
-    """encoders/modules.py:358-420 (HF openai/clip-vit-large-patch14 text encoder): (B, 77, 768)."""
-    what = "CLIP text embedding (B,77,768)"
-    rank = 3
+class FrozenCLIPEmbedder(AbstractEmbModel):
+    """encoders/modules.py:358-420: HF CLIP text encoder, layer="last" -> last_hidden_state (B, 77, 768).
+    `forward` accepts what the reference accepts (a list of strings; needs the tokenizer files of `version` on local
+    disk — there is no network here) and, in addition, token ids (B, L<=77) int64 or a precomputed embedding."""
+
+    LAYERS = ["last", "pooled", "hidden"]
+
+    def __init__(self, version="openai/clip-vit-large-patch14", device="cuda", max_length=77, freeze=True, layer="last",
+                 layer_idx=None, always_return_pooled=False):
+        super().__init__()
+        assert layer in self.LAYERS
+        if layer != "last" or always_return_pooled:
+            raise NotImplementedError("FrozenCLIPEmbedder: the CCEdit configs use layer='last' without the pooled output")
+        from ccedit_amd.clip import CLIPTextModel
+        self.version, self.max_length, self.layer = version, max_length, layer
+        self.transformer = CLIPTextModel()
+        self._tokenizer = None
+
+    def freeze(self):
+        self.transformer = self.transformer.eval()
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def pack(self, device=None):
+        self.transformer.pack(device)
+        return self
+
+    def tokenize(self, text) -> torch.Tensor:
+        if self._tokenizer is None:
+            try:
+                from transformers import CLIPTokenizer
+                tok = CLIPTokenizer.from_pretrained(self.version, local_files_only=True)
+                if len(tok) < 49408:        # recent transformers build an EMPTY tokenizer when the files are missing
+                    raise FileNotFoundError(f"vocabulary of {self.version} not found locally ({len(tok)} entries)")
+                self._tokenizer = tok
+            except Exception as e:          # no vocabulary files offline
+                raise NotImplementedError(
+                    f"FrozenCLIPEmbedder: the tokenizer files of {self.version!r} are not on this machine ({type(e).__name__}); "
+                    f"pass token ids (B,{self.max_length}) int64 or a precomputed (B,{self.max_length},768) embedding as batch['txt']")
+        enc = self._tokenizer(text, truncation=True, max_length=self.max_length, return_length=True,
+                              return_overflowing_tokens=False, padding="max_length", return_tensors="pt")
+        return enc["input_ids"]
+
+    def forward(self, text):
+        if torch.is_tensor(text) and text.is_floating_point():
+            if text.dim() != 3:
+                raise ValueError(f"precomputed text embedding must be (B, L, C), got {tuple(text.shape)}")
+            return text
+        tokens = text if torch.is_tensor(text) else self.tokenize(text)
+        return self.transformer(tokens)
+
+    def encode(self, text):
+        return self(text)
 
 
 class DepthMidasEncoder(_Precomputed):

@@ -20,6 +20,10 @@ synthetic weights of ccedit_amd/utils/synth.py, runs them on CPU in fp32 and wri
                       image in, moments digests + the posterior samples out (the CPU global-generator noise the
                       reference drew is recorded); Img2ImgDiscretizationWrapper sigma tables (SDEdit)
 
+  clip_text.npz       HF CLIPTextModel (the network inside FrozenCLIPEmbedder; transformers is a third-party dependency
+                      of the reference, not under /root/reference) at the ViT-L/14 text configuration with name-keyed
+                      synthetic weights: token ids in, last_hidden_state out
+
 A digest of a tensor = (shape, mean, std, abs-max, 256 evenly spaced samples) — enough to pin a
 restatement while keeping every fixture well under 1 MB.
 """
@@ -330,7 +334,36 @@ def gen_vae_encode():
           mom5[:, 4:].min().item(), mom5[:, 4:].max().item(), "size", os.path.getsize(os.path.join(HERE, "vae_enc_g32.npz")))
 
 
+CLIP_PREFIX = "conditioner.embedders.0.transformer.text_model."
+
+
+def gen_clip():
+    """FrozenCLIPEmbedder.forward, layer='last' (encoders/modules.py:393-413): tokens -> CLIPTextModel -> last_hidden_state."""
+    import transformers
+    from transformers import CLIPTextConfig, CLIPTextModel
+    cfg = CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                         num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=768)
+    m = CLIPTextModel(cfg).eval()
+    inner = m.text_model if hasattr(m, "text_model") and any(k.startswith("text_model.") for k in m.state_dict()) else m
+    fill_module_(inner, prefix=CLIP_PREFIX)
+    g = torch.Generator().manual_seed(31)
+    tokens = torch.full((2, 77), 49407, dtype=torch.int64)          # CLIP pads with the end-of-text token
+    for b, n in enumerate((9, 40)):
+        tokens[b, 0] = 49406
+        tokens[b, 1:1 + n] = torch.randint(0, 49406, (n,), generator=g)
+    out = m(input_ids=tokens).last_hidden_state
+    keys = {CLIP_PREFIX + k: list(v.shape) for k, v in inner.state_dict().items()}
+    with open(os.path.join(HERE, "keys_clip_text.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "clip_text.npz"), tokens=tokens.numpy(), last_hidden_state=out.numpy().astype(np.float32))
+    print("clip_text.npz transformers", transformers.__version__, "out rms", out.pow(2).mean().sqrt().item(), "keys", len(keys),
+          "size", os.path.getsize(os.path.join(HERE, "clip_text.npz")))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "clip":
+        gen_clip()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "vae_encode":          # add this fixture without regenerating the others
         gen_vae_encode()
         sys.exit(0)
@@ -342,3 +375,4 @@ if __name__ == "__main__":
     gen_vae()
     gen_net_tvi2v()
     gen_vae_encode()
+    gen_clip()

@@ -38,7 +38,13 @@ def test_reference_config_instantiates_with_reference_keys(golden_dir):
     with open(os.path.join(golden_dir, "keys_tv2v.json")) as f:
         ref = json.load(f)
     assert set(ref) - set(mine) == set(), sorted(set(ref) - set(mine))[:5]
-    assert set(mine) - set(ref) == {"denoiser.sigmas"}
+    extra = set(mine) - set(ref)
+    clip = {k for k in extra if k.startswith("conditioner.embedders.0.transformer.text_model.")}
+    assert extra - clip == {"denoiser.sigmas"}
+    with open(os.path.join(golden_dir, "keys_clip_text.json")) as f:
+        clip_ref = json.load(f)                  # HF CLIPTextModel keys (+ the position_ids buffer of transformers 4.19.1)
+    assert clip - {"conditioner.embedders.0.transformer.text_model.embeddings.position_ids"} == set(clip_ref)
+    assert all(mine[k] == clip_ref[k] for k in clip_ref)
     assert all(mine[k] == ref[k] for k in ref)
     n = sum(int(np.prod(s)) for k, s in mine.items() if k.startswith("model."))
     assert n == 1608747976            # 1608.7 M parameters

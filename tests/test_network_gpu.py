@@ -287,3 +287,31 @@ def test_prior_mix_and_sdedit_start_vs_oracle(golden_dir, g32_vae):
     torch.manual_seed(12)
     got = sdedit_start(model, sampler, x5.cuda())
     assert _rel(got, want) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------
+# CLIP text encoder inside FrozenCLIPEmbedder
+# ------------------------------------------------------------------------------------------
+def test_clip_text_encoder_vs_transformers_golden(golden_dir):
+    _need_gpu()
+    from ccedit_amd.config import instantiate_from_config
+    from ccedit_amd.utils.synth import fill_module_
+    z = np.load(os.path.join(golden_dir, "clip_text.npz"))
+    emb = instantiate_from_config(dict(target="sgm.modules.encoders.modules.FrozenCLIPEmbedder", params=dict(freeze=True)))
+    fill_module_(emb, prefix="conditioner.embedders.0.")
+    emb.pack("cuda")
+    tokens = torch.from_numpy(z["tokens"])
+    out = emb(tokens.cuda())
+    assert out.shape == (2, 77, 768) and out.dtype == torch.float32
+    r = _rel(out, torch.from_numpy(z["last_hidden_state"]))
+    print(f"CLIP text encoder rel rms err vs transformers golden: {r:.4f}")
+    assert r < NET_TOL
+    # causality: changing tokens after position 5 must not change the first 6 outputs
+    t2 = tokens.clone()
+    t2[:, 6:] = 1234
+    out2 = emb(t2.cuda())
+    assert _rel(out2[:, :6], out[:, :6]) < 2e-2 and _rel(out2[:, 6:], out[:, 6:]) > 0.1
+    with pytest.raises(NotImplementedError):          # no tokenizer vocabulary offline: a clear error, not a download attempt
+        emb(["a photo of a cat"])
+    with pytest.raises(ValueError):
+        emb(torch.full((1, 77), 60000, dtype=torch.int64).cuda())

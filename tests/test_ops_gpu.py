@@ -281,6 +281,34 @@ def test_layernorm(c):
 
 
 # ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,l", [(64, 77), (64, 130), (40, 64), (128, 33)])
+def test_attention_causal(d, l):
+    """CcAttnDesc.causal (CLIP text encoder): key j visible to query i iff j <= i."""
+    _dev()
+    from ccedit_amd import ops
+    b, heads = 3, 4
+    q, k, v = (_rnd(b * l, heads * d, seed=s).to(BF) for s in (1, 2, 3))
+    o = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, d, batches=b, lq=l, lk=l, causal=True)
+    qq, kk, vv = (t.float().view(b, l, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qq, kk, vv, is_causal=True).transpose(1, 2).reshape(b * l, heads * d)
+    _close(o, ref, what=f"causal attention d={d} L={l}")
+
+
+def test_quick_gelu_and_embedding_lookup():
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.hip import ACT_QUICK_GELU
+    from ccedit_amd.packing import pack_weight
+    x, w, b = _rnd(77, 128, seed=1), _rnd(256, 128, seed=2, scale=128 ** -0.5), _rnd(256, seed=3)
+    y = ops.linear(x.to(BF).cuda(), pack_weight(w, b).to("cuda"), act=ACT_QUICK_GELU)
+    h = F.linear(x, w, b)
+    _close(y, h * torch.sigmoid(1.702 * h), what="quick_gelu epilogue")
+    tok, pos = _rnd(100, 64, seed=4), _rnd(7, 64, seed=5)
+    ids = torch.randint(0, 100, (3, 7), generator=torch.Generator().manual_seed(6))
+    e = ops.embedding_lookup(ids.cuda(), tok.cuda(), pos.cuda())
+    _close(e, (tok[ids] + pos[None]).reshape(21, 64), what="embedding lookup")
+
+
 def _sdpa_ref(q, k, v, heads):
     b, n, c = q.shape
     d = c // heads

@@ -169,6 +169,22 @@ def test_img2img_sigma_pruning_bit_exact(golden_dir):
         assert got.dtype == ref.dtype == np.float32 and np.array_equal(got, ref), (n, strength)
 
 
+def test_clip_text_encoder_matches_transformers(golden_dir):
+    """the oracle's CLIP text tower against HF CLIPTextModel (golden recorded with the transformers
+    installed in the authoring container; the reference pins transformers==4.19.1, same architecture)."""
+    import json
+    z = np.load(os.path.join(golden_dir, "clip_text.npz"))
+    with open(os.path.join(golden_dir, "keys_clip_text.json")) as f:
+        spec = [(k, tuple(v)) for k, v in json.load(f).items()]
+    sd = synth_state_dict(spec)
+    out = O.clip_text_forward(sd, "conditioner.embedders.0.transformer.text_model", O.CLIPTextConfig(),
+                              torch.from_numpy(z["tokens"]))
+    ref = torch.from_numpy(z["last_hidden_state"])
+    assert out.shape == ref.shape == (2, 77, 768)
+    rel = (out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()
+    assert rel < 1e-5, f"clip text rel rms err {rel}"
+
+
 def test_tvi2v_network_eval_matches_reference(golden_dir):
     """TVI2V branch (BASELINE.json config 3): controlnet_img on `cond_feat` + SpatialTransformer3DCA
     anchor cross-frame attention, against the reference's own output."""
