@@ -30,6 +30,9 @@ def add_common_args(p: argparse.ArgumentParser) -> None:
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--config_path", type=str, default="")
     p.add_argument("--ckpt_path", type=str, default="")
+    p.add_argument("--basemodel_path", type=str, default="", help="load a new base model instead of original sd-1.5")
+    p.add_argument("--lora_path", type=str, default="")
+    p.add_argument("--lora_strength", type=float, default=0.8)
     p.add_argument("--vae_path", type=str, default="")
     p.add_argument("--cond_path", type=str, default="", help="precomputed conditioning tensors (see module docstring)")
     p.add_argument("--synthetic", action="store_true", help="seeded random conditioning + name-keyed synthetic weights")
@@ -57,17 +60,24 @@ def build_model(args):
     if not args.config_path:
         raise SystemExit("--config_path is required (e.g. configs/inference_ccedit/keyframe_no2ndca_depthmidas.yaml)")
     dev = torch.device("cuda")
+    from scripts.sampling.util import load_lora_file, load_vae_file, model_load_ckpt
     model = create_model(args.config_path, dev)
     if args.ckpt_path:
-        model.init_from_ckpt(args.ckpt_path)
+        model_load_ckpt(model, path=args.ckpt_path)
     elif args.synthetic:
         fill_module_(model.model, prefix="model.")
         fill_module_(model.first_stage_model, prefix="first_stage_model.")
         fill_module_(model.conditioner, prefix="conditioner.")
     else:
         raise SystemExit("need --ckpt_path or --synthetic")
+    # sampling_tv2v.py:190-262: optional base-model swap, LoRA merge at --lora_strength, replacement VAE — all weight-space,
+    # before the kernels' operands are packed
+    if args.basemodel_path:
+        model_load_ckpt(model, args.basemodel_path, True)
+    if args.lora_path:
+        load_lora_file(model, args.lora_path, args.lora_strength)
     if args.vae_path:
-        model.first_stage_model.load_state_dict(torch.load(args.vae_path, map_location="cpu")["state_dict"], strict=False)
+        load_vae_file(model, args.vae_path)
     model.pack(dev)
     args.context_dim = model.model.diffusion_model.context_dim     # 768 for the shipped configs
     return model, dev

@@ -123,3 +123,134 @@ class ResumeLog:
     def add(self, tag: str) -> None:
         self.log["done"].append(tag)
         json.dump(self.log, open(self.path, "w"))
+
+
+# ------------------------------------------------------------------------------------------
+# checkpoint ingestion: reference scripts/sampling/util.py:45-272
+# ------------------------------------------------------------------------------------------
+import re
+
+# kohya "down_blocks_i / attentions_j" and "up_blocks_i / attentions_j" -> sgm input_blocks / output_blocks index
+_LORA_IN = {(0, 0): 1, (0, 1): 2, (1, 0): 4, (1, 1): 5, (2, 0): 7, (2, 1): 8}
+_LORA_OUT = {(1, 0): 3, (1, 1): 4, (1, 2): 5, (2, 0): 6, (2, 1): 7, (2, 2): 8, (3, 0): 9, (3, 1): 10, (3, 2): 11}
+_RE_TE = re.compile(r"^lora_te_text_model_encoder_layers_(\d+)_(self_attn_([qkv]|out)_proj|mlp_(fc1|fc2))$")
+_RE_UNET = re.compile(r"^lora_unet_(?:(down|up)_blocks_(\d+)|mid_block)_attentions_(\d+)_(.+)$")
+_RE_TAIL = re.compile(r"^(?:proj_(in|out)|transformer_blocks_(\d+)_(?:(attn[12])_to_(?:([qkv])|out_(\d+))|ff_net_(\d+)(?:_(proj))?))$")
+
+
+def lora_target_key(key: str) -> str:
+    """State-dict key of the weight a kohya-format LoRA tensor (`<module>.lora_up/down.weight`) is merged into."""
+    mod = key.split(".")[0]
+    m = _RE_TE.match(mod)
+    if m:
+        layer = m.group(1)
+        leaf = f"self_attn.{m.group(3)}_proj" if m.group(3) else f"mlp.{m.group(4)}"
+        return f"conditioner.embedders.0.transformer.text_model.encoder.layers.{layer}.{leaf}.weight"
+    m = _RE_UNET.match(mod)
+    t = _RE_TAIL.match(m.group(4)) if m else None
+    if not (m and t):
+        raise ValueError("Unknown key: ", key)
+    if m.group(1) is None:
+        base = "model.diffusion_model.middle_block.1"
+    else:
+        table, name = (_LORA_IN, "input_blocks") if m.group(1) == "down" else (_LORA_OUT, "output_blocks")
+        base = f"model.diffusion_model.{name}.{table[(int(m.group(2)), int(m.group(3)))]}.1"
+    if t.group(1):
+        return f"{base}.proj_{t.group(1)}.weight"
+    tb = f"{base}.transformer_blocks.{t.group(2)}"
+    if t.group(3):
+        return f"{tb}.{t.group(3)}.to_{t.group(4)}.weight" if t.group(4) else f"{tb}.{t.group(3)}.to_out.{t.group(5)}.weight"
+    return f"{tb}.ff.net.{t.group(6)}" + (".proj" if t.group(7) else "") + ".weight"
+
+
+def convert_load_lora(sd_state_dict: Dict[str, torch.Tensor], state_dict: Dict[str, torch.Tensor],
+                      LORA_PREFIX_UNET="lora_unet", LORA_PREFIX_TEXT_ENCODER="lora_te", alpha=0.6):
+    """util.py:115-272: W += alpha * (lora_up @ lora_down) for every LoRA pair, in place in `sd_state_dict`
+    (1x1-conv projections keep their (O, I, 1, 1) shape; `.alpha` entries are ignored like the reference does)."""
+    if (LORA_PREFIX_UNET, LORA_PREFIX_TEXT_ENCODER) != ("lora_unet", "lora_te"):
+        raise NotImplementedError("non-default LoRA prefixes")
+    done = set()
+    for key in state_dict:
+        if ".alpha" in key or key in done:
+            continue
+        up_key = key.replace("lora_down", "lora_up")
+        down_key = key.replace("lora_up", "lora_down")
+        up, down = state_dict[up_key].to(torch.float32), state_dict[down_key].to(torch.float32)
+        target = lora_target_key(key)
+        if up.dim() == 4:
+            delta = torch.mm(up.squeeze(3).squeeze(2), down.squeeze(3).squeeze(2)).unsqueeze(2).unsqueeze(3)
+        else:
+            delta = torch.mm(up, down)
+        sd_state_dict[target] += alpha * delta
+        done.update((up_key, down_key))
+    return sd_state_dict
+
+
+def read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
+    if path.endswith(("ckpt", ".pt", ".pth")):
+        sd = torch.load(path, map_location="cpu")
+        if "deepspeed" in path:
+            return {k.replace("_forward_module.", ""): v for k, v in sd.items()}
+        return sd["state_dict"] if "state_dict" in sd else sd
+    if path.endswith("safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    raise NotImplementedError(f"Unknown checkpoint format: {path}")
+
+
+def remap_checkpoint_keys(sd: Dict[str, torch.Tensor], newbasemodel: bool = False) -> Dict[str, torch.Tensor]:
+    """util.py:63-82: VAE copies nested under conditioner embedders lose that prefix; with `newbasemodel` (a plain
+    SD-1.5 checkpoint as base) `cond_stage_model.*` becomes `conditioner.embedders.0.*`."""
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("conditioner.embedders.") and "first_stage_model" in k:
+            k = k[k.find("first_stage_model"):]
+        if newbasemodel and "cond_stage_model" in k:
+            k = k.replace("cond_stage_model", "conditioner.embedders.0")
+        out[k] = v
+    return out
+
+
+def model_load_ckpt(model, path: str, newbasemodel: bool = False):
+    """util.py:45-112: non-strict load with the key surgery above; LoRA tensors embedded in the checkpoint
+    (`lora*` keys, e.g. majicmixRealistic) are merged at alpha = 0.8 like the reference does, then loaded."""
+    sd = remap_checkpoint_keys(read_checkpoint(path), newbasemodel)
+    lora = {k: v for k, v in sd.items() if k.startswith("lora")}
+    if lora:
+        for k in lora:
+            del sd[k]
+        convert_load_lora(sd_state_dict=sd, state_dict=lora, alpha=0.8)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    if newbasemodel:
+        unwanted = ["temporal", "controlnet", "conditioner.embedders.1."]
+        missing = [k for k in missing if all(s not in k for s in unwanted)]
+    print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
+    if missing:
+        print(f"Missing Keys: {missing}")
+    if unexpected:
+        print(f"Unexpected Keys: {unexpected}")
+    return model
+
+
+def load_lora_file(model, lora_path: str, strength: float) -> None:
+    """sampling_tv2v.py:212-236: merge a kohya .safetensors LoRA into the model's weights at `strength`."""
+    if not lora_path.endswith(".safetensors"):
+        raise NotImplementedError
+    from safetensors.torch import load_file
+    lora_sd = load_file(lora_path)
+    if not all("lora" in k for k in lora_sd):
+        raise ValueError(f"The model you provided in [{lora_path}] is not a LoRA model. ")
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(convert_load_lora(sd, lora_sd, alpha=strength))
+
+
+def load_vae_file(model, vae_path: str) -> None:
+    """sampling_tv2v.py:238-260: replacement first stage (.pt with `state_dict`, or .safetensors)."""
+    if vae_path.endswith(".pt"):
+        vae_sd = torch.load(vae_path, map_location="cpu")["state_dict"]
+    elif vae_path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        vae_sd = load_file(vae_path)
+    else:
+        raise ValueError("Cannot load vae model from {}".format(vae_path))
+    print("msg of loading vae: ", model.first_stage_model.load_state_dict(vae_sd, strict=False))

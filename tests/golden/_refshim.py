@@ -94,3 +94,16 @@ def ref_class_from_file(relpath: str, classname: str):
     ns = {"torch": torch}
     exec(compile(ast.Module(body=[node], type_ignores=[]), f"{REF_ROOT}/{relpath}", "exec"), ns)
     return ns[classname]
+
+
+def ref_func_from_file(relpath: str, funcname: str, extra_ns=None):
+    """Same as ref_class_from_file for ONE top-level function (e.g. convert_load_lora of scripts/sampling/util.py,
+    whose module imports omegaconf / decord / cv2 / imageio / torchvision at the top)."""
+    import ast
+    src = open(f"{REF_ROOT}/{relpath}").read()
+    tree = ast.parse(src)
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == funcname)
+    ns = {"torch": torch}
+    ns.update(extra_ns or {})
+    exec(compile(ast.Module(body=[node], type_ignores=[]), f"{REF_ROOT}/{relpath}", "exec"), ns)
+    return ns[funcname]

@@ -47,6 +47,14 @@ def test_sampling_tv2v_entry_point(tmp_path):
     prior, _ = _run("sampling_tv2v.py", cfg, str(tmp_path / "prior"), "--prior_coefficient_x", "0.5")
     sdedit, _ = _run("sampling_tv2v.py", cfg, str(tmp_path / "sdedit"), "--sdedit_denoise_strength", "0.7")
     assert not np.allclose(plain, prior) and not np.allclose(plain, sdedit)
+    # --lora_path: a kohya-format LoRA on one UNet attention weight, merged at --lora_strength before packing
+    from safetensors.torch import save_file
+    lora = {"lora_unet_mid_block_attentions_0_transformer_blocks_0_attn1_to_q.lora_up.weight": torch.randn(256, 4),
+            "lora_unet_mid_block_attentions_0_transformer_blocks_0_attn1_to_q.lora_down.weight": torch.randn(4, 256)}
+    save_file(lora, str(tmp_path / "toy_lora.safetensors"))
+    with_lora, _ = _run("sampling_tv2v.py", cfg, str(tmp_path / "lora"), "--lora_path", str(tmp_path / "toy_lora.safetensors"),
+                        "--lora_strength", "0.5")
+    assert not np.allclose(plain, with_lora)
 
 
 @pytest.mark.timeout(900)
