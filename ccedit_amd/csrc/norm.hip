@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void gn_spatial_stats_kernel(const bf16* __res
     }
 }
 
+template <int COLS>      // 16-byte granules per lane: ceil(C / 512); fewer live coefficient registers -> more resident waves
 __global__ __launch_bounds__(256) void gn_spatial_apply_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
                                                                const float* __restrict__ stats,
                                                                const float* __restrict__ gamma,
@@ -87,22 +88,40 @@ __global__ __launch_bounds__(256) void gn_spatial_apply_kernel(const bf16* __res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int G8 = C >> 3, cpg = C >> 5;
     const float inv_n = 1.0f / ((float)cpg * (float)hw);
-    float a[kMaxCols][8], b[kMaxCols][8];
+    // per-lane affine coefficients of its 8 * COLS channels.  A granule of 8 aligned channels spans at most two groups
+    // (C/32 >= 8): two statistics loads and four 16-byte gamma/beta loads per granule — this set-up is paid once per
+    // wave and would otherwise dominate at the small latent levels, where a wave normalises only a few pixel rows.
+    float a[COLS][8], b[COLS][8];
 #pragma unroll
-    for (int k = 0; k < kMaxCols; ++k) {
+    for (int k = 0; k < COLS; ++k) {
         const int gc = lane + 64 * k;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            a[k][e] = 0.f;
-            b[k][e] = 0.f;
-            if (gc < G8) {
+        for (int e = 0; e < 8; ++e) a[k][e] = b[k][e] = 0.f;
+        if (gc < G8 && cpg < 8) {                          // narrow test configurations: a granule spans several groups
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
                 const int c = gc * 8 + e;
                 const int g = c / cpg;
                 const float mean = stats[(frame * 32 + g) * 2] * inv_n;
-                const float var = fmaxf(stats[(frame * 32 + g) * 2 + 1] * inv_n - mean * mean, 0.f);
-                const float rstd = rsqrtf(var + eps);
+                const float rstd = rsqrtf(fmaxf(stats[(frame * 32 + g) * 2 + 1] * inv_n - mean * mean, 0.f) + eps);
                 a[k][e] = rstd * gamma[c];
                 b[k][e] = beta[c] - mean * a[k][e];
+            }
+        } else if (gc < G8) {
+            const int c0 = gc * 8;
+            const int g0 = c0 / cpg, g1 = min(g0 + 1, 31);
+            const int split = (g0 + 1) * cpg - c0;           // channels of this granule that belong to group g0
+            const f32x2 st0 = *(const f32x2*)(stats + (frame * 32 + g0) * 2), st1 = *(const f32x2*)(stats + (frame * 32 + g1) * 2);
+            const f32x4 ga0 = *(const f32x4*)(gamma + c0), ga1 = *(const f32x4*)(gamma + c0 + 4);
+            const f32x4 be0 = *(const f32x4*)(beta + c0), be1 = *(const f32x4*)(beta + c0 + 4);
+            const float m0 = st0[0] * inv_n, m1 = st1[0] * inv_n;
+            const float r0 = rsqrtf(fmaxf(st0[1] * inv_n - m0 * m0, 0.f) + eps), r1 = rsqrtf(fmaxf(st1[1] * inv_n - m1 * m1, 0.f) + eps);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float ga = e < 4 ? ga0[e & 3] : ga1[e & 3], be = e < 4 ? be0[e & 3] : be1[e & 3];
+                const bool first = e < split;
+                a[k][e] = (first ? r0 : r1) * ga;
+                b[k][e] = be - (first ? m0 : m1) * a[k][e];
             }
         }
     }
@@ -112,7 +131,7 @@ __global__ __launch_bounds__(256) void gn_spatial_apply_kernel(const bf16* __res
     bf16* yf = y + (size_t)frame * hw * C;
     for (int pix = p0 + wave; pix < p1; pix += kGnWaves) {
 #pragma unroll
-        for (int k = 0; k < kMaxCols; ++k) {
+        for (int k = 0; k < COLS; ++k) {
             const int gc = lane + 64 * k;
             if (gc < G8) {
                 const bf16x8 v = *(const bf16x8*)(xf + (size_t)pix * C + gc * 8);
@@ -426,57 +445,98 @@ __global__ __launch_bounds__(256) void gn_temporal_apply_kernel(const bf16* __re
 // ------------------------------------------------------------------------------------------
 constexpr int kLnCols = 3;     // C <= 1536
 
+// One wave normalises kLnRowsPerWave consecutive rows, two at a time (two independent 16-byte-per-lane row loads in
+// flight, the two reductions interleaved); gamma / beta live in registers for all of them.
+constexpr int kLnRowsPerWave = 8;   // upper bound; the launch picks 8 / 4 / 2 / 1 so that small inputs still fill the chip
+
+template <int COLS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        int64_t rows, int C, float eps) {
+                                                        int64_t rows, int C, float eps, int rpw) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-    if (row >= rows) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * rpw;
+    if (row0 >= rows) return;
     const int G8 = C >> 3;
-    float v[kLnCols][8];
-    float s = 0.f;
+    const float inv_c = 1.0f / (float)C;
+    float g[COLS][8], bta[COLS][8];
 #pragma unroll
-    for (int k = 0; k < kLnCols; ++k) {
+    for (int k = 0; k < COLS; ++k) {
         const int gc = lane + 64 * k;
+        f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, b0 = g0, b1 = g0;
         if (gc < G8) {
-            const bf16x8 t = *(const bf16x8*)(x + (size_t)row * C + gc * 8);
+            g0 = *(const f32x4*)(gamma + gc * 8);
+            g1 = *(const f32x4*)(gamma + gc * 8 + 4);
+            b0 = *(const f32x4*)(beta + gc * 8);
+            b1 = *(const f32x4*)(beta + gc * 8 + 4);
+        }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v[k][e] = bf2f(t[e]);
-                s += v[k][e];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            g[k][e] = g0[e];
+            g[k][4 + e] = g1[e];
+            bta[k][e] = b0[e];
+            bta[k][4 + e] = b1[e];
         }
     }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
+    const int nr = (int)min((int64_t)rpw, rows - row0);
+    for (int r = 0; r < nr; r += 2) {
+        const bool two = r + 1 < nr;
+        const bf16* x0 = x + (size_t)(row0 + r) * C;
+        const bf16* x1 = x0 + (two ? C : 0);
+        bf16x8 t0[COLS], t1[COLS];
 #pragma unroll
-    for (int k = 0; k < kLnCols; ++k) {
-        const int gc = lane + 64 * k;
-        if (gc < G8) {
+        for (int k = 0; k < COLS; ++k) {
+            const int gc = lane + 64 * k;
+            if (gc < G8) {
+                t0[k] = *(const bf16x8*)(x0 + gc * 8);
+                t1[k] = *(const bf16x8*)(x1 + gc * 8);
+            }
+        }
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float dlt = v[k][e] - mean;
-                q += dlt * dlt;
+        for (int k = 0; k < COLS; ++k)
+            if (lane + 64 * k < G8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s0 += bf2f(t0[k][e]);
+                    s1 += bf2f(t1[k][e]);
+                }
+            }
+        const float m0 = wave_sum(s0) * inv_c, m1 = wave_sum(s1) * inv_c;
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < COLS; ++k)
+            if (lane + 64 * k < G8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d0 = bf2f(t0[k][e]) - m0, d1 = bf2f(t1[k][e]) - m1;
+                    q0 += d0 * d0;
+                    q1 += d1 * d1;
+                }
+            }
+        const float r0 = rsqrtf(wave_sum(q0) * inv_c + eps), r1 = rsqrtf(wave_sum(q1) * inv_c + eps);
+#pragma unroll
+        for (int k = 0; k < COLS; ++k) {
+            const int gc = lane + 64 * k;
+            if (gc < G8) {
+                bf16x8 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o0[e] = f2bf((bf2f(t0[k][e]) - m0) * r0 * g[k][e] + bta[k][e]);
+                    o1[e] = f2bf((bf2f(t1[k][e]) - m1) * r1 * g[k][e] + bta[k][e]);
+                }
+                *(bf16x8*)(y + (size_t)(row0 + r) * C + gc * 8) = o0;
+                if (two) *(bf16x8*)(y + (size_t)(row0 + r + 1) * C + gc * 8) = o1;
             }
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-#pragma unroll
-    for (int k = 0; k < kLnCols; ++k) {
-        const int gc = lane + 64 * k;
-        if (gc < G8) {
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = gc * 8 + e;
-                o[e] = f2bf((v[k][e] - mean) * rstd * gamma[c] + beta[c]);
-            }
-            *(bf16x8*)(y + (size_t)row * C + gc * 8) = o;
-        }
-    }
+}
+
+void launch_gn_apply(dim3 grid, hipStream_t s, const bf16* x, bf16* y, const float* stats, const float* gamma,
+                     const float* beta, int hw, int C, float eps, int silu, int apb) {
+    const int cols = (C / 8 + 63) / 64;
+#define CC_GA(N) hipLaunchKernelGGL(gn_spatial_apply_kernel<N>, grid, dim3(256), 0, s, x, y, stats, gamma, beta, hw, C, eps, silu, apb)
+    if (cols == 1) CC_GA(1); else if (cols == 2) CC_GA(2); else if (cols == 3) CC_GA(3); else if (cols == 4) CC_GA(4); else CC_GA(kMaxCols);
+#undef CC_GA
 }
 
 }  // namespace
@@ -501,8 +561,7 @@ extern "C" int ccedit_groupnorm_spatial(const void* x, void* y, const float* gam
     while (spb > 16 && (int64_t)((hw + spb - 1) / spb) * frames < 512) spb >>= 1;
     dim3 sgrid((hw + spb - 1) / spb, frames);
     hipLaunchKernelGGL(gn_spatial_stats_kernel, sgrid, dim3(256), 0, s, (const bf16*)x, stats_ws, hw, C, spb);
-    hipLaunchKernelGGL(gn_spatial_apply_kernel, grid, dim3(256), 0, s, (const bf16*)x, (bf16*)y, stats_ws, gamma, beta, hw,
-                       C, eps, silu, apb);
+    launch_gn_apply(grid, s, (const bf16*)x, (bf16*)y, stats_ws, gamma, beta, hw, C, eps, silu, apb);
     return cc_launch_status("groupnorm_spatial");
 }
 
@@ -515,8 +574,7 @@ extern "C" int ccedit_groupnorm_spatial_apply(const void* x, void* y, const floa
                    kMaxCols * 512);
     const int apb = gn_pix_per_block(hw, frames, 4, 2048);
     dim3 grid((hw + apb - 1) / apb, frames);
-    hipLaunchKernelGGL(gn_spatial_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, stats,
-                       gamma, beta, hw, C, eps, silu, apb);
+    launch_gn_apply(grid, (hipStream_t)stream, (const bf16*)x, (bf16*)y, stats, gamma, beta, hw, C, eps, silu, apb);
     return cc_launch_status("groupnorm_spatial_apply");
 }
 
@@ -569,8 +627,12 @@ extern "C" int ccedit_layernorm(const void* x, void* y, const float* gamma, cons
     CC_CHECK_ARG(x && y && gamma && beta, "ccedit_layernorm: null pointer");
     CC_CHECK_ARG(rows > 0 && C > 0, "ccedit_layernorm: bad sizes");
     CC_UNSUPPORTED(C % 8 != 0 || C > kLnCols * 512, "ccedit_layernorm: C=%d (need C%%8==0, C<=%d)", C, kLnCols * 512);
-    dim3 grid((unsigned)((rows + 3) / 4));
-    hipLaunchKernelGGL(layernorm_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, gamma, beta,
-                       rows, C, eps);
+    int rpw = kLnRowsPerWave;
+    while (rpw > 1 && (rows + 4 * rpw - 1) / (4 * rpw) < 4096) rpw >>= 1;
+    dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
+    const int cols = (C / 8 + 63) / 64;
+#define CC_LN(N) hipLaunchKernelGGL(layernorm_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, gamma, beta, rows, C, eps, rpw)
+    if (cols == 1) CC_LN(1); else if (cols == 2) CC_LN(2); else CC_LN(kLnCols);
+#undef CC_LN
     return cc_launch_status("layernorm");
 }

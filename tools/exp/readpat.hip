@@ -1,0 +1,169 @@
+// Experiment: HBM read bandwidth of two access patterns through global_load_lds (DMA to LDS), 134 MB matrix [M][320] bf16.
+//  pat 0: GEMM-like — block owns 256 rows; 5 steps, each step loads a 128-byte piece of every row (row pitch 640 B), barrier
+//  pat 1: panel-like — block owns 64 rows; loads all 640 B of every row at once, one wait
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+extern "C" __global__ __launch_bounds__(256) void pat0(const char* a, int64_t M, int* sink) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const int p = tid & 7, rsub = tid >> 3;          // 32 rows x 8 granules per issue
+    for (int kt = 0; kt < 5; ++kt) {
+        char* dst = smem + (kt & 1) * 32768;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = row0 + i * 32 + rsub;
+            glds16(a + (r < M ? r : 0) * 640 + kt * 128 + p * 16, dst + i * 4096 + wave * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (smem[tid] == 123 && sink) sink[0] = 1;
+}
+extern "C" __global__ __launch_bounds__(256) void pat1(const char* a, int64_t M, int* sink) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const char* base = a + row0 * 640;               // 64 rows x 640 B = 40960 B contiguous = 2560 granules = 10 per thread
+#pragma unroll
+    for (int i = 0; i < 10; ++i) glds16(base + (i * 256 + tid) * 16, smem + i * 4096 + wave * 1024);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (smem[tid] == 123 && sink) sink[0] = 1;
+}
+// pat 2: same bytes per block as pat1 but issued as the GEMM staging does (8 rows x 128 B per wave instruction), all k-tiles at once
+extern "C" __global__ __launch_bounds__(256) void pat2(const char* a, int64_t M, int* sink) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int p = tid & 7, rsub = tid >> 3;
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            glds16(a + (row0 + i * 32 + rsub) * 640 + kt * 128 + p * 16, smem + kt * 8192 + i * 4096 + wave * 1024);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (smem[tid] == 123 && sink) sink[0] = 1;
+}
+
+// pat3: pat0 with every 256-row tile read by 5 consecutive blocks (channel tiles re-reading the activation tile)
+extern "C" __global__ __launch_bounds__(256) void pat3(const char* a, int64_t M, int* sink) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t bid = blockIdx.x; const int xcd = bid & 7; const int64_t local = bid >> 3;
+    const int64_t ptn = (M + 255) / 256, ppx = (ptn + 7) / 8;
+    const int64_t pt = xcd * ppx + local / 5;
+    if (pt >= ptn) return;
+    const int64_t row0 = pt * 256;
+    const int p = tid & 7, rsub = tid >> 3;
+    for (int kt = 0; kt < 5; ++kt) {
+        char* dst = smem + (kt & 1) * 32768;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = row0 + i * 32 + rsub;
+            glds16(a + (r < M ? r : 0) * 640 + kt * 128 + p * 16, dst + i * 4096 + wave * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (smem[tid] == 123 && sink) sink[0] = 1;
+}
+// pat4: pat0 + a 64-row x 128-byte weight tile per step from a small shared matrix (row pitch 640 B), like t2
+extern "C" __global__ __launch_bounds__(256) void pat4(const char* a, int64_t M, int* sink) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const char* w = (const char*)sink;               // 512 x 640 B weight matrix
+    const int p = tid & 7, rsub = tid >> 3;
+    for (int kt = 0; kt < 5; ++kt) {
+        char* dst = smem + (kt & 1) * 40960;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(w + (int64_t)(i * 32 + rsub) * 640 + kt * 128 + p * 16, dst + 32768 + i * 4096 + wave * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = row0 + i * 32 + rsub;
+            glds16(a + (r < M ? r : 0) * 640 + kt * 128 + p * 16, dst + i * 4096 + wave * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (smem[tid] == 123 && a == nullptr) ((int*)sink)[0] = 1;
+}
+
+// pat5: GEMM-shaped copy: pat0 loads (5 steps of 128-byte row pieces), then an epilogue that writes the 256 x 640 B tile
+// to `out` the way the GEMM epilogue does (16 B per lane, 16 lanes per 256-byte row piece, 3 channel tiles = 3 passes)
+extern "C" __global__ __launch_bounds__(256) void pat5(const char* a, int64_t M, char* out) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const int p = tid & 7, rsub = tid >> 3;
+    for (int kt = 0; kt < 5; ++kt) {
+        char* dst = smem + (kt & 1) * 16384;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t r = row0 + i * 32 + rsub;
+            glds16(a + (r < M ? r : 0) * 640 + kt * 128 + p * 16, dst + i * 4096 + wave * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // epilogue: 128 rows x 640 B; thread -> (row r0 + 16 j, granule g) with 40 granules per row -> use 40 threads per row, 6 rows per pass
+    const int g = tid % 40, r0 = tid / 40;
+    if (r0 < 6) {
+        for (int row = r0; row < 128; row += 6) {
+            const int64_t m = row0 + row;
+            if (m >= M) break;
+            const uint4 v = *(const uint4*)(smem + ((row * 40 + g) * 16) % 32768);
+            *(uint4*)(out + m * 640 + g * 16) = v;
+        }
+    }
+}
+
+// pat6: pat3's traffic (every tile read by 5 blocks) with ordinary 16-byte loads into VGPRs, then ds_write_b128 to LDS
+extern "C" __global__ __launch_bounds__(256) void pat6(const char* a, int64_t M, int* sink) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x;
+    const int64_t bid = blockIdx.x; const int xcd = bid & 7; const int64_t local = bid >> 3;
+    const int64_t ptn = (M + 255) / 256, ppx = (ptn + 7) / 8;
+    const int64_t pt = xcd * ppx + local / 5;
+    if (pt >= ptn) return;
+    const int64_t row0 = pt * 256;
+    const int p = tid & 7, rsub = tid >> 3;
+    for (int kt = 0; kt < 5; ++kt) {
+        char* dst = smem + (kt & 1) * 32768;
+        uint4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = row0 + i * 32 + rsub;
+            v[i] = *(const uint4*)(a + (r < M ? r : 0) * 640 + kt * 128 + p * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(uint4*)(dst + i * 4096 + tid * 16) = v[i];
+        __syncthreads();
+    }
+    if (smem[tid] == 123 && sink) sink[0] = 1;
+}
+// pat7: pat6 without the LDS write (loads only, xor-reduced)
+extern "C" __global__ __launch_bounds__(256) void pat7(const char* a, int64_t M, int* sink) {
+    const int tid = threadIdx.x;
+    const int64_t bid = blockIdx.x; const int xcd = bid & 7; const int64_t local = bid >> 3;
+    const int64_t ptn = (M + 255) / 256, ppx = (ptn + 7) / 8;
+    const int64_t pt = xcd * ppx + local / 5;
+    if (pt >= ptn) return;
+    const int64_t row0 = pt * 256;
+    const int p = tid & 7, rsub = tid >> 3;
+    uint4 acc = {0, 0, 0, 0};
+    for (int kt = 0; kt < 5; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = row0 + i * 32 + rsub;
+            const uint4 v = *(const uint4*)(a + (r < M ? r : 0) * 640 + kt * 128 + p * 16);
+            acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345 && sink) sink[0] = 1;
+}
