@@ -296,25 +296,47 @@ __global__ __launch_bounds__(256) void gn_temporal_cached_kernel(const bf16* __r
                     sq[e] += f * f;
                 }
             }
+        if (cpg >= 8) {           // a granule spans at most two groups: four LDS atomics per lane instead of sixteen
+            const int g0 = (gc * 8) / cpg, split = (g0 + 1) * cpg - gc * 8;
+            float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int g = (gc * 8 + e) / cpg;
-            atomicAdd(&s_sum[wave][g], sum[e]);
-            atomicAdd(&s_sq[wave][g], sq[e]);
+            for (int e = 0; e < 8; ++e) {
+                const bool first = e < split;
+                s0 += first ? sum[e] : 0.f;
+                q0 += first ? sq[e] : 0.f;
+                s1 += first ? 0.f : sum[e];
+                q1 += first ? 0.f : sq[e];
+            }
+            atomicAdd(&s_sum[wave][g0], s0);
+            atomicAdd(&s_sq[wave][g0], q0);
+            if (split < 8) {
+                atomicAdd(&s_sum[wave][g0 + 1], s1);
+                atomicAdd(&s_sq[wave][g0 + 1], q1);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int g = (gc * 8 + e) / cpg;
+                atomicAdd(&s_sum[wave][g], sum[e]);
+                atomicAdd(&s_sq[wave][g], sq[e]);
+            }
         }
     }
     __syncthreads();
     if (!lane_on) return;
     const float inv_n = 1.0f / ((float)cpg * (float)T);
     float a[8], bb[8];
+    {
+        const f32x4 ga0 = *(const f32x4*)(gamma + gc * 8), ga1 = *(const f32x4*)(gamma + gc * 8 + 4);
+        const f32x4 be0 = *(const f32x4*)(beta + gc * 8), be1 = *(const f32x4*)(beta + gc * 8 + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = gc * 8 + e;
-        const int g = c / cpg;
-        const float mean = s_sum[wave][g] * inv_n;
-        const float var = fmaxf(s_sq[wave][g] * inv_n - mean * mean, 0.f);
-        a[e] = rsqrtf(var + eps) * gamma[c];
-        bb[e] = beta[c] - mean * a[e];
+        for (int e = 0; e < 8; ++e) {
+            const int g = (gc * 8 + e) / cpg;
+            const float mean = s_sum[wave][g] * inv_n;
+            const float var = fmaxf(s_sq[wave][g] * inv_n - mean * mean, 0.f);
+            a[e] = rsqrtf(var + eps) * (e < 4 ? ga0[e & 3] : ga1[e & 3]);
+            bb[e] = (e < 4 ? be0[e & 3] : be1[e & 3]) - mean * a[e];
+        }
     }
 #pragma unroll
     for (int t = 0; t < kGtCacheT; ++t)
