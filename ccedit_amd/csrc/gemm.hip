@@ -32,6 +32,9 @@
 #include <math.h>
 #include <stdlib.h>
 
+bool cc_small_conv_applicable(const CcGemmDesc& d);       // smallconv.hip
+int cc_small_conv_launch(const CcGemmDesc& d, hipStream_t s);
+
 namespace {
 
 __device__ __attribute__((aligned(64))) char g_zero_page[64];
@@ -592,6 +595,7 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
                        "ccedit_gemm: gn_stats needs N%%32==0, N>=256, bf16 output, no GEGLU (N=%d)", d.N);
     }
     hipStream_t s = (hipStream_t)stream;
+    if (d.tile == 0 && cc_small_conv_applicable(d)) return cc_small_conv_launch(d, s);     // few-channel 3x3 (hint stem top)
     int tile = d.tile;
     if (tile == 0) {
         // Chosen from IN-NETWORK timings (bench.py --breakdown), where operands arrive cold from HBM; the isolated

@@ -126,6 +126,31 @@ def test_conv3x3(cin, cout, h, w, stride, tile):
     _close(_nchw(y)[:, :cout], ref, what=f"conv3x3 {cin}->{cout} s{stride}")
 
 
+@pytest.mark.parametrize("cin,cout,stride,act", [(3, 16, 1, 1), (16, 16, 1, 1), (16, 32, 2, 1), (32, 32, 1, 0), (8, 4, 1, 0)])
+def test_conv3x3_few_channels_many_pixels(cin, cout, stride, act):
+    """The LDS-free small-channel kernel (smallconv.hip) that ccedit_gemm routes Cin, Cout <= 32 layers with >= 64 K
+    output pixels to (top of the ControlNet hint stem), against F.conv2d and against the tiled kernel (tile=2)."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    n, h, w = 2, 200, 328                              # 65,600 output pixels at stride 1, ragged last 32-pixel group
+    if stride == 2:
+        h, w = 2 * h, 2 * w - 2
+    x = _rnd(n, cin, h, w, seed=1)
+    wt, b = _rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), _rnd(cout, seed=3)
+    cp = (cin + 7) // 8 * 8
+    xp = torch.zeros(n, cp, h, w)
+    xp[:, :cin] = x
+    pw = pack_weight(wt, b).to("cuda")
+    y = ops.conv2d(_nhwc(xp), pw, stride=stride, act=act)
+    ref = F.conv2d(x, wt, b, stride=stride, padding=1)
+    if act:
+        ref = F.silu(ref)
+    _close(_nchw(y)[:, :cout], ref, what=f"small conv {cin}->{cout} s{stride}")
+    y2 = ops.conv2d(_nhwc(xp), pw, stride=stride, act=act, tile=2)          # the tiled path on the same operands
+    _close(y.float(), y2.float(), rel=2.0 ** -7, what="small conv vs tiled")
+
+
 def test_conv3x3_channel_padding():
     """Cin = 4 (latent) / 3 (hint) are zero-padded to 8 channels at the layout boundary."""
     _dev()
