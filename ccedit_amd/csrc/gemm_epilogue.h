@@ -1,0 +1,204 @@
+// Shared epilogue of the MFMA GEMM kernels (tap_gemm_kernel in gemm.hip, conv_halo_kernel in convhalo.hip):
+// accumulators -> LDS (fp32, [pixel][channel]) -> row-wise, fully coalesced stores with bias, timestep-embedding row
+// bias, SiLU / quick-GELU / GEGLU, two residuals and the optional GroupNorm(32) statistics of the tensor written.
+#pragma once
+#include "common.h"
+
+// Dynamic LDS a kernel needs so that the epilogue can stage at least one wave column (host and device agree on it).
+constexpr int epi_lds_total(int bmc, int bnp, int tj, int lds_main) {
+    const int erow = bmc * 4 + 16, full = bnp * erow, one_col = tj * 32 * erow;
+    return (full > lds_main && full <= 70 * 1024) ? full : (lds_main > one_col ? lds_main : one_col);
+}
+
+// In the MFMA layout a lane owns 4 channels of 32 different pixels, i.e. 8-byte pieces of 32 different output rows
+// per store.  Staging the tile through LDS turns that into 16-byte-per-lane accesses that walk each pixel row
+// contiguously (bias / timestep-embedding / activation / residual reads use the same coalesced pattern).
+//   rowmap(p): output row (pixel index into out / residuals / group_bias) of tile pixel p in [0, BNP), or -1 when the
+//              tile pixel lies outside the tensor; stat_frame: frame index for the GroupNorm statistics.
+template <int WM, int WN, int TI, int TJ, int LDS_MAIN, class RowMap>
+__device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)[TI][TJ], char* smem, int ch0,
+                                              RowMap rowmap, int64_t stat_frame) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    constexpr int EROW = BMC * 4 + 16;        // +16 B: the ds_write_b128 of 8 consecutive lanes cover all banks
+    // (the 128x128 shape allocates 3.5 KB more than its operand ring so that the whole tile is staged at once)
+    constexpr int WPIX = TJ * 32;             // pixels per wave column
+    constexpr int LDS_TOTAL = epi_lds_total(BMC, BNP, TJ, LDS_MAIN);
+    constexpr int ECH = (LDS_TOTAL / EROW / WPIX) * WPIX < BNP ? (LDS_TOTAL / EROW / WPIX) * WPIX : BNP;   // pixels per chunk
+    static_assert(ECH >= WPIX && BNP % ECH == 0, "epilogue chunking");
+    char* const sE = smem;
+    const float* __restrict__ bias = d.bias;
+    const float* __restrict__ gbias = d.group_bias;
+    const bf16* __restrict__ r1 = (const bf16*)d.res1;
+    const bf16* __restrict__ r2 = (const bf16*)d.res2;
+    float gs[8], gq[8];                       // GroupNorm statistics of this thread's 8 output channels (gn_stats)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
+  for (int ec = 0; ec < BNP / ECH; ++ec) {
+    __syncthreads();                          // operand tiles (or the previous chunk) are no longer being read
+    if (wn * WPIX >= ec * ECH && wn * WPIX < (ec + 1) * ECH) {
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[ti][tj][q * 4 + 0], acc[ti][tj][q * 4 + 1], acc[ti][tj][q * 4 + 2], acc[ti][tj][q * 4 + 3]};
+                    *(f32x4*)(sE + (wn * WPIX - ec * ECH + tj * 32 + l31) * EROW + (wm * TI * 32 + ti * 32 + q * 8 + hi * 4) * 4) = v;
+                }
+    }
+    __syncthreads();
+
+    if (d.act == CCEDIT_ACT_GEGLU) {
+        constexpr int CPR = BMC / 16;                    // 16 packed rows = 8 value + 8 gate channels
+        const int g = tid % CPR, r0 = tid / CPR;
+        const int rx = ch0 + g * 16;                      // packed row of the 8 values; gates at rx + 8
+        if (rx < d.N) {
+            float bx[8], bg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bx[e] = bias ? bias[rx + e] : 0.f;
+                bg[e] = bias ? bias[rx + 8 + e] : 0.f;
+            }
+            for (int row = r0; row < ECH; row += NT / CPR) {
+                const int64_t m = rowmap(ec * ECH + row);
+                if (m < 0) continue;
+                const char* src = sE + row * EROW + g * 64;
+                const f32x4 x0 = *(const f32x4*)(src), x1 = *(const f32x4*)(src + 16);
+                const f32x4 g0 = *(const f32x4*)(src + 32), g1 = *(const f32x4*)(src + 48);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = f2bf((x0[e] + bx[e]) * gelu_erf_f(g0[e] + bg[e]));
+                    o[4 + e] = f2bf((x1[e] + bx[4 + e]) * gelu_erf_f(g1[e] + bg[4 + e]));
+                }
+                *(bf16x8*)((bf16*)d.out + (size_t)m * d.ldc + (rx >> 1)) = o;
+            }
+        }
+    } else {
+        constexpr int CPR = BMC / 8;
+        const int g = tid % CPR, r0 = tid / CPR;
+        const int cb = ch0 + g * 8;
+        if (cb < d.N) {
+            const bool full = (cb + 8 <= d.N);            // otherwise exactly 4 valid channels (N % 4 == 0)
+            float bv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = (bias && (full || e < 4)) ? bias[cb + e] : 0.f;
+            for (int row = r0; row < ECH; row += NT / CPR) {
+                const int64_t m = rowmap(ec * ECH + row);
+                if (m < 0) continue;
+                const char* src = sE + row * EROW + g * 32;
+                const f32x4 a0 = *(const f32x4*)(src), a1 = *(const f32x4*)(src + 16);
+                float v[8] = {a0[0] + bv[0], a0[1] + bv[1], a0[2] + bv[2], a0[3] + bv[3],
+                              a1[0] + bv[4], a1[1] + bv[5], a1[2] + bv[6], a1[3] + bv[7]};
+                if (gbias) {
+                    const float* gb = gbias + (size_t)(m / d.group_rows) * d.N + cb;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (full || e < 4) v[e] += gb[e];
+                }
+                if (d.act == CCEDIT_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                } else if (d.act == CCEDIT_ACT_QUICK_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+                }
+                if (full) {
+                    if (r1) {
+                        const bf16x8 rv = *(const bf16x8*)(r1 + (size_t)m * d.ldr1 + cb);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
+                    }
+                    if (r2) {
+                        const bf16x8 rv = *(const bf16x8*)(r2 + (size_t)m * d.ldr2 + cb);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
+                    }
+                    if (d.out_f32) {
+                        float* op = (float*)d.out + (size_t)m * d.ldc + cb;
+                        *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    } else {
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+                        *(bf16x8*)((bf16*)d.out + (size_t)m * d.ldc + cb) = o;
+                        if (d.gn_stats) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float f = bf2f(o[e]);      // statistics of what the consumer will read
+                                gs[e] += f;
+                                gq[e] += f * f;
+                            }
+                        }
+                    }
+                } else {
+                    if (r1) {
+                        const bf16x4 rv = *(const bf16x4*)(r1 + (size_t)m * d.ldr1 + cb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bf2f(rv[e]);
+                    }
+                    if (r2) {
+                        const bf16x4 rv = *(const bf16x4*)(r2 + (size_t)m * d.ldr2 + cb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bf2f(rv[e]);
+                    }
+                    if (d.out_f32) {
+                        *(f32x4*)((float*)d.out + (size_t)m * d.ldc + cb) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                        *(bf16x4*)((bf16*)d.out + (size_t)m * d.ldc + cb) = o;
+                    }
+                }
+            }
+        }
+    }
+  }   // epilogue chunks
+
+    // ---- fused GroupNorm(32) statistics: thread -> lanes sharing the channel granule -> LDS -> global atomics ----
+    if (d.gn_stats) {
+        constexpr int CPR = BMC / 8;
+        float* const sS = (float*)smem;           // [32 groups][sum, sumsq]
+        __syncthreads();                          // the last chunk's staging area has been consumed
+        if (tid < 64) sS[tid] = 0.f;
+        __syncthreads();
+        const int cb = ch0 + (tid % CPR) * 8;
+        const int cpg = d.N >> 5;                 // >= 8: eight aligned channels span at most two groups
+        const int g0 = cb / cpg;
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool first = (cb + e) < (g0 + 1) * cpg;
+            s0 += first ? gs[e] : 0.f;
+            q0 += first ? gq[e] : 0.f;
+            s1 += first ? 0.f : gs[e];
+            q1 += first ? 0.f : gq[e];
+        }
+#pragma unroll
+        for (int off = CPR; off < 64; off <<= 1) {
+            s0 += __shfl_xor(s0, off);
+            q0 += __shfl_xor(q0, off);
+            s1 += __shfl_xor(s1, off);
+            q1 += __shfl_xor(q1, off);
+        }
+        if ((tid & 63) < CPR && cb < d.N) {
+            atomicAdd(&sS[g0 * 2], s0);
+            atomicAdd(&sS[g0 * 2 + 1], q0);
+            if (g0 < 31) {
+                atomicAdd(&sS[g0 * 2 + 2], s1);
+                atomicAdd(&sS[g0 * 2 + 3], q1);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const float v = sS[tid];
+            if (v != 0.f) atomicAdd(d.gn_stats + (size_t)stat_frame * 64 + tid, v);
+        }
+    }
+}
