@@ -33,6 +33,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+bool cc_conv_halo_applicable(const CcGemmDesc& d);        // convhalo.hip
+int cc_conv_halo_launch(const CcGemmDesc& d, hipStream_t s);
 bool cc_small_conv_applicable(const CcGemmDesc& d);       // smallconv.hip
 int cc_small_conv_launch(const CcGemmDesc& d, hipStream_t s);
 
@@ -406,13 +408,18 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     if (d.gn_stats) {
         CC_CHECK_ARG(d.gn_rows > 0 && d.gn_rows % 128 == 0 && d.M % d.gn_rows == 0,
                      "ccedit_gemm: gn_stats needs gn_rows %% 128 == 0 dividing M (gn_rows=%d)", d.gn_rows);
-        CC_CHECK_ARG(d.gn_rows % 256 == 0 || d.tile <= 1,
+        CC_CHECK_ARG(d.gn_rows % 256 == 0 || d.tile <= 1 || d.tile == 8,
                      "ccedit_gemm: gn_rows=%d is not a multiple of 256: only the 128-pixel block shape (tile 1) applies", d.gn_rows);
         CC_UNSUPPORTED(d.N % 32 != 0 || d.N < 256 || d.out_f32 || d.act == CCEDIT_ACT_GEGLU,
                        "ccedit_gemm: gn_stats needs N%%32==0, N>=256, bf16 output, no GEGLU (N=%d)", d.N);
     }
     hipStream_t s = (hipStream_t)stream;
     if (d.tile == 0 && cc_small_conv_applicable(d)) return cc_small_conv_launch(d, s);     // few-channel 3x3 (hint stem top)
+    static const int halo_env = getenv("CCEDIT_CONV_HALO") ? atoi(getenv("CCEDIT_CONV_HALO")) : 1;   // 0: A/B against the gather path
+    if ((d.tile == 0 && halo_env) || d.tile == 8) {
+        if (cc_conv_halo_applicable(d)) return cc_conv_halo_launch(d, s);
+        CC_UNSUPPORTED(d.tile == 8, "ccedit_gemm: tile 8 (LDS-halo 3x3 conv) does not apply to this descriptor");
+    }
     int tile = d.tile;
     if (tile == 0) {
         // Chosen from IN-NETWORK timings (bench.py --breakdown), where operands arrive cold from HBM; the isolated

@@ -151,6 +151,34 @@ def test_conv3x3_few_channels_many_pixels(cin, cout, stride, act):
     _close(y.float(), y2.float(), rel=2.0 ** -7, what="small conv vs tiled")
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 16, 32), (128, 320, 16, 24), (320, 320, 32, 48), (192, 64, 8, 16), (640, 1280, 16, 24)])
+@pytest.mark.parametrize("tile", [0, 8])
+def test_conv3x3_lds_halo(cin, cout, h, w, tile):
+    """convhalo.hip: the input rectangle (+halo) is staged once per 64-channel chunk and the nine taps are read from
+    LDS at shifted rows.  16x8 and 8x16 pixel rectangles, image borders, several channel tiles / chunks; the full
+    epilogue (bias, timestep-embedding row bias, residual, GroupNorm statistics) is shared with the gather kernel."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    n = 3
+    x = _rnd(n, cin, h, w, seed=1)
+    wt, b = _rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), _rnd(cout, seed=3)
+    res, gb = _rnd(n, cout, h, w, seed=4), _rnd(n, cout, seed=5)
+    pw = pack_weight(wt, b).to("cuda")
+    y = ops.conv2d(_nhwc(x), pw, res1=_nhwc(res).view(-1, cout), group_bias=gb.cuda(), group_rows=h * w, gn=True, tile=tile)
+    ref = F.conv2d(x, wt, b, padding=1) + gb[:, :, None, None] + res
+    _close(_nchw(y), ref, what=f"halo conv {cin}->{cout} {h}x{w} tile{tile}")
+    y1 = ops.conv2d(_nhwc(x), pw, res1=_nhwc(res).view(-1, cout), group_bias=gb.cuda(), group_rows=h * w, tile=1)
+    assert torch.equal(y, y1) or (y.float() - y1.float()).abs().max() <= 2.0 ** -6 * ref.abs().max()
+    st = ops.gn_stats_of(y, h * w)
+    if cout >= 256 and (h * w) % 128 == 0:
+        yf = y.float().view(n, h * w, 32, cout // 32)
+        assert torch.allclose(st[..., 0], yf.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+        assert torch.allclose(st[..., 1], (yf * yf).sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+    ys = ops.conv2d(_nhwc(x), pw, act=1, tile=tile)
+    _close(_nchw(ys), F.silu(F.conv2d(x, wt, b, padding=1)), what="halo conv + SiLU")
+
+
 def test_conv3x3_channel_padding():
     """Cin = 4 (latent) / 3 (hint) are zero-padded to 8 channels at the layout boundary."""
     _dev()

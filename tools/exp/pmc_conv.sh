@@ -7,7 +7,7 @@ import csv, glob, collections
 acc = collections.defaultdict(lambda: [0, 0.0])
 for f in glob.glob("/tmp/pm1/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "tap_gemm" in r["Kernel_Name"]:
+        if "tap_gemm" in r["Kernel_Name"] or "conv_halo" in r["Kernel_Name"]:
             a = acc[r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
 for k, (n, v) in sorted(acc.items()):
     print(f"  {k:40s} avg/launch {v/n:16.1f}  (n={n})")
