@@ -180,7 +180,7 @@ def main():
         ops.PROFILE = None
         g = prof["tap_gemm"]
         ach = g["flops"] / (g["total_ms"] * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="tap_gemm_kernel", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+        roof = dict(bound="mfma", kernel="ccedit_gemm (tap_gemm_kernel, conv_halo_kernel, small_conv3x3_kernel)", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None, launches=g["launches"],
                     avg_launch_us=round(g["avg_us"], 2), algorithmic_flops_per_step=g["flops"])
         # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 PMC passes of this
@@ -192,7 +192,7 @@ def main():
                 tg = json.load(f).get("tap_gemm")
             if tg and tg["launches"]:
                 roof["traffic"] = round((tg["fetch_bytes_x2"] + tg["write_bytes"]) / tg["launches"])
-                roof["traffic_unit"] = "HBM bytes per tap_gemm launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)"
+                roof["traffic_unit"] = "HBM bytes per ccedit_gemm launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)"
                 roof["algorithmic_bytes_per_launch"] = round(g["bytes"] / g["launches"])
         a = prof.get("attention")
         if a:
