@@ -89,7 +89,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
     // that does not fit in the 4 MB L2 is shared by 64/Q concurrently running workgroups instead of being
     // re-fetched by every one of them.  Q = ct_n (weights L2-resident) degenerates to "all channel tiles of one
     // pixel tile back to back".
-    const int Q = d.cgroup > 0 ? d.cgroup : ct_n;
+    const int Q = (d.cgroup & 0xFFFF) > 0 ? (d.cgroup & 0xFFFF) : ct_n;
     const int64_t gsz = pt_per_xcd * Q;
     const int cg = (int)(local / gsz);
     const int64_t rr = local - cg * gsz;
@@ -155,7 +155,17 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
         s_cg = gcol;
     }
 
+    // LINEAR: workgroups that share an operand tile (the channel tiles of one pixel tile share its activation rows, the
+    // pixel tiles of one channel tile share its weight rows) start their K loops at different K tiles, so that at any
+    // moment they pull different lines through L2 instead of queueing on the same ones (tools/exp/readpat.hip pat3 ->
+    // pat9: 5 workgroups re-reading one tile, 53.6 -> 39.6 us).  The sum over K is order-independent up to fp32 rounding.
+    const int krot = (MODE == M_LINEAR && (d.cgroup >> 16)) ? (int)((pt + ch0 / BMC) % nk) : 0;
     auto stage = [&](int kt, int buf) {
+        if constexpr (MODE == M_LINEAR) {
+            kt += krot;
+            if (kt >= nk) kt -= nk;
+            s_cg = kt * GPR + gcol;                   // taps == 1: the granule index is the K tile position
+        }
         // weights: always in range (rows and K are zero-padded by the packer)
 #pragma unroll
         for (int i = 0; i < A_ISSUES; ++i) {
@@ -347,6 +357,8 @@ int launch(const CcGemmDesc& d, hipStream_t s) {
             dd.cgroup = (int)((ct_n + ng - 1) / ng);
         }
     }
+    static const int krot_env = getenv("CCEDIT_KROT") ? atoi(getenv("CCEDIT_KROT")) : 1;     // 0: A/B without the K rotation
+    if (krot_env && d.Kpad <= 640) dd.cgroup |= 1 << 16;                                         // short K only: measured neutral or -3 % at K = 1280
     hipLaunchKernelGGL((tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>), grid, dim3(WM * WN * 64), lds, s, dd);
     return cc_launch_status("tap_gemm_kernel");
 }
@@ -433,6 +445,7 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         const int w128 = (d.N + 127) / 128 * 128, w64 = (d.N + 63) / 64 * 64;
         if (w64 < w128) tile = (d.taps > 1 || d.Kpad <= 512) ? 2 : 1;
         else if (d.M >= 150000 && d.Kpad >= 2048) tile = 3;
+        else if (d.act == CCEDIT_ACT_GEGLU && d.Kpad <= 640) tile = 2;    // with the K rotation: +9 / +5 % over t1 at K = 320 / 640
         else tile = 1;
         if (d.gn_stats && d.gn_rows % 256 != 0) tile = 1;     // a block must not straddle two frames
     }

@@ -90,7 +90,7 @@ typedef struct CcGemmDesc {
      * per clip — tsrc_off halo frames received from the previous rank, the T local frames, then the next rank's —
      * and local frame 0 is global keyframe t0 of Tglob; taps outside [0, Tglob) read zeros (Conv1d padding). */
     int32_t Tsrc, tsrc_off, t0, Tglob;
-    int32_t cgroup;       /* internal (set by the library): channel-tile group width of the block order; pass 0 */
+    int32_t cgroup;       /* internal (set by the library): block-order parameters; pass 0 */
     const void* A;        /* bf16 [rows][lda] */
     const void* A2;       /* optional second source */
     const void* W;        /* bf16 [ceil(N,256)][Kpad] (rows zero-padded to the widest block shape) */

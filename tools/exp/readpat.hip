@@ -167,3 +167,78 @@ extern "C" __global__ __launch_bounds__(256) void pat7(const char* a, int64_t M,
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345 && sink) sink[0] = 1;
 }
+
+// pat8<AUX>: pat3 with a cache-policy aux argument on the LDS-DMA load (sc0 = 1, nt = 2, sc1 = 16 on gfx94x/95x)
+template <int AUX>
+__device__ __forceinline__ void glds16x(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, AUX);
+}
+#define PAT8(NAME, AUX) extern "C" __global__ __launch_bounds__(256) void NAME(const char* a, int64_t M, int* sink) { \
+    extern __shared__ char smem[]; \
+    const int tid = threadIdx.x, wave = tid >> 6; \
+    const int64_t bid = blockIdx.x; const int xcd = bid & 7; const int64_t local = bid >> 3; \
+    const int64_t ptn = (M + 255) / 256, ppx = (ptn + 7) / 8; \
+    const int64_t pt = xcd * ppx + local / 5; \
+    if (pt >= ptn) return; \
+    const int64_t row0 = pt * 256; \
+    const int p = tid & 7, rsub = tid >> 3; \
+    for (int kt = 0; kt < 5; ++kt) { \
+        char* dst = smem + (kt & 1) * 32768; \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) { \
+            const int64_t r = row0 + i * 32 + rsub; \
+            glds16x<AUX>(a + (r < M ? r : 0) * 640 + kt * 128 + p * 16, dst + i * 4096 + wave * 1024); \
+        } \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        __syncthreads(); \
+    } \
+    if (smem[tid] == 123 && sink) sink[0] = 1; }
+PAT8(pat8_1, 1)
+PAT8(pat8_2, 2)
+PAT8(pat8_3, 3)
+PAT8(pat8_16, 16)
+PAT8(pat8_17, 17)
+PAT8(pat8_18, 18)
+
+// pat9: pat3 with the k-step order rotated per workgroup (the 5 workgroups sharing a tile touch different lines at any time)
+extern "C" __global__ __launch_bounds__(256) void pat9(const char* a, int64_t M, int* sink) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t bid = blockIdx.x; const int xcd = bid & 7; const int64_t local = bid >> 3;
+    const int64_t ptn = (M + 255) / 256, ppx = (ptn + 7) / 8;
+    const int64_t pt = xcd * ppx + local / 5;
+    if (pt >= ptn) return;
+    const int rot = (int)(local % 5);
+    const int64_t row0 = pt * 256;
+    const int p = tid & 7, rsub = tid >> 3;
+    for (int k0 = 0; k0 < 5; ++k0) {
+        const int kt = (k0 + rot) % 5;
+        char* dst = smem + (k0 & 1) * 32768;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = row0 + i * 32 + rsub;
+            glds16(a + (r < M ? r : 0) * 640 + kt * 128 + p * 16, dst + i * 4096 + wave * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (smem[tid] == 123 && sink) sink[0] = 1;
+}
+// pat10: one workgroup reads its own 256-row tile 5 times in a row (same bytes through the L1-miss path, no sharing between CUs)
+extern "C" __global__ __launch_bounds__(256) void pat10(const char* a, int64_t M, int* sink) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const int p = tid & 7, rsub = tid >> 3;
+    for (int rep = 0; rep < 5; ++rep)
+    for (int kt = 0; kt < 5; ++kt) {
+        char* dst = smem + (kt & 1) * 32768;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = row0 + i * 32 + rsub;
+            glds16(a + (r < M ? r : 0) * 640 + kt * 128 + p * 16, dst + i * 4096 + wave * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (smem[tid] == 123 && sink) sink[0] = 1;
+}

@@ -29,6 +29,7 @@ def run(name, rows_per_block, lds, mult=1, usew=False, useout=False):
     t = t[len(t) // 2] * 1e-3
     print(f"{name}: {t*1e6:.1f} us  {M*640/t/1e12:.2f} TB/s")
 run("pat0", 256, 65536); run("pat1", 64, 40960); run("pat2", 64, 40960); run("pat3", 256, 65536, mult=5); run("pat4", 256, 81920, usew=True); run("pat5", 128, 32768, useout=True); run("pat6", 256, 65536, mult=5); run("pat7", 256, 0, mult=5)
+run("pat9", 256, 65536, mult=5); run("pat10", 256, 65536)
 x = bufs[0]; y = torch.empty_like(x)
 for _ in range(2): y.copy_(x)
 torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
