@@ -69,6 +69,17 @@ def conv(name, n, h, w, cin, cout):
     bench(name, mk, 2.0 * n * h * w * cout * cin * 9, n * h * w, 9 * cin)
 
 
+def temp(name, n, h, w, c):
+    pw = pack_weight(torch.randn(c, c, 3) * (3 * c) ** -0.5, torch.randn(c)).to(dev)
+    src = [torch.randn(n * h * w, c, device=dev).to(torch.bfloat16) for _ in range(NB)]
+    a = [torch.empty_like(s) for s in src]
+    g, b = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+
+    def mk(i, tile):
+        return (lambda: hip_ln(src[i], a[i], g, b)), (lambda: ops.conv_temporal(a[i].view(n, h, w, c), 17, pw, res1=src[i], tile=tile))
+    bench(name, mk, 2.0 * n * h * w * c * c * 3, n * h * w, 3 * c)
+
+
 M0, M1, M2 = 34 * 6144, 34 * 1536, 34 * 384
 sel = sys.argv[1:] or ["all"]
 def want(k): return "all" in sel or k in sel
@@ -85,6 +96,10 @@ if want("l1"):
 if want("l2"):
     lin("L2 to_out 1280->1280 +res", M2, 1280, 1280, res=True)
     lin("L2 GEGLU 1280->10240", M2, 1280, 10240, geglu=True)
+if want("temp"):
+    temp("temporal L0 320", 34, 64, 96, 320)
+    temp("temporal L1 640", 34, 32, 48, 640)
+    temp("temporal L2 1280", 34, 16, 24, 1280)
 if want("conv"):
     conv("conv L0 320->320", 34, 64, 96, 320, 320)
     conv("conv L1 640->640", 34, 32, 48, 640, 640)
