@@ -19,6 +19,7 @@ Anything else raises NotImplementedError at construction.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -628,7 +629,7 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
             self.controlnet_img = instantiate_from_config(controlnet_img_config)
 
     def run(self, x_nhwc, timesteps, ctx2d, ctx_len, control: List[torch.Tensor], geo: Geometry,
-            img_control: Optional[List[torch.Tensor]] = None):
+            img_control: Optional[List[torch.Tensor]] = None, control_ready=None):
         """x_nhwc (B*T, h, w, 8) bf16; control = 13 NHWC residuals (consumed); img_control = 13 (B, h, w, C)
         residuals added in place to the centre frame T//2 of every clip (controlmodel.py:529-535)
         -> eps (B*T, h, w, out) fp32."""
@@ -654,6 +655,8 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
                 h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
             hs.append(add_center(h))
         h = add_center(self.middle_block.run(h, emb_silu, geo, ctx2d, ctx_len))
+        if control_ready is not None:      # ControlNet ran on a side stream while the encoder above was running
+            torch.cuda.current_stream().wait_event(control_ready)
         h = ops.add(h, control.pop())
         for block in self.output_blocks:
             h = ops.cat_add(h, hs.pop(), control.pop(), gn=True)          # cat([h, hs.pop() + control.pop()], dim=1)
@@ -714,6 +717,11 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     _hint_key = None
     _hint_val = None
     frame_shard = None          # parallel.FrameShard: split the T keyframes of each clip over the ranks (config 4)
+    # The ControlNet's residuals are first needed after the UNet's middle block: with overlap_controlnet the ControlNet
+    # (16 TFLOP) is launched on a side HIP stream and runs concurrently with the UNet encoder (25 TFLOP) — the two fill
+    # each other's launch tails and the small 16x24 / 8x12-level kernels that cannot occupy 256 CUs alone.
+    overlap_controlnet = os.environ.get("CCEDIT_OVERLAP_CONTROLNET", "1") != "0"
+    _side_stream = None
 
     def _guided_hint(self, hint5d: torch.Tensor):
         net = self.diffusion_model.controlnet
@@ -754,14 +762,31 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         context = c["crossattn"]
         ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
         x8 = ops.ncthw_to_nhwc(x.float().contiguous(), 8)
-        guided = self._guided_hint(hint5)
-        control = net.controlnet.run(x8, guided, t, ctx2d, context.shape[1], geo)
+        control_ready = None
+        if self.overlap_controlnet and sh is None and ops.PROFILE is None:
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                OpenAIWrapperControlLDM3DTV2V._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+            side.wait_stream(main)                      # x8 / ctx2d / t are ready
+            with torch.cuda.stream(side):
+                guided = self._guided_hint(hint5)
+                control = net.controlnet.run(x8, guided, t, ctx2d, context.shape[1], geo)
+                control_ready = torch.cuda.Event()
+                control_ready.record(side)
+            for tns in (x8, ctx2d):
+                tns.record_stream(side)                 # allocated on the main stream, read on the side stream
+            for tns in control:
+                tns.record_stream(main)                 # and vice versa
+        else:
+            guided = self._guided_hint(hint5)
+            control = net.controlnet.run(x8, guided, t, ctx2d, context.shape[1], geo)
         img_control = None
         cond_feat = c.get("cond_feat", None)
         if cond_feat is not None:        # TVI2V (wrappers.py:176-190): controlnet_img on the reference latent
             cf8 = ops.ncthw_to_nhwc(cond_feat.float()[:, :, None].contiguous(), 8)
             img_control = net.controlnet_img.run(None, cf8, t, None, 0, Geometry(b, 1))
-        eps = net.run(x8, t, ctx2d, context.shape[1], control, geo, img_control)
+        eps = net.run(x8, t, ctx2d, context.shape[1], control, geo, img_control, control_ready=control_ready)
         if sh is not None:             # all ranks get the full (B, C, T, h, w) prediction (1.6 MB at 17x64x96)
             eps = sh.gather_frames(eps, b)
         return ops.nhwc_to_ncthw(eps, b, nt, net.out_channels)
