@@ -111,7 +111,7 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
     stats = None
     if (gn_rows > 0 and FUSE_GN_STATS and gn_rows % 128 == 0 and m % gn_rows == 0 and pw.n % 32 == 0 and pw.n >= 256
             and not pw.geglu and out.dtype == BF16 and out.shape[1] == pw.n and out.is_contiguous()):
-        stats = torch.zeros((m // gn_rows, 32, 2), dtype=torch.float32, device=out.device)
+        stats = zero_stats(m // gn_rows, out.device)
         d.gn_rows, d.gn_stats = gn_rows, stats.data_ptr()
         out._gn_stats = (stats, gn_rows)
     if PROFILE is not None:
@@ -185,6 +185,31 @@ def _stats_ws(frames: int, device) -> torch.Tensor:
         ws = torch.empty(max(frames * 64, 4096), dtype=torch.float32, device=device)
         _ws_cache[key] = ws
     return ws
+
+
+class _ZeroArena:
+    """Zero-initialised fp32 scratch for the fused GroupNorm statistics: one memset per ~256 requests instead of one
+    per producer launch (150 per network evaluation).  A slice is handed out once and never recycled — the tensors
+    that carry the statistics keep the slab alive — and arenas are per (device, stream)."""
+    SLAB = 256 * 34 * 64
+
+    def __init__(self):
+        self.slabs = {}
+
+    def take(self, numel: int, device) -> torch.Tensor:
+        key = (device, torch.cuda.current_stream().cuda_stream)
+        slab, used = self.slabs.get(key, (None, 0))
+        if slab is None or used + numel > slab.numel():
+            slab, used = torch.zeros(max(self.SLAB, numel), dtype=torch.float32, device=device), 0
+        self.slabs[key] = (slab, used + numel)
+        return slab[used:used + numel]
+
+
+_ZEROS = _ZeroArena()
+
+
+def zero_stats(frames: int, device) -> torch.Tensor:
+    return _ZEROS.take(frames * 64, device).view(frames, 32, 2)
 
 
 FUSE_GN_STATS = os.environ.get("CCEDIT_FUSE_GN_STATS", "1") != "0"      # 0: always the two-pass GroupNorm
@@ -330,7 +355,7 @@ def cat_add(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor], gn: boo
     out = torch.empty((*a.shape[:-1], c1 + c2), dtype=BF16, device=a.device)
     if gn and FUSE_GN_STATS and a.dim() == 4 and (c1 + c2) % 32 == 0 and c1 + c2 <= 2560:
         n, hw = a.shape[0], a.shape[1] * a.shape[2]
-        stats = torch.zeros((n, 32, 2), dtype=torch.float32, device=a.device)
+        stats = zero_stats(n, a.device)
         hip.check(hip.lib().ccedit_cat_add_gn(a.data_ptr(), b.data_ptr(), _ptr(c), out.data_ptr(), stats.data_ptr(), n, hw,
                                               c1, c2, _stream()), "ccedit_cat_add_gn")
         out._gn_stats = (stats, hw)
