@@ -36,6 +36,10 @@ def add_common_args(p: argparse.ArgumentParser) -> None:
     p.add_argument("--vae_path", type=str, default="")
     p.add_argument("--cond_path", type=str, default="", help="precomputed conditioning tensors (see module docstring)")
     p.add_argument("--synthetic", action="store_true", help="seeded random conditioning + name-keyed synthetic weights")
+    p.add_argument("--video_path", type=str, default="", help="directory of frame images or .gif: source of `keyframes`")
+    p.add_argument("--original_fps", type=int, default=20)
+    p.add_argument("--target_fps", type=int, default=3)
+    p.add_argument("--save_type", type=str, default="npy", choices=["npy", "gif"])
     p.add_argument("--save_path", type=str, default="outputs/demo/tv2v")
     p.add_argument("--H", type=int, default=256)
     p.add_argument("--W", type=int, default=384)
@@ -100,6 +104,13 @@ def conditioning_tensors(args, g: torch.Generator, need_frames: bool, need_ref: 
             cond["keyframes"] = torch.rand(1, 3, T, args.H, args.W, generator=g) * 2 - 1
         if need_ref:
             cond["cond_img"] = torch.rand(1, 3, args.H, args.W, generator=g) * 2 - 1
+    if args.video_path:           # sampling_tv2v.py:314-331: keyframes (T,3,H,W) -> (1,3,T,H,W)
+        from scripts.sampling.util import load_video_keyframes
+        kf = load_video_keyframes(args.video_path, args.original_fps, args.target_fps, T, (args.H, args.W))
+        cond["keyframes"] = kf.permute(1, 0, 2, 3)[None].contiguous()
+    if need_ref and getattr(args, "reference_path", ""):
+        from scripts.sampling.util import load_img
+        cond["cond_img"] = load_img(args.reference_path, (args.H, args.W))
     for k in (["keyframes"] if need_frames else []) + (["cond_img"] if need_ref else []):
         if k not in cond:
             raise SystemExit(f"--cond_path must hold `{k}` for the requested options")
@@ -112,6 +123,15 @@ def text_inputs(cond, dev):
     if "tokens" in cond:
         return cond["tokens"].to(dev), cond["tokens_uc"].to(dev)
     return cond["crossattn"].to(dev), cond["crossattn_uc"].to(dev)
+
+
+def save_result(args, tag, x):
+    """sampling_tv2v.py:473-515: clamp to [0,1]; .npy frames (default) or an animated gif + frame grid."""
+    from scripts.sampling.util import perform_save_locally_video, save_frames
+    if args.save_type == "gif":
+        perform_save_locally_video(os.path.join(args.save_path, "result"), torch.clamp((x + 1.0) / 2.0, 0.0, 1.0),
+                                   fps=args.target_fps, savetype="gif")
+    save_frames(args.save_path, tag, x)
 
 
 def sample_one(args, model, dev, c, uc, randn, keyframes=None, ref=None, prior_type="video"):
@@ -165,7 +185,7 @@ def main():
         t0 = time.time()
         x = sample_one(args, model, dev, c, uc, randn, keyframes=keyframes)
         torch.cuda.synchronize()
-        save_frames(args.save_path, tag, x)
+        save_result(args, tag, x)
         print(f"{tag}: {T} frames {args.H}x{args.W} in {time.time() - t0:.2f}s")
         log.add(tag)
 

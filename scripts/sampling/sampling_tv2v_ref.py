@@ -19,17 +19,18 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from scripts.sampling.sampling_tv2v import add_common_args, build_model, conditioning_tensors, sample_one, text_inputs  # noqa: E402
+from scripts.sampling.sampling_tv2v import add_common_args, build_model, conditioning_tensors, sample_one, save_result, text_inputs  # noqa: E402
 
 
 def main():
     p = argparse.ArgumentParser()
     add_common_args(p)
     p.add_argument("--prior_type", type=str, default="ref", choices=["video", "ref", "video_ref"])
+    p.add_argument("--reference_path", type=str, default="", help="edited centre frame (image file) -> cond_img")
     args = p.parse_args()
     torch.manual_seed(args.seed)
     torch.set_grad_enabled(False)
-    from scripts.sampling.util import ResumeLog, save_frames
+    from scripts.sampling.util import ResumeLog
     model, dev = build_model(args)
     T, h, w = args.num_keyframes, args.H // 8, args.W // 8
     g = torch.Generator().manual_seed(args.seed)
@@ -50,7 +51,7 @@ def main():
         t0 = time.time()
         x = sample_one(args, model, dev, c, uc, randn, keyframes=keyframes, ref=ref, prior_type=args.prior_type)
         torch.cuda.synchronize()
-        save_frames(args.save_path, tag, x)
+        save_result(args, tag, x)
         print(f"{tag}: {T} frames {args.H}x{args.W} in {time.time() - t0:.2f}s")
         log.add(tag)
 

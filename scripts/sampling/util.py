@@ -254,3 +254,103 @@ def load_vae_file(model, vae_path: str) -> None:
     else:
         raise ValueError("Cannot load vae model from {}".format(vae_path))
     print("msg of loading vae: ", model.first_stage_model.load_state_dict(vae_sd, strict=False))
+
+
+# ------------------------------------------------------------------------------------------
+# frame / video I/O: reference scripts/sampling/util.py:288-382, 689-762
+# Image files and GIFs go through Pillow; mp4 needs a codec library (decord / cv2 / imageio-ffmpeg) that is not
+# installed here and raises.
+# ------------------------------------------------------------------------------------------
+def load_img(p_cond_img: str, size: tuple = None) -> torch.Tensor:
+    """util.py:360-382: image file -> (1, 3, H, W) in [-1, 1], optional bicubic resize to size = (H, W)."""
+    from PIL import Image
+    img = Image.open(p_cond_img)
+    if size:
+        assert len(size) == 2, "size should be (H, W)"
+        h, w = size
+        img = img.resize((w, h), Image.BICUBIC)
+    t = torch.from_numpy(np.array(img)).permute(2, 0, 1).unsqueeze(0).float() / 255.0
+    return torch.clamp(t * 2.0 - 1.0, -1.0, 1.0)
+
+
+def keyframe_indices(num_allframes: int, original_fps: int, target_fps: int, num_keyframes: int) -> np.ndarray:
+    """util.py:708-720 / 735-745: every round(original_fps / target_fps)-th frame, the first `num_keyframes` of them;
+    when the video is too short, `num_keyframes` indices spread evenly over it instead."""
+    gap = int(np.round(original_fps / target_fps).astype(int))
+    assert gap > 0, f"gap {gap} should be positive."
+    idx = list(range(0, num_allframes, gap))
+    if len(idx) < num_keyframes:
+        print("[WARNING]: not enough keyframes, use linspace instead. "
+              f"len(keyindexs): [{len(idx)}] < num_keyframes [{num_keyframes}]")
+        return np.linspace(0, num_allframes - 1, num_keyframes).astype(int)
+    return np.asarray(idx[:num_keyframes])
+
+
+def HWC3(x: np.ndarray) -> np.ndarray:
+    """util.py:559-576: uint8 image with 1 / 3 / 4 channels (or none) -> 3 channels (alpha blended on white)."""
+    assert x.dtype == np.uint8
+    if x.ndim == 2:
+        x = x[:, :, None]
+    assert x.ndim == 3
+    c = x.shape[2]
+    assert c in (1, 3, 4)
+    if c == 3:
+        return x
+    if c == 1:
+        return np.concatenate([x, x, x], axis=2)
+    color = x[:, :, 0:3].astype(np.float32)
+    alpha = x[:, :, 3:4].astype(np.float32) / 255.0
+    return (color * alpha + 255.0 * (1.0 - alpha)).clip(0, 255).astype(np.uint8)
+
+
+def load_video_keyframes(video_path: str, original_fps: int, target_fps: int, num_keyframes: int, size: tuple = None) -> torch.Tensor:
+    """util.py:689-762: directory of frame images or a .gif -> keyframes (T, 3, H, W) in [-1, 1]."""
+    if os.path.isdir(video_path):
+        files = sorted(os.listdir(video_path))
+        idx = keyframe_indices(len(files), original_fps, target_fps, num_keyframes)
+        return torch.cat([load_img(os.path.join(video_path, files[i]), size) for i in idx], dim=0)
+    if video_path.endswith(".gif"):
+        from PIL import Image, ImageSequence
+        frames = np.stack([HWC3(np.array(fr.convert("RGBA") if fr.mode == "P" and "transparency" in fr.info else fr.convert("RGB")))
+                           for fr in ImageSequence.Iterator(Image.open(video_path))], axis=0)
+        frames = torch.from_numpy(frames).permute(0, 3, 1, 2).float() / 255.0
+        frames = frames[keyframe_indices(frames.shape[0], original_fps, target_fps, num_keyframes)]
+        frames = torch.clamp(frames * 2.0 - 1.0, -1.0, 1.0)
+        if size:
+            assert len(size) == 2, "size should be (H, W)"
+            frames = torch.nn.functional.interpolate(frames, size=size, mode="bicubic", align_corners=False)
+        return frames
+    if video_path.endswith(".mp4"):
+        raise NotImplementedError("mp4 decoding needs decord / cv2 / imageio-ffmpeg, none of which is installed; "
+                                  "extract the frames to a directory of images (or a .gif) instead")
+    raise ValueError("Unsupported video format. Only support dirctory, .mp4 and .gif.")
+
+
+def perform_save_locally_video(save_path: str, samples: torch.Tensor, fps: int, savetype: str = "gif",
+                               return_savepaths: bool = False, save_grid: bool = True):
+    """util.py:288-352: samples (B, 3, T, H, W) in [0, 1] -> <save_path>/gif/animation-XXXX.gif (+ grid/grid-XXXX.png:
+    the T frames side by side).  savetype='mp4' needs a codec library and raises."""
+    from PIL import Image
+    assert samples.dim() == 5, "Expected samples to have shape (B, C, T, H, W)"
+    assert savetype in ["gif", "mp4"]
+    if savetype == "mp4":
+        raise NotImplementedError("mp4 encoding needs imageio-ffmpeg / cv2, not installed here: use savetype='gif'")
+    os.makedirs(os.path.join(save_path, savetype), exist_ok=True)
+    count = len(os.listdir(os.path.join(save_path, savetype)))
+    if save_grid:
+        os.makedirs(os.path.join(save_path, "grid"), exist_ok=True)
+        count_grid = len(os.listdir(os.path.join(save_path, "grid")))
+    savepaths = []
+    for sample in samples:
+        frames_f = sample.detach().float().cpu().permute(1, 2, 3, 0).numpy()              # (T, H, W, C)
+        if save_grid:
+            # torchvision.utils.save_image(normalize=False, padding=0): x * 255 + 0.5, clamp, uint8
+            grid = np.concatenate(list(np.clip(frames_f * 255.0 + 0.5, 0, 255).astype(np.uint8)), axis=1)
+            Image.fromarray(grid).save(os.path.join(save_path, "grid", f"grid-{count_grid:04}.png"))
+            count_grid += 1
+        frames = [Image.fromarray(f) for f in (255.0 * frames_f).astype(np.uint8)]
+        savepath = os.path.join(save_path, "gif", f"animation-{count:04}.gif")
+        frames[0].save(savepath, save_all=True, append_images=frames[1:], duration=int(round(1000.0 / fps)), loop=0)
+        count += 1
+        savepaths.append(savepath)
+    return savepaths if return_savepaths else None

@@ -113,13 +113,42 @@ class FrozenCLIPEmbedder(AbstractEmbModel):
 
 
 class DepthMidasEncoder(_Precomputed):
-    """encoders/modules.py:1346-1392: MiDaS depth of every keyframe, min-max normalised to [-1,1], 3 channels."""
-    what = "depth hint (B,3,T,H,W) in [-1,1]"
+    """encoders/modules.py:1346-1392: MiDaS depth of every keyframe, min-max normalised to [-1,1], 3 channels.
+    The MiDaS network itself (un-vendored ControlNet-v1-1 annotator) is outside this build; the encoder takes either
+    the finished hint (B,3,T,H,W) or the network's RAW depth (B,1,T,H,W) and applies the reference's normalisation."""
+    what = "depth hint (B,3,T,H,W) in [-1,1], or raw MiDaS depth (B,1,T,H,W)"
     rank = 5
+
+    @staticmethod
+    def normalize(depth: torch.Tensor) -> torch.Tensor:
+        """:1376-1386 — global min / max over the whole batch of frames, sign flipped (near = bright), 3 channels."""
+        d = depth.float().clone()
+        d -= torch.min(d)
+        d /= torch.max(d)
+        d = -(torch.clamp(d, 0, 1) * 2 - 1)
+        return d.repeat(1, 3, 1, 1, 1).to(depth.dtype)
+
+    def forward(self, x):
+        if torch.is_tensor(x) and x.dim() == 5 and x.shape[1] == 1:
+            return self.normalize(x)
+        return super().forward(x)
 
 
 class DepthZoeEncoder(DepthMidasEncoder):
-    """encoders/modules.py:1289-1342 (ZoeDepth, percentile normalisation)."""
+    """encoders/modules.py:1289-1342 (ZoeDepth): per-clip 2nd / 85th percentile normalisation via kthvalue."""
+    what = "depth hint (B,3,T,H,W) in [-1,1], or raw ZoeDepth output (B,1,T,H,W)"
+
+    @staticmethod
+    def normalize(depth: torch.Tensor) -> torch.Tensor:
+        """:1324-1336 — vmin / vmax = kthvalue at int(0.02 n) / int(0.85 n) over each clip's C*T*H*W values."""
+        d = depth.float().clone()
+        flat = d.view(d.shape[0], -1)
+        vmin = torch.kthvalue(flat, int(0.02 * d[0].numel()), dim=1).values
+        vmax = torch.kthvalue(flat, int(0.85 * d[0].numel()), dim=1).values
+        d -= vmin[:, None, None, None, None]
+        d /= (vmax - vmin)[:, None, None, None, None]
+        d = torch.clamp(d, 0, 1) * 2 - 1
+        return d.repeat(1, 3, 1, 1, 1).to(depth.dtype)
 
 
 class VAEEmbedder(AbstractEmbModel):

@@ -55,6 +55,16 @@ def test_sampling_tv2v_entry_point(tmp_path):
     with_lora, _ = _run("sampling_tv2v.py", cfg, str(tmp_path / "lora"), "--lora_path", str(tmp_path / "toy_lora.safetensors"),
                         "--lora_strength", "0.5")
     assert not np.allclose(plain, with_lora)
+    # --video_path (directory of frames -> keyframes for the noise prior) and --save_type gif
+    from PIL import Image
+    vdir = tmp_path / "frames"
+    vdir.mkdir()
+    rs = np.random.RandomState(0)
+    for i in range(12):
+        Image.fromarray(rs.randint(0, 256, (48, 64, 3)).astype(np.uint8)).save(str(vdir / f"f{i:03d}.png"))
+    _run("sampling_tv2v.py", cfg, str(tmp_path / "video"), "--prior_coefficient_x", "0.3", "--video_path", str(vdir),
+         "--original_fps", "12", "--target_fps", "4", "--save_type", "gif")
+    assert os.path.exists(str(tmp_path / "video" / "result" / "gif" / "animation-0000.gif"))
 
 
 @pytest.mark.timeout(900)
