@@ -705,6 +705,12 @@ class IdentityWrapper(nn.Module):
         return self.diffusion_model(*args, **kwargs)
 
 
+# The two CFG halves (uncond / cond clip of the doubled batch) are independent: evaluated as two B = 1 passes on two
+# HIP streams (each with its own ControlNet side stream) they fill each other's launch tails for the whole step, not
+# only during the encoder: another -1.5...2.5 % per step.  CCEDIT_SPLIT_CFG=0 keeps the single batched pass.
+_SPLIT_CFG = os.environ.get("CCEDIT_SPLIT_CFG", "1") == "1"
+
+
 class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     """wrappers.py:155-207: hint remap -> ControlNet -> UNet.  Stays in the channels-last layout between
     the two networks; only x (4 ch) and the eps output (4 ch) cross the (B, C, T, H, W) boundary."""
@@ -722,20 +728,36 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     # each other's launch tails and the small 16x24 / 8x12-level kernels that cannot occupy 256 CUs alone.
     overlap_controlnet = os.environ.get("CCEDIT_OVERLAP_CONTROLNET", "1") != "0"
     _side_stream = None
+    _half_stream = None
 
     def _guided_hint(self, hint5d: torch.Tensor):
         net = self.diffusion_model.controlnet
         key = (hint5d.data_ptr(), tuple(hint5d.shape), hint5d._version, hint5d.dtype)
-        if self.cache_hint_stem and key == self._hint_key and self._hint_val is not None:
-            return self._hint_val
+        if self.cache_hint_stem and isinstance(self._hint_val, dict) and key in self._hint_val:
+            return self._hint_val[key]
         # control_hint in [-1,1] -> 1 - (h+1)/2 (wrappers.py:160-162), fused into the layout change
         hint8 = ops.ncthw_to_nhwc(hint5d.float().contiguous(), 8, scale=-0.5, shift=0.5)
         g = net.hint_stem(hint8)
         if self.cache_hint_stem:
-            self._hint_key, self._hint_val = key, g
+            if not isinstance(self._hint_val, dict) or len(self._hint_val) >= 4:     # one entry per CFG half (+ shards)
+                self._hint_val = {}
+            self._hint_val[key] = g
         return g
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, c: Dict[str, torch.Tensor], **kwargs) -> torch.Tensor:
+        if _SPLIT_CFG and x.shape[0] == 2 and self.frame_shard is None and ops.PROFILE is None and not kwargs.get("_half"):
+            main = torch.cuda.current_stream()
+            if OpenAIWrapperControlLDM3DTV2V._half_stream is None:
+                OpenAIWrapperControlLDM3DTV2V._half_stream = torch.cuda.Stream()
+            hs = OpenAIWrapperControlLDM3DTV2V._half_stream
+            hs.wait_stream(main)
+            halves = [{k: (v[i:i + 1].contiguous() if torch.is_tensor(v) else v) for k, v in c.items()} for i in range(2)]
+            with torch.cuda.stream(hs):
+                e1 = self.forward(x[1:2].contiguous(), t[1:2].contiguous(), halves[1], _half=True)
+            e0 = self.forward(x[0:1].contiguous(), t[0:1].contiguous(), halves[0], _half=True)
+            main.wait_stream(hs)
+            e1.record_stream(main)
+            return torch.cat([e0, e1])
         if c.get("concat") is not None and c["concat"].numel():
             raise NotImplementedError("'concat' conditioning is not used by the TV2V configs")
         net = self.diffusion_model
@@ -765,9 +787,11 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         control_ready = None
         if self.overlap_controlnet and sh is None and ops.PROFILE is None:
             main = torch.cuda.current_stream()
-            if self._side_stream is None:
-                OpenAIWrapperControlLDM3DTV2V._side_stream = torch.cuda.Stream()
-            side = self._side_stream
+            if OpenAIWrapperControlLDM3DTV2V._side_stream is None:
+                OpenAIWrapperControlLDM3DTV2V._side_stream = {}
+            side = OpenAIWrapperControlLDM3DTV2V._side_stream.setdefault(main.cuda_stream, None)
+            if side is None:
+                side = OpenAIWrapperControlLDM3DTV2V._side_stream[main.cuda_stream] = torch.cuda.Stream()
             side.wait_stream(main)                      # x8 / ctx2d / t are ready
             with torch.cuda.stream(side):
                 guided = self._guided_hint(hint5)
