@@ -94,6 +94,19 @@ class LegacyDDPMDiscretization(Discretization):
 # ------------------------------------------------------------------------------------------
 # denoiser
 # ------------------------------------------------------------------------------------------
+class EDMDiscretization(Discretization):
+    """discretizer.py:28-39 (Karras rho schedule)."""
+
+    def __init__(self, sigma_min=0.02, sigma_max=80.0, rho=7.0):
+        self.sigma_min, self.sigma_max, self.rho = sigma_min, sigma_max, rho
+
+    def get_sigmas(self, n, device="cpu"):
+        ramp = torch.linspace(0, 1, n, device="cpu")                      # host math
+        min_inv_rho = self.sigma_min ** (1 / self.rho)
+        max_inv_rho = self.sigma_max ** (1 / self.rho)
+        return ((max_inv_rho + ramp * (min_inv_rho - max_inv_rho)) ** self.rho).to(device)
+
+
 class Img2ImgDiscretizationWrapper:
     """scripts/demo/streamlit_helpers.py:212-233 (SDEdit): wraps a discretizer and keeps only the
     max(int(strength * len), 1) smallest sigmas (the tail of the descending schedule, trailing zero included)."""
@@ -384,3 +397,132 @@ class DPMPP2SAncestralSampler(AncestralSampler):
             # sigma_down > 0 here, so the reference's torch.where picks x_dpmpp2s
             x = ops.axpby(x, denoised2, m3, -m4)
         return self.ancestral_step(x, sigma, next_sigma, sigma_up)
+
+
+class EDMSampler(SingleStepDiffusionSampler):
+    """sampling.py:86-133: Euler step on the probability-flow ODE with optional churn (gamma)."""
+
+    def __init__(self, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.s_churn, self.s_tmin, self.s_tmax, self.s_noise = s_churn, s_tmin, s_tmax, s_noise
+        self.noise_sampler = lambda x: torch.randn_like(x)
+
+    def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc=None, gamma=0.0):
+        sigma_hat = sigma * (gamma + 1.0)
+        if gamma > 0:
+            eps = self.noise_sampler(x).float().contiguous()
+            x = ops.axpby(x, eps, 1.0, self.s_noise * float(((sigma_hat ** 2 - sigma ** 2) ** 0.5)[0]))
+        denoised = self.denoise(x, denoiser, sigma_hat, cond, uc)
+        dt = next_sigma - sigma_hat
+        r = float((dt / sigma_hat)[0])
+        euler_step = ops.axpby(x, denoised, 1.0 + r, -r)              # x + dt * (x - denoised) / sigma_hat
+        return self.possible_correction_step(euler_step, x, denoised, sigma_hat, dt, next_sigma, denoiser, cond, uc)
+
+    def possible_correction_step(self, euler_step, x, denoised, sigma_hat, dt, next_sigma, denoiser, cond, uc):
+        raise NotImplementedError
+
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None):
+        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        for i in self.get_sigma_gen(num_sigmas):
+            gamma = min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if self.s_tmin <= sigmas[i] <= self.s_tmax else 0.0
+            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, gamma)
+        return x
+
+
+class EulerEDMSampler(EDMSampler):
+    """sampling.py:307-311 — the reference script's default `--sampler_name`."""
+
+    def possible_correction_step(self, euler_step, x, denoised, sigma_hat, dt, next_sigma, denoiser, cond, uc):
+        return euler_step
+
+
+class HeunEDMSampler(EDMSampler):
+    """sampling.py:314-329: second evaluation at next_sigma, trapezoidal slope; plain Euler on the final step."""
+
+    def possible_correction_step(self, euler_step, x, denoised, sigma_hat, dt, next_sigma, denoiser, cond, uc):
+        if torch.sum(next_sigma) < 1e-14:
+            return euler_step
+        denoised2 = self.denoise(euler_step, denoiser, next_sigma, cond, uc)
+        a = float((dt / (2.0 * sigma_hat))[0])                         # x + dt * (d + d_new) / 2
+        b = float((dt / (2.0 * next_sigma))[0])
+        t1 = ops.axpby(x, denoised, 1.0 + a, -a)
+        t2 = ops.axpby(euler_step, denoised2, b, -b)
+        return ops.axpby(t1, t2, 1.0, 1.0)
+
+
+class DPMPP2MSampler(BaseDiffusionSampler):
+    """sampling.py:408-485: multistep DPM-Solver++(2M); one evaluation per step."""
+
+    def get_variables(self, sigma, next_sigma, previous_sigma=None):
+        t, t_next = [to_neg_log_sigma(s) for s in (sigma, next_sigma)]
+        h = t_next - t
+        if previous_sigma is not None:
+            h_last = t - to_neg_log_sigma(previous_sigma)
+            return h, h_last / h, t, t_next
+        return h, None, t, t_next
+
+    def get_mult(self, h, r, t, t_next, previous_sigma):
+        mult1 = to_sigma(t_next) / to_sigma(t)
+        mult2 = (-h).expm1()
+        if previous_sigma is not None:
+            return mult1, mult2, 1 + 1 / (2 * r), 1 / (2 * r)
+        return mult1, mult2
+
+    def sampler_step(self, old_denoised, previous_sigma, sigma, next_sigma, denoiser, x, cond, uc=None):
+        denoised = self.denoise(x, denoiser, sigma, cond, uc)
+        h, r, t, t_next = self.get_variables(sigma, next_sigma, previous_sigma)
+        mult = [float(m[0]) for m in self.get_mult(h, r, t, t_next, previous_sigma)]
+        if old_denoised is None or torch.sum(next_sigma) < 1e-14:
+            return ops.axpby(x, denoised, mult[0], -mult[1]), denoised
+        denoised_d = ops.axpby(denoised, old_denoised, mult[2], -mult[3])
+        return ops.axpby(x, denoised_d, mult[0], -mult[1]), denoised        # next_sigma > 0 here: the advanced branch
+
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, **kwargs):
+        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        old_denoised = None
+        for i in self.get_sigma_gen(num_sigmas):
+            x, old_denoised = self.sampler_step(old_denoised, None if i == 0 else s_in * sigmas[i - 1], s_in * sigmas[i],
+                                                s_in * sigmas[i + 1], denoiser, x, cond, uc=uc)
+        return x
+
+
+def linear_multistep_coeff(order, t, i, j, epsrel=1e-4):
+    """sampling_utils.py:12-24 (Adams-Bashforth weights by quadrature of the Lagrange basis)."""
+    from scipy import integrate
+    if order - 1 > i:
+        raise ValueError(f"Order {order} too high for step {i}")
+
+    def fn(tau):
+        prod = 1.0
+        for k in range(order):
+            if j == k:
+                continue
+            prod *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return prod
+
+    return integrate.quad(fn, t[i], t[i + 1], epsrel=epsrel)[0]
+
+
+class LinearMultistepSampler(BaseDiffusionSampler):
+    """sampling.py:268-304 (LMS, order 4 by default)."""
+
+    def __init__(self, order=4, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.order = order
+
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, **kwargs):
+        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        ds = []
+        sigmas_cpu = sigmas.detach().cpu().numpy()
+        for i in self.get_sigma_gen(num_sigmas):
+            sigma = s_in * sigmas[i]
+            denoised = self.denoise(x, denoiser, sigma, cond, uc)
+            inv = 1.0 / float(sigma[0])
+            ds.append(ops.axpby(x, denoised, inv, -inv))                # to_d: (x - denoised) / sigma
+            if len(ds) > self.order:
+                ds.pop(0)
+            cur_order = min(i + 1, self.order)
+            coeffs = [linear_multistep_coeff(cur_order, sigmas_cpu, i, j) for j in range(cur_order)]
+            for coeff, d in zip(coeffs, reversed(ds)):
+                x = ops.axpby(x, d, 1.0, float(coeff))
+        return x

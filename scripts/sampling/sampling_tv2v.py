@@ -48,7 +48,7 @@ def add_common_args(p: argparse.ArgumentParser) -> None:
     p.add_argument("--negative_prompt", type=str, default="ugly, low quality")
     p.add_argument("--add_prompt", type=str, default="masterpiece, high quality")
     p.add_argument("--sample_steps", type=int, default=50)
-    p.add_argument("--sampler_name", type=str, default="DPMPP2SAncestralSampler")
+    p.add_argument("--sampler_name", type=str, default="EulerEDMSampler")       # the reference script's default
     p.add_argument("--discretization_name", type=str, default="LegacyDDPMDiscretization")
     p.add_argument("--cfg_scale", type=float, default=7.5)
     p.add_argument("--prior_coefficient_x", type=float, default=0.0)

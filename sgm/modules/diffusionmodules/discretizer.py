@@ -1,2 +1,2 @@
-from ccedit_amd.sampling import (Discretization, LegacyDDPMDiscretization,  # noqa: F401
+from ccedit_amd.sampling import (Discretization, EDMDiscretization, LegacyDDPMDiscretization,  # noqa: F401
                                  generate_roughly_equally_spaced_steps)

@@ -1,1 +1,2 @@
-from ccedit_amd.sampling import NoDynamicThresholding, get_ancestral_step, to_neg_log_sigma, to_sigma  # noqa: F401
+from ccedit_amd.sampling import (NoDynamicThresholding, get_ancestral_step, linear_multistep_coeff,  # noqa: F401
+                                 to_neg_log_sigma, to_sigma)

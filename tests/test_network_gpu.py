@@ -315,3 +315,28 @@ def test_clip_text_encoder_vs_transformers_golden(golden_dir):
         emb(["a photo of a cat"])
     with pytest.raises(ValueError):
         emb(torch.full((1, 77), 60000, dtype=torch.int64).cuda())
+
+
+def test_other_samplers_vs_reference_golden(golden_dir):
+    """The samplers selectable with --sampler_name besides DPMPP2SAncestral (scripts/sampling/util.py:483-556) and the
+    EDM discretization, on the analytic toy denoiser the goldens were recorded with (tests/golden/make_golden.py)."""
+    _need_gpu()
+    from scripts.sampling.util import get_discretization, get_guider, get_sampler
+    z = np.load(os.path.join(golden_dir, "samplers_toy.npz"))
+    c = {"crossattn": torch.from_numpy(z["cross_c"]).cuda()}
+    uc = {"crossattn": torch.from_numpy(z["cross_uc"]).cuda()}
+
+    def toy_denoiser(x, sigma, cond):
+        s = sigma.to(x.device).reshape(-1, *([1] * (x.dim() - 1)))
+        return x / (1.0 + s * s) + 0.1 * torch.tanh(cond["crossattn"].mean()) * s / (1.0 + s)
+
+    from ccedit_amd.sampling import EDMDiscretization
+    assert np.allclose(EDMDiscretization(0.03, 14.61, 3.0)(7).numpy(), z["edm_sigmas_7"], rtol=1e-6)
+    guider = get_guider("sgm.modules.diffusionmodules.guiders.VanillaCFG", scale=3.0)
+    for name in ("EulerEDMSampler", "HeunEDMSampler", "DPMPP2MSampler", "LinearMultistepSampler"):
+        for dname, disc in (("legacy", "LegacyDDPMDiscretization"), ("edm", "EDMDiscretization")):
+            smp = get_sampler(name, 7, get_discretization(disc), guider)
+            smp.verbose = False
+            out = smp(toy_denoiser, torch.from_numpy(z["x0"]).cuda(), c, uc=uc)
+            r = _rel(out, torch.from_numpy(z[f"{name}_{dname}"]))
+            assert r < 1e-4, (name, dname, r)
