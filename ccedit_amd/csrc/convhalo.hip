@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int TW = 1 << tw_log2, TH = BNP >> tw_log2, HW_ = TW + 2;
-    const int tiles_x = d.Wout >> tw_log2, tiles_y = d.Hout / TH;
+    const int tiles_x = (d.Wout + TW - 1) >> tw_log2, tiles_y = d.Hout / TH;      // the last column of rectangles may be ragged
     const int tpf = tiles_x * tiles_y;
 
     // XCD-aware block order, same scheme as tap_gemm_kernel (pixel tiles contiguous per XCD, channel tiles in groups)
@@ -182,7 +182,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc
     const int64_t row_base = ((int64_t)frame * d.Hout + y0) * d.Wout + x0;
     gemm_epilogue<WM, WN, TI, TJ, LDS_MAIN>(
         d, acc, smem, ch0,
-        [&](int px) -> int64_t { return row_base + (int64_t)(px >> tw_log2) * d.Wout + (px & (TW - 1)); }, (int64_t)frame);
+        [&](int px) -> int64_t {
+            const int tx = px & (TW - 1);
+            return x0 + tx < d.Wout ? row_base + (int64_t)(px >> tw_log2) * d.Wout + tx : -1;
+        },
+        (int64_t)frame);
 }
 
 }  // namespace
@@ -194,7 +198,8 @@ bool cc_conv_halo_applicable(const CcGemmDesc& d) {
         return false;
     if (d.M % ((int64_t)d.Hout * d.Wout) != 0) return false;
     if (d.gn_stats && d.gn_rows != d.Hout * d.Wout) return false;
-    return (d.Wout % 16 == 0 && d.Hout % 8 == 0) || (d.Wout % 8 == 0 && d.Hout % 16 == 0);
+    // whole rectangles vertically; a ragged last column (8x12 frames: 12 of 16 columns used) is masked
+    return d.Hout % 8 == 0 || (d.Wout % 8 == 0 && d.Hout % 16 == 0);
 }
 
 int cc_conv_halo_launch(const CcGemmDesc& d, hipStream_t s) {
@@ -210,9 +215,13 @@ int cc_conv_halo_launch(const CcGemmDesc& d, hipStream_t s) {
         }
         attr_set = true;
     }
-    const int tw_log2 = (d.Wout % 16 == 0 && d.Hout % 8 == 0) ? 4 : 3;
+    // orientation with the least padding: 8 x 16 needs Hout % 8 == 0, 16 x 8 needs Hout % 16 == 0
+    const int pad16 = (d.Hout % 8 == 0) ? (d.Wout + 15) / 16 * 16 : 1 << 30;
+    const int pad8 = (d.Hout % 16 == 0) ? (d.Wout + 7) / 8 * 8 : 1 << 30;
+    const int tw_log2 = pad16 <= pad8 ? 4 : 3;
+    const int TWh = 1 << tw_log2, THh = BNP >> tw_log2;
     const int64_t frames = d.M / ((int64_t)d.Hout * d.Wout);
-    const int64_t pt_n = frames * ((int64_t)d.Hout * d.Wout / BNP), ct_n = (d.N + BMC - 1) / BMC;
+    const int64_t pt_n = frames * ((d.Wout + TWh - 1) / TWh) * (d.Hout / THh), ct_n = (d.N + BMC - 1) / BMC;
     const int64_t nblk = 8 * ((pt_n + 7) / 8) * ct_n;
     if (nblk > 2147483647LL) {
         cc_set_error("ccedit_gemm: grid too large");

@@ -151,7 +151,8 @@ def test_conv3x3_few_channels_many_pixels(cin, cout, stride, act):
     _close(y.float(), y2.float(), rel=2.0 ** -7, what="small conv vs tiled")
 
 
-@pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 16, 32), (128, 320, 16, 24), (320, 320, 32, 48), (192, 64, 8, 16), (640, 1280, 16, 24)])
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 16, 32), (128, 320, 16, 24), (320, 320, 32, 48), (192, 64, 8, 16), (640, 1280, 16, 24),
+                                          (128, 256, 8, 12), (64, 320, 16, 20), (1280, 1280, 8, 12)])   # ragged last column
 @pytest.mark.parametrize("tile", [0, 8])
 def test_conv3x3_lds_halo(cin, cout, h, w, tile):
     """convhalo.hip: the input rectangle (+halo) is staged once per 64-channel chunk and the nine taps are read from
