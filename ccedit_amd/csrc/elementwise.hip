@@ -194,6 +194,13 @@ __global__ void gaussian_sample_kernel(const float* __restrict__ mom, const floa
     }
 }
 
+// y = x * m + z * (1 - m): the known-region re-injection of sample_inpainting (sampling.py:150-153, 213-216)
+__global__ void mask_blend_kernel(const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ m,
+                                  float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = x[i] * m[i] + z[i] * (1.0f - m[i]);
+}
+
 __global__ void cfg_denoise_kernel(const float* __restrict__ x, const float* __restrict__ eps2, float* __restrict__ den,
                                    int64_t n, float sigma, float scale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -339,6 +346,12 @@ extern "C" int ccedit_gaussian_sample(const float* moments, const float* noise, 
     hipLaunchKernelGGL(gaussian_sample_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, moments, noise,
                        out, total, zc, hw, ldm, scale);
     return cc_launch_status("gaussian_sample");
+}
+
+extern "C" int ccedit_mask_blend(const float* x, const float* z, const float* mask, float* y, int64_t n, void* stream) {
+    CC_CHECK_ARG(x && z && mask && y && n > 0, "ccedit_mask_blend: bad args");
+    hipLaunchKernelGGL(mask_blend_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, z, mask, y, n);
+    return cc_launch_status("mask_blend");
 }
 
 extern "C" int ccedit_cfg_denoise(const float* x, const float* eps2, float* den, int64_t n, float sigma, float scale,

@@ -411,6 +411,16 @@ def gaussian_sample(moments: torch.Tensor, noise: torch.Tensor, zc: int, scale: 
     return out
 
 
+def mask_blend(x: torch.Tensor, z: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """x * mask + z * (1 - mask), fp32 tensors of one shape."""
+    for tns in (x, z, mask):
+        assert tns.dtype == torch.float32 and tns.is_cuda and tns.is_contiguous() and tns.shape == x.shape
+    y = torch.empty_like(x)
+    hip.check(hip.lib().ccedit_mask_blend(x.data_ptr(), z.data_ptr(), mask.data_ptr(), y.data_ptr(), x.numel(), _stream()),
+              "ccedit_mask_blend")
+    return y
+
+
 def cfg_denoise(x: torch.Tensor, eps2: torch.Tensor, sigma: float, scale: float) -> torch.Tensor:
     """x: fp32 latent (n elems); eps2: fp32 [2, n] (uncond first). -> denoised (guided) fp32."""
     assert x.dtype == torch.float32 and eps2.dtype == torch.float32 and x.is_contiguous() and eps2.is_contiguous()

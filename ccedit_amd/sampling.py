@@ -330,6 +330,16 @@ class SingleStepDiffusionSampler(BaseDiffusionSampler):
     def euler_step(self, x, d, dt):
         return x + dt * d
 
+    def _noised_original(self, x0, sigma_i):
+        """(x0 + randn * sigma_i) / sqrt(1 + sigma_i^2): the known content at the current noise level
+        (sampling.py:150-152, 213-215, 236-238)."""
+        noise = self.noise_sampler(x0).float().contiguous()
+        inv = 1.0 / float(torch.sqrt(1.0 + sigma_i ** 2))
+        return ops.axpby(x0.float().contiguous(), noise, inv, float(sigma_i) * inv)
+
+    def _inpaint_blend(self, x, x0, mask, sigma_i):
+        return ops.mask_blend(x, self._noised_original(x0, sigma_i), mask.float().expand_as(x).contiguous())
+
 
 class AncestralSampler(SingleStepDiffusionSampler):
     """sampling.py:168-205"""
@@ -354,6 +364,33 @@ class AncestralSampler(SingleStepDiffusionSampler):
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None):
         x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
         for i in self.get_sigma_gen(num_sigmas):
+            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc)
+        return x
+
+    def sample_inpainting(self, denoiser, x, cond, x0, mask, uc=None, num_steps=None):
+        """sampling.py:206-225: before every step the region with mask == 0 is reset to the noised original."""
+        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        for i in self.get_sigma_gen(num_sigmas):
+            x = self._inpaint_blend(x, x0, mask, sigmas[i])
+            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc)
+        return x
+
+    def sampling_blending(self, denoiser, x, cond, x0, uc=None, num_steps=None):
+        """sampling.py:227-249: the first T//2 frames are overwritten with the noised LAST T//2 frames of x0."""
+        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        t = x.shape[2]
+        for i in self.get_sigma_gen(num_sigmas):
+            img_orig = self._noised_original(x0, sigmas[i])
+            x[:, :, : t // 2] = img_orig[:, :, t // 2 + 1:]
+            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc)
+        return x
+
+    def sdedit(self, denoise_steps, denoiser, x, cond, uc=None, num_steps=None):
+        """sampling.py:251-266: run only the last `denoise_steps` steps of the schedule."""
+        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        for i in self.get_sigma_gen(num_sigmas):
+            if i < num_sigmas - 1 - denoise_steps:
+                continue
             x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc)
         return x
 
@@ -425,6 +462,15 @@ class EDMSampler(SingleStepDiffusionSampler):
         x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
         for i in self.get_sigma_gen(num_sigmas):
             gamma = min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if self.s_tmin <= sigmas[i] <= self.s_tmax else 0.0
+            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, gamma)
+        return x
+
+    def sample_inpainting(self, denoiser, x, cond, x0, mask, uc=None, num_steps=None):
+        """sampling.py:138-166."""
+        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        for i in self.get_sigma_gen(num_sigmas):
+            gamma = min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if self.s_tmin <= sigmas[i] <= self.s_tmax else 0.0
+            x = self._inpaint_blend(x, x0, mask, sigmas[i])
             x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, gamma)
         return x
 

@@ -220,7 +220,9 @@ int ccedit_gaussian_sample(const float* moments, const float* noise, float* out,
  *   ccedit_cfg_denoise : den = x + (-sigma) * (eps_u + scale*(eps_c - eps_u))        [denoiser.py:40 with
  *                        c_skip=1, c_out=-sigma; guiders.py:25-29]   eps = fp32 [2][n]
  *   ccedit_axpby       : y = a*x + b*z                                                [sampling.py:388, 398-402]
+ *   ccedit_mask_blend  : y = x*m + z*(1-m), all fp32 [n]                              [sampling.py:150-153, 213-216]
  */
+int ccedit_mask_blend(const float* x, const float* z, const float* mask, float* y, int64_t n, void* stream);
 int ccedit_cfg_denoise(const float* x, const float* eps2, float* den, int64_t n, float sigma, float scale,
                        void* stream);
 int ccedit_axpby(const float* x, const float* z, float* y, int64_t n, float a, float b, void* stream);

@@ -54,6 +54,7 @@ def add_common_args(p: argparse.ArgumentParser) -> None:
     p.add_argument("--prior_coefficient_x", type=float, default=0.0)
     p.add_argument("--prior_coefficient_noise", type=float, default=1.0)
     p.add_argument("--sdedit_denoise_strength", type=float, default=0.0)
+    p.add_argument("--inpainting_mode", action="store_true", help="inpainting mode")
     p.add_argument("--num_samples", type=int, default=1)
     p.add_argument("--disable_check_repeat", action="store_true")
 
@@ -141,6 +142,10 @@ def sample_one(args, model, dev, c, uc, randn, keyframes=None, ref=None, prior_t
     def denoiser(inp, sigma, cc):
         return model.denoiser(model.model, inp, sigma, cc)
 
+    if getattr(args, "inpainting_mode", False):
+        # the reference script raises here too (sampling_tv2v.py:385-386, 444-445: the mask is not a user input yet);
+        # the loop itself is available as sampler.sample_inpainting(denoiser, x, c, x0=z, mask=mask, uc=uc)
+        raise NotImplementedError
     if args.sdedit_denoise_strength == 0.0:
         if args.prior_coefficient_x != 0.0:
             randn = prior_latent(model, randn, args.prior_coefficient_x, args.prior_coefficient_noise, keyframes, ref, prior_type)

@@ -340,3 +340,38 @@ def test_other_samplers_vs_reference_golden(golden_dir):
             out = smp(toy_denoiser, torch.from_numpy(z["x0"]).cuda(), c, uc=uc)
             r = _rel(out, torch.from_numpy(z[f"{name}_{dname}"]))
             assert r < 1e-4, (name, dname, r)
+
+
+@pytest.mark.gpu
+def test_inpainting_blending_sdedit_loops_match_reference(golden_dir):
+    """sample_inpainting (EDM + ancestral samplers), sampling_blending and sdedit (sampling.py:138-166, 206-292),
+    replaying the noise sequence the reference consumed when the golden was recorded."""
+    _need_gpu()
+    from scripts.sampling.util import get_discretization, get_guider, get_sampler
+    z = np.load(os.path.join(golden_dir, "samplers_toy.npz"))
+    c = {"crossattn": torch.from_numpy(z["cross_c"]).cuda()}
+    uc = {"crossattn": torch.from_numpy(z["cross_uc"]).cuda()}
+
+    def toy_denoiser(x, sigma, cond):
+        s = sigma.to(x.device).reshape(-1, *([1] * (x.dim() - 1)))
+        return x / (1.0 + s * s) + 0.1 * torch.tanh(cond["crossattn"].mean()) * s / (1.0 + s)
+
+    guider = get_guider("sgm.modules.diffusionmodules.guiders.VanillaCFG", scale=3.0)
+    x, x0, mask = (torch.from_numpy(z[k]).cuda() for k in ("inp_x", "inp_x0", "inp_mask"))
+    noise = torch.from_numpy(z["inp_noise"]).cuda()
+
+    def run(name, method, *a):
+        smp = get_sampler(name, 7, get_discretization("LegacyDDPMDiscretization"), guider)
+        smp.verbose = False
+        it = iter(noise)
+        smp.noise_sampler = lambda t: next(it)
+        return getattr(smp, method)(*a)
+
+    cases = [("inpaint_EulerEDMSampler", "EulerEDMSampler", "sample_inpainting", (toy_denoiser, x.clone(), c, x0, mask, uc)),
+             ("inpaint_EulerAncestralSampler", "EulerAncestralSampler", "sample_inpainting", (toy_denoiser, x.clone(), c, x0, mask, uc)),
+             ("inpaint_DPMPP2SAncestralSampler", "DPMPP2SAncestralSampler", "sample_inpainting", (toy_denoiser, x.clone(), c, x0, mask, uc)),
+             ("blend_DPMPP2SAncestralSampler", "DPMPP2SAncestralSampler", "sampling_blending", (toy_denoiser, x.clone(), c, x0, uc)),
+             ("sdedit3_DPMPP2SAncestralSampler", "DPMPP2SAncestralSampler", "sdedit", (3, toy_denoiser, x.clone(), c, uc))]
+    for key, name, method, a in cases:
+        r = _rel(run(name, method, *a), torch.from_numpy(z[key]))
+        assert r < 1e-4, (key, r)
