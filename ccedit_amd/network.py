@@ -167,7 +167,7 @@ class BasicTransformerSingleLayerBlock(nn.Module):
         self.ff = FeedForward(dim)
         self.norm1, self.norm2 = Norm(dim, 1e-5), Norm(dim, 1e-5)
 
-    def run_frames(self, tok, frames: int, hw: int, anchor_t: Optional[int] = None, frames_per_clip: int = 1):
+    def run_frames(self, tok, frames: int, hw: int, anchor_t: Optional[int] = None, frames_per_clip: int = 1, shard=None):
         """Per-frame attention with K/V from the un-normalised tokens.  anchor_t is None: plain self-attention
         (controlnet_img's SpatialTransformer, disable_text_ca).  Otherwise the keys are
         [tokens of frame anchor_t of the same clip ; own tokens] — SpatialTransformer3DCA 'center_self'."""
@@ -178,6 +178,21 @@ class BasicTransformerSingleLayerBlock(nn.Module):
         kv = ops.linear(tok, a.kv)
         if anchor_t is None:
             o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=frames, lq=hw, lk=hw)
+        elif shard is not None:
+            # keyframes sharded over ranks: `anchor_t` is a GLOBAL frame index; its K/V rows are broadcast by the owning
+            # rank and appended as one extra kv frame per clip (frames [frames, frames + B)), which the kernel's leading
+            # segment then addresses: clip b = frame // t_local -> kv frame frames + b
+            nb = frames // frames_per_clip
+            owner = shard.owner_of(anchor_t)
+            kv3 = kv.view(nb, frames_per_clip, hw, 2 * c)
+            if shard.rank == owner:
+                anchor = kv3[:, anchor_t - shard.t0].contiguous()
+            else:
+                anchor = torch.empty((nb, hw, 2 * c), dtype=kv.dtype, device=kv.device)
+            shard.broadcast(anchor, owner)
+            kvx = torch.cat([kv.view(frames, hw, 2 * c), anchor]).view(-1, 2 * c)
+            o = ops.attention(q, kvx[:, :c], kvx[:, c:], a.heads, a.dim_head, batches=frames, lq=hw, lk=2 * hw,
+                              kv_outer_rows=hw, seg1_len=hw, seg1_div=frames_per_clip, seg1_mul=1, seg1_add=frames)
         else:
             o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=frames, lq=hw, lk=2 * hw,
                               kv_outer_rows=hw, seg1_len=hw, seg1_div=frames_per_clip, seg1_mul=frames_per_clip,
@@ -278,14 +293,14 @@ class SpatialTransformer3DCA(SpatialTransformer3D):
         self.proj_out_temporal_ca = Conv(inner, in_channels, 1)
 
     def run(self, x, geo, ctx2d, ctx_len):
-        if geo.shard is not None:
-            raise NotImplementedError("frame sharding of the TVI2V anchor attention (broadcast of the centre frame)")
         y = super().run(x, geo, ctx2d, ctx_len)
         n, h, w, c = y.shape
         nc = self.norm_temporal_ca
         a = ops.groupnorm_spatial(y, nc.g, nc.b, nc.eps, False)
         tok = ops.linear(a.view(-1, c), self.proj_in_temporal_ca.pw)
-        tok = self.transformer_blocks_temporal_ca[0].run_frames(tok, n, h * w, anchor_t=geo.t // 2, frames_per_clip=geo.t)
+        t_glob = geo.t if geo.shard is None else geo.shard.t_glob
+        tok = self.transformer_blocks_temporal_ca[0].run_frames(tok, n, h * w, anchor_t=t_glob // 2, frames_per_clip=geo.t,
+                                                                shard=geo.shard)
         z = ops.linear(tok, self.proj_out_temporal_ca.pw, res1=y.view(-1, c), gn_rows=h * w)
         return ops.carry_gn_stats(z, z.view(n, h, w, c))
 
@@ -638,8 +653,13 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
         def add_center(hh):
             if img_control is not None:
                 ic = img_control.pop(0)
+                centre = geo.t // 2                              # controlmodel.py:529-535: frame T//2 of every clip
+                if geo.shard is not None:                        # sharded: only the rank that holds that keyframe adds
+                    centre = geo.shard.t_glob // 2 - geo.shard.t0
+                    if not 0 <= centre < geo.t:
+                        return hh
                 for b in range(geo.b):
-                    fr = hh[b * geo.t + geo.t // 2]
+                    fr = hh[b * geo.t + centre]
                     ops.add(fr, ic[b], out=fr)
                 if hasattr(hh, "_gn_stats"):
                     del hh._gn_stats                             # modified in place: the producer's statistics are stale
@@ -807,7 +827,9 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             control = net.controlnet.run(x8, guided, t, ctx2d, context.shape[1], geo)
         img_control = None
         cond_feat = c.get("cond_feat", None)
-        if cond_feat is not None:        # TVI2V (wrappers.py:176-190): controlnet_img on the reference latent
+        if cond_feat is not None and (sh is None or sh.owner_of(nt // 2) == sh.rank):
+            # TVI2V (wrappers.py:176-190): controlnet_img on the reference latent; its residuals only touch keyframe T//2,
+            # so under frame sharding only the rank holding that keyframe evaluates it
             cf8 = ops.ncthw_to_nhwc(cond_feat.float()[:, :, None].contiguous(), 8)
             img_control = net.controlnet_img.run(None, cf8, t, None, 0, Geometry(b, 1))
         eps = net.run(x8, t, ctx2d, context.shape[1], control, geo, img_control, control_ready=control_ready)

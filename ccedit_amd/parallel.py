@@ -113,6 +113,29 @@ class FrameShard:
         nxt = None if next_buf is None else next_buf.to(dev)
         return prev, nxt
 
+    def owner_of(self, t_global: int) -> int:
+        """Rank holding global keyframe t_global."""
+        for r, (lo, hi) in enumerate(self.bounds):
+            if lo <= t_global < hi:
+                return r
+        raise ValueError(f"keyframe {t_global} outside [0, {self.t_glob})")
+
+    def broadcast(self, t: torch.Tensor, src: int) -> torch.Tensor:
+        """In-place broadcast of a contiguous tensor from rank `src` (TVI2V: the centre keyframe's K/V rows)."""
+        if self.staged and t.is_cuda:
+            h = t.detach().cpu()
+            self.dist.broadcast(h, src=self._global_rank(src), group=self.group)
+            if self.rank != src:
+                t.copy_(h)
+        else:
+            self.dist.broadcast(t, src=self._global_rank(src), group=self.group)
+        if self.rank == src:
+            self.bytes_sent += t.numel() * t.element_size()
+        return t
+
+    def _global_rank(self, r: int) -> int:
+        return r if self.group is None else self.dist.get_global_rank(self.group, r)
+
     def gather_frames(self, x: torch.Tensor, b: int) -> torch.Tensor:
         """x: (b * t_local, ...) local frames of every clip -> (b * t_glob, ...) with all ranks' frames in order."""
         rest = x.shape[1:]

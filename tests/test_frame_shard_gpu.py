@@ -21,17 +21,19 @@ def _free_port():
     return p
 
 
-def _inputs():
+def _inputs(crossframe=False):
     g = torch.Generator().manual_seed(21)
     x = torch.randn(1, 4, T, H, W, generator=g)
     x2 = torch.cat([x, x])
     c = dict(crossattn=torch.randn(2, 77, G["context_dim"], generator=g),
              control_hint=(torch.rand(1, 3, T, 8 * H, 8 * W, generator=g) * 2 - 1).repeat(2, 1, 1, 1, 1))
     t = torch.tensor([501, 501], dtype=torch.int64)
+    if crossframe:          # TVI2V: the reference latent, identical in the c / uc halves
+        c["cond_feat"] = (0.18215 * torch.randn(1, 4, H, W, generator=g)).repeat(2, 1, 1, 1)
     return x2, t, c
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, crossframe=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,10 +42,11 @@ def _worker(rank, world, port, q):
     from ccedit_amd.parallel import FrameShard
     from ccedit_amd.sgm_compat import build_network
     from ccedit_amd.utils.synth import fill_module_
-    w = build_network("cpu", **G)
+    cfg = dict(G, crossframe=True) if crossframe else G
+    w = build_network("cpu", **cfg)
     fill_module_(w, prefix="model.")
     w.diffusion_model.pack("cuda")
-    x2, t, c = _inputs()
+    x2, t, c = _inputs(crossframe)
     cc = {k: v.cuda() for k, v in c.items()}
     ref = w(x2.cuda(), t.cuda(), cc).cpu() if rank == 0 else None      # unsharded evaluation
     w.frame_shard = FrameShard(T)
@@ -54,7 +57,7 @@ def _worker(rank, world, port, q):
         from ccedit_amd.sgm_compat import build_network_spec
         from ccedit_amd.utils.synth import synth_state_dict
         from oracle import ccedit_oracle as O
-        orc = O.network_forward(synth_state_dict(build_network_spec(G)), O.NetConfig(**G), x2, t, c)
+        orc = O.network_forward(synth_state_dict(build_network_spec(cfg)), O.NetConfig(**cfg), x2, t, c)
     q.put((rank, out.numpy(), None if ref is None else ref.numpy(), w.frame_shard.bytes_sent,
            None if orc is None else orc.numpy()))      # numpy: pickled by value (the child may exit before the parent reads)
     dist.barrier()
@@ -62,16 +65,17 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [1, 2])     # uneven 3-way splits: primitives in test_parallel_gloo.py (three processes
-                                              # time-slicing one GPU through host-staged gloo take minutes)
-def test_sharded_network_matches_unsharded(world):
+@pytest.mark.parametrize("world,crossframe", [(1, False), (2, False), (2, True)])
+# uneven 3-way splits: primitives in test_parallel_gloo.py (three processes time-slicing one GPU through host-staged gloo
+# take minutes).  crossframe=True: TVI2V — the centre keyframe (rank 1 of 2 at T=5) adds img_control and broadcasts its K/V
+def test_sharded_network_matches_unsharded(world, crossframe):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, crossframe)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=500) for _ in range(world)), key=lambda r: r[0])

@@ -89,6 +89,13 @@ def _shard_worker(rank, world, port, t_glob, q):
     st = local.sum(dim=1)                      # partial statistic over the local frames
     sh.allreduce(st)
     ok &= torch.allclose(st, full.sum(dim=1))
+    # TVI2V: the centre keyframe's rows travel from the rank that holds it to every rank
+    centre = t_glob // 2
+    owner = sh.owner_of(centre)
+    ok &= sh.bounds[owner][0] <= centre < sh.bounds[owner][1]
+    anchor = local[:, centre - sh.t0].contiguous() if sh.rank == owner else torch.empty(b, hw, c)
+    sh.broadcast(anchor, owner)
+    ok &= torch.equal(anchor, full[:, centre])
     q.put((rank, bool(ok), sh.t0, sh.t1))
     dist.destroy_process_group()
 
@@ -96,7 +103,8 @@ def _shard_worker(rank, world, port, t_glob, q):
 @pytest.mark.timeout(180)
 @pytest.mark.parametrize("world,t_glob", [(2, 17), (3, 5)])
 def test_frame_shard_primitives_gloo(world, t_glob):
-    """halo exchange / statistics all-reduce / K-V all-gather of the frame-sharded mode, uneven shards included."""
+    """halo exchange / statistics all-reduce / K-V all-gather / centre-frame broadcast of the frame-sharded mode, uneven
+    shards included."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
