@@ -107,13 +107,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # CCEDIT_DIST_BACKEND=gloo: development only — lets N ranks share the GPUs of a smaller box (ranks wrap around the
+    # visible devices, collectives stage through host memory).  The driver's runs use the default: RCCL, one GPU per rank.
+    backend = os.environ.get("CCEDIT_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from ccedit_amd import hip, ops
@@ -152,7 +160,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(out).all()
@@ -162,13 +170,15 @@ def main():
     # ---- roofline of the dominant kernel family, measured live with HIP events (one extra step) ----
     roof = None
     extra = {}
-    if rank == 0 and args.dump_shapes:
+    if rank == 0 and args.dump_shapes and not shard:
         ops.PROFILE = ops.LaunchProfile()
         step()
         torch.cuda.synchronize()
         with open(args.dump_shapes, "w") as f:
             json.dump([list(map(str, r[4])) + [r[2]] for r in ops.PROFILE.records["tap_gemm"]], f)
         ops.PROFILE = None
+    if shard and rank != 0 and not args.no_profile_step:
+        step()                                      # rank 0's profiled step below still needs its collective partners
     if rank == 0 and not args.no_profile_step:
         ops.PROFILE = ops.LaunchProfile()
         step()
@@ -234,6 +244,7 @@ def main():
             line["clip"] = clip
         print(json.dumps(line))
     if dist is not None:
+        dist.barrier()                              # rank 0 may still have been profiling: leave together
         dist.destroy_process_group()
 
 
