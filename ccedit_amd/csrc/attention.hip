@@ -20,6 +20,10 @@
 //   * K/V tiles are staged by global_load_lds_dwordx4 into a 2-deep LDS ring (tile j+1 in flight while
 //     tile j is consumed), one barrier per tile.  Pad columns / rows past Lk come from a zero page.
 #include "common.h"
+#include <stdlib.h>
+
+bool cc_attn_short_applicable(const CcAttnDesc& a);      // attnshort.hip
+int cc_attn_short_launch(const CcAttnDesc& a, hipStream_t s);
 
 namespace {
 
@@ -375,6 +379,9 @@ extern "C" int ccedit_attention(const CcAttnDesc* desc, void* stream) {
     CC_CHECK_ARG(!a.causal || (a.Lq == a.Lk && a.seg1_len == 0), "ccedit_attention: causal needs Lq == Lk and no leading segment");
     CC_UNSUPPORTED(((int64_t)a.batches * a.heads + 8) * ((a.Lq + 31) / 32) > 2147483647LL, "ccedit_attention: grid too large");
     hipStream_t s = (hipStream_t)stream;
+    // temporal self-attention (T <= 32 keyframes per pixel): HBM-bound, own kernel organised around whole-row loads
+    static const int short_env = getenv("CCEDIT_ATTN_SHORT") ? atoi(getenv("CCEDIT_ATTN_SHORT")) : 1;   // 0: A/B against attn_kernel
+    if (short_env && cc_attn_short_applicable(a)) return cc_attn_short_launch(a, s);
     switch (a.d) {
         case 8: return dispatch_nw<8>(a, s);
         case 16: return dispatch_nw<16>(a, s);

@@ -365,6 +365,7 @@ int launch(const CcGemmDesc& d, hipStream_t s) {
 
 template <int MODE>
 int launch_tile(const CcGemmDesc& d, int tile, hipStream_t s) {
+    if (tile == 6) return launch<2, 2, 5, 2, 2, 32, MODE>(d, s);  // 320ch x 128pix, 4 waves of 160ch x 64pix, 2 stages of K=32, 2 WG/CU
     if (tile == 5) return launch<2, 4, 2, 4, 4, 32, MODE>(d, s);  // 128ch x 512pix, 8 waves of 64ch x 128pix, 4 stages of K=32
     if (tile == 4) return launch<2, 4, 4, 2, 4, 32, MODE>(d, s);  // 256ch x 256pix, 8 waves of 128ch x 64pix, 4 stages of K=32
     if (tile == 3) return launch<2, 4, 2, 2, 3, 64, MODE>(d, s);
@@ -422,6 +423,7 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
                      "ccedit_gemm: gn_stats needs gn_rows %% 128 == 0 dividing M (gn_rows=%d)", d.gn_rows);
         CC_CHECK_ARG(d.gn_rows % 256 == 0 || d.tile <= 1 || d.tile == 8,
                      "ccedit_gemm: gn_rows=%d is not a multiple of 256: only the 128-pixel block shape (tile 1) applies", d.gn_rows);
+        CC_UNSUPPORTED(d.tile == 6, "ccedit_gemm: gn_stats is not available with the 320-channel block shape (tile 6)");
         CC_UNSUPPORTED(d.N % 32 != 0 || d.N < 256 || d.out_f32 || d.act == CCEDIT_ACT_GEGLU,
                        "ccedit_gemm: gn_stats needs N%%32==0, N>=256, bf16 output, no GEGLU (N=%d)", d.N);
     }
@@ -432,6 +434,7 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         if (cc_conv_halo_applicable(d)) return cc_conv_halo_launch(d, s);
         CC_UNSUPPORTED(d.tile == 8, "ccedit_gemm: tile 8 (LDS-halo 3x3 conv) does not apply to this descriptor");
     }
+    CC_UNSUPPORTED(d.tile == 6 && d.N % 320 != 0, "ccedit_gemm: tile 6 (320-channel block shape) needs N %% 320 == 0 (N=%d)", d.N);
     int tile = d.tile;
     if (tile == 0) {
         // Chosen from IN-NETWORK timings (bench.py --breakdown), where operands arrive cold from HBM; the isolated
@@ -447,6 +450,14 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         else if (d.M >= 150000 && d.Kpad >= 2048) tile = 3;
         else if (d.act == CCEDIT_ACT_GEGLU && d.Kpad <= 640) tile = 2;    // with the K rotation: +9 / +5 % over t1 at K = 320 / 640
         else tile = 1;
+        //   long K with Cout % 320 == 0 (every UNet width): 320ch x 128pix, K tiles of 32, still two workgroups per CU
+        //   (t6: 91 FLOP per staged byte against 64 for t1; cold sweep +4 % at 1280 -> 1280 / 3840 / 10240 and +8 % at
+        //   1280 -> 320 on 209k pixels, +22 % on the 1280-channel temporal conv; slower for K <= 640 and below 8k pixels;
+        //   in the network +0.6 % per step, CCEDIT_T6=0 switches it off for A/B)
+        static const int t6_env = getenv("CCEDIT_T6") ? atoi(getenv("CCEDIT_T6")) : 1;
+        if (t6_env && d.N % 320 == 0 && !d.gn_stats && d.M >= 8192 &&
+            ((d.mode == CCEDIT_GEMM_LINEAR && d.Kpad >= 1280) || (d.mode == CCEDIT_GEMM_TEMPORAL && d.Kpad >= 3840)))
+            tile = 6;
         if (d.gn_stats && d.gn_rows % 256 != 0) tile = 1;     // a block must not straddle two frames
     }
     const int mode = d.mode == CCEDIT_GEMM_CONV2D ? (d.upsample ? M_CONV_UP : M_CONV)

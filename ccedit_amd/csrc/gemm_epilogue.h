@@ -6,8 +6,10 @@
 
 // Dynamic LDS a kernel needs so that the epilogue can stage at least one wave column (host and device agree on it).
 constexpr int epi_lds_total(int bmc, int bnp, int tj, int lds_main) {
-    const int erow = bmc * 4 + 16, full = bnp * erow, one_col = tj * 32 * erow;
-    return (full > lds_main && full <= 70 * 1024) ? full : (lds_main > one_col ? lds_main : one_col);
+    const int erow = bmc * 4 + 16, full = bnp * erow, one_col = tj * 32 * erow, one_tile = 32 * erow;
+    if (full > lds_main && full <= 70 * 1024) return full;
+    if (lds_main >= one_col) return lds_main;
+    return lds_main >= one_tile ? lds_main : one_col;      // wide channel tiles: stage 32 pixels at a time
 }
 
 // In the MFMA layout a lane owns 4 channels of 32 different pixels, i.e. 8-byte pieces of 32 different output rows
@@ -29,8 +31,10 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
     // (the 128x128 shape allocates 3.5 KB more than its operand ring so that the whole tile is staged at once)
     constexpr int WPIX = TJ * 32;             // pixels per wave column
     constexpr int LDS_TOTAL = epi_lds_total(BMC, BNP, TJ, LDS_MAIN);
-    constexpr int ECH = (LDS_TOTAL / EROW / WPIX) * WPIX < BNP ? (LDS_TOTAL / EROW / WPIX) * WPIX : BNP;   // pixels per chunk
-    static_assert(ECH >= WPIX && BNP % ECH == 0, "epilogue chunking");
+    // pixels staged per chunk: whole wave columns, or single 32-pixel MFMA tile columns when a wave column does not fit
+    constexpr int EGR = LDS_TOTAL / EROW >= WPIX ? WPIX : 32;
+    constexpr int ECH = (LDS_TOTAL / EROW / EGR) * EGR < BNP ? (LDS_TOTAL / EROW / EGR) * EGR : BNP;
+    static_assert(ECH >= EGR && BNP % ECH == 0, "epilogue chunking");
     char* const sE = smem;
     const float* __restrict__ bias = d.bias;
     const float* __restrict__ gbias = d.group_bias;
@@ -41,24 +45,26 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
     for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
   for (int ec = 0; ec < BNP / ECH; ++ec) {
     __syncthreads();                          // operand tiles (or the previous chunk) are no longer being read
-    if (wn * WPIX >= ec * ECH && wn * WPIX < (ec + 1) * ECH) {
 #pragma unroll
-        for (int tj = 0; tj < TJ; ++tj)
+    for (int tj = 0; tj < TJ; ++tj) {
+        const int pb = wn * WPIX + tj * 32;       // first tile pixel of this wave's MFMA tile column tj
+        if (pb >= ec * ECH && pb < (ec + 1) * ECH) {
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x4 v = {acc[ti][tj][q * 4 + 0], acc[ti][tj][q * 4 + 1], acc[ti][tj][q * 4 + 2], acc[ti][tj][q * 4 + 3]};
-                    *(f32x4*)(sE + (wn * WPIX - ec * ECH + tj * 32 + l31) * EROW + (wm * TI * 32 + ti * 32 + q * 8 + hi * 4) * 4) = v;
+                    *(f32x4*)(sE + (pb - ec * ECH + l31) * EROW + (wm * TI * 32 + ti * 32 + q * 8 + hi * 4) * 4) = v;
                 }
+        }
     }
     __syncthreads();
 
     if (d.act == CCEDIT_ACT_GEGLU) {
         constexpr int CPR = BMC / 16;                    // 16 packed rows = 8 value + 8 gate channels
-        const int g = tid % CPR, r0 = tid / CPR;
+        const int g = tid % CPR, r0 = tid / CPR;          // (threads past (NT / CPR) * CPR idle when CPR does not divide NT)
         const int rx = ch0 + g * 16;                      // packed row of the 8 values; gates at rx + 8
-        if (rx < d.N) {
+        if (rx < d.N && r0 < NT / CPR) {
             float bx[8], bg[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -84,7 +90,7 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
         constexpr int CPR = BMC / 8;
         const int g = tid % CPR, r0 = tid / CPR;
         const int cb = ch0 + g * 8;
-        if (cb < d.N) {
+        if (cb < d.N && r0 < NT / CPR) {
             const bool full = (cb + 8 <= d.N);            // otherwise exactly 4 valid channels (N % 4 == 0)
             float bv[8];
 #pragma unroll
@@ -163,7 +169,7 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
 
     // ---- fused GroupNorm(32) statistics: thread -> lanes sharing the channel granule -> LDS -> global atomics ----
     if (d.gn_stats) {
-        constexpr int CPR = BMC / 8;
+        constexpr int CPR = BMC / 8;              // (power of two: the launcher keeps gn_stats off the 320-channel shape)
         float* const sS = (float*)smem;           // [32 groups][sum, sumsq]
         __syncthreads();                          // the last chunk's staging area has been consumed
         if (tid < 64) sS[tid] = 0.f;

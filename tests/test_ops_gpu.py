@@ -47,9 +47,11 @@ def _nchw(y_nhwc):
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (300, 320, 320), (77, 960, 768), (1000, 4, 320), (257, 1280, 2560),
                                    (64, 640, 40)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
 def test_linear(m, n, k, tile):
     _dev()
+    if tile == 6 and n % 320:
+        pytest.skip("tile 6 = 320-channel block shape: Cout must be a multiple of 320")
     from ccedit_amd import ops
     from ccedit_amd.packing import pack_weight
     x, w, b = _rnd(m, k, seed=1), _rnd(n, k, seed=2, scale=k ** -0.5), _rnd(n, seed=3)
@@ -80,11 +82,15 @@ def test_linear_epilogues():
     r1, r2 = _rnd(m, n, seed=4), _rnd(m, n, seed=5)
     gb = _rnd(3, n, seed=6)
     pw = pack_weight(w, b).to("cuda")
-    y = ops.linear(x.to(BF).cuda(), pw, res1=r1.to(BF).cuda(), res2=r2.to(BF).cuda(), group_bias=gb.cuda(), group_rows=50)
-    ref = F.linear(x, w, b) + gb.repeat_interleave(50, 0) + r1 + r2
-    _close(y, ref, what="bias+group_bias+2 residuals")
-    y = ops.linear(x.to(BF).cuda(), pw, act=1)
-    _close(y, F.silu(F.linear(x, w, b)), what="silu epilogue")
+    for tile in (0, 6):        # 6: 320-channel block shape (epilogue staged 32 pixels at a time, 240 of 256 threads store)
+        y = ops.linear(x.to(BF).cuda(), pw, res1=r1.to(BF).cuda(), res2=r2.to(BF).cuda(), group_bias=gb.cuda(), group_rows=50,
+                       tile=tile)
+        ref = F.linear(x, w, b) + gb.repeat_interleave(50, 0) + r1 + r2
+        _close(y, ref, what=f"bias+group_bias+2 residuals tile{tile}")
+        y = ops.linear(x.to(BF).cuda(), pw, act=1, tile=tile)
+        _close(y, F.silu(F.linear(x, w, b)), what=f"silu epilogue tile{tile}")
+        y = ops.linear(x.to(BF).cuda(), pw, out_f32=True, tile=tile)
+        _close(y, F.linear(x, w, b), rel=1e-5, abs_=1e-4, what=f"fp32 out tile{tile}")
     y = ops.linear(x.to(BF).cuda(), pw, out_f32=True)
     assert y.dtype == torch.float32
     _close(y, F.linear(x, w, b), rel=1e-5, abs_=1e-4, what="fp32 out")
@@ -106,9 +112,10 @@ def test_geglu():
     inner = 4 * c
     x, w, b = _rnd(m, c, seed=1), _rnd(2 * inner, c, seed=2, scale=c ** -0.5), _rnd(2 * inner, seed=3)
     pw = pack_weight(w, b, geglu=True).to("cuda")
-    y = ops.linear(x.to(BF).cuda(), pw)
     a, g = F.linear(x, w, b).chunk(2, dim=-1)
-    _close(y, a * F.gelu(g), what="GEGLU")
+    for tile in (0, 1, 2, 6):
+        y = ops.linear(x.to(BF).cuda(), pw, tile=tile)
+        _close(y, a * F.gelu(g), what=f"GEGLU tile{tile}")
 
 
 @pytest.mark.parametrize("tile", [0, 3, 4, 5])
@@ -421,9 +428,11 @@ def test_attention_fused_qkv_and_shared_text_kv():
     _close(o.reshape(n, lq, c), _sdpa_ref(q, kk, vv, heads), rel=2.0 ** -6, abs_=4e-3, what="text cross-attention")
 
 
-@pytest.mark.parametrize("d,heads,t", [(40, 8, 17), (160, 8, 3), (80, 4, 4)])
+@pytest.mark.parametrize("d,heads,t", [(40, 8, 17), (160, 8, 3), (80, 4, 4), (80, 8, 17), (160, 8, 32), (40, 16, 1), (32, 4, 9)])
 def test_attention_temporal(d, heads, t):
-    """Sequences run over the T frames of one pixel: rows H*W apart, batch = (clip, pixel)."""
+    """Sequences run over the T frames of one pixel: rows H*W apart, batch = (clip, pixel).  d in {40, 80, 160} with
+    heads*d a multiple of 320 takes attn_short_kernel (attnshort.hip: one workgroup per pixel and 320-channel group);
+    the last case the general flash kernel."""
     _dev()
     from ccedit_amd import ops
     clips, hw = 2, 12

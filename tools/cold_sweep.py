@@ -34,6 +34,7 @@ def bench(name, make_call, flops, m, k):
             t = sum(a.elapsed_time(b) for a, b in evs) / len(evs) * 1e-3
             res.append(flops / t / 1e12)
         except Exception as e:
+            print("   ", type(e).__name__, str(e)[:200], file=sys.stderr)
             res.append(float("nan"))
     print(f"{name:40s} " + "  ".join(f"t{t}:{v:6.0f}" for t, v in zip(TILES, res)), flush=True)
 
@@ -96,6 +97,14 @@ if want("l1"):
 if want("l2"):
     lin("L2 to_out 1280->1280 +res", M2, 1280, 1280, res=True)
     lin("L2 GEGLU 1280->10240", M2, 1280, 10240, geglu=True)
+    lin("L2 ff.out 5120->1280 +res", M2, 5120, 1280, res=True)
+    lin("L2 qkv 1280->3840", M2, 1280, 3840)
+    lin("L2 proj 1280->1280", M2, 1280, 1280)
+if want("l3"):
+    M3 = 34 * 96
+    lin("L3 to_out 1280->1280 +res", M3, 1280, 1280, res=True)
+    lin("L3 GEGLU 1280->10240", M3, 1280, 10240, geglu=True)
+    lin("L3 ff.out 5120->1280 +res", M3, 5120, 1280, res=True)
 if want("temp"):
     temp("temporal L0 320", 34, 64, 96, 320)
     temp("temporal L1 640", 34, 32, 48, 640)
