@@ -380,7 +380,8 @@ def _sdpa_ref(q, k, v, heads):
 
 
 @pytest.mark.parametrize("d,heads,lq,lk", [(40, 8, 384, 384), (80, 4, 200, 200), (160, 2, 96, 96), (40, 8, 150, 77),
-                                           (64, 2, 129, 65), (32, 3, 64, 64), (8, 4, 40, 40), (128, 1, 70, 130)])
+                                           (64, 2, 129, 65), (32, 3, 64, 64), (8, 4, 40, 40), (128, 1, 70, 130),
+                                           (40, 16, 300, 77), (40, 8, 70, 33), (40, 8, 64, 96), (40, 8, 2000, 77)])
 def test_attention_spatial_and_text(d, heads, lq, lk):
     _dev()
     from ccedit_amd import ops
