@@ -275,6 +275,9 @@ def time_clip(wrapper, device, num_steps=30, scale=7.5):
         return wrapper(xx, tt, cond)
 
     wrapper.cache_hint_stem = True                 # whole-clip run: the hint stem is evaluated once per clip
+    # warm-up of the decoder like the W warm-up steps of the network: its first call loads code objects and grows the
+    # caching allocator by ~10 GB (measured 0.10 s warm, 0.23-0.38 s on the first call of a fresh process)
+    vae.decode(torch.randn(1, 4, T, H, W, device=device))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     z = sampler(lambda inp, sig, cc: denoiser(network, inp, sig, cc), x.clone(), c, uc=uc)
@@ -287,6 +290,7 @@ def time_clip(wrapper, device, num_steps=30, scale=7.5):
     assert frames.shape == (1, 3, T, 8 * H, 8 * W)
     wrapper.cache_hint_stem = False
     return dict(sampler_s=round(t1 - t0, 3), vae_decode_s=round(t2 - t1, 3), evaluations=evals[0], hint_stem="once per clip",
+                decoder_warmup="one untimed decode",
                 frames_per_s=round(T / (t2 - t0), 3), finite=bool(torch.isfinite(frames).all()))
 
 
