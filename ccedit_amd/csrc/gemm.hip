@@ -95,8 +95,19 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
     const int64_t rr = local - cg * gsz;
     const int qn = min(Q, ct_n - cg * Q);
     const int64_t pl = rr / qn;
-    const int64_t pt = xcd * pt_per_xcd + pl;
+    int64_t pt = xcd * pt_per_xcd + pl;
     if (pt >= pt_n) return;
+    if constexpr (MODE == M_TEMPORAL) {
+        // Conv1d over T: the three taps of pixel tile (frame t, pixel block b) read frames t-1, t, t+1 of the SAME pixel
+        // block.  Walk the frames of one pixel block back to back (frame-minor order), so that the tiles sharing input
+        // rows are resident on one XCD together and the 2 re-reads hit its L2 instead of going back to the fabric.
+        const int tpf = d.HW / BNP;                       // pixel tiles per frame (the launcher checks divisibility)
+        if ((d.cgroup >> 17) & 1) {
+            const int64_t nfr = pt_n / tpf;
+            const int64_t pb = pt / nfr;
+            pt = (pt - pb * nfr) * tpf + pb;
+        }
+    }
     const int64_t pix0 = pt * BNP;
     const int ch0 = (cg * Q + (int)(rr - pl * qn)) * BMC;
 
@@ -359,6 +370,8 @@ int launch(const CcGemmDesc& d, hipStream_t s) {
     }
     static const int krot_env = getenv("CCEDIT_KROT") ? atoi(getenv("CCEDIT_KROT")) : 1;     // 0: A/B without the K rotation
     if (krot_env && d.Kpad <= 640) dd.cgroup |= 1 << 16;                                         // short K only: measured neutral or -3 % at K = 1280
+    static const int tord_env = getenv("CCEDIT_TEMPORAL_ORDER") ? atoi(getenv("CCEDIT_TEMPORAL_ORDER")) : 1;   // 0: frames-outermost tile order
+    if (MODE == M_TEMPORAL && tord_env && d.HW % BNP == 0 && d.M % d.HW == 0) dd.cgroup |= 1 << 17;
     hipLaunchKernelGGL((tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>), grid, dim3(WM * WN * 64), lds, s, dd);
     return cc_launch_status("tap_gemm_kernel");
 }
