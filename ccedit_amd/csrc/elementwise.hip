@@ -75,13 +75,13 @@ __global__ void cat_add_kernel(const bf16* __restrict__ a, const bf16* __restric
 constexpr int kCatCols = 5;       // C1 + C2 <= 2560
 __global__ __launch_bounds__(256) void cat_add_gn_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b,
                                                          const bf16* __restrict__ c, bf16* __restrict__ out,
-                                                         float* __restrict__ stats, int hw, int C1, int C2,
+                                                         double* __restrict__ stats, int hw, int C1, int C2,
                                                          int pix_per_block) {
-    __shared__ float sS[64];
+    __shared__ float sS[4][64];           // one slot set per wave, summed in a fixed order (reproducible, see norm.hip)
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g1 = C1 >> 3, gt = (C1 + C2) >> 3, cpg = (C1 + C2) >> 5;
-    if (threadIdx.x < 64) sS[threadIdx.x] = 0.f;
+    (&sS[0][0])[threadIdx.x] = 0.f;
     __syncthreads();
     float sum[kCatCols][8], sq[kCatCols][8];
 #pragma unroll
@@ -123,13 +123,15 @@ __global__ __launch_bounds__(256) void cat_add_gn_kernel(const bf16* __restrict_
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int grp = (g * 8 + e) / cpg;
-                atomicAdd(&sS[grp * 2], sum[k][e]);
-                atomicAdd(&sS[grp * 2 + 1], sq[k][e]);
+                atomicAdd(&sS[wave][grp * 2], sum[k][e]);
+                atomicAdd(&sS[wave][grp * 2 + 1], sq[k][e]);
             }
         }
     }
     __syncthreads();
-    if (threadIdx.x < 64) atomicAdd(&stats[frame * 64 + threadIdx.x], sS[threadIdx.x]);
+    if (threadIdx.x < 64)
+        unsafeAtomicAdd(&stats[frame * 64 + threadIdx.x], (double)sS[0][threadIdx.x] + (double)sS[1][threadIdx.x] +
+                                                              (double)sS[2][threadIdx.x] + (double)sS[3][threadIdx.x]);
 }
 
 __global__ void add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ y, int64_t n8) {
@@ -296,7 +298,7 @@ extern "C" int ccedit_cat_add(const void* a, const void* b, const void* c, void*
     return cc_launch_status("cat_add");
 }
 
-extern "C" int ccedit_cat_add_gn(const void* a, const void* b, const void* c, void* out, float* stats, int32_t frames,
+extern "C" int ccedit_cat_add_gn(const void* a, const void* b, const void* c, void* out, double* stats, int32_t frames,
                                  int32_t hw, int32_t C1, int32_t C2, void* stream) {
     CC_CHECK_ARG(a && b && out && stats && frames > 0 && hw > 0, "ccedit_cat_add_gn: bad args");
     CC_UNSUPPORTED(C1 % 8 || C2 % 8 || (C1 + C2) % 32 || C1 + C2 > kCatCols * 512,

@@ -170,9 +170,11 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
     // ---- fused GroupNorm(32) statistics: thread -> lanes sharing the channel granule -> LDS -> global atomics ----
     if (d.gn_stats) {
         constexpr int CPR = BMC / 8;              // (power of two: the launcher keeps gn_stats off the 320-channel shape)
-        float* const sS = (float*)smem;           // [32 groups][sum, sumsq]
+        // [wave][32 groups][sum, sumsq]: a wave adds into its own slots and the slots are summed in a fixed order, the
+        // workgroups meet in double-precision global atomics — reproducible from run to run (see norm.hip)
+        float* const sS = (float*)smem;
         __syncthreads();                          // the last chunk's staging area has been consumed
-        if (tid < 64) sS[tid] = 0.f;
+        sS[tid] = 0.f;                            // NT = 64 * waves entries
         __syncthreads();
         const int cb = ch0 + (tid % CPR) * 8;
         const int cpg = d.N >> 5;                 // >= 8: eight aligned channels span at most two groups
@@ -194,17 +196,20 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
             q1 += __shfl_xor(q1, off);
         }
         if ((tid & 63) < CPR && cb < d.N) {
-            atomicAdd(&sS[g0 * 2], s0);
-            atomicAdd(&sS[g0 * 2 + 1], q0);
+            float* const mine = sS + wave * 64;
+            atomicAdd(&mine[g0 * 2], s0);
+            atomicAdd(&mine[g0 * 2 + 1], q0);
             if (g0 < 31) {
-                atomicAdd(&sS[g0 * 2 + 2], s1);
-                atomicAdd(&sS[g0 * 2 + 3], q1);
+                atomicAdd(&mine[g0 * 2 + 2], s1);
+                atomicAdd(&mine[g0 * 2 + 3], q1);
             }
         }
         __syncthreads();
         if (tid < 64) {
-            const float v = sS[tid];
-            if (v != 0.f) atomicAdd(d.gn_stats + (size_t)stat_frame * 64 + tid, v);
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM * WN; ++w) v += (double)sS[w * 64 + tid];
+            if (v != 0.0) unsafeAtomicAdd(d.gn_stats + (size_t)stat_frame * 64 + tid, v);
         }
     }
 }

@@ -24,15 +24,20 @@ inline int gn_pix_per_block(int hw, int frames, int lo, int64_t want_blocks) {
     return ppb;
 }
 
-__global__ __launch_bounds__(256) void gn_spatial_stats_kernel(const bf16* __restrict__ x, float* __restrict__ stats,
+// Run-to-run reproducibility of the statistics: a wave accumulates into its OWN LDS slots (same-wave LDS atomics
+// retire in program / lane order), the waves' slots are added in a fixed order, and only the cross-workgroup sum uses
+// global atomics — in double, so that the arrival order moves the total by ~1e-16 relative, far below the fp32 rounding
+// of the mean / rstd derived from it.  (With fp32 atomics the order noise flipped bf16 roundings downstream and two runs
+// of the same clip differed by the full bf16 noise floor, ~2 % rel. RMS at 17x512x768.)
+__global__ __launch_bounds__(256) void gn_spatial_stats_kernel(const bf16* __restrict__ x, double* __restrict__ stats,
                                                                int hw, int C, int pix_per_block) {
-    __shared__ float s_sum[32], s_sq[32];
+    __shared__ float s_sum[kGnWaves][32], s_sq[kGnWaves][32];
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int G8 = C >> 3, cpg = C >> 5;
-    if (threadIdx.x < 32) {
-        s_sum[threadIdx.x] = 0.f;
-        s_sq[threadIdx.x] = 0.f;
+    if (threadIdx.x < kGnWaves * 32) {
+        (&s_sum[0][0])[threadIdx.x] = 0.f;
+        (&s_sq[0][0])[threadIdx.x] = 0.f;
     }
     __syncthreads();
     float sum[kMaxCols][8], sq[kMaxCols][8];
@@ -66,21 +71,27 @@ __global__ __launch_bounds__(256) void gn_spatial_stats_kernel(const bf16* __res
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int g = (gc * 8 + e) / cpg;
-                atomicAdd(&s_sum[g], sum[k][e]);
-                atomicAdd(&s_sq[g], sq[k][e]);
+                atomicAdd(&s_sum[wave][g], sum[k][e]);
+                atomicAdd(&s_sq[wave][g], sq[k][e]);
             }
         }
     }
     __syncthreads();
     if (threadIdx.x < 32) {
-        atomicAdd(&stats[(frame * 32 + threadIdx.x) * 2 + 0], s_sum[threadIdx.x]);
-        atomicAdd(&stats[(frame * 32 + threadIdx.x) * 2 + 1], s_sq[threadIdx.x]);
+        double ts = 0.0, tq = 0.0;
+#pragma unroll
+        for (int w = 0; w < kGnWaves; ++w) {
+            ts += (double)s_sum[w][threadIdx.x];
+            tq += (double)s_sq[w][threadIdx.x];
+        }
+        unsafeAtomicAdd(&stats[(frame * 32 + threadIdx.x) * 2 + 0], ts);
+        unsafeAtomicAdd(&stats[(frame * 32 + threadIdx.x) * 2 + 1], tq);
     }
 }
 
 template <int COLS>      // 16-byte granules per lane: ceil(C / 512); fewer live coefficient registers -> more resident waves
 __global__ __launch_bounds__(256) void gn_spatial_apply_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
-                                                               const float* __restrict__ stats,
+                                                               const double* __restrict__ stats,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int hw, int C, float eps,
                                                                int silu, int pix_per_block) {
@@ -102,8 +113,8 @@ __global__ __launch_bounds__(256) void gn_spatial_apply_kernel(const bf16* __res
             for (int e = 0; e < 8; ++e) {
                 const int c = gc * 8 + e;
                 const int g = c / cpg;
-                const float mean = stats[(frame * 32 + g) * 2] * inv_n;
-                const float rstd = rsqrtf(fmaxf(stats[(frame * 32 + g) * 2 + 1] * inv_n - mean * mean, 0.f) + eps);
+                const float mean = (float)stats[(frame * 32 + g) * 2] * inv_n;
+                const float rstd = rsqrtf(fmaxf((float)stats[(frame * 32 + g) * 2 + 1] * inv_n - mean * mean, 0.f) + eps);
                 a[k][e] = rstd * gamma[c];
                 b[k][e] = beta[c] - mean * a[k][e];
             }
@@ -111,7 +122,9 @@ __global__ __launch_bounds__(256) void gn_spatial_apply_kernel(const bf16* __res
             const int c0 = gc * 8;
             const int g0 = c0 / cpg, g1 = min(g0 + 1, 31);
             const int split = (g0 + 1) * cpg - c0;           // channels of this granule that belong to group g0
-            const f32x2 st0 = *(const f32x2*)(stats + (frame * 32 + g0) * 2), st1 = *(const f32x2*)(stats + (frame * 32 + g1) * 2);
+            const double* sp0 = stats + (frame * 32 + g0) * 2;
+            const double* sp1 = stats + (frame * 32 + g1) * 2;
+            const f32x2 st0 = {(float)sp0[0], (float)sp0[1]}, st1 = {(float)sp1[0], (float)sp1[1]};
             const f32x4 ga0 = *(const f32x4*)(gamma + c0), ga1 = *(const f32x4*)(gamma + c0 + 4);
             const f32x4 be0 = *(const f32x4*)(beta + c0), be1 = *(const f32x4*)(beta + c0 + 4);
             const float m0 = st0[0] * inv_n, m1 = st1[0] * inv_n;
@@ -553,7 +566,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__
     }
 }
 
-void launch_gn_apply(dim3 grid, hipStream_t s, const bf16* x, bf16* y, const float* stats, const float* gamma,
+void launch_gn_apply(dim3 grid, hipStream_t s, const bf16* x, bf16* y, const double* stats, const float* gamma,
                      const float* beta, int hw, int C, float eps, int silu, int apb) {
     const int cols = (C / 8 + 63) / 64;
 #define CC_GA(N) hipLaunchKernelGGL(gn_spatial_apply_kernel<N>, grid, dim3(256), 0, s, x, y, stats, gamma, beta, hw, C, eps, silu, apb)
@@ -563,14 +576,14 @@ void launch_gn_apply(dim3 grid, hipStream_t s, const bf16* x, bf16* y, const flo
 
 }  // namespace
 
-extern "C" int ccedit_groupnorm_spatial(const void* x, void* y, const float* gamma, const float* beta, float* stats_ws,
+extern "C" int ccedit_groupnorm_spatial(const void* x, void* y, const float* gamma, const float* beta, double* stats_ws,
                                         int32_t frames, int32_t hw, int32_t C, float eps, int32_t silu, void* stream) {
     CC_CHECK_ARG(x && y && gamma && beta && stats_ws, "ccedit_groupnorm_spatial: null pointer");
     CC_CHECK_ARG(frames > 0 && hw > 0 && C > 0, "ccedit_groupnorm_spatial: bad sizes");
     CC_UNSUPPORTED(C % 32 != 0 || C > kMaxCols * 512, "ccedit_groupnorm_spatial: C=%d (need C%%32==0, C<=%d)", C,
                    kMaxCols * 512);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * 32 * (size_t)frames, s);
+    hipError_t e = hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * 32 * (size_t)frames, s);
     if (e != hipSuccess) {
         cc_set_error("groupnorm_spatial memset: %s", hipGetErrorString(e));
         return (int)e;
@@ -588,7 +601,7 @@ extern "C" int ccedit_groupnorm_spatial(const void* x, void* y, const float* gam
 }
 
 extern "C" int ccedit_groupnorm_spatial_apply(const void* x, void* y, const float* gamma, const float* beta,
-                                              const float* stats, int32_t frames, int32_t hw, int32_t C, float eps,
+                                              const double* stats, int32_t frames, int32_t hw, int32_t C, float eps,
                                               int32_t silu, void* stream) {
     CC_CHECK_ARG(x && y && gamma && beta && stats, "ccedit_groupnorm_spatial_apply: null pointer");
     CC_CHECK_ARG(frames > 0 && hw > 0 && C > 0, "ccedit_groupnorm_spatial_apply: bad sizes");

@@ -182,13 +182,13 @@ def _stats_ws(frames: int, device) -> torch.Tensor:
     key = (device, torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < frames * 64:
-        ws = torch.empty(max(frames * 64, 4096), dtype=torch.float32, device=device)
+        ws = torch.empty(max(frames * 64, 4096), dtype=torch.float64, device=device)
         _ws_cache[key] = ws
     return ws
 
 
 class _ZeroArena:
-    """Zero-initialised fp32 scratch for the fused GroupNorm statistics: one memset per ~256 requests instead of one
+    """Zero-initialised fp64 scratch for the fused GroupNorm statistics (double: see include/ccedit_hip.h): one memset per ~256 requests instead of one
     per producer launch (150 per network evaluation).  A slice is handed out once and never recycled — the tensors
     that carry the statistics keep the slab alive — and arenas are per (device, stream)."""
     SLAB = 256 * 34 * 64
@@ -200,7 +200,7 @@ class _ZeroArena:
         key = (device, torch.cuda.current_stream().cuda_stream)
         slab, used = self.slabs.get(key, (None, 0))
         if slab is None or used + numel > slab.numel():
-            slab, used = torch.zeros(max(self.SLAB, numel), dtype=torch.float32, device=device), 0
+            slab, used = torch.zeros(max(self.SLAB, numel), dtype=torch.float64, device=device), 0
         self.slabs[key] = (slab, used + numel)
         return slab[used:used + numel]
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCEDIT_ABI_VERSION 3
+#define CCEDIT_ABI_VERSION 4
 
 #define CCEDIT_OK 0
 #define CCEDIT_EINVAL (-1)       /* null pointer / bad size */
@@ -104,7 +104,7 @@ typedef struct CcGemmDesc {
      * following normalisation (openaimodel.py:441-444, 479-482; attention.py:153-156) does not re-read it:
      * float[M/gn_rows][32][2] (sum, sum of squares of the bf16-rounded outputs), ZEROED BY THE CALLER, added to
      * atomically.  Needs N % 32 == 0, N >= 256, bf16 output, no GEGLU.  Consumed by ccedit_groupnorm_spatial_apply. */
-    float* gn_stats;
+    double* gn_stats;
 } CcGemmDesc;
 
 int ccedit_gemm(const CcGemmDesc* desc, void* stream);
@@ -114,14 +114,16 @@ int ccedit_gemm(const CcGemmDesc* desc, void* stream);
  * ------------------------------------------------------------------------------------------ */
 /* GroupNorm(32, C) over (C/32 x H x W) per frame, optional fused SiLU.
  * Replaces nn.GroupNorm + nn.SiLU of openaimodel.py:441-444, 479-482 (eps 1e-5), attention.py:153-156,
- * model.py:50-53 (eps 1e-6).  x: [frames][hw][C]; stats workspace: float[frames*32*2] (zeroed here). */
+ * model.py:50-53 (eps 1e-6).  x: [frames][hw][C]; stats workspace: double[frames*32*2] (zeroed here). */
 int ccedit_groupnorm_spatial(const void* x, void* y, const float* gamma, const float* beta,
-                             float* stats_ws, int32_t frames, int32_t hw, int32_t C, float eps,
+                             double* stats_ws, int32_t frames, int32_t hw, int32_t C, float eps,
                              int32_t silu, void* stream);
 /* The apply half alone, for statistics that a producer already accumulated (CcGemmDesc.gn_stats):
- * stats: float[frames][32][2] = (sum, sum of squares) over the C/32 x hw elements of each group. */
+ * stats: double[frames][32][2] = (sum, sum of squares) over the C/32 x hw elements of each group (double: the
+ * producers' workgroups meet in global atomics, and in double their arrival order cannot move the fp32 mean / rstd —
+ * results are reproducible from run to run). */
 int ccedit_groupnorm_spatial_apply(const void* x, void* y, const float* gamma, const float* beta,
-                                   const float* stats, int32_t frames, int32_t hw, int32_t C, float eps,
+                                   const double* stats, int32_t frames, int32_t hw, int32_t C, float eps,
                                    int32_t silu, void* stream);
 /* GroupNorm(32, C) over (C/32 x T) per pixel — the normalization() / norm_temporal applied to the
  * '(b h w) c t' view (openaimodel.py:617-619, 674-676; attention.py:1085, 1176).
@@ -186,9 +188,9 @@ int ccedit_nhwc_to_ncthw(const void* x, int32_t x_is_f32, int32_t ld, float* y, 
 int ccedit_cat_add(const void* a, const void* b, const void* c, void* out, int64_t rows, int32_t C1,
                    int32_t C2, void* stream);
 /* The same, additionally accumulating the GroupNorm(32, C1+C2) statistics of `out` ([frames][hw][C1+C2]) into
- * stats = float[frames][32][2] (sum, sum of squares; ZEROED BY THE CALLER) for ccedit_groupnorm_spatial_apply —
+ * stats = double[frames][32][2] (sum, sum of squares; ZEROED BY THE CALLER) for ccedit_groupnorm_spatial_apply —
  * the decoder ResBlock's in_layers.0 (openaimodel.py:441-444) then does not re-read the concatenation. */
-int ccedit_cat_add_gn(const void* a, const void* b, const void* c, void* out, float* stats, int32_t frames,
+int ccedit_cat_add_gn(const void* a, const void* b, const void* c, void* out, double* stats, int32_t frames,
                       int32_t hw, int32_t C1, int32_t C2, void* stream);
 /* y = a + b (bf16), n elements — `h = h + control.pop()` (controlmodel.py:537), `h += guided_hint` (:300) */
 int ccedit_add(const void* a, const void* b, void* y, int64_t n, void* stream);

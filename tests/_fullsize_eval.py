@@ -1,0 +1,48 @@
+"""Helper of test_fullsize_gpu.py: one network evaluation (and one VAE decode) at BASELINE.json's full size
+(17 keyframes, 512x768, CFG-doubled batch) under whatever kernel-policy environment the parent test set, saved to .npz.
+Run as a subprocess because the policy switches are read once per process."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+
+def main(out_path):
+    from ccedit_amd.sgm_compat import build_network, build_vae
+    from ccedit_amd.utils.synth import fill_module_
+    torch.set_grad_enabled(False)
+    dev = torch.device("cuda")
+    T, H, W = 17, 64, 96
+    w = build_network(dev)
+    fill_module_(w, prefix="model.")
+    w.diffusion_model.pack(dev)
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(1, 4, T, H, W, generator=g)
+    xb = torch.randn(1, 4, T, H, W, generator=g)
+    cc, cu = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
+    hint = (torch.rand(1, 1, T, 8 * H, 8 * W, generator=g) * 2 - 1).repeat(1, 3, 1, 1, 1)
+    t = torch.tensor([601, 601], dtype=torch.int64, device=dev)
+
+    def run(xa, xb_, ca, cb):
+        c = dict(crossattn=torch.cat([ca, cb]).to(dev), control_hint=torch.cat([hint, hint]).to(dev))
+        return w(torch.cat([xa, xb_]).to(dev), t, c).float().cpu().numpy()
+
+    out = dict(eps=run(x, x, cu, cc),                 # the CFG pair of the benchmark: same latent, two prompts
+               eps_same=run(x, x, cc, cc),            # identical halves -> identical predictions
+               eps_other=run(x, xb, cu, cc))          # clips do not interact: half 0 must not change
+    del w
+    torch.cuda.empty_cache()
+    vae = build_vae(dev)
+    fill_module_(vae, prefix="first_stage_model.")
+    vae.pack(dev)
+    z = torch.randn(1, 4, 3, H, W, generator=g).to(dev)           # 3 frames of the full 512x768 size
+    out["frames"] = vae.decode(z).float().cpu().numpy()
+    np.savez(out_path, **out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

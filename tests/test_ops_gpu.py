@@ -181,8 +181,8 @@ def test_conv3x3_lds_halo(cin, cout, h, w, tile):
     st = ops.gn_stats_of(y, h * w)
     if cout >= 256 and (h * w) % 128 == 0:
         yf = y.float().view(n, h * w, 32, cout // 32)
-        assert torch.allclose(st[..., 0], yf.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
-        assert torch.allclose(st[..., 1], (yf * yf).sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+        assert torch.allclose(st[..., 0].float(), yf.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+        assert torch.allclose(st[..., 1].float(), (yf * yf).sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
     ys = ops.conv2d(_nhwc(x), pw, act=1, tile=tile)
     _close(_nchw(ys), F.silu(F.conv2d(x, wt, b, padding=1)), what="halo conv + SiLU")
 
@@ -236,8 +236,8 @@ def test_gemm_fused_groupnorm_statistics(tile, cout):
     assert st is not None and st.shape == (n, 32, 2)
     yf = y.float().view(n, h * w, 32, cout // 32)
     ref_sum, ref_sq = yf.sum(dim=(1, 3)), (yf * yf).sum(dim=(1, 3))
-    assert torch.allclose(st[..., 0], ref_sum, rtol=1e-4, atol=1e-2), (st[..., 0] - ref_sum).abs().max()
-    assert torch.allclose(st[..., 1], ref_sq, rtol=1e-4, atol=1e-2), (st[..., 1] - ref_sq).abs().max()
+    assert torch.allclose(st[..., 0].float(), ref_sum, rtol=1e-4, atol=1e-2), (st[..., 0].float() - ref_sum).abs().max()
+    assert torch.allclose(st[..., 1].float(), ref_sq, rtol=1e-4, atol=1e-2), (st[..., 1].float() - ref_sq).abs().max()
     g, be = (_rnd(cout, seed=6) * 0.1 + 1).cuda(), (_rnd(cout, seed=7) * 0.1).cuda()
     fused = ops.groupnorm_spatial(y, g, be, 1e-5, True)
     two_pass = ops.groupnorm_spatial(y.clone(), g, be, 1e-5, True)
@@ -247,18 +247,18 @@ def test_gemm_fused_groupnorm_statistics(tile, cout):
     z = ops.linear(tok.to(BF).cuda(), pack_weight(_rnd(cout, 128, seed=9, scale=128 ** -0.5)).to("cuda"),
                    gn_rows=h * w, tile=tile)
     zf = z.float().view(n, h * w, 32, cout // 32)
-    assert torch.allclose(ops.gn_stats_of(z, h * w)[..., 0], zf.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(ops.gn_stats_of(z, h * w)[..., 0].float(), zf.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
     wt3 = _rnd(cout, 128, 3, seed=10, scale=384 ** -0.5)
     zt = ops.conv_temporal(tok.to(BF).cuda().view(n, h, w, 128), n, pack_weight(wt3).to("cuda"), gn=True, tile=tile)
     ztf = zt.float().view(n, h * w, 32, cout // 32)
-    assert torch.allclose(ops.gn_stats_of(zt, h * w)[..., 1], (ztf * ztf).sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(ops.gn_stats_of(zt, h * w)[..., 1].float(), (ztf * ztf).sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
     small = ops.conv2d(_nhwc(_rnd(2, cin, 8, 8, seed=11)), pack_weight(wt, b).to("cuda"), gn=True)
     assert ops.gn_stats_of(small, 64) is None
     if tile <= 1:            # 384 pixels per frame (the 16x24 latent level): only the 128-pixel block shape qualifies
         x3 = _rnd(2, cin, 16, 24, seed=12)
         y3 = ops.conv2d(_nhwc(x3), pack_weight(wt, b).to("cuda"), gn=True, tile=tile)
         y3f = y3.float().view(2, 384, 32, cout // 32)
-        assert torch.allclose(ops.gn_stats_of(y3, 384)[..., 0], y3f.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+        assert torch.allclose(ops.gn_stats_of(y3, 384)[..., 0].float(), y3f.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
 
 
 def test_cat_add_fused_groupnorm_statistics():
@@ -271,8 +271,8 @@ def test_cat_add_fused_groupnorm_statistics():
     assert torch.equal(o, plain)
     st = ops.gn_stats_of(o, h * w)
     of = o.float().view(n, h * w, 32, (c1 + c2) // 32)
-    assert torch.allclose(st[..., 0], of.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
-    assert torch.allclose(st[..., 1], (of * of).sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[..., 0].float(), of.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[..., 1].float(), (of * of).sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
     o2 = ops.cat_add(a.to(BF).cuda(), bb.to(BF).cuda(), None, gn=True)
     assert torch.equal(o2, torch.cat([a.to(BF), bb.to(BF)], -1).cuda())
 
