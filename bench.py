@@ -185,7 +185,7 @@ def main():
         prof = ops.PROFILE.summary()
         if args.breakdown:
             for fam in ("tap_gemm", "attention"):
-                for shape, n, ms, tf in ops.PROFILE.by_shape(fam)[:40]:
+                for shape, n, ms, tf in ops.PROFILE.by_shape(fam)[:int(os.environ.get('CCEDIT_BREAKDOWN_ROWS', '40'))]:
                     print(f"{fam:9s} {str(shape):60s} x{n:3d} {ms:8.3f} ms {tf:7.1f} TF/s", file=sys.stderr)
         ops.PROFILE = None
         g = prof["tap_gemm"]
