@@ -35,6 +35,8 @@
 
 bool cc_conv_halo_applicable(const CcGemmDesc& d);        // convhalo.hip
 int cc_conv_halo_launch(const CcGemmDesc& d, hipStream_t s);
+bool cc_lin320_applicable(const CcGemmDesc& d);           // lin320.hip
+int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s);
 bool cc_small_conv_applicable(const CcGemmDesc& d);       // smallconv.hip
 int cc_small_conv_launch(const CcGemmDesc& d, hipStream_t s);
 
@@ -446,6 +448,12 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     if ((d.tile == 0 && halo_env) || d.tile == 8) {
         if (cc_conv_halo_applicable(d)) return cc_conv_halo_launch(d, s);
         CC_UNSUPPORTED(d.tile == 8, "ccedit_gemm: tile 8 (LDS-halo 3x3 conv) does not apply to this descriptor");
+    }
+    // K = 320 Linear over many pixels: weights resident in registers, activations streamed once (lin320.hip)
+    static const int l320_env = getenv("CCEDIT_LIN320") ? atoi(getenv("CCEDIT_LIN320")) : 1;    // 0: A/B against tap_gemm
+    if ((d.tile == 0 && l320_env && d.M >= 32768) || d.tile == 9) {
+        if (cc_lin320_applicable(d)) return cc_lin320_launch(d, s);
+        CC_UNSUPPORTED(d.tile == 9, "ccedit_gemm: tile 9 (register-resident weights, K = 320) does not apply to this descriptor");
     }
     CC_UNSUPPORTED(d.tile == 6 && d.N % 320 != 0, "ccedit_gemm: tile 6 (320-channel block shape) needs N %% 320 == 0 (N=%d)", d.N);
     int tile = d.tile;

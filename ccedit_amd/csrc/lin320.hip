@@ -1,0 +1,240 @@
+// Linear layers with K = 320 (the 64x96 level: to_q / to_k,v / proj_in and the GEGLU projection) with the WEIGHTS HELD
+// IN REGISTERS and the epilogue of tile i running under the MFMAs of tile i+1 — gfx950.
+//
+// These GEMMs are bound by the L2 -> LDS path of a CU (~20 B/clk), and every LDS-tiled shape re-stages either
+// the activation tile per channel tile or the weight tile per pixel tile.  With K = 320 a 320-channel slice of W is
+// 205 KB: too big for LDS, but as MFMA A-operand fragments it fits the register file of a CU: eight waves, wave (g, h)
+// holding channel rows [96 g, 96 g + 96) x k-steps [10 h, 10 h + 10) = 30 fragments (120 VGPRs) — two waves per SIMD.
+// A persistent workgroup (one per CU) loads its slice once, then streams 32-pixel activation tiles (global -> LDS by DMA,
+// three buffers, 640-byte rows).  Per tile: the 30 MFMAs of a wave are ISSUED, then — while they execute — the wave does
+// its share of the previous tile's output pass (staging tile -> bias / GEGLU -> bf16 -> whole-row stores); then the two K
+// halves meet in this tile's staging tile (half 1 stores, barrier, half 0 adds).
+// Slices of wider layers (640 / 960 / 2560 rows) run as different workgroups of one XCD on the SAME pixel tiles at the
+// same time, so the activation rows come out of that XCD's L2 for all but the first.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+__device__ __attribute__((aligned(64))) char g_zero_page_w[64];
+
+constexpr int kK = 320, kKS = kK / 16;          // 20 MFMA k-steps, 10 per K half
+constexpr int kP = 32;                          // pixels per tile
+constexpr int kRS = kK * 2 + 16;                // LDS row stride of the activation tile: 164 dwords (36 banks apart)
+constexpr int kGPR = kRS / 16;                  // 41 sixteen-byte slots per padded row
+constexpr int kWaveIssues = (kP * kGPR + 63) / 64;          // 21 wave-wide DMA instructions per tile (the last half used)
+constexpr int kXBuf = kWaveIssues * 1024;       // 21,504 B
+constexpr int kSlice = 320;                     // channels per workgroup (MFMA rows: 4 wave groups x 3 tiles x 32 = 384)
+constexpr int kERow = kSlice * 4 + 16;          // fp32 staging row of one pixel: 1296 B (324 dwords: rows 4 banks apart)
+constexpr int kStage = kP * kERow;              // 41,472 B
+constexpr int kNT = 512;
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool GEGLU>
+__global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int nslice, int pt_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sS = smem;                      // [2][kStage] fp32 staging tiles
+    char* const sX = smem + 2 * kStage;         // [3][kXBuf]: tile i is consumed while tiles i+1 and i+2 are in flight
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave & 3, khalf = wave >> 2;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // workgroup b runs on XCD b % 8: its 32 workgroups take (32 / nslice) pixel lanes x nslice channel slices
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int lanes = 32 / nslice;
+    const int slice = j % nslice, plane = j / nslice;
+    if (plane >= lanes) return;
+    const int per_xcd = (pt_n + 7) >> 3;
+    const int pt_lo = xcd * per_xcd, pt_hi = min(pt_lo + per_xcd, pt_n);
+    int pt = pt_lo + plane;
+    if (pt >= pt_hi) return;
+    const int ch0 = slice * kSlice;
+
+    // ---- the weight slice: A-operand fragments, resident for the whole kernel ----
+    bf16x8 wf[3][kKS / 2];
+    {
+        const bf16* __restrict__ Wp = (const bf16*)d.W;
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti) {
+            const int rs = grp * 96 + ti * 32 + l31;                  // row inside the slice; rows >= 320 are padding
+            const bool ok = rs < kSlice && ch0 + rs < d.N;
+            const bf16* row = ok ? Wp + (size_t)(ch0 + rs) * d.Kpad + khalf * (kK / 2) + hi * 8 : (const bf16*)g_zero_page_w;
+#pragma unroll
+            for (int ks = 0; ks < kKS / 2; ++ks) wf[ti][ks] = *(const bf16x8*)(ok ? row + ks * 16 : row);
+        }
+    }
+
+    // ---- output pass plan: task t = tid + 512 k covers 16 fp32 columns... (plain: 8 channels; GEGLU: 8 values + 8 gates)
+    //      of one staged pixel row.  Tasks per tile: 32 rows x (GEGLU ? 20 : 40). ----
+    constexpr int kCols = GEGLU ? 16 : 8;       // staged channels per task
+    constexpr int kTPR = kSlice / kCols;        // tasks per row: 20 / 40
+    constexpr int kTasks = kP * kTPR;           // 640 / 1280
+    constexpr int kTI = (kTasks + kNT - 1) / kNT;                // 2 / 3 tasks per thread
+    int trow[kTI], tcol[kTI];                   // staged row / first staged column of this thread's tasks (row -1: none)
+    float tb[kTI][kCols];                       // bias of those columns (the channel slice never changes)
+#pragma unroll
+    for (int k = 0; k < kTI; ++k) {
+        const int t = tid + kNT * k;
+        trow[k] = t < kTasks ? t / kTPR : -1;
+        tcol[k] = (t % kTPR) * kCols;
+#pragma unroll
+        for (int e = 0; e < kCols; ++e) tb[k][e] = (d.bias && t < kTasks) ? d.bias[ch0 + tcol[k] + e] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < kTI; ++k)
+#pragma unroll
+        for (int e = 0; e < kCols; ++e) asm volatile("" ::"v"(tb[k][e]));      // consumed here: no vmcnt wait later
+
+    // ---- activation tile staging: the DMA writes LDS lane-linearly (64 consecutive 16-byte slots per wave instruction);
+    //      slot n of the tile = row n / 41, granule n % 41 (granule 40 = row padding) ----
+    const bf16* __restrict__ Ap = (const bf16*)d.A;
+    constexpr int kIssues = (kWaveIssues + 7) / 8;             // 3 per thread
+    int srow[kIssues], soff[kIssues];
+#pragma unroll
+    for (int i = 0; i < kIssues; ++i) {
+        const int n = (i * 8 + wave) * 64 + lane;
+        const int r = n / kGPR, g = n - r * kGPR;
+        const bool ok = r < kP && g < kK / 8;
+        srow[i] = ok ? r : (1 << 30);
+        soff[i] = ok ? r * d.lda + g * 8 : 0;
+    }
+    auto stage = [&](int ptile, int buf) {
+        const int64_t pix0 = (int64_t)ptile * kP;
+        const bf16* base = Ap + pix0 * d.lda;
+        const int64_t left = d.M - pix0;
+#pragma unroll
+        for (int i = 0; i < kIssues; ++i) {
+            if (i * 8 + wave < kWaveIssues) {    // wave-uniform
+                const void* src = srow[i] < left ? (const void*)(base + soff[i]) : (const void*)g_zero_page_w;
+                glds16(src, sX + buf * kXBuf + (i * 8 + wave) * 1024);
+            }
+        }
+    };
+    // output pass of tile `optile` from staging tile `sb`: read the sums, bias / GEGLU, bf16, 16-byte stores
+    auto output_pass = [&](int optile, int sb) {
+        const int64_t pix0 = (int64_t)optile * kP;
+        char* const st = sS + sb * kStage;
+#pragma unroll
+        for (int k = 0; k < kTI; ++k) {
+            if (trow[k] < 0) continue;
+            float* src = (float*)(st + trow[k] * kERow + tcol[k] * 4);
+            f32x4 v[kCols / 4];
+#pragma unroll
+            for (int q = 0; q < kCols / 4; ++q) {
+                v[q] = *(f32x4*)(src + 4 * q);
+            }
+            const int64_t m = pix0 + trow[k];
+            if (m >= d.M) continue;
+            bf16x8 o;
+            if constexpr (GEGLU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    o[e] = f2bf((v[e >> 2][e & 3] + tb[k][e]) * gelu_erf_f(v[2 + (e >> 2)][e & 3] + tb[k][8 + e]));
+                *(bf16x8*)((bf16*)d.out + (size_t)m * d.ldc + ((ch0 + tcol[k]) >> 1)) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e >> 2][e & 3] + tb[k][e]);
+                *(bf16x8*)((bf16*)d.out + (size_t)m * d.ldc + ch0 + tcol[k]) = o;
+            }
+        }
+    };
+
+    const int my_issues = (2 * 8 + wave < kWaveIssues) ? 3 : 2;      // DMA instructions of this wave per tile
+    stage(pt, 0);
+    if (pt + lanes < pt_hi) stage(pt + lanes, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int buf = 0, sb = 0, prev_pt = -1;
+    for (; pt < pt_hi; pt += lanes) {
+        // tile `pt` has landed for every wave; the sums of tile pt-1 are complete in staging tile sb^1; staging tile sb has
+        // been read out (tile pt-2); the X buffer of tile pt-1 is free
+        lds_barrier();
+        const bool more = pt + 2 * lanes < pt_hi;
+        if (more) stage(pt + 2 * lanes, buf == 0 ? 2 : buf - 1);      // (buf + 2) % 3
+
+        f32x16 acc[3];
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+        const char* xb = sX + buf * kXBuf + l31 * kRS + khalf * kK + hi * 16;
+#pragma unroll
+        for (int ks = 0; ks < kKS / 2; ++ks) {
+            const bf16x8 x0 = *(const bf16x8*)(xb + ks * 32);
+#pragma unroll
+            for (int ti = 0; ti < 3; ++ti) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ti][ks], x0, acc[ti], 0, 0, 0);
+        }
+        // Tile pt+1 (staged one iteration ago) must have landed before the next loop-top barrier.  Waited for HERE, before
+        // this iteration's stores are issued: loads complete in order, so once at most `my_issues` operations (the DMA just
+        // issued for tile pt+2) are outstanding, tile pt+1 is complete — and so are the previous output pass's stores, which
+        // share the counter but have had a whole iteration to drain.
+        if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (my_issues == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        // while the MFMAs execute: the previous tile's output pass
+        if (prev_pt >= 0) output_pass(prev_pt, sb ^ 1);
+
+        // the two K halves meet in the staging tile: half 1 stores its accumulators, barrier, half 0 adds its own on top.
+        // Register j of lane (pixel l31, hi) of tile ti is channel 96 grp + 32 ti + (j & 3) + 8 (j >> 2) + 4 hi; 16-byte
+        // accesses, rows 1296 B apart: conflict-free like the shared epilogue's staging.
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (khalf == 1 - pass) {
+                char* const st = sS + sb * kStage + l31 * kERow;
+#pragma unroll
+                for (int ti = 0; ti < 3; ++ti) {
+                    const int cb = grp * 96 + ti * 32 + 4 * hi;
+                    if (cb < kSlice) {           // 320 = 3 * 96 + 32: wave group 3 keeps its first tile only
+#pragma unroll
+                        for (int jq = 0; jq < 4; ++jq) {
+                            f32x4 v = {acc[ti][jq * 4 + 0], acc[ti][jq * 4 + 1], acc[ti][jq * 4 + 2], acc[ti][jq * 4 + 3]};
+                            f32x4* dst = (f32x4*)(st + (cb + 8 * jq) * 4);
+                            if (pass == 1) v += *dst;
+                            *dst = v;
+                        }
+                    }
+                }
+            }
+            if (pass == 0) lds_barrier();
+        }
+        prev_pt = pt;
+        buf = buf == 2 ? 0 : buf + 1;
+        sb ^= 1;
+    }
+    lds_barrier();
+    output_pass(prev_pt, sb ^ 1);
+}
+
+}  // namespace
+
+// bias, GEGLU or no activation, bf16 out, no residual / group bias / statistics (the other K = 320 layers keep tap_gemm)
+bool cc_lin320_applicable(const CcGemmDesc& d) {
+    return d.mode == CCEDIT_GEMM_LINEAR && d.taps == 1 && d.A2 == nullptr && d.Cin == kK && d.Kpad == kK &&
+           d.N % kSlice == 0 && d.N / kSlice <= 8 && d.gn_stats == nullptr && d.res1 == nullptr && d.res2 == nullptr &&
+           d.group_bias == nullptr && !d.out_f32 && (d.act == CCEDIT_ACT_NONE || d.act == CCEDIT_ACT_GEGLU) && d.ldc % 8 == 0;
+}
+
+int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s) {
+    const int lds = 2 * kStage + 3 * kXBuf;
+    const bool geglu = d.act == CCEDIT_ACT_GEGLU;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)lin320_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lin320_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            cc_set_error("hipFuncSetAttribute(lin320): %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    const int64_t pt_n = (d.M + kP - 1) / kP;
+    if (pt_n > 2147483647LL) {
+        cc_set_error("ccedit_gemm: grid too large");
+        return CCEDIT_EUNSUPPORTED;
+    }
+    if (geglu) hipLaunchKernelGGL(lin320_kernel<true>, dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
+    else hipLaunchKernelGGL(lin320_kernel<false>, dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
+    return cc_launch_status("lin320_kernel");
+}

@@ -217,6 +217,36 @@ def test_conv3x3_upsample_and_concat():
     _close(_nchw(y), F.conv2d(torch.cat([x, x2], 1), wt2, b, padding=1), what="dual-source conv3x3")
 
 
+@pytest.mark.parametrize("m,n", [(1000, 320), (130, 960), (64, 640), (33000, 320), (40000, 2560), (70000, 960)])
+def test_linear_k320_register_resident_weights(m, n):
+    """tile 9 = lin320_kernel (lin320.hip): K = 320, a 320-channel weight slice lives in registers as MFMA fragments (two
+    K halves in two wave sets), 32-pixel activation tiles stream past it and the output pass of a tile runs under the MFMAs
+    of the next.  Bias, GEGLU, strided operands, tail in M, slices in N."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    k = 320
+    x, w, b = _rnd(m, k, seed=1), _rnd(n, k, seed=2, scale=k ** -0.5), _rnd(n, seed=3)
+    pw = pack_weight(w, b).to("cuda")
+    xc = x.to(BF).cuda()
+    tile = 0 if m >= 32768 else 9                      # large M: the automatic dispatch must pick it on its own
+    ref = F.linear(x, w, b)
+    _close(ops.linear(xc, pw, tile=tile), ref, what=f"lin320 {m}x{n}")
+    _close(ops.linear(xc, pack_weight(w).to("cuda"), tile=tile), F.linear(x, w), what="lin320 no bias")
+    wide = torch.zeros(m, 2 * n, dtype=BF, device="cuda")
+    xs = torch.cat([_rnd(m, 64, seed=9), x], dim=1).to(BF).cuda()
+    ops.linear(xs[:, 64:], pw, out=wide[:, n:], tile=tile)
+    _close(wide[:, n:], ref, what="lin320 strided source / out")
+    assert wide[:, :n].abs().max().item() == 0
+    if n <= 1280:
+        wg, bg = _rnd(2 * n, k, seed=12, scale=k ** -0.5), _rnd(2 * n, seed=13)
+        a, g = F.linear(x, wg, bg).chunk(2, dim=-1)
+        _close(ops.linear(xc, pack_weight(wg, bg, geglu=True).to("cuda"), tile=tile), a * F.gelu(g), what="lin320 GEGLU")
+    if tile == 9:                                      # epilogues it does not implement are refused, not mis-computed
+        with pytest.raises(Exception):
+            ops.linear(xc, pw, res1=torch.zeros(m, n, dtype=BF, device="cuda"), tile=9)
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("cout", [320, 640, 256])
 def test_gemm_fused_groupnorm_statistics(tile, cout):
