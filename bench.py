@@ -190,7 +190,7 @@ def main():
         ops.PROFILE = None
         g = prof["tap_gemm"]
         ach = g["flops"] / (g["total_ms"] * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="ccedit_gemm (tap_gemm_kernel, conv_halo_kernel, small_conv3x3_kernel)", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+        roof = dict(bound="mfma", kernel="ccedit_gemm (tap_gemm_kernel, conv_halo_kernel, lin320_kernel, small_conv3x3_kernel)", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None, launches=g["launches"],
                     avg_launch_us=round(g["avg_us"], 2), algorithmic_flops_per_step=g["flops"])
         # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 PMC passes of this
