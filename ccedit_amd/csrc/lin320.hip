@@ -31,8 +31,9 @@ constexpr int kNT = 512;
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool GEGLU>
+template <bool GEGLU, bool RES>
 __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int nslice, int pt_n) {
+    static_assert(!(GEGLU && RES), "the GEGLU projection has no residual");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sS = smem;                      // [2][kStage] fp32 staging tiles
     char* const sX = smem + 2 * kStage;         // [3][kXBuf]: tile i is consumed while tiles i+1 and i+2 are in flight
@@ -74,19 +75,15 @@ __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int 
     constexpr int kTasks = kP * kTPR;           // 640 / 1280
     constexpr int kTI = (kTasks + kNT - 1) / kNT;                // 2 / 3 tasks per thread
     int trow[kTI], tcol[kTI];                   // staged row / first staged column of this thread's tasks (row -1: none)
-    float tb[kTI][kCols];                       // bias of those columns (the channel slice never changes)
 #pragma unroll
     for (int k = 0; k < kTI; ++k) {
         const int t = tid + kNT * k;
         trow[k] = t < kTasks ? t / kTPR : -1;
         tcol[k] = (t % kTPR) * kCols;
-#pragma unroll
-        for (int e = 0; e < kCols; ++e) tb[k][e] = (d.bias && t < kTasks) ? d.bias[ch0 + tcol[k] + e] : 0.f;
     }
-#pragma unroll
-    for (int k = 0; k < kTI; ++k)
-#pragma unroll
-        for (int e = 0; e < kCols; ++e) asm volatile("" ::"v"(tb[k][e]));      // consumed here: no vmcnt wait later
+    // bias of the slice: 320 floats in LDS (the channel slice never changes; registers are needed for the weights)
+    float* const sBias = (float*)(smem + 2 * kStage + 3 * kXBuf);
+    if (tid < kSlice) sBias[tid] = d.bias ? d.bias[ch0 + tid] : 0.f;
 
     // ---- activation tile staging: the DMA writes LDS lane-linearly (64 consecutive 16-byte slots per wave instruction);
     //      slot n of the tile = row n / 41, granule n % 41 (granule 40 = row padding) ----
@@ -114,6 +111,16 @@ __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int 
         }
     };
     // output pass of tile `optile` from staging tile `sb`: read the sums, bias / GEGLU, bf16, 16-byte stores
+    bf16x8 rr[kTI];                             // RES: residual granules of the tile whose output pass comes next
+    auto load_residual = [&](int optile) {
+        const int64_t pix0 = (int64_t)optile * kP;
+        const bf16* __restrict__ r1 = (const bf16*)d.res1;
+#pragma unroll
+        for (int k = 0; k < kTI; ++k) {
+            const int64_t m = pix0 + trow[k];
+            if (trow[k] >= 0 && m < d.M) rr[k] = *(const bf16x8*)(r1 + (size_t)m * d.ldr1 + ch0 + tcol[k]);
+        }
+    };
     auto output_pass = [&](int optile, int sb) {
         const int64_t pix0 = (int64_t)optile * kP;
         char* const st = sS + sb * kStage;
@@ -121,10 +128,11 @@ __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int 
         for (int k = 0; k < kTI; ++k) {
             if (trow[k] < 0) continue;
             float* src = (float*)(st + trow[k] * kERow + tcol[k] * 4);
-            f32x4 v[kCols / 4];
+            f32x4 v[kCols / 4], tb[kCols / 4];
 #pragma unroll
             for (int q = 0; q < kCols / 4; ++q) {
                 v[q] = *(f32x4*)(src + 4 * q);
+                tb[q] = *(const f32x4*)(sBias + tcol[k] + 4 * q);
             }
             const int64_t m = pix0 + trow[k];
             if (m >= d.M) continue;
@@ -132,11 +140,11 @@ __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int 
             if constexpr (GEGLU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    o[e] = f2bf((v[e >> 2][e & 3] + tb[k][e]) * gelu_erf_f(v[2 + (e >> 2)][e & 3] + tb[k][8 + e]));
+                    o[e] = f2bf((v[e >> 2][e & 3] + tb[e >> 2][e & 3]) * gelu_erf_f(v[2 + (e >> 2)][e & 3] + tb[2 + (e >> 2)][e & 3]));
                 *(bf16x8*)((bf16*)d.out + (size_t)m * d.ldc + ((ch0 + tcol[k]) >> 1)) = o;
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e >> 2][e & 3] + tb[k][e]);
+                for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e >> 2][e & 3] + tb[e >> 2][e & 3] + (RES ? bf2f(rr[k][e]) : 0.f));
                 *(bf16x8*)((bf16*)d.out + (size_t)m * d.ldc + ch0 + tcol[k]) = o;
             }
         }
@@ -151,6 +159,13 @@ __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int 
         // tile `pt` has landed for every wave; the sums of tile pt-1 are complete in staging tile sb^1; staging tile sb has
         // been read out (tile pt-2); the X buffer of tile pt-1 is free
         lds_barrier();
+        if constexpr (RES) {
+            // the residual rows loaded at the end of the previous iteration are consumed HERE, while nothing recent is in
+            // the vmcnt queue: the compiler's wait for them drains loads and stores alike, and later in the iteration it
+            // would wait for the DMA just issued
+#pragma unroll
+            for (int k = 0; k < kTI; ++k) asm volatile("" : "+v"(rr[k]));
+        }
         const bool more = pt + 2 * lanes < pt_hi;
         if (more) stage(pt + 2 * lanes, buf == 0 ? 2 : buf - 1);      // (buf + 2) % 3
 
@@ -199,6 +214,7 @@ __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int 
             }
             if (pass == 0) lds_barrier();
         }
+        if constexpr (RES) load_residual(pt);     // for this tile's output pass, one iteration from now
         prev_pt = pt;
         buf = buf == 2 ? 0 : buf + 1;
         sb ^= 1;
@@ -207,22 +223,25 @@ __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int 
     output_pass(prev_pt, sb ^ 1);
 }
 
+
 }  // namespace
 
 // bias, GEGLU or no activation, bf16 out, no residual / group bias / statistics (the other K = 320 layers keep tap_gemm)
 bool cc_lin320_applicable(const CcGemmDesc& d) {
     return d.mode == CCEDIT_GEMM_LINEAR && d.taps == 1 && d.A2 == nullptr && d.Cin == kK && d.Kpad == kK &&
-           d.N % kSlice == 0 && d.N / kSlice <= 8 && d.gn_stats == nullptr && d.res1 == nullptr && d.res2 == nullptr &&
-           d.group_bias == nullptr && !d.out_f32 && (d.act == CCEDIT_ACT_NONE || d.act == CCEDIT_ACT_GEGLU) && d.ldc % 8 == 0;
+           d.N % kSlice == 0 && d.N / kSlice <= 8 && d.gn_stats == nullptr && d.res2 == nullptr && d.group_bias == nullptr && !d.out_f32 &&
+           (d.act == CCEDIT_ACT_NONE || (d.act == CCEDIT_ACT_GEGLU && d.res1 == nullptr)) && d.ldc % 8 == 0 &&
+           (d.res1 == nullptr || d.ldr1 % 8 == 0);
 }
 
 int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s) {
-    const int lds = 2 * kStage + 3 * kXBuf;
+    const int lds = 2 * kStage + 3 * kXBuf + kSlice * 4;
     const bool geglu = d.act == CCEDIT_ACT_GEGLU;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lin320_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lin320_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)lin320_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lin320_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lin320_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             cc_set_error("hipFuncSetAttribute(lin320): %s", hipGetErrorString(e));
             return (int)e;
@@ -234,7 +253,8 @@ int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s) {
         cc_set_error("ccedit_gemm: grid too large");
         return CCEDIT_EUNSUPPORTED;
     }
-    if (geglu) hipLaunchKernelGGL(lin320_kernel<true>, dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
-    else hipLaunchKernelGGL(lin320_kernel<false>, dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
+    if (geglu) hipLaunchKernelGGL((lin320_kernel<true, false>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
+    else if (d.res1) hipLaunchKernelGGL((lin320_kernel<false, true>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
+    else hipLaunchKernelGGL((lin320_kernel<false, false>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
     return cc_launch_status("lin320_kernel");
 }

@@ -242,9 +242,11 @@ def test_linear_k320_register_resident_weights(m, n):
         wg, bg = _rnd(2 * n, k, seed=12, scale=k ** -0.5), _rnd(2 * n, seed=13)
         a, g = F.linear(x, wg, bg).chunk(2, dim=-1)
         _close(ops.linear(xc, pack_weight(wg, bg, geglu=True).to("cuda"), tile=tile), a * F.gelu(g), what="lin320 GEGLU")
+    r1 = _rnd(m, n, seed=4)
+    _close(ops.linear(xc, pw, res1=r1.to(BF).cuda(), tile=tile), ref + r1, what="lin320 residual")
     if tile == 9:                                      # epilogues it does not implement are refused, not mis-computed
         with pytest.raises(Exception):
-            ops.linear(xc, pw, res1=torch.zeros(m, n, dtype=BF, device="cuda"), tile=9)
+            ops.linear(xc, pw, act=1, tile=9)
 
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
