@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage: pmc_l320.sh "<counters...>"  (one rocprofv3 --pmc pass, kernel-trace only), per-kernel averages for lin320_kernel
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/pm1
+rocprofv3 --pmc $1 --kernel-trace --output-format csv -d /tmp/pm1 -- python $GRAFT_REPO_ROOT/tools/exp/l320_time.py > /dev/null 2>&1
+python - <<'PY'
+import csv, glob, collections
+acc = collections.defaultdict(lambda: [0, 0.0])
+for f in glob.glob("/tmp/pm1/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        kn = r["Kernel_Name"]
+        if "lin320" in kn and ("false, false" in kn or "Lb0ELb0" in kn):
+            a = acc[r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+for k, (n, v) in sorted(acc.items()):
+    print(f"  {k:40s} avg/launch {v/n:16.1f}  (n={n})")
+PY
