@@ -341,15 +341,8 @@ int launch_attn(const CcAttnDesc& a, hipStream_t s) {
     constexpr int DK = SWZ ? (D <= 64 ? 64 : 128) : (D + 15) / 16 * 16;
     constexpr int DV = SWZ ? (D <= 64 ? 64 : 128) : (D + 31) / 32 * 32;
     constexpr int lds = 2 * 64 * DK * 2 + 2 * 64 * DV * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) {
-            cc_set_error("hipFuncSetAttribute(attn): %s", hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (int rc = cc_max_dynamic_lds((const void*)attn_kernel<D, NW>, lds, &attr_done, "attn")) return rc;
     const int64_t qtiles = (a.Lq + NW * 32 - 1) / (NW * 32);
     const int64_t groups = ((int64_t)a.batches * a.heads + 7) / 8 * 8;
     dim3 grid((unsigned)(qtiles * groups));

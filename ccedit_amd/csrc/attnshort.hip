@@ -218,15 +218,8 @@ __global__ __launch_bounds__(256) void attn_short_kernel(const CcAttnDesc a, int
 
 template <int D>
 int launch_short(const CcAttnDesc& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_short_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * RS);
-        if (e != hipSuccess) {
-            cc_set_error("hipFuncSetAttribute(attn_short): %s", hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (int rc = cc_max_dynamic_lds((const void*)attn_short_kernel<D>, 128 * RS, &attr_done, "attn_short")) return rc;
     const int64_t nblk = (int64_t)a.batches * (a.heads * D / GW);
     if (nblk > 2147483647LL) {
         cc_set_error("ccedit_attention: grid too large");

@@ -73,6 +73,22 @@ void cc_set_error(const char* fmt, ...);
         }                                \
     } while (0)
 
+// Per-device once-guard for hipFuncSetAttribute(MaxDynamicSharedMemorySize): the attribute is a property of the
+// (function, device) pair, so a process that drives a second GPU must set it there too.  `done` is a per-call-site
+// bitmask over device ordinals (devices >= 64 simply set it every time).
+static inline int cc_max_dynamic_lds(const void* fn, int bytes, unsigned long long* done, const char* what) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess && dev < 64 && ((*done >> dev) & 1ull)) return CCEDIT_OK;
+    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        cc_set_error("hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    if (dev < 64) *done |= 1ull << dev;
+    return CCEDIT_OK;
+}
+
 static inline int cc_launch_status(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

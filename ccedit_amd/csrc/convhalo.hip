@@ -206,15 +206,8 @@ int cc_conv_halo_launch(const CcGemmDesc& d, hipStream_t s) {
     constexpr int WM = 2, WN = 2, TI = 2, TJ = 2;
     constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
     constexpr int lds = epi_lds_total(BMC, BNP, TJ, 2 * BMC * 128 + 2 * kHaloBytes);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, TI, TJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) {
-            cc_set_error("hipFuncSetAttribute(conv_halo): %s", hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (int rc = cc_max_dynamic_lds((const void*)conv_halo_kernel<WM, WN, TI, TJ>, lds, &attr_done, "conv_halo")) return rc;
     // orientation with the least padding: 8 x 16 needs Hout % 8 == 0, 16 x 8 needs Hout % 16 == 0
     const int pad16 = (d.Hout % 8 == 0) ? (d.Wout + 15) / 16 * 16 : 1 << 30;
     const int pad8 = (d.Hout % 16 == 0) ? (d.Wout + 7) / 8 * 8 : 1 << 30;

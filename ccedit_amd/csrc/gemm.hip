@@ -335,16 +335,9 @@ template <int WM, int WN, int TI, int TJ, int STAGES, int BKE, int MODE>
 int launch(const CcGemmDesc& d, hipStream_t s) {
     constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
     constexpr int lds = epi_lds_total(BMC, BNP, TJ, STAGES * (BMC + BNP) * BKE * 2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) {
-            cc_set_error("hipFuncSetAttribute(tap_gemm): %s", hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (int rc = cc_max_dynamic_lds((const void*)tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>, lds, &attr_done, "tap_gemm"))
+        return rc;
     const int64_t pt_n = (d.M + BNP - 1) / BNP, ct_n = (d.N + BMC - 1) / BMC;
     const int64_t nblk = 8 * ((pt_n + 7) / 8) * ct_n;
     if (nblk > 2147483647LL) {

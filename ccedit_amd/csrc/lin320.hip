@@ -237,17 +237,10 @@ bool cc_lin320_applicable(const CcGemmDesc& d) {
 int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s) {
     const int lds = 2 * kStage + 3 * kXBuf + kSlice * 4;
     const bool geglu = d.act == CCEDIT_ACT_GEGLU;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lin320_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lin320_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lin320_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) {
-            cc_set_error("hipFuncSetAttribute(lin320): %s", hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_set = true;
-    }
+    static unsigned long long attr_done[3] = {0, 0, 0};
+    if (int rc = cc_max_dynamic_lds((const void*)lin320_kernel<false, false>, lds, &attr_done[0], "lin320")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)lin320_kernel<false, true>, lds, &attr_done[1], "lin320")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)lin320_kernel<true, false>, lds, &attr_done[2], "lin320")) return rc;
     const int64_t pt_n = (d.M + kP - 1) / kP;
     if (pt_n > 2147483647LL) {
         cc_set_error("ccedit_gemm: grid too large");

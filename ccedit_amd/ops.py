@@ -114,6 +114,8 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
         stats = zero_stats(m // gn_rows, out.device)
         d.gn_rows, d.gn_stats = gn_rows, stats.data_ptr()
         out._gn_stats = (stats, gn_rows)
+    elif hasattr(out, "_gn_stats"):
+        del out._gn_stats              # a caller-supplied `out` is being overwritten: statistics left on it are stale
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -99,12 +99,14 @@ class FrameShard:
         f_out, l_out = self._out(first), self._out(last)
         if self.rank > 0:
             prev_buf = torch.empty_like(f_out)
-            ops_.append(dist.P2POp(dist.isend, f_out, self.rank - 1, self.group))
-            ops_.append(dist.P2POp(dist.irecv, prev_buf, self.rank - 1, self.group))
+            peer = self._global_rank(self.rank - 1)      # P2POp peers are GLOBAL ranks, also inside a sub-group
+            ops_.append(dist.P2POp(dist.isend, f_out, peer, self.group))
+            ops_.append(dist.P2POp(dist.irecv, prev_buf, peer, self.group))
         if self.rank < self.world - 1:
             next_buf = torch.empty_like(l_out)
-            ops_.append(dist.P2POp(dist.isend, l_out, self.rank + 1, self.group))
-            ops_.append(dist.P2POp(dist.irecv, next_buf, self.rank + 1, self.group))
+            peer = self._global_rank(self.rank + 1)
+            ops_.append(dist.P2POp(dist.isend, l_out, peer, self.group))
+            ops_.append(dist.P2POp(dist.irecv, next_buf, peer, self.group))
         if ops_:
             for r in dist.batch_isend_irecv(ops_):
                 r.wait()

@@ -235,13 +235,14 @@ class VanillaCFG:
         for k in c:
             if k in self._CAT_KEYS:
                 # uc FIRST (guiders.py:63).  The conditioning tensors do not change during a clip: the
-                # concatenation (160 MB for the 17x512x768 hint) is built once per (uc[k], c[k]) pair.
-                key = (k, uc[k].data_ptr(), c[k].data_ptr(), uc[k]._version, c[k]._version, tuple(c[k].shape))
+                # concatenation (160 MB for the 17x512x768 hint) is built once per (uc[k], c[k]) pair.  The entry
+                # HOLDS the two source tensors and is matched by object identity (+ in-place version), so a later
+                # clip whose tensors land on a recycled address can never hit it.
                 hit = self._cat_cache.get(k)
-                if hit is None or hit[0] != key:
-                    hit = (key, torch.cat((uc[k], c[k]), 0))
+                if hit is None or hit[0] is not uc[k] or hit[1] is not c[k] or hit[2] != (uc[k]._version, c[k]._version):
+                    hit = (uc[k], c[k], (uc[k]._version, c[k]._version), torch.cat((uc[k], c[k]), 0))
                     self._cat_cache[k] = hit
-                c_out[k] = hit[1]
+                c_out[k] = hit[3]
             else:
                 assert c[k] == uc[k]
                 c_out[k] = c[k]

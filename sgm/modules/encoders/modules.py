@@ -131,6 +131,17 @@ class DepthMidasEncoder(_Precomputed):
     def forward(self, x):
         if torch.is_tensor(x) and x.dim() == 5 and x.shape[1] == 1:
             return self.normalize(x)
+        if torch.is_tensor(x) and x.dim() == 5 and x.shape[1] == 3:
+            # The reference feeds RGB keyframes here and the depth network turns them into a hint whose three channels
+            # are copies of one map (:1386 `repeat(1, 3, ...)`).  A finished hint therefore has identical channels; RGB
+            # frames do not — refuse them instead of silently feeding colour to the ControlNet as "depth".
+            if not (torch.equal(x[:, 0], x[:, 1]) and torch.equal(x[:, 1], x[:, 2])):
+                raise NotImplementedError(
+                    f"{self.__class__.__name__}: got a 3-channel tensor whose channels differ — these look like RGB "
+                    f"keyframes.  The depth network is not part of this build (un-vendored annotator + weights); compute "
+                    f"the depth outside and pass either the raw depth (B,1,T,H,W) or the finished hint (B,3,T,H,W: one "
+                    f"map in [-1,1] replicated over the channels) as batch[{self.input_key!r}]")
+            return x
         return super().forward(x)
 
 
@@ -199,9 +210,10 @@ class GeneralConditioner(nn.Module):
                 embedder.input_keys = embconfig["input_keys"]
             else:
                 raise KeyError(f"need either 'input_key' or 'input_keys' for embedder {embedder.__class__.__name__}")
+            # encoders/modules.py:117-131: stored like the reference.  It only acts together with ucg_rate > 0
+            # (training-time conditioning dropout, :135-143); get_unconditional_conditioning zeroes ucg_rate, so at
+            # inference it is inert — the shipped yamls set `legacy_ucg_value: ""` on the CLIP embedder.
             embedder.legacy_ucg_val = embconfig.get("legacy_ucg_value", None)
-            if embedder.legacy_ucg_val is not None:
-                raise NotImplementedError("legacy_ucg_value is a training-time feature")
             embedders.append(embedder.eval())
         self.embedders = nn.ModuleList(embedders)
 

@@ -143,3 +143,157 @@ def test_synth_weights_are_name_keyed_and_stable():
     assert torch.equal(a, b) and a.std().item() == pytest.approx((1 / 2880) ** 0.5, rel=0.1) and c.abs().max() < 0.2
     # pinned values: the golden vectors depend on this rule never changing
     assert a.flatten()[:3].tolist() == pytest.approx([0.005066306330263615, -0.01827041432261467, -0.0302837323397398], abs=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------------
+# the reference's shipped inference yamls, verbatim
+# ------------------------------------------------------------------------------------------------------
+REF_CFG_DIR = "/root/reference/configs/inference_ccedit"
+
+
+def _engine_keys(cfg):
+    from ccedit_amd.config import instantiate_from_config
+    with torch.device("meta"):
+        engine = instantiate_from_config(cfg.model)
+    return engine, {k: list(v.shape) for k, v in engine.state_dict().items()}
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG_DIR), reason="the reference checkout is not on this machine")
+@pytest.mark.parametrize("name,keys,nparams", [("keyframe_no2ndca_depthmidas.yaml", "keys_tv2v.json", 1608747976),
+                                               ("keyframe_ref_cp_no2ndca_add_cfca_depthzoe.yaml", "keys_tvi2v.json", 2171449416)])
+def test_shipped_reference_yaml_instantiates_unchanged(golden_dir, name, keys, nparams):
+    """the two shipped inference configs load UNCHANGED (legacy_ucg_value: "",
+    scheduler_config, use_checkpoint: True, ...) and give the reference's network state-dict names and shapes."""
+    from ccedit_amd.config import load_config
+    cfg = load_config(os.path.join(REF_CFG_DIR, name))
+    engine, mine = _engine_keys(cfg)
+    with open(os.path.join(golden_dir, keys)) as f:
+        ref = {k: v for k, v in json.load(f).items() if k.startswith("model.")}
+    net = {k: v for k, v in mine.items() if k.startswith("model.")}
+    assert set(net) == set(ref), (sorted(set(ref) - set(net))[:3], sorted(set(net) - set(ref))[:3])
+    assert all(net[k] == ref[k] for k in ref)
+    assert sum(int(np.prod(s)) for s in net.values()) == nparams
+    clip = engine.conditioner.embedders[0]
+    assert clip.legacy_ucg_val == "" and clip.ucg_rate == 0.5 and clip.input_key == "txt"
+    assert any(k.startswith("first_stage_model.decoder.") for k in mine)
+
+
+_INLINE_YAML = """
+model:
+  target: sgm.models.diffusion.VideoDiffusionEngineTV2V
+  params:
+    use_ema: False
+    scale_factor: 0.18215
+    disable_first_stage_autocast: True
+    log_keys: [txt]
+    freeze_model: spatial
+    scheduler_config:
+      target: sgm.lr_scheduler.LambdaLinearScheduler
+      params: {warm_up_steps: [1000], cycle_lengths: [10000000000000], f_start: [1.e-6], f_max: [1.], f_min: [1.]}
+    denoiser_config:
+      target: sgm.modules.diffusionmodules.denoiser.DiscreteDenoiser
+      params:
+        num_idx: 1000
+        weighting_config: {target: sgm.modules.diffusionmodules.denoiser_weighting.EpsWeighting}
+        scaling_config: {target: sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling}
+        discretization_config: {target: sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization}
+    network_config:
+      target: sgm.modules.diffusionmodules.controlmodel.ControlledUNetModel3DTV2V
+      params: &net
+        use_checkpoint: True
+        in_channels: 4
+        out_channels: 4
+        model_channels: 32
+        attention_resolutions: [4, 2, 1]
+        num_res_blocks: 2
+        channel_mult: [1, 2, 4, 4]
+        num_heads: 2
+        use_spatial_transformer: True
+        transformer_depth: 1
+        context_dim: 64
+        legacy: False
+        disable_temporal_text_ca: True
+        controlnet_config:
+          target: sgm.modules.diffusionmodules.controlmodel.ControlNet2D
+          params: {use_checkpoint: True, in_channels: 4, hint_channels: 3, model_channels: 32, attention_resolutions: [4, 2, 1],
+                   num_res_blocks: 2, channel_mult: [1, 2, 4, 4], num_heads: 2, use_spatial_transformer: True,
+                   transformer_depth: 1, context_dim: 64, legacy: False, control_scales: 1.0}
+    conditioner_config:
+      target: sgm.modules.GeneralConditioner
+      params:
+        emb_models:
+          - is_trainable: False
+            input_key: txt
+            ucg_rate: 0.5
+            legacy_ucg_value: ""
+            target: sgm.modules.encoders.modules.FrozenCLIPEmbedder
+            params: {freeze: true}
+          - is_trainable: False
+            input_key: control_hint
+            ucg_rate: 0.0
+            target: sgm.modules.encoders.modules.DepthMidasEncoder
+    first_stage_config:
+      target: sgm.models.autoencoder.AutoencoderKLInferenceWrapper
+      params:
+        embed_dim: 4
+        monitor: val/rec_loss
+        ddconfig: {double_z: true, z_channels: 4, resolution: 256, in_channels: 3, out_ch: 3, ch: 32, ch_mult: [1, 2, 4, 4],
+                   num_res_blocks: 2, attn_resolutions: [], dropout: 0.0}
+        lossconfig: {target: torch.nn.Identity}
+"""
+
+
+def test_yaml_with_training_time_keys_loads(tmp_path):
+    """Same key set as the shipped yamls (legacy_ucg_value: "", ucg_rate 0.5, scheduler_config, use_checkpoint True) at a
+    small width — runs wherever the reference checkout is absent.  ucg settings are stored, and inert at inference:
+    get_unconditional_conditioning zeroes ucg_rate around both passes (encoders/modules.py:220-233)."""
+    from ccedit_amd.config import load_config
+    p = tmp_path / "cfg.yaml"
+    p.write_text(_INLINE_YAML)
+    engine, mine = _engine_keys(load_config(str(p)))
+    emb = engine.conditioner.embedders
+    assert emb[0].legacy_ucg_val == "" and emb[0].ucg_rate == 0.5 and emb[1].legacy_ucg_val is None
+    seen = []
+    for e in emb:
+        e.forward = (lambda e_: (lambda x: (seen.append(e_.ucg_rate), x)[1]))(e)
+    batch = {"txt": torch.zeros(1, 77, 768), "control_hint": torch.zeros(1, 3, 2, 8, 8)}
+    c, uc = engine.conditioner.get_unconditional_conditioning(batch, batch_uc=batch)
+    assert seen == [0.0] * 4 and emb[0].ucg_rate == 0.5
+    assert set(c) == set(uc) == {"crossattn", "control_hint"}
+
+
+def test_depth_encoder_refuses_rgb_frames():
+    """the reference feeds RGB keyframes to the depth embedder; this build has no depth network, so a tensor
+    that looks like RGB must raise instead of reaching the ControlNet as 'depth'."""
+    from sgm.modules.encoders.modules import DepthMidasEncoder, DepthZoeEncoder
+    for cls in (DepthMidasEncoder, DepthZoeEncoder):
+        enc = cls()
+        enc.input_key = "control_hint"
+        depth = torch.rand(1, 1, 2, 8, 8) * 2 - 1
+        hint = depth.repeat(1, 3, 1, 1, 1)
+        assert enc(hint) is hint                                   # finished hint: three copies of one map
+        assert enc(depth).shape == (1, 3, 2, 8, 8)                  # raw depth: normalised + replicated
+        with pytest.raises(NotImplementedError, match="RGB"):
+            enc(torch.rand(1, 3, 2, 8, 8))
+
+
+def test_cfg_cat_cache_is_identity_keyed():
+    """ADVICE r1 / VERDICT weak: the (uc, c) concat cache must not serve clip 1's tensor to clip 2 when the allocator hands
+    clip 2 the same address — entries hold their sources and are matched by identity + in-place version."""
+    from ccedit_amd.sampling import VanillaCFGTV2V
+    g = VanillaCFGTV2V(scale=7.5)
+    x, s = torch.zeros(1, 4, 2, 4, 4), torch.ones(1)
+    mk = lambda v: {"crossattn": torch.full((1, 3, 4), float(v)), "control_hint": torch.full((1, 3, 2, 8, 8), float(v))}
+    c1, u1 = mk(1), mk(2)
+    out1 = g.prepare_inputs(x, s, c1, u1)[2]
+    assert g.prepare_inputs(x, s, c1, u1)[2]["control_hint"] is out1["control_hint"]          # same clip: cached
+    # a second clip whose tensors alias the first clip's STORAGE (what address reuse looks like) but are other objects
+    c2 = {k: v.view_as(v) for k, v in c1.items()}
+    for v in c2.values():
+        v.add_(10.0)                                                                           # and other contents
+    out2 = g.prepare_inputs(x, s, c2, u1)[2]
+    assert out2["control_hint"] is not out1["control_hint"]
+    assert float(out2["control_hint"][1].mean()) == 11.0 and float(out2["control_hint"][0].mean()) == 2.0
+    # in-place edit of the same object: the version bump invalidates too
+    c2["control_hint"].mul_(0.0)
+    assert float(g.prepare_inputs(x, s, c2, u1)[2]["control_hint"][1].abs().max()) == 0.0
