@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the library is loaded: to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCEDIT_HIP_LIB") or os.path.join(_HERE, "libccedit_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 GEMM_LINEAR, GEMM_CONV2D, GEMM_TEMPORAL = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
@@ -49,6 +49,14 @@ class CcAttnDesc(C.Structure):
     ]
 
 
+class CcFf320Desc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int64), ("dim", C.c_int32), ("inner", C.c_int32), ("ldx", C.c_int32), ("ldo", C.c_int32),
+        ("eps", C.c_float), ("ln", C.c_int32),
+        ("x", C.c_void_p), ("out", C.c_void_p), ("wstream", C.c_void_p), ("b2p", C.c_void_p),
+    ]
+
+
 class HipLibraryError(RuntimeError):
     pass
 
@@ -60,6 +68,7 @@ _SIGS = {
     "ccedit_last_error": (C.c_char_p, []),
     "ccedit_device_info": (C.c_int, [C.c_char_p, C.c_int]),
     "ccedit_gemm": (C.c_int, [C.POINTER(CcGemmDesc), C.c_void_p]),
+    "ccedit_ff320": (C.c_int, [C.POINTER(CcFf320Desc), C.c_void_p]),
     "ccedit_groupnorm_spatial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ccedit_groupnorm_spatial_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -126,9 +126,23 @@ class FeedForward(nn.Module):
         geglu.proj = Linear(dim, inner * 2, geglu=True)
         self.net = _seq(geglu, Slot(), Linear(inner, dim))
 
-    def run(self, x2d, residual):
-        g = ops.linear(x2d, self.net[0].proj.pw)
-        return ops.linear(g, self.net[2].pw, res1=residual)
+        self.fused = None          # PackedFF320 (dim 320): LayerNorm + GEGLU projection + output projection + residual, one kernel
+
+    def pack_fused(self, norm: "Norm", device):
+        """Weight stream of the fused dim-320 kernel; `norm` is the LayerNorm the owning block applies in front of this FF."""
+        if self.net[2].cout == 320 and self.net[2].cin == 1280 and self.net[0].proj.cin == 320:
+            from .packing import pack_ff320
+            p, o = self.net[0].proj, self.net[2]
+            self.fused = pack_ff320(p.weight, p.bias, o.weight, o.bias, norm.weight, norm.bias, device=device)
+            self.fused_eps = norm.eps
+
+    def run(self, tok, norm: "Norm"):
+        """tok + FF(LayerNorm(tok)) (attention.py:695-716 `x = self.ff(self.norm3(x)) + x`)."""
+        if self.fused is not None and ops.FF320 and tok.shape[0] >= 1024:
+            return ops.ff320(tok, self.fused, eps=self.fused_eps)
+        n = ops.layernorm(tok, norm.g, norm.b, norm.eps)
+        g = ops.linear(n, self.net[0].proj.pw)
+        return ops.linear(g, self.net[2].pw, res1=tok)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -154,8 +168,10 @@ class BasicTransformerBlock(nn.Module):
         o = ops.attention(q, kv[:, :c], kv[:, c:], a2.heads, a2.dim_head, batches=frames, lq=hw, lk=ctx_len,
                           kv_div=frames_per_clip)
         tok = ops.linear(o, a2.to_out[0].pw, res1=tok)
-        n3 = ops.layernorm(tok, self.norm3.g, self.norm3.b)
-        return self.ff.run(n3, tok)
+        return self.ff.run(tok, self.norm3)
+
+    def post_pack(self, device):
+        self.ff.pack_fused(self.norm3, device)
 
 
 class BasicTransformerSingleLayerBlock(nn.Module):
@@ -198,8 +214,10 @@ class BasicTransformerSingleLayerBlock(nn.Module):
                               kv_outer_rows=hw, seg1_len=hw, seg1_div=frames_per_clip, seg1_mul=frames_per_clip,
                               seg1_add=anchor_t)
         tok = ops.linear(o, a.to_out[0].pw, res1=tok)
-        n2 = ops.layernorm(tok, self.norm2.g, self.norm2.b)
-        return self.ff.run(n2, tok)
+        return self.ff.run(tok, self.norm2)
+
+    def post_pack(self, device):
+        self.ff.pack_fused(self.norm2, device)
 
     def run_temporal(self, tok, geo: Geometry, hw: int):
         a = self.attn1
@@ -215,8 +233,7 @@ class BasicTransformerSingleLayerBlock(nn.Module):
                           q_inner=hw, q_outer_rows=t * hw, q_inner_rows=1, q_seq_rows=hw,
                           kv_inner=hw, kv_outer_rows=tk * hw, kv_inner_rows=1, kv_seq_rows=hw)
         tok = ops.linear(o, a.to_out[0].pw, res1=tok)
-        n2 = ops.layernorm(tok, self.norm2.g, self.norm2.b)
-        return self.ff.run(n2, tok)
+        return self.ff.run(tok, self.norm2)
 
 
 class SpatialTransformer(nn.Module):

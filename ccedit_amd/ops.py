@@ -14,8 +14,9 @@ from typing import Optional
 import torch
 
 from . import hip
-from .hip import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, CcAttnDesc, CcGemmDesc, GEMM_CONV2D, GEMM_LINEAR, GEMM_TEMPORAL
-from .packing import PackedWeight
+from .hip import (ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, CcAttnDesc, CcFf320Desc, CcGemmDesc, GEMM_CONV2D, GEMM_LINEAR,
+                  GEMM_TEMPORAL)
+from .packing import PackedFF320, PackedWeight
 
 BF16 = torch.bfloat16
 
@@ -134,6 +135,30 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
 
 def linear(x2d, pw, **kw):
     return gemm(x2d, pw, mode=GEMM_LINEAR, **kw)
+
+
+FF320 = os.environ.get("CCEDIT_FF320", "1") != "0"      # 0: LayerNorm + two GEMMs instead of the fused dim-320 feed-forward
+
+
+def ff320(x2d: torch.Tensor, pk: PackedFF320, eps: float = 1e-5, ln: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = x + W2 . GEGLU(W1 . LayerNorm(x) + b1) + b2 for dim 320 in one kernel (csrc/ff320.hip).  x2d: [tokens, 320]."""
+    assert x2d.dtype == BF16 and x2d.is_cuda and x2d.stride(-1) == 1 and x2d.shape[1] == 320
+    if out is None:
+        out = torch.empty((x2d.shape[0], 320), dtype=BF16, device=x2d.device)
+    assert out.dtype == BF16 and out.stride(-1) == 1 and out.shape == (x2d.shape[0], 320) and out.data_ptr() != x2d.data_ptr()
+    d = CcFf320Desc()
+    d.M, d.dim, d.inner, d.ldx, d.ldo, d.eps, d.ln = x2d.shape[0], 320, 1280, x2d.stride(0), out.stride(0), eps, int(ln)
+    d.x, d.out, d.wstream, d.b2p = x2d.data_ptr(), out.data_ptr(), pk.stream.data_ptr(), pk.b2p.data_ptr()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        hip.check(hip.lib().ccedit_ff320(C.byref(d), _stream()), "ccedit_ff320")
+        e1.record()
+        m = x2d.shape[0]
+        PROFILE.add("tap_gemm", e0, e1, pk.flops_per_row * m, float(2 * m * 320 * 2 + pk.stream.numel()), ("ff320", m, 320, 1280, 1, 1, 2))
+        return out
+    hip.check(hip.lib().ccedit_ff320(C.byref(d), _stream()), "ccedit_ff320")
+    return out
 
 
 def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, upsample: bool = False,

@@ -102,3 +102,78 @@ def pack_concat(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optio
     if biases is not None and any(x is not None for x in biases):
         b = torch.cat([torch.zeros(wi.shape[0]) if bi is None else bi.detach().float() for wi, bi in zip(weights, biases)])
     return pack_weight(w, b, device=device)
+
+
+# ------------------------------------------------------------------------------------------
+# fused feed-forward (dim 320): the weight stream of csrc/ff320.hip
+# ------------------------------------------------------------------------------------------
+FF320_DIM, FF320_INNER, FF320_CHUNKS, FF320_CHUNK_BYTES = 320, 1280, 40, 62 * 1024
+
+
+@dataclass
+class PackedFF320:
+    stream: torch.Tensor            # uint8 [40 * 63488]: per 32 hidden units 40 GEMM1 + 20 GEMM2 MFMA A-fragments + s1 / b1'
+    b2p: torch.Tensor               # fp32 [320]: b2 in accumulator order [tile 20][lane group 4][reg 4]
+    flops_per_row: float = 2.0 * 320 * 2560 + 2.0 * 1280 * 320
+
+
+def ff320_out_channel(t: torch.Tensor, i: torch.Tensor) -> torch.Tensor:
+    """Output channel held by row i (0..15) of GEMM2 accumulator tile t (0..19): tiles (2s, 2s+1) of lane group g cover
+    channels 32 s + 8 g .. + 7 — the channels of X fragment s of the same lane (residual / store without a shuffle)."""
+    return 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3)
+
+
+def ff320_hidden_of_k(q: torch.Tensor, k: torch.Tensor) -> torch.Tensor:
+    """Hidden unit at K position k (0..31) of chunk q in GEMM2: lane group g = k >> 3 supplies registers 0..3 of GEMM1
+    tile a (hidden 32 q + 4 g + e) as e = 0..3 and of tile b (hidden 32 q + 16 + 4 g + e - 4) as e = 4..7."""
+    g, e = k >> 3, k & 7
+    return 32 * q + torch.where(e < 4, 4 * g + e, 16 + 4 * g + e - 4)
+
+
+def pack_ff320(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, ln_g: Optional[torch.Tensor],
+               ln_b: Optional[torch.Tensor], device: Optional[torch.device] = None) -> PackedFF320:
+    """w1 (2560, 320) = GEGLU proj [value rows | gate rows] (attention.py:118-126), b1 (2560,), w2 (320, 1280),
+    b2 (320,), LayerNorm gamma / beta (320,) or None (no normalisation)."""
+    D, H, Q = FF320_DIM, FF320_INNER, FF320_CHUNKS
+    if tuple(w1.shape) != (2 * H, D) or tuple(w2.shape) != (D, H):
+        raise ValueError(f"pack_ff320: expected w1 (2560, 320), w2 (320, 1280); got {tuple(w1.shape)}, {tuple(w2.shape)}")
+    w1 = w1.detach().double().cpu()
+    w2 = w2.detach().float().cpu()
+    b1 = torch.zeros(2 * H, dtype=torch.float64) if b1 is None else b1.detach().double().cpu()
+    b2 = torch.zeros(D) if b2 is None else b2.detach().float().cpu()
+    gam = torch.ones(D, dtype=torch.float64) if ln_g is None else ln_g.detach().double().cpu()
+    bet = torch.zeros(D, dtype=torch.float64) if ln_b is None else ln_b.detach().double().cpu()
+    w1g = (w1 * gam[None, :]).float().to(torch.bfloat16)                  # W1 diag(gamma), what the MFMA multiplies
+    s1 = w1g.double().sum(dim=1).float()                                  # row sums of the ROUNDED weights (exact fold)
+    b1p = (b1 + w1 @ bet).float()                                         # b1 + W1 beta
+    w2b = w2.to(torch.bfloat16)
+
+    lane = torch.arange(64)
+    i, g = lane & 15, lane >> 4
+    e = torch.arange(8)
+    # GEMM1 fragments [q][s][tk][lane][e]
+    q = torch.arange(Q)[:, None, None, None, None]
+    s = torch.arange(10)[None, :, None, None, None]
+    tk = torch.arange(4)[None, None, :, None, None]
+    row1 = (tk & 1) * H + 32 * q + 16 * (tk >> 1) + i[None, None, None, :, None]                  # [q,1,tk,lane,1]
+    col1 = 32 * s + 8 * g[None, None, None, :, None] + e[None, None, None, None, :]              # [1,s,1,lane,e]
+    f1 = w1g[row1.expand(Q, 10, 4, 64, 8), col1.expand(Q, 10, 4, 64, 8)]                          # bf16 [q,s,tk,lane,e]
+    # GEMM2 fragments [q][t][lane][e]
+    t = torch.arange(20)[None, :, None, None]
+    q2 = torch.arange(Q)[:, None, None, None]
+    row2 = ff320_out_channel(t, i[None, None, :, None])                                           # [1,t,lane,1]
+    col2 = ff320_hidden_of_k(q2, 8 * g[None, None, :, None] + e[None, None, None, :])             # [q,1,lane,e]
+    f2 = w2b[row2.expand(Q, 20, 64, 8), col2.expand(Q, 20, 64, 8)]
+    # s1 / b1' [q][tk][16]
+    i16 = torch.arange(16)
+    rowa = ((torch.arange(4)[None, :, None] & 1) * H + 32 * torch.arange(Q)[:, None, None]
+            + 16 * (torch.arange(4)[None, :, None] >> 1) + i16[None, None, :])                    # [q,tk,16]
+    aux = torch.stack([s1[rowa], b1p[rowa]], dim=1).contiguous()                                  # [q, 2, tk, 16] fp32
+    stream = torch.zeros(Q, FF320_CHUNK_BYTES, dtype=torch.uint8)
+    stream[:, : 40 * 1024] = f1.contiguous().view(torch.uint8).reshape(Q, -1)
+    stream[:, 40 * 1024: 60 * 1024] = f2.contiguous().view(torch.uint8).reshape(Q, -1)
+    stream[:, 60 * 1024: 60 * 1024 + 512] = aux.view(torch.uint8).reshape(Q, -1)
+    tt, gg, rr = torch.meshgrid(torch.arange(20), torch.arange(4), torch.arange(4), indexing="ij")
+    b2p = b2[32 * (tt >> 1) + 8 * gg + 4 * (tt & 1) + rr].reshape(-1).contiguous()
+    dev = device if device is not None else torch.device("cpu")
+    return PackedFF320(stream.reshape(-1).to(dev), b2p.to(dev))

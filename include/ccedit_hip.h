@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCEDIT_ABI_VERSION 4
+#define CCEDIT_ABI_VERSION 5
 
 #define CCEDIT_OK 0
 #define CCEDIT_EINVAL (-1)       /* null pointer / bad size */
@@ -109,6 +109,33 @@ typedef struct CcGemmDesc {
 } CcGemmDesc;
 
 int ccedit_gemm(const CcGemmDesc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused transformer feed-forward, dim 320 (the 64x96 level of the UNet / ControlNet):
+ *     out = x + W2 . GEGLU(W1 . LayerNorm(x) + b1) + b2
+ * = `x = self.ff(self.norm3(x)) + x` of BasicTransformerBlock._forward (attention.py:695-716) and
+ * `x = self.ff(self.norm2(x)) + x` of BasicTransformerSingleLayerBlock._forward (:758-761), with FeedForward /
+ * GEGLU as in attention.py:115-141.  One kernel: x is read once, out written once, the 1280-wide hidden activation
+ * stays in registers (ff320.hip).  Replaces ccedit_layernorm + two ccedit_gemm calls.
+ *   wstream: the weights as ccedit_amd/packing.py:pack_ff320 lays them out — 40 chunks of 62 KB (one per 32 hidden
+ *            units): 40 GEMM1 A-fragments of W1 diag(gamma) (bf16, lane order), 20 GEMM2 A-fragments of W2, then
+ *            float s1[4][16] (row sums of the bf16 W1 diag(gamma) rows) and float b1'[4][16] (b1 + W1 beta).
+ *   b2p:     b2 in accumulator order, float[20][4][4].
+ *   ln = 0:  no normalisation (mean 0, rstd 1; the packer must then be given gamma = 1, beta = 0).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct CcFf320Desc {
+    int64_t M;            /* tokens (rows of x / out) */
+    int32_t dim, inner;   /* 320, 1280 */
+    int32_t ldx, ldo;     /* row strides in elements (multiples of 8) */
+    float eps;            /* LayerNorm eps (1e-5) */
+    int32_t ln;           /* 1: LayerNorm folded in (statistics computed in the kernel) */
+    const void* x;        /* bf16 [M][ldx] */
+    void* out;            /* bf16 [M][ldo]; may NOT alias x (other workgroups' reads are not ordered against the stores) */
+    const void* wstream;  /* packed weights, 40 * 63488 bytes */
+    const float* b2p;     /* float[320] in accumulator order */
+} CcFf320Desc;
+
+int ccedit_ff320(const CcFf320Desc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Normalisation (fp32 statistics, bf16 in/out)

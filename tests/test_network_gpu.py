@@ -298,7 +298,7 @@ def test_vae_encode_vs_reference_golden(golden_dir, g32_vae):
     a = g32_vae.encode(x5)
     torch.manual_seed(4242)
     assert torch.equal(a, g32_vae.encode(x5))
-    assert _rel(a, z5) < 1.5          # another draw than the golden's: same scale, O(1) apart
+    assert _rel(a, z5) < 1e-6         # seed 4242 is the golden's draw: the same sample as with the explicit noise
 
 
 def test_prior_mix_and_sdedit_start_vs_oracle(golden_dir, g32_vae):

@@ -574,3 +574,65 @@ def test_temporal_ops_frame_sharded_equal_unsharded():
     ops.groupnorm_temporal_apply(x5[:, lo:hi].contiguous().view(-1, h, w, c), stats, b, hi - lo, t, g, be, 1e-5, True, out=ext,
                                  dst_frames=hi - lo + 2, dst_off=1)
     _close(ext.view(b, hi - lo + 2, h, w, c)[:, 1:hi - lo + 1], gn_full[:, lo:hi], rel=0, abs_=0, what="GN apply into ext buffer")
+
+
+# ------------------------------------------------------------------------------------------
+# fused feed-forward, dim 320 (ccedit_ff320): x + W2 GEGLU(W1 LN(x) + b1) + b2 in one kernel
+# ------------------------------------------------------------------------------------------
+def _ff_ref(x, w1, b1, w2, b2, g, b, eps, ln=True):
+    h = F.layer_norm(x, (320,), g, b, eps) if ln else x
+    v, gate = F.linear(h, w1, b1).chunk(2, dim=-1)
+    return x + F.linear(v * F.gelu(gate), w2, b2)
+
+
+@pytest.mark.parametrize("m", [48, 192, 1000, 6144 + 17, 70000])
+@pytest.mark.parametrize("ln", [True, False])
+def test_ff320_fused_vs_fp32_reference(m, ln):
+    """Against the fp32 formula of attention.py:115-141 + :695-716 on bf16-representable inputs.  The hidden activation is
+    rounded to bf16 once (as the two-GEMM path does when it stores it); tolerance: relative RMS of the FF BRANCH
+    (out - x) <= 1e-2, and max error within bf16 rounding of the output."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_ff320
+    x = _rnd(m, 320, seed=11, scale=1.5) + 0.5
+    x = x.to(BF).float()
+    w1, b1 = _rnd(2560, 320, seed=12, scale=320 ** -0.5), _rnd(2560, seed=13, scale=0.2)
+    w2, b2 = _rnd(320, 1280, seed=14, scale=1280 ** -0.5), _rnd(320, seed=15, scale=0.2)
+    g, b = 1.0 + _rnd(320, seed=16, scale=0.2), _rnd(320, seed=17, scale=0.2)
+    pk = pack_ff320(w1, b1, w2, b2, g if ln else None, b if ln else None, device="cuda")
+    y = ops.ff320(x.to(BF).cuda(), pk, eps=1e-5, ln=ln)
+    ref = _ff_ref(x, w1, b1, w2, b2, g, b, 1e-5, ln)
+    got = y.float().cpu()
+    assert torch.isfinite(got).all()
+    branch = ((got - ref).pow(2).mean().sqrt() / (ref - x).pow(2).mean().sqrt()).item()
+    print(f"ff320 m={m} ln={ln}: branch rel rms {branch:.4f}")
+    assert branch < 1e-2
+    _close(y, ref, rel=2.0 ** -7, abs_=2e-2, what=f"ff320 m={m}")
+
+
+def test_ff320_equals_unfused_path():
+    """Same weights through LayerNorm + GEGLU GEMM + output GEMM (the path the other widths use): the two agree to the
+    bf16 rounding of the intermediate tensors the unfused path stores."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_ff320, pack_weight
+    m = 4096 + 48
+    x = (_rnd(m, 320, seed=21, scale=2.0) - 0.3).to(BF)
+    w1, b1 = _rnd(2560, 320, seed=22, scale=320 ** -0.5), _rnd(2560, seed=23, scale=0.2)
+    w2, b2 = _rnd(320, 1280, seed=24, scale=1280 ** -0.5), _rnd(320, seed=25, scale=0.2)
+    g, b = 1.0 + _rnd(320, seed=26, scale=0.2), _rnd(320, seed=27, scale=0.2)
+    xc = x.cuda()
+    fused = ops.ff320(xc, pack_ff320(w1, b1, w2, b2, g, b, device="cuda"))
+    n = ops.layernorm(xc, g.cuda(), b.cuda(), 1e-5)
+    h = ops.linear(n, pack_weight(w1, b1, geglu=True).to("cuda"))
+    two = ops.linear(h, pack_weight(w2, b2).to("cuda"), res1=xc)
+    d = (fused.float() - two.float())
+    rel = (d.pow(2).mean().sqrt() / (two.float() - xc.float()).pow(2).mean().sqrt()).item()
+    print(f"ff320 vs unfused: branch rel rms {rel:.4f}")
+    assert rel < 1e-2
+    # strided input / output rows (column slices of wider buffers)
+    wide_in = torch.zeros(m, 328, dtype=BF, device="cuda")
+    wide_in[:, :320] = xc
+    wide_out = torch.full((m, 336), 7.0, dtype=BF, device="cuda")
+    ops.ff320(wide_in[:, :320], pack_ff320(w1, b1, w2, b2, g, b, device="cuda"), out=wide_out[:, :320])
+    assert torch.equal(wide_out[:, :320], fused) and bool((wide_out[:, 320:] == 7.0).all())
