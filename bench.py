@@ -5,8 +5,8 @@ One "step" = one network evaluation of the TV2V hot path on the CFG-doubled batc
 (OpenAIWrapperControlLDM3DTV2V.forward: hint remap -> ControlNet2D on 34 frames -> pseudo-3D UNet ->
 eps), B=2 (uncond+cond), T=17 keyframes, latent 64x96, context 77x768, hint 3x512x768 per frame —
 77.68 TFLOP algorithmic.  The DPMPP2SAncestral sampler calls exactly this 59 times per
-30-step clip; `--clip` additionally times one whole clip (sampler loop + AutoencoderKL decode) and adds
-frames/s to the JSON line.
+30-step clip; after the timed steps one whole clip (sampler loop + AutoencoderKL decode) is timed as well and
+its frames/s are added to the JSON line (`clip`; `--no-clip` skips it).
 
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
@@ -35,6 +35,7 @@ FLOP_PER_STEP = 77.68e12          # SURVEY.md §8d, measured from the reference 
 FLOP_PER_STEP_TVI2V = 110.31e12   # BASELINE.json config 3 (controlnet_img + anchor cross-frame attention)
 MFMA_PEAK_TFLOPS = 2500.0         # MI355X dense bf16 (MI355X_MICROARCH.md)
 T, H, W, L, CTX = 17, 64, 96, 77, 768
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"      # committed rocprofv3 PMC capture (FETCH_SIZE / WRITE_SIZE passes)
 
 
 def synth_inputs(device, seed=42, b=1):
@@ -89,7 +90,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clip", action="store_true", help="also time one full 30-step clip + VAE decode (frames/s)")
+    ap.add_argument("--clip", action="store_true", help="(default on) time one full 30-step clip + VAE decode (frames/s)")
+    ap.add_argument("--no-clip", action="store_true", help="skip the whole-clip timing (30-step sampler + VAE decode, ~7 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard-frames", action="store_true",
                     help="N>1: BASELINE.json config 4 — ONE clip, its T=17 keyframes sharded over the ranks (halo p2p, "
@@ -190,20 +192,29 @@ def main():
         ops.PROFILE = None
         g = prof["tap_gemm"]
         ach = g["flops"] / (g["total_ms"] * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="ccedit_gemm (tap_gemm_kernel, conv_halo_kernel, lin320_kernel, small_conv3x3_kernel)", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+        roof = dict(bound="mfma", kernel="ccedit_gemm + ccedit_ff320 (tap_gemm_kernel, conv_halo_kernel, lin320_kernel, small_conv3x3_kernel, ff320_kernel)", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None, launches=g["launches"],
                     avg_launch_us=round(g["avg_us"], 2), algorithmic_flops_per_step=g["flops"])
         # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 PMC passes of this
         # same workload (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH x2 per
         # MI355X_MICROARCH.md), averaged per tap_gemm launch like `achieved`.
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        # The capture records the hash of the kernel sources it was taken from (tools/pmc_traffic.sh); a capture of OTHER
+        # kernels is not reported: traffic stays null and the line says why.
+        pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
+        roof["algorithmic_bytes_per_launch"] = round(g["bytes"] / g["launches"])
         if not tvi2v and os.path.exists(pmc):
             with open(pmc) as f:
-                tg = json.load(f).get("tap_gemm")
-            if tg and tg["launches"]:
+                cap = json.load(f)
+            tg = cap.get("tap_gemm")
+            src = cap.get("kernel_source_hash")
+            if src != kernel_source_hash():
+                roof["traffic_note"] = (f"profiles/{PMC_TRAFFIC_FILE} was captured from kernel sources {src}, this build is "
+                                        f"{kernel_source_hash()}: stale, not reported (re-run tools/pmc_traffic.sh)")
+            elif tg and tg["launches"]:
                 roof["traffic"] = round((tg["fetch_bytes_x2"] + tg["write_bytes"]) / tg["launches"])
-                roof["traffic_unit"] = "HBM bytes per ccedit_gemm launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)"
-                roof["algorithmic_bytes_per_launch"] = round(g["bytes"] / g["launches"])
+                roof["traffic_unit"] = f"HBM bytes per ccedit_gemm launch (rocprofv3 PMC, profiles/{PMC_TRAFFIC_FILE})"
+                roof["traffic_launches"] = tg["launches"]
+                roof["traffic_kernel_source_hash"] = src
         a = prof.get("attention")
         if a:
             extra["attention"] = dict(tflops=round(a["flops"] / (a["total_ms"] * 1e-3) / 1e12, 1), launches=a["launches"],
@@ -212,9 +223,16 @@ def main():
         extra["step_tflops"] = round(flop_per_step / (ms_per_step * 1e-3) / 1e12, 1)
         extra["step_frac_of_mfma_peak"] = round(flop_per_step / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
 
+    # BASELINE.json's metric names frames/s next to UNet steps/s: one whole clip (59 evaluations + sampler math + VAE decode)
+    # outside the timed region above.  N > 1 replicas: every rank runs its own clip at the same time (rank 0's is reported);
+    # frame-sharded: the one clip runs through the sharded wrapper on all ranks.
     clip = None
-    if args.clip and rank == 0:
-        clip = time_clip(wrapper, device)
+    if not args.no_clip and not tvi2v:
+        if dist is not None:
+            dist.barrier()
+        clip = time_clip(wrapper, device, seed=43 if shard else 43 + rank)
+        if rank != 0:
+            clip = None
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not tvi2v:
@@ -248,7 +266,19 @@ def main():
         dist.destroy_process_group()
 
 
-def time_clip(wrapper, device, num_steps=30, scale=7.5):
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources: ties a committed PMC capture to the code it was taken from."""
+    import hashlib
+    d = os.path.join(ROOT, "ccedit_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def time_clip(wrapper, device, num_steps=30, scale=7.5, seed=43):
     """One full clip: DPMPP2SAncestral (30 steps = 59 evaluations) + AutoencoderKL decode -> frames/s."""
     from ccedit_amd.config import instantiate_from_config
     from ccedit_amd.sgm_compat import build_vae
@@ -265,7 +295,7 @@ def time_clip(wrapper, device, num_steps=30, scale=7.5):
     sampler = instantiate_from_config(dict(target=dd + "sampling.DPMPP2SAncestralSampler", params=dict(
         num_steps=num_steps, eta=1.0, s_noise=1.0, discretization_config=dict(target=dd + "discretizer.LegacyDDPMDiscretization"),
         guider_config=dict(target=dd + "guiders.VanillaCFGTV2V", params=dict(scale=scale)))))
-    x, cross_c, cross_uc, hint = synth_inputs(device, seed=43)
+    x, cross_c, cross_uc, hint = synth_inputs(device, seed=seed)
     c = dict(crossattn=cross_c, control_hint=hint)
     uc = dict(crossattn=cross_uc, control_hint=hint.clone())
     evals = [0]

@@ -12,6 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.abspath(os.path.join(HERE, "..", "libccedit_hip.so"))
 SOURCES = ["gemm.hip", "convhalo.hip", "smallconv.hip", "lin320.hip", "ff320.hip", "norm.hip", "attention.hip", "attnshort.hip", "elementwise.hip", "core.cpp"]
 ARCH = "gfx950"
+# per-file flags: ff320's GEGLU must stay scalar fp32 (packed fp32 VALU is several times slower beside MFMAs, see the file)
+EXTRA_FLAGS = {"ff320.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -38,7 +40,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for s in SOURCES:
         o = os.path.join(HERE, s.rsplit(".", 1)[0] + ".o")
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", os.path.join(HERE, s), "-o", o]
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *EXTRA_FLAGS.get(s, []), "-x", "hip", "-c",
+               os.path.join(HERE, s), "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(o)
     ok = True

@@ -107,12 +107,12 @@ def pack_concat(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optio
 # ------------------------------------------------------------------------------------------
 # fused feed-forward (dim 320): the weight stream of csrc/ff320.hip
 # ------------------------------------------------------------------------------------------
-FF320_DIM, FF320_INNER, FF320_CHUNKS, FF320_CHUNK_BYTES = 320, 1280, 40, 62 * 1024
+FF320_DIM, FF320_INNER, FF320_CHUNKS, FF320_CHUNK_BYTES = 320, 1280, 40, 64 * 1024
 
 
 @dataclass
 class PackedFF320:
-    stream: torch.Tensor            # uint8 [40 * 63488]: per 32 hidden units 40 GEMM1 + 20 GEMM2 MFMA A-fragments + s1 / b1'
+    stream: torch.Tensor            # uint8 [41 * 65536]: per pipeline iteration 40 GEMM1 + 20 GEMM2 MFMA A-fragments + s1 / b1'
     b2p: torch.Tensor               # fp32 [320]: b2 in accumulator order [tile 20][lane group 4][reg 4]
     flops_per_row: float = 2.0 * 320 * 2560 + 2.0 * 1280 * 320
 
@@ -151,28 +151,34 @@ def pack_ff320(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.T
     lane = torch.arange(64)
     i, g = lane & 15, lane >> 4
     e = torch.arange(8)
-    # GEMM1 fragments [q][s][tk][lane][e]
-    q = torch.arange(Q)[:, None, None, None, None]
-    s = torch.arange(10)[None, :, None, None, None]
-    tk = torch.arange(4)[None, None, :, None, None]
-    row1 = (tk & 1) * H + 32 * q + 16 * (tk >> 1) + i[None, None, None, :, None]                  # [q,1,tk,lane,1]
-    col1 = 32 * s + 8 * g[None, None, None, :, None] + e[None, None, None, None, :]              # [1,s,1,lane,e]
-    f1 = w1g[row1.expand(Q, 10, 4, 64, 8), col1.expand(Q, 10, 4, 64, 8)]                          # bf16 [q,s,tk,lane,e]
+    # GEMM1 fragments in consumption order [q][half (hidden 16 a | 16 b)][k-step s][kind (value | gate)][lane][e]
+    q = torch.arange(Q)[:, None, None, None, None, None]
+    half = torch.arange(2)[None, :, None, None, None, None]
+    s = torch.arange(10)[None, None, :, None, None, None]
+    kind = torch.arange(2)[None, None, None, :, None, None]
+    row1 = kind * H + 32 * q + 16 * half + i[None, None, None, None, :, None]                     # [q,half,1,kind,lane,1]
+    col1 = 32 * s + 8 * g[None, None, None, None, :, None] + e[None, None, None, None, None, :]   # [1,1,s,1,lane,e]
+    shp = (Q, 2, 10, 2, 64, 8)
+    f1 = w1g[row1.expand(shp), col1.expand(shp)]                                                  # bf16
     # GEMM2 fragments [q][t][lane][e]
     t = torch.arange(20)[None, :, None, None]
     q2 = torch.arange(Q)[:, None, None, None]
     row2 = ff320_out_channel(t, i[None, None, :, None])                                           # [1,t,lane,1]
     col2 = ff320_hidden_of_k(q2, 8 * g[None, None, :, None] + e[None, None, None, :])             # [q,1,lane,e]
     f2 = w2b[row2.expand(Q, 20, 64, 8), col2.expand(Q, 20, 64, 8)]
-    # s1 / b1' [q][tk][16]
+    # s1 / b1' per half: [q][half][s1 value, s1 gate, b1' value, b1' gate][16 rows] fp32 (256 B per half)
     i16 = torch.arange(16)
-    rowa = ((torch.arange(4)[None, :, None] & 1) * H + 32 * torch.arange(Q)[:, None, None]
-            + 16 * (torch.arange(4)[None, :, None] >> 1) + i16[None, None, :])                    # [q,tk,16]
-    aux = torch.stack([s1[rowa], b1p[rowa]], dim=1).contiguous()                                  # [q, 2, tk, 16] fp32
-    stream = torch.zeros(Q, FF320_CHUNK_BYTES, dtype=torch.uint8)
-    stream[:, : 40 * 1024] = f1.contiguous().view(torch.uint8).reshape(Q, -1)
-    stream[:, 40 * 1024: 60 * 1024] = f2.contiguous().view(torch.uint8).reshape(Q, -1)
-    stream[:, 60 * 1024: 60 * 1024 + 512] = aux.view(torch.uint8).reshape(Q, -1)
+    rowa = (torch.arange(2)[None, None, :, None] * H + 32 * torch.arange(Q)[:, None, None, None]
+            + 16 * torch.arange(2)[None, :, None, None] + i16[None, None, None, :])               # [q,half,kind,16]
+    aux = torch.cat([s1[rowa], b1p[rowa]], dim=2).contiguous()                                    # [q, half, 4, 16]
+    # Stream chunk c = 0 .. 40 is what iteration c of the kernel's software pipeline reads: GEMM1 fragments of hidden chunk c,
+    # GEMM2 fragments of chunk c - 1, s1 / b1' of half a of chunk c and of half b of chunk c - 1; the missing neighbours of
+    # the first / last iteration are zero fragments (their MFMAs add zeros).
+    stream = torch.zeros(Q + 1, FF320_CHUNK_BYTES, dtype=torch.uint8)
+    stream[:Q, : 40 * 1024] = f1.contiguous().view(torch.uint8).reshape(Q, -1)
+    stream[1:, 40 * 1024: 60 * 1024] = f2.contiguous().view(torch.uint8).reshape(Q, -1)
+    stream[:Q, 60 * 1024: 60 * 1024 + 256] = aux[:, 0].contiguous().view(torch.uint8).reshape(Q, -1)
+    stream[1:, 60 * 1024 + 256: 60 * 1024 + 512] = aux[:, 1].contiguous().view(torch.uint8).reshape(Q, -1)
     tt, gg, rr = torch.meshgrid(torch.arange(20), torch.arange(4), torch.arange(4), indexing="ij")
     b2p = b2[32 * (tt >> 1) + 8 * gg + 4 * (tt & 1) + rr].reshape(-1).contiguous()
     dev = device if device is not None else torch.device("cpu")

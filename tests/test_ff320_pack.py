@@ -39,7 +39,7 @@ def gelu(v):
 
 def emulate_wave(stream, b2p, x48, eps, ln=True, chunks=40):
     """x48: [48][320] bf16-representable floats.  Returns [48][320]."""
-    stream = stream.numpy().reshape(40, FF320_CHUNK_BYTES)
+    stream = stream.numpy().reshape(41, FF320_CHUNK_BYTES)
     # X fragments: xf[nt][s][lane][e] = x[16 nt + n][32 s + 8 g + e]
     xf = np.zeros((3, 10, 64, 8))
     for nt in range(3):
@@ -60,28 +60,36 @@ def emulate_wave(stream, b2p, x48, eps, ln=True, chunks=40):
     for t in range(20):
         for nt in range(3):
             acc2[t, nt] = b2[t][G_]
-    for q in range(chunks):
-        ch = stream[q]
-        f1 = torch.from_numpy(ch[: 40 * 1024].copy()).view(torch.bfloat16).float().numpy().reshape(10, 4, 64, 8)
+    # the kernel's software pipeline: iteration c does GEMM1 half a of chunk c (+ GEGLU of half b of chunk c - 1 with the
+    # s1 / b1' at +256), GEMM2 of chunk c - 1, GEMM1 half b of chunk c (+ GEGLU of half a of chunk c, s1 / b1' at +0)
+    hf = np.zeros((3, 64, 8))
+    accs = {1: np.zeros((2, 3, 64, 4))}
+    for c in range(chunks + 1):
+        ch = stream[c]
+        f1 = torch.from_numpy(ch[: 40 * 1024].copy()).view(torch.bfloat16).float().numpy().reshape(2, 10, 2, 64, 8)
         f2 = torch.from_numpy(ch[40 * 1024: 60 * 1024].copy()).view(torch.bfloat16).float().numpy().reshape(20, 64, 8)
         aux = np.frombuffer(ch[60 * 1024: 60 * 1024 + 512].tobytes(), dtype=np.float32).reshape(2, 4, 16)
-        acc1 = np.zeros((4, 3, 64, 4))
-        for s in range(10):
-            for tk in range(4):
-                for nt in range(3):
-                    acc1[tk, nt] = mfma16(f1[s, tk], xf[nt, s], acc1[tk, nt])
-        hf = np.zeros((3, 64, 8))
-        for nt in range(3):
-            for half in range(2):
-                for r in range(4):
-                    s1v, b1v = aux[0, 2 * half][4 * G_ + r], aux[1, 2 * half][4 * G_ + r]
-                    s1g, b1g = aux[0, 2 * half + 1][4 * G_ + r], aux[1, 2 * half + 1][4 * G_ + r]
-                    v = rstd[nt] * (acc1[2 * half, nt][:, r] - mean[nt] * s1v) + b1v
-                    u = rstd[nt] * (acc1[2 * half + 1, nt][:, r] - mean[nt] * s1g) + b1g
-                    hf[nt][:, half * 4 + r] = bf16_round(v * gelu(u))
-        for t in range(20):
+        for phase in (0, 1, 2):
+            if phase == 1:
+                for t in range(20):
+                    for nt in range(3):
+                        acc2[t, nt] = mfma16(f2[t], hf[nt], acc2[t, nt])
+                continue
+            half = 0 if phase == 0 else 1           # GEMM1 half of chunk c computed in this phase
+            ge = 1 - half                           # GEGLU half finished in this phase (b of c - 1 in phase 1, a of c in phase 3)
+            acc1 = accs[ge]
             for nt in range(3):
-                acc2[t, nt] = mfma16(f2[t], hf[nt], acc2[t, nt])
+                for r in range(4):
+                    s1v, s1g, b1v, b1g = (aux[ge, k][4 * G_ + r] for k in range(4))
+                    v = rstd[nt] * acc1[0, nt][:, r] - rstd[nt] * mean[nt] * s1v + b1v
+                    u = rstd[nt] * acc1[1, nt][:, r] - rstd[nt] * mean[nt] * s1g + b1g
+                    hf[nt][:, ge * 4 + r] = bf16_round(v * gelu(u))
+            acc1 = np.zeros((2, 3, 64, 4))
+            for s in range(10):
+                for kind in range(2):
+                    for nt in range(3):
+                        acc1[kind, nt] = mfma16(f1[half, s, kind], xf[nt, s], acc1[kind, nt])
+            accs[half] = acc1
     out = np.zeros((48, 320))
     for nt in range(3):
         for s in range(10):
@@ -110,7 +118,7 @@ def test_weight_stream_matches_kernel_dataflow():
     lb = 0.1 * torch.randn(320, generator=gen)
     x = (torch.randn(48, 320, generator=gen) * 1.5 + 0.7).to(torch.bfloat16).float()
     pk = pack_ff320(w1, b1, w2, b2, lg, lb)
-    assert pk.stream.numel() == 40 * FF320_CHUNK_BYTES and pk.stream.dtype == torch.uint8 and pk.b2p.shape == (320,)
+    assert pk.stream.numel() == 41 * FF320_CHUNK_BYTES and pk.stream.dtype == torch.uint8 and pk.b2p.shape == (320,)
     got = emulate_wave(pk.stream, pk.b2p, x.numpy().astype(np.float64), 1e-5)
     # expected with the SAME bf16 weights the stream carries, so that only the dataflow / index maps are under test
     w1g = (w1.double() * lg.double()[None]).float().to(torch.bfloat16)

@@ -8,7 +8,7 @@ def load(d, name):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != name: continue
             k = r["Kernel_Name"]
-            fam = "tap_gemm" if ("tap_gemm" in k or "conv_halo" in k or "small_conv" in k or "lin320" in k) else "attn" if ("attn_kernel" in k or "attn_short" in k) else "gn_spatial_stats" if "gn_spatial_stats" in k else \
+            fam = "tap_gemm" if ("tap_gemm" in k or "conv_halo" in k or "small_conv" in k or "lin320" in k or "ff320" in k) else "attn" if ("attn_kernel" in k or "attn_short" in k) else "gn_spatial_stats" if "gn_spatial_stats" in k else \
                   "gn_spatial_apply" if "gn_spatial_apply" in k else "gn_temporal" if "gn_temporal" in k else "layernorm" if "layernorm" in k else \
                   "cat_add" if "cat_add" in k else "ours_other" if "anonymous namespace" in k or "_GLOBAL__N_" in k else "torch/setup"
             acc[fam][0] += 1; acc[fam][1] += float(r["Counter_Value"])
@@ -23,8 +23,12 @@ for k in sorted(set(f) | set(w)):
 print(f"{'TOTAL (ours)':20s} {'':8s} {tf:10.2f} {2*tf:11.2f} {tw:10.2f}")
 if os.environ.get("PMC_JSON"):
     import json as _json
-    _json.dump({k: {"launches": f[k][0], "fetch_bytes_x2": 2 * f[k][1] * 1024, "write_bytes": w[k][1] * 1024}
-                for k in sorted(set(f) | set(w))}, open(os.environ["PMC_JSON"], "w"), indent=1)
+    sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+    from bench import kernel_source_hash
+    out = {k: {"launches": f[k][0], "fetch_bytes_x2": 2 * f[k][1] * 1024, "write_bytes": w[k][1] * 1024}
+           for k in sorted(set(f) | set(w))}
+    out["kernel_source_hash"] = kernel_source_hash()
+    _json.dump(out, open(os.environ["PMC_JSON"], "w"), indent=1)
 
 # optional per-shape table for tap_gemm: argv[3] = shapes json dumped by bench.py --dump-shapes (same launch order)
 if len(sys.argv) > 3:
@@ -34,7 +38,7 @@ if len(sys.argv) > 3:
         rows = []
         for f_ in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f_)):
-                if r["Counter_Name"] == name and any(t in r["Kernel_Name"] for t in ("tap_gemm", "conv_halo", "small_conv", "lin320")):
+                if r["Counter_Name"] == name and any(t in r["Kernel_Name"] for t in ("tap_gemm", "conv_halo", "small_conv", "lin320", "ff320")):
                     rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
         rows.sort()
         return [v for _, v in rows]
