@@ -3,45 +3,53 @@
 //     out = x + W2 . GEGLU( W1 . LayerNorm(x) + b1 ) + b2          (attention.py:115-141, 695-716 / 758-761)
 //
 // in ONE kernel that reads x once and writes out once.  The 4C = 1280-wide hidden activation (535 MB per call at
-// 34 x 64 x 96 tokens) never exists in memory, LayerNorm is folded into the first GEMM, and the residual is the very
-// operand registers the kernel already holds.
+// 34 x 64 x 96 tokens) never exists in memory, LayerNorm is applied to the operand registers, and the residual is folded
+// into the accumulator initialisation.
 //
-// Register chaining.  A wave owns 48 tokens (3 MFMA column tiles of 16) for the whole call:
-//   * X fragments: the wave's raw x rows as v_mfma_f32_16x16x32_bf16 B operands — lane (n = l & 15, g = l >> 4) holds
-//     channels 32 s + 8 g .. + 7 of token n for k-step s: 10 k-steps x 3 tiles = 120 VGPRs, loaded once (16 B per lane).
-//   * GEMM1 (hidden rows = A operand from LDS, K = 320): C tile = 16 hidden x 16 tokens, lane (n, g) register r is
-//     hidden row 4 g + r of token n.  Two such tiles (hidden 16 a .. and 16 b ..) are, after bias / GEGLU / bf16,
-//     EXACTLY one B operand of the second GEMM (k = 8 g + e: e < 4 from tile a, e >= 4 from tile b): the packer orders
-//     W2's K axis accordingly, no lane ever exchanges data.
-//   * GEMM2 (output channels = A operand, K = 32 hidden per chunk) accumulates out[320 x 48] in 240 accumulator
-//     registers across the 40 hidden chunks.  W2's rows are permuted so that accumulator tile pair (2 s, 2 s + 1) of
-//     lane (n, g) holds channels 32 s + 8 g .. + 7 — the same channels as X fragment s: the residual add and the final
-//     16-byte store need no shuffle either.
-//   * LayerNorm: W1' = W1 diag(gamma) is packed, so GEMM1 runs on the RAW x and its accumulators are corrected with the
-//     token's statistics: h_pre = rstd (acc - mean s1[row]) + b1'[row], s1 = row sums of bf16(W1'), b1' = b1 + W1 beta.
-//     mean / rstd come from the X registers (two-pass, 4-lane reduction).
+// Register chaining (v_mfma_f32_32x32x16_bf16; A = weights from LDS, B = tokens, C/D = [rows][tokens]).  A wave owns 32
+// tokens for the whole call:
+//   * X fragments: lane (token n = l & 31, hi = l >> 5) holds channels 16 s + 8 hi .. + 7 for k-step s: 20 k-steps = 80
+//     VGPRs, loaded once, normalised in place (gamma / beta live in the packed W1' / b1').
+//   * GEMM1 (K = 320): value tile and gate tile of 32 hidden units each; in the C layout lane (n, hi) register r is hidden
+//     row (r & 3) + 8 (r >> 2) + 4 hi of token n.  After GEGLU the 16 results of a lane, taken in register order, ARE the
+//     two B operands of the second GEMM (k-step kappa = registers 8 kappa .. 8 kappa + 7): the packer orders W2's K axis
+//     accordingly, no lane ever exchanges data.
+//   * GEMM2 (K = 32 hidden per chunk) accumulates out[320 x 32] in 160 accumulator registers across the 40 hidden
+//     chunks.  W2's rows are permuted so that registers 0..7 / 8..15 of accumulator tile t of lane (n, hi) are channels
+//     32 t + 8 hi .. + 7 / 32 t + 16 + 8 hi .. + 7 — the channels of X fragments 2 t / 2 t + 1 of the same lane: the
+//     accumulators start from b2 + x (the residual, exact in fp32) and are stored with 16-byte writes, no shuffle.
 //
-// Weights stream through LDS in 64 KB chunks (one per 32 hidden units: 40 GEMM1 fragments, 20 GEMM2 fragments, 512 B of
-// s1 / b1'), pre-packed in fragment order so that every ds_read_b128 is lane-linear (conflict-free) and every
-// global_load_lds moves 1 KB contiguous.  Two chunk buffers; chunk j+1 is in flight while chunk j is consumed, one
-// barrier per chunk.  One 4-wave workgroup per CU (a wave uses ~450 of the 512 registers of its SIMD); every weight byte
-// staged serves 192 tokens: 21 B/clk of L2 -> LDS traffic at the MFMA peak (the per-CU L1-miss path sustains ~20).
+// One wave per SIMD (a wave needs ~340 registers): only the wave's own instruction stream hides latencies, and every
+// instruction costs the wave ~4 cycles of issue time (PMC: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.1 cycles), so the
+// kernel is an instruction-count problem: per 32 hidden units 60 MFMAs (1920 cycles of matrix pipe) against ~400 VALU
+// (the exact-erf GELU is 16 per element), 68 LDS reads and 16 DMA instructions.  Hence the 32x32x16 shape (the 16x16x32
+// version of this kernel, three 16-token tiles per wave, was at its register limit and ran at the SUM of its MFMA, VALU
+// and DMA issue times: 750 us against 620-640 us for this one and 940 us for LayerNorm + two GEMMs at 34 x 64 x 96
+// tokens), the asm-pinned LDS read ring, scalar fp32 GEGLU, and the software pipeline below.  Measured on this version:
+// MFMA pipe busy 36 % of the kernel; waves issue 53 %, wait 23 %, stall 24 % of their cycles.
+//
+// Weights stream through LDS in 64 KB chunks, pre-packed in fragment order so that every ds_read_b128 is lane-linear
+// (conflict-free) and every global_load_lds moves 1 KB contiguous; two chunk buffers, one barrier per chunk.  Every
+// weight byte staged serves 128 tokens: 64 KB per ~2800 cycles = the ~23 B/clk a CU's L2 -> LDS path sustains, i.e. the
+// weight stream and the MFMA + exposed VALU time are co-limiting.
 #include "common.h"
+#ifndef KD_VALUE
+#define KD_VALUE 6
+#endif
 #include <stdlib.h>
 #include <utility>
 
 namespace {
 
 constexpr int kC = 320;                 // model width
-constexpr int kKS = kC / 32;            // 10 k-steps of 32
-constexpr int kOT = kC / 16;            // 20 output-channel tiles of 16
-constexpr int kIters = 1280 / 32 + 1;   // 40 hidden chunks of 32, software-pipelined over 41 iterations
-constexpr int kW2Off = 4 * kKS * 1024;  // 40 KB of GEMM1 fragments, then 20 KB of GEMM2 fragments
-constexpr int kAuxOff = kW2Off + kOT * 1024;
-constexpr int kChunkBytes = 64 * 1024;  // + s1 / b1' (512 B used of the last 4 KB: every wave issues exactly 16 DMA instructions)
-constexpr int kNT = 3;                  // 16-token MFMA column tiles per wave
-constexpr int kWavePix = 16 * kNT;
-constexpr int kD = 6;                   // fragment reads in flight ahead of their use
+constexpr int kKS = kC / 16;            // 20 k-steps of 16
+constexpr int kOT = kC / 32;            // 10 output-channel tiles of 32
+constexpr int kIters = 1280 / 32 + 2;   // 40 hidden chunks of 32, software-pipelined (three stages) over 42 iterations
+constexpr int kAuxOff = 60 * 1024;      // 40 GEMM1 + 20 GEMM2 fragments of 1 KB, then b1'
+constexpr int kChunkBytes = 64 * 1024;  // every wave issues exactly 16 DMA instructions per chunk
+constexpr int kWavePix = 32;
+constexpr int kD = KD_VALUE;            // fragment reads in flight ahead of their use (divides 60: the ring runs across chunks)
+static_assert(60 % kD == 0, "ring depth");
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
@@ -50,50 +58,40 @@ __device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, J...>)
     (f(std::integral_constant<int, J>{}), ...);
 }
 
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // LDS reads the compiler cannot move: one wave per SIMD means nothing but the wave's own later instructions hides a
-// ds_read's latency, and under this kernel's register pressure hipcc sinks every read next to its consumer (measured:
-// 2 reads, lgkmcnt(0), 6 MFMAs, ... = 34 - 61 cycles per MFMA).  The reads are issued kD fragments ahead through these
-// statements and retired with counted waits (LDS returns in order); the wait names the register, so no consumer can be
-// scheduled above it.
+// ds_read's latency, and hipcc sinks reads next to their consumer under register pressure (measured on the first version
+// of this kernel: 2 reads, lgkmcnt(0), 6 MFMAs, ... = 34 - 61 cycles per MFMA).  The reads are issued kD fragments ahead
+// through these statements and retired with counted waits (LDS returns in order); the wait names the register, so no
+// consumer can be scheduled above it.
 #define FF_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define FF_WAIT(reg, cnt) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "i"(cnt))
-// Fragment used at step j of an iteration: GEMM1 half a (0..19), GEMM2 (40..59), GEMM1 half b (20..39).
-__device__ __forceinline__ constexpr int frag_of(int j) { return j < 20 ? j : (j < 40 ? j + 20 : j - 20); }
 
-// Two GEGLU elements (rows r, r + 1 of one token tile): value x exact-erf GELU(gate) (common.h) -> bf16 pair; the biases
-// arrived as the C operand of the first MFMA.  Scalar fp32 on purpose, and this file is built with -fno-slp-vectorize:
-// beside MFMAs a v_pk_fma_f32 / v_pk_mul_f32 costs several times a v_fma_f32 (MI355X_MICROARCH.md, "price of one filler
-// beside MFMAs"; measured here: the packed form of this function made the kernel slower).
-__device__ __forceinline__ bf16x2 geglu2(f32x2 v, f32x2 u, bool plain) {
-    bf16x2 o;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) o[i] = f2bf(plain ? v[i] + u[i] : v[i] * gelu_erf_f(u[i]));
-    return o;
-}
-
-// ABL (tuning only, CCEDIT_FF320_ABL, bit mask): 1 = no weight stream after the first chunk; 2 = GEGLU replaced by an add; 4 = no
-// barrier; 8 = no LDS fragment reads; 16 = no GEGLU at all.
+// ABL (tuning only, CCEDIT_FF320_ABL, bit mask): 1 = no weight stream after the first chunk; 2 = GEGLU replaced by an add; 32 = phase
+// cycle counters into d.dbg.  Results are wrong for ABL & 3.
 //
-// Software pipeline over the 40 hidden chunks (iteration c = 0 .. 40 works on stream chunk c = [W1(c) | W2(c-1) | s1,b1'(c) a-half | (c-1) b-half]):
-//     phase 1   GEMM1 half a of chunk c       with the GEGLU of half b of chunk c-1 between its MFMA steps  -> completes h(c-1)
-//     phase 2   GEMM2 of chunk c-1            out += W2(c-1) . h(c-1)
-//     phase 3   GEMM1 half b of chunk c       with the GEGLU of half a of chunk c between its MFMA steps
-// Chunk -1 / 40 do not exist: the packer supplies zero fragments, so iteration 0's GEMM2 and iteration 40's GEMM1 add zeros.
+// Software pipeline over the 40 hidden chunks, three stages deep: iteration c = 0 .. 41 works on stream chunk
+// c = [W1'(c) | W2(c-2) | b1'(c)], its 60 fragments interleaved per k-step s as (value_s, gate_s, W2 fragment s):
+//     MFMA   GEMM1 of chunk c  (value / gate accumulators: a dependent MFMA every third issue = 96 cycles apart)
+//            GEMM2 of chunk c-2 (twenty different accumulators)
+//     VALU   GEGLU of chunk c-1, one accumulator register (one hidden row of the lane's token) per k-step
+// Chunks -2, -1, 40, 41 do not exist: the packer supplies zero fragments / biases, so those MFMAs add zeros.
+// The fragment ring runs across iterations: barrier B (step 58 - kD, after the wait for the next chunk's DMA) lets the last
+// steps prefetch the next chunk; barrier A (iteration top) lets the DMA overwrite the buffer every wave has left.
 template <int ABL>
 __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int n_rounds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][kChunkBytes]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15, g = lane >> 4;
+    const int n = lane & 31, hi = lane >> 5;
     const char* __restrict__ wstream = (const char*)d.wstream;
     const bf16* __restrict__ xp = (const bf16*)d.x;
     bf16* __restrict__ op = (bf16*)d.out;
-    const f32x4* __restrict__ b2p = (const f32x4*)d.b2p;                 // [kOT][4 lane groups] x 4 floats
+    const f32x4* __restrict__ b2p = (const f32x4*)d.b2p;                 // [kOT][2 lane halves][16 registers]
     const int lane16 = lane * 16;
 
     // DMA share of this wave: fragments wave, wave + 4, ... (16 per chunk); uniform base + lane offset
@@ -101,47 +99,55 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
         const char* src = wstream + ((size_t)c * kChunkBytes + (size_t)(k * 4 + wave) * 1024);     // wave-uniform
         glds16(src + lane16, smem + buf * kChunkBytes + (k * 4 + wave) * 1024);
     };
+    const unsigned la0 = (unsigned)(uintptr_t)(LDS_AS const char*)(smem + lane16);                  // fragment base, buffer 0
+    const unsigned lx0 = (unsigned)(uintptr_t)(LDS_AS const char*)(smem + kAuxOff + hi * 64);      // b1' of this lane half, buffer 0
 
     const int gdim = (int)gridDim.x;
-    int cc = 0;                          // running chunk counter: buffer = cc & 1
 #pragma unroll
     for (int k = 0; k < 16; ++k) issue_frag(0, 0, k);
-
-    f32x4 accB[2][kNT];                  // GEMM1 half b of the previous iteration (zero at c = 0: iteration 40 leaves zeros)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // the read stream starts: b1' of chunk 0 and its first kD fragments
+    f32x4 bq[2][4];                      // b1' (value, gate) of the chunk GEMM1 starts next, in accumulator order
+    bf16x8 ring[kD];
+    FF_DS_READ(ring[0], la0, 0);          // same order as in the steady state: fragment 0, b1', fragments 1 .. kD - 1
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int nt = 0; nt < kNT; ++nt) accB[k][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 hf[kNT];                      // the hidden chunk as GEMM2 B operands: elements 0..3 half a, 4..7 half b
+        for (int q4 = 0; q4 < 4; ++q4) FF_DS_READ(bq[k][q4], lx0, k * 128 + q4 * 16);
 #pragma unroll
-    for (int nt = 0; nt < kNT; ++nt)
+    for (int j = 1; j < kD; ++j) FF_DS_READ(ring[j], la0, j * 1024);
+
+    f32x16 acc1[2][2];                   // [chunk parity][value, gate]
+    bf16x8 hf[2][2];                     // [chunk parity][kappa]: GEGLU outputs = GEMM2 B operands
 #pragma unroll
-        for (int e = 0; e < 8; ++e) hf[nt][e] = f2bf(0.f);
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hf[k][q][e] = f2bf(0.f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[k][q][r] = 0.f;
+        }
 
     for (int round = blockIdx.x; round < n_rounds; round += gdim) {
-        const int64_t pix0 = ((int64_t)round * 4 + wave) * kWavePix;
+        const int64_t p = ((int64_t)round * 4 + wave) * kWavePix + n;
         // ---- this wave's tokens: raw x as B-operand fragments (rows past M repeat the last row; never stored) ----
-        bf16x8 xf[kNT][kKS];
+        bf16x8 xf[kKS];
+        {
+            const bf16* row = xp + (p < d.M ? p : d.M - 1) * d.ldx + hi * 8;
 #pragma unroll
-        for (int nt = 0; nt < kNT; ++nt) {
-            const int64_t p = pix0 + nt * 16 + n;
-            const bf16* row = xp + (p < d.M ? p : d.M - 1) * d.ldx + g * 8;
-#pragma unroll
-            for (int s = 0; s < kKS; ++s) xf[nt][s] = *(const bf16x8*)(row + s * 32);
+            for (int s = 0; s < kKS; ++s) xf[s] = *(const bf16x8*)(row + s * 16);
         }
-        // ---- LayerNorm statistics of each token (two passes over the registers, 4 lanes share a token); the accumulators
-        //      of the second GEMM start from b2 + x (the residual, exact in fp32: accumulator tiles (2 s, 2 s + 1) hold the
-        //      channels of X fragment s); then the fragments are normalised IN PLACE: xf <- bf16((x - mean) rstd), gamma and
-        //      beta live in W1' / b1' ----
-        f32x4 acc2[kOT][kNT];
-#pragma unroll
-        for (int nt = 0; nt < kNT; ++nt) {
+        // ---- LayerNorm statistics (two passes over the registers, the two lanes of a token meet once); the accumulators of the
+        //      second GEMM start from b2 + x; then the fragments are normalised in place ----
+        f32x16 acc2[kOT];
+        {
             float sm = 0.f;
 #pragma unroll
             for (int s = 0; s < kKS; ++s)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sm += bf2f(xf[nt][s][e]);
-            sm += __shfl_xor(sm, 16);
+                for (int e = 0; e < 8; ++e) sm += bf2f(xf[s][e]);
             sm += __shfl_xor(sm, 32);
             const float mu = sm * (1.0f / kC);
             float sq = 0.f;
@@ -149,127 +155,132 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
             for (int s = 0; s < kKS; ++s)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float dv = bf2f(xf[nt][s][e]) - mu;
+                    const float dv = bf2f(xf[s][e]) - mu;
                     sq = fmaf(dv, dv, sq);
                 }
-            sq += __shfl_xor(sq, 16);
             sq += __shfl_xor(sq, 32);
             const float rs = d.ln ? rsqrtf(sq * (1.0f / kC) + d.eps) : 1.f;
             const float rm = d.ln ? rs * mu : 0.f;
 #pragma unroll
-            for (int s = 0; s < kKS; ++s) {
-                const f32x4 b0 = b2p[(2 * s) * 4 + g], b1 = b2p[(2 * s + 1) * 4 + g];
+            for (int t = 0; t < kOT; ++t) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc2[2 * s][nt][e] = b0[e] + bf2f(xf[nt][s][e]);
-                    acc2[2 * s + 1][nt][e] = b1[e] + bf2f(xf[nt][s][4 + e]);
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 bv = b2p[(t * 2 + hi) * 4 + q4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = q4 * 4 + e;
+                        acc2[t][r] = bv[e] + bf2f(xf[2 * t + (r >> 3)][r & 7]);
+                    }
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xf[nt][s][e] = f2bf(fmaf(rs, bf2f(xf[nt][s][e]), -rm));
             }
+#pragma unroll
+            for (int s = 0; s < kKS; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xf[s][e] = f2bf(fmaf(rs, bf2f(xf[s][e]), -rm));
         }
 
-        for (int c = 0; c < kIters; ++c, ++cc) {
-            // chunk c (issued during the previous iteration) has landed for this wave; after the barrier: for every wave, and
-            // every wave has finished reading the other buffer
-            if constexpr (!(ABL & 4)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
+        unsigned long long tacc[2] = {0, 0};            // ABL & 32: cycles in [barrier A, the 60 steps]
+        // one iteration; PAR = c & 1 selects the register sets (static indices: the loop below is unrolled by two)
+        auto iteration = [&](auto parc, int c) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(parc)::value;
+            unsigned long long tm0 = 0, tm1 = 0;
+            if constexpr (ABL & 32) tm0 = __builtin_amdgcn_s_memtime();
+            // barrier A: every wave has left the other buffer (chunk c - 1) -> the DMA of chunk c + 1 may overwrite it
+            __builtin_amdgcn_s_barrier();
+            if constexpr (ABL & 32) tm1 = __builtin_amdgcn_s_memtime();
             const bool last = (c == kIters - 1) && (round + gdim >= n_rounds);
-            const bool issue_next = !last && !((ABL & 1) && cc >= 1);
+            const bool issue_next = !last && !((ABL & 1) && (c > 0 || round != (int)blockIdx.x));
             const int cn = c + 1 == kIters ? 0 : c + 1;
-            const int nb = (cc + 1) & 1;
-            const char* buf = smem + (cc & 1) * kChunkBytes;
-            const unsigned la = (unsigned)(uintptr_t)(LDS_AS const char*)(buf + lane16);                  // fragment base
-            const unsigned lx = (unsigned)(uintptr_t)(LDS_AS const char*)(buf + kAuxOff + g * 16);       // s1 / b1' of this lane group
-
-            // LDS read sequence of the iteration: b1' of this chunk's half a, then the 60 fragments in use order (GEMM1 a =
-            // 0..19, GEMM2 = 40..59, GEMM1 b = 20..39) kD ahead of their use; b1' of half b is slipped in behind step 30.
-            f32x4 biasA[2], biasB[2];    // b1' [value, gate], rows 4 g .. 4 g + 3 of the half: the C operand of the first k-step
-#pragma unroll
-            for (int k = 0; k < 2; ++k) FF_DS_READ(biasA[k], lx, k * 64);
-            bf16x8 ring[kD];
-#pragma unroll
-            for (int j = 0; j < kD; ++j) FF_DS_READ(ring[j], la, frag_of(j) * 1024);
-            f32x4 accA[2][kNT];
+            const unsigned la = la0 + PAR * kChunkBytes, lan = la0 + (1 - PAR) * kChunkBytes;       // kIters is even: chunk c sits in buffer c & 1
+            const unsigned lxn = lx0 + (1 - PAR) * kChunkBytes;
 
             auto step = [&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                constexpr int f = frag_of(j);
-                constexpr int left = 59 - j < kD - 1 ? 59 - j : kD - 1;      // younger fragment reads that may stay in flight
-                if constexpr (!(ABL & 8)) FF_WAIT(ring[j % kD], (j > 30 && j <= 30 + kD ? left + 2 : left));
+                constexpr int s = j / 3, role = j % 3;                        // k-step, (value, gate, GEMM2) fragment
+                // younger reads that may stay in flight: the kD - 1 fragments behind this one, + the 8 b1' reads slipped in
+                // behind fragment 60 (= fragment 0 of the next chunk, read at step 60 - kD) while that one is among them
+                FF_WAIT(ring[j % kD], (j >= 61 - kD ? (kD - 1 + 8 > 15 ? 15 : kD - 1 + 8) : kD - 1));      // (lgkmcnt is a 4-bit counter)
                 if constexpr (j == 0) {
+                    FF_WAIT(ring[0], (kD - 1 + 8 > 15 ? 15 : kD - 1 + 8));                             // (fragment 0 itself: the b1' reads behind it may still fly)
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) FF_WAIT(biasA[k], kD - 1);  // older than fragment 0: already complete
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) FF_WAIT(bq[k][q4], kD - 1);      // older than fragment 1
                 }
-                if constexpr (j == 40) {
+                if constexpr (role < 2) {        // GEMM1 of chunk c: value / gate tile, C operand of the first k-step = b1'
+                    if constexpr (s == 0) {
+                        f32x16 c0;
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) FF_WAIT(biasB[k], kD - 1);  // older than fragment 31 + kD
-                }
-                if constexpr (f < 20) {          // phase 1: GEMM1 half a of chunk c
-                    constexpr int s = f >> 1, kind = f & 1;
-#pragma unroll
-                    for (int nt = 0; nt < kNT; ++nt) {
-                        accA[kind][nt] = mfma16(ring[j % kD], xf[nt][s], s == 0 ? biasA[kind] : accA[kind][nt]);
+                        for (int r = 0; r < 16; ++r) c0[r] = bq[role][r >> 2][r & 3];
+                        acc1[PAR][role] = mfma32(ring[j % kD], xf[s], c0);
+                    } else {
+                        acc1[PAR][role] = mfma32(ring[j % kD], xf[s], acc1[PAR][role]);
                     }
-                } else if constexpr (f >= 40) {  // phase 2: GEMM2 of chunk c - 1
-                    constexpr int t = f - 40;
+                } else {                         // GEMM2 of chunk c - 2: fragment s = (kappa = s / 10, out tile s % 10)
+                    acc2[s % kOT] = mfma32(ring[j % kD], hf[PAR][s / kOT], acc2[s % kOT]);
+                }
+                // the ring continues into the next chunk's buffer behind barrier B
+                if constexpr (j + kD < 60) FF_DS_READ(ring[j % kD], la, (j + kD) * 1024);
+                else FF_DS_READ(ring[j % kD], lan, (j + kD - 60) * 1024);
+                if constexpr (j == 60 - kD) {
 #pragma unroll
-                    for (int nt = 0; nt < kNT; ++nt) acc2[t][nt] = mfma16(ring[j % kD], hf[nt], acc2[t][nt]);
-                } else {                         // phase 3: GEMM1 half b of chunk c
-                    constexpr int s = (f - 20) >> 1, kind = f & 1;
+                    for (int k = 0; k < 2; ++k)
 #pragma unroll
-                    for (int nt = 0; nt < kNT; ++nt) {
-                        accB[kind][nt] = mfma16(ring[j % kD], xf[nt][s], s == 0 ? biasB[kind] : accB[kind][nt]);
-                    }
+                        for (int q4 = 0; q4 < 4; ++q4) FF_DS_READ(bq[k][q4], lxn, k * 128 + q4 * 16);
                 }
-                if constexpr (j + kD < 60 && !(ABL & 8)) FF_DS_READ(ring[j % kD], la, frag_of(j + kD) * 1024);
-                if constexpr (j == 30) {
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) FF_DS_READ(biasB[k], lx, 128 + k * 64);
+                if constexpr (j < 32 && (j & 1) == 0) {
+                    if (issue_next) issue_frag(cn, 1 - PAR, j >> 1);          // the next chunk's DMA, spread over the MFMA steps
                 }
-                if constexpr (j < 16) {
-                    if (issue_next) issue_frag(cn, nb, j);                   // the next chunk's DMA, spread over the MFMA steps
+                if constexpr (j == 58 - kD) {    // barrier B: chunk c + 1 has landed for every wave
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
                 }
-                // GEGLU pairs between the MFMA steps: half b of chunk c - 1 in phase 1 (steps 1, 4, .. 16), half a of chunk c
-                // in phase 3 (steps 41, 44, .. 56); pair p = (token tile p / 2, rows 2 (p % 2), + 1)
-                if constexpr (j < 20 && j % 3 == 1 && j / 3 < 2 * kNT && !(ABL & 16)) {
-                    constexpr int p = j / 3, nt = p >> 1, r = 2 * (p & 1);
-                    const bf16x2 h = geglu2(f32x2{accB[0][nt][r], accB[0][nt][r + 1]}, f32x2{accB[1][nt][r], accB[1][nt][r + 1]}, (ABL & 2) != 0);
-                    hf[nt][4 + r] = h[0];
-                    hf[nt][4 + r + 1] = h[1];
-                }
-                if constexpr (j >= 40 && (j - 40) % 3 == 1 && (j - 40) / 3 < 2 * kNT && !(ABL & 16)) {
-                    constexpr int p = (j - 40) / 3, nt = p >> 1, r = 2 * (p & 1);
-                    const bf16x2 h = geglu2(f32x2{accA[0][nt][r], accA[0][nt][r + 1]}, f32x2{accA[1][nt][r], accA[1][nt][r + 1]}, (ABL & 2) != 0);
-                    hf[nt][r] = h[0];
-                    hf[nt][r + 1] = h[1];
+                // GEGLU of chunk c - 1, one accumulator register per k-step; scalar fp32 on purpose (and -fno-slp-vectorize):
+                // beside MFMAs a v_pk_*_f32 costs several v_fma_f32
+                if constexpr (role == 2 && s >= 1 && s < 17) {
+                    constexpr int r = s - 1;
+                    const float v = acc1[1 - PAR][0][r], u = acc1[1 - PAR][1][r];
+                    hf[1 - PAR][r >> 3][r & 7] = f2bf((ABL & 2) ? v + u : v * gelu_erf_f(u));
                 }
             };
             for_seq(step, std::make_integer_sequence<int, 60>{});
+            if constexpr (ABL & 32) {
+                const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
+                tacc[0] += tm1 - tm0;
+                tacc[1] += tm2 - tm1;
+            }
+        };
+        static_assert(kIters % 2 == 0, "the iteration loop is unrolled by two");
+        for (int c = 0; c < kIters; c += 2) {
+            iteration(std::integral_constant<int, 0>{}, c);
+            iteration(std::integral_constant<int, 1>{}, c + 1);
+        }
+        if constexpr (ABL & 32) {
+            if (round == (int)blockIdx.x && lane == 0 && d.dbg) {
+                unsigned long long* o = (unsigned long long*)d.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
+                o[0] = tacc[0];
+                o[1] = tacc[1];
+                o[2] = o[3] = 0;
+            }
         }
 
-        // ---- store: accumulator tiles (2 s, 2 s + 1) of lane (n, g) are channels 32 s + 8 g .. + 7 of token n ----
+        // ---- store: registers 0..7 / 8..15 of accumulator tile t are channels 32 t + 8 hi .. / 32 t + 16 + 8 hi .. of token n ----
+        if (p < d.M) {
+            bf16* row = op + p * d.ldo + hi * 8;
 #pragma unroll
-        for (int nt = 0; nt < kNT; ++nt) {
-            const int64_t p = pix0 + nt * 16 + n;
-            if (p < d.M) {
-                bf16* row = op + p * d.ldo + g * 8;
+            for (int t = 0; t < kOT; ++t) {
+                bf16x8 o0, o1;
 #pragma unroll
-                for (int s = 0; s < kKS; ++s) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o[e] = f2bf(acc2[2 * s][nt][e]);
-                        o[4 + e] = f2bf(acc2[2 * s + 1][nt][e]);
-                    }
-                    *(bf16x8*)(row + s * 32) = o;
+                for (int e = 0; e < 8; ++e) {
+                    o0[e] = f2bf(acc2[t][e]);
+                    o1[e] = f2bf(acc2[t][8 + e]);
                 }
+                *(bf16x8*)(row + t * 32) = o0;
+                *(bf16x8*)(row + t * 32 + 16) = o1;
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
 }  // namespace
@@ -288,15 +299,12 @@ extern "C" int ccedit_ff320(const CcFf320Desc* desc, void* stream) {
     switch (abl) {        // tuning only (bit mask, see the kernel); results are wrong for abl != 0
         case 1: kern = ff320_kernel<1>; break;
         case 2: kern = ff320_kernel<2>; break;
-        case 4: kern = ff320_kernel<4>; break;
-        case 8: kern = ff320_kernel<8>; break;
-        case 16: kern = ff320_kernel<16>; break;
-        case 24: kern = ff320_kernel<24>; break;
-        case 29: kern = ff320_kernel<29>; break;
+        case 3: kern = ff320_kernel<3>; break;
+        case 32: kern = ff320_kernel<32>; break;
         default: break;
     }
-    static unsigned long long attr_done[32] = {0};
-    if (int rc = cc_max_dynamic_lds((const void*)kern, 2 * kChunkBytes, &attr_done[abl & 31], "ff320")) return rc;
+    static unsigned long long attr_done[64] = {0};
+    if (int rc = cc_max_dynamic_lds((const void*)kern, 2 * kChunkBytes, &attr_done[abl & 63], "ff320")) return rc;
     int cus = 256;
     {
         int dev = 0;

@@ -53,7 +53,7 @@ class CcFf320Desc(C.Structure):
     _fields_ = [
         ("M", C.c_int64), ("dim", C.c_int32), ("inner", C.c_int32), ("ldx", C.c_int32), ("ldo", C.c_int32),
         ("eps", C.c_float), ("ln", C.c_int32),
-        ("x", C.c_void_p), ("out", C.c_void_p), ("wstream", C.c_void_p), ("b2p", C.c_void_p),
+        ("x", C.c_void_p), ("out", C.c_void_p), ("wstream", C.c_void_p), ("b2p", C.c_void_p), ("dbg", C.c_void_p),
     ]
 
 

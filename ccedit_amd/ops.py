@@ -140,7 +140,8 @@ def linear(x2d, pw, **kw):
 FF320 = os.environ.get("CCEDIT_FF320", "1") != "0"      # 0: LayerNorm + two GEMMs instead of the fused dim-320 feed-forward
 
 
-def ff320(x2d: torch.Tensor, pk: PackedFF320, eps: float = 1e-5, ln: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def ff320(x2d: torch.Tensor, pk: PackedFF320, eps: float = 1e-5, ln: bool = True, out: Optional[torch.Tensor] = None,
+          dbg: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = x + W2 . GEGLU(W1 . LayerNorm(x) + b1) + b2 for dim 320 in one kernel (csrc/ff320.hip).  x2d: [tokens, 320]."""
     assert x2d.dtype == BF16 and x2d.is_cuda and x2d.stride(-1) == 1 and x2d.shape[1] == 320
     if out is None:
@@ -149,6 +150,7 @@ def ff320(x2d: torch.Tensor, pk: PackedFF320, eps: float = 1e-5, ln: bool = True
     d = CcFf320Desc()
     d.M, d.dim, d.inner, d.ldx, d.ldo, d.eps, d.ln = x2d.shape[0], 320, 1280, x2d.stride(0), out.stride(0), eps, int(ln)
     d.x, d.out, d.wstream, d.b2p = x2d.data_ptr(), out.data_ptr(), pk.stream.data_ptr(), pk.b2p.data_ptr()
+    d.dbg = None if dbg is None else dbg.data_ptr()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -112,28 +112,29 @@ FF320_DIM, FF320_INNER, FF320_CHUNKS, FF320_CHUNK_BYTES = 320, 1280, 40, 64 * 10
 
 @dataclass
 class PackedFF320:
-    stream: torch.Tensor            # uint8 [41 * 65536]: per pipeline iteration 40 GEMM1 + 20 GEMM2 MFMA A-fragments + s1 / b1'
-    b2p: torch.Tensor               # fp32 [320]: b2 in accumulator order [tile 20][lane group 4][reg 4]
+    stream: torch.Tensor            # uint8 [42 * 65536]: per pipeline iteration 40 GEMM1 + 20 GEMM2 MFMA A-fragments + b1'
+    b2p: torch.Tensor               # fp32 [320]: b2 in accumulator order [tile 10][lane half 2][register 16]
     flops_per_row: float = 2.0 * 320 * 2560 + 2.0 * 1280 * 320
 
 
+def ff320_acc_row(r: torch.Tensor, hi: torch.Tensor) -> torch.Tensor:
+    """Row of a v_mfma_f32_32x32x16 C/D tile held by accumulator register r (0..15) of a lane in half hi (= lane >> 5)."""
+    return (r & 3) + 8 * (r >> 2) + 4 * hi
+
+
 def ff320_out_channel(t: torch.Tensor, i: torch.Tensor) -> torch.Tensor:
-    """Output channel held by row i (0..15) of GEMM2 accumulator tile t (0..19): tiles (2s, 2s+1) of lane group g cover
-    channels 32 s + 8 g .. + 7 — the channels of X fragment s of the same lane (residual / store without a shuffle)."""
-    return 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3)
-
-
-def ff320_hidden_of_k(q: torch.Tensor, k: torch.Tensor) -> torch.Tensor:
-    """Hidden unit at K position k (0..31) of chunk q in GEMM2: lane group g = k >> 3 supplies registers 0..3 of GEMM1
-    tile a (hidden 32 q + 4 g + e) as e = 0..3 and of tile b (hidden 32 q + 16 + 4 g + e - 4) as e = 4..7."""
-    g, e = k >> 3, k & 7
-    return 32 * q + torch.where(e < 4, 4 * g + e, 16 + 4 * g + e - 4)
+    """Output channel computed by row i (0..31) of GEMM2 accumulator tile t (0..9).  Row i is register r = (i & 3) + 4 (i >> 3)
+    of lane half hi = (i >> 2) & 1; registers 0..7 / 8..15 of a lane must be channels 32 t + 8 hi .. + 7 / 32 t + 16 + 8 hi .. + 7 —
+    the channels of X fragments 2 t / 2 t + 1 of the same lane (residual initialisation and 16-byte stores without a shuffle)."""
+    hi, r = (i >> 2) & 1, (i & 3) + 4 * (i >> 3)
+    return 32 * t + torch.where(r < 8, 8 * hi + r, 16 + 8 * hi + r - 8)
 
 
 def pack_ff320(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, ln_g: Optional[torch.Tensor],
                ln_b: Optional[torch.Tensor], device: Optional[torch.device] = None) -> PackedFF320:
     """w1 (2560, 320) = GEGLU proj [value rows | gate rows] (attention.py:118-126), b1 (2560,), w2 (320, 1280),
-    b2 (320,), LayerNorm gamma / beta (320,) or None (no normalisation)."""
+    b2 (320,), LayerNorm gamma / beta (320,) or None (no normalisation).  LayerNorm's affine part is folded into the
+    weights (W1' = W1 diag(gamma), b1' = b1 + W1 beta); the kernel normalises x itself."""
     D, H, Q = FF320_DIM, FF320_INNER, FF320_CHUNKS
     if tuple(w1.shape) != (2 * H, D) or tuple(w2.shape) != (D, H):
         raise ValueError(f"pack_ff320: expected w1 (2560, 320), w2 (320, 1280); got {tuple(w1.shape)}, {tuple(w2.shape)}")
@@ -144,42 +145,44 @@ def pack_ff320(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.T
     gam = torch.ones(D, dtype=torch.float64) if ln_g is None else ln_g.detach().double().cpu()
     bet = torch.zeros(D, dtype=torch.float64) if ln_b is None else ln_b.detach().double().cpu()
     w1g = (w1 * gam[None, :]).float().to(torch.bfloat16)                  # W1 diag(gamma), what the MFMA multiplies
-    s1 = w1g.double().sum(dim=1).float()                                  # row sums of the ROUNDED weights (exact fold)
     b1p = (b1 + w1 @ bet).float()                                         # b1 + W1 beta
     w2b = w2.to(torch.bfloat16)
 
     lane = torch.arange(64)
-    i, g = lane & 15, lane >> 4
+    i, hi = lane & 31, lane >> 5
     e = torch.arange(8)
-    # GEMM1 fragments in consumption order [q][half (hidden 16 a | 16 b)][k-step s][kind (value | gate)][lane][e]
-    q = torch.arange(Q)[:, None, None, None, None, None]
-    half = torch.arange(2)[None, :, None, None, None, None]
-    s = torch.arange(10)[None, None, :, None, None, None]
-    kind = torch.arange(2)[None, None, None, :, None, None]
-    row1 = kind * H + 32 * q + 16 * half + i[None, None, None, None, :, None]                     # [q,half,1,kind,lane,1]
-    col1 = 32 * s + 8 * g[None, None, None, None, :, None] + e[None, None, None, None, None, :]   # [1,1,s,1,lane,e]
-    shp = (Q, 2, 10, 2, 64, 8)
-    f1 = w1g[row1.expand(shp), col1.expand(shp)]                                                  # bf16
-    # GEMM2 fragments [q][t][lane][e]
-    t = torch.arange(20)[None, :, None, None]
-    q2 = torch.arange(Q)[:, None, None, None]
-    row2 = ff320_out_channel(t, i[None, None, :, None])                                           # [1,t,lane,1]
-    col2 = ff320_hidden_of_k(q2, 8 * g[None, None, :, None] + e[None, None, None, :])             # [q,1,lane,e]
-    f2 = w2b[row2.expand(Q, 20, 64, 8), col2.expand(Q, 20, 64, 8)]
-    # s1 / b1' per half: [q][half][s1 value, s1 gate, b1' value, b1' gate][16 rows] fp32 (256 B per half)
-    i16 = torch.arange(16)
-    rowa = (torch.arange(2)[None, None, :, None] * H + 32 * torch.arange(Q)[:, None, None, None]
-            + 16 * torch.arange(2)[None, :, None, None] + i16[None, None, None, :])               # [q,half,kind,16]
-    aux = torch.cat([s1[rowa], b1p[rowa]], dim=2).contiguous()                                    # [q, half, 4, 16]
-    # Stream chunk c = 0 .. 40 is what iteration c of the kernel's software pipeline reads: GEMM1 fragments of hidden chunk c,
-    # GEMM2 fragments of chunk c - 1, s1 / b1' of half a of chunk c and of half b of chunk c - 1; the missing neighbours of
-    # the first / last iteration are zero fragments (their MFMAs add zeros).
-    stream = torch.zeros(Q + 1, FF320_CHUNK_BYTES, dtype=torch.uint8)
-    stream[:Q, : 40 * 1024] = f1.contiguous().view(torch.uint8).reshape(Q, -1)
-    stream[1:, 40 * 1024: 60 * 1024] = f2.contiguous().view(torch.uint8).reshape(Q, -1)
-    stream[:Q, 60 * 1024: 60 * 1024 + 256] = aux[:, 0].contiguous().view(torch.uint8).reshape(Q, -1)
-    stream[1:, 60 * 1024 + 256: 60 * 1024 + 512] = aux[:, 1].contiguous().view(torch.uint8).reshape(Q, -1)
-    tt, gg, rr = torch.meshgrid(torch.arange(20), torch.arange(4), torch.arange(4), indexing="ij")
-    b2p = b2[32 * (tt >> 1) + 8 * gg + 4 * (tt & 1) + rr].reshape(-1).contiguous()
+    # GEMM1 A fragments in use order [q][k-step s][kind (value | gate)][lane][e]: row = hidden unit 32 q + (lane & 31)
+    q = torch.arange(Q)[:, None, None, None, None]
+    s = torch.arange(20)[None, :, None, None, None]
+    kind = torch.arange(2)[None, None, :, None, None]
+    row1 = kind * H + 32 * q + i[None, None, None, :, None]                                       # [q,1,kind,lane,1]
+    col1 = 16 * s + 8 * hi[None, None, None, :, None] + e[None, None, None, None, :]             # [1,s,1,lane,e]
+    shp = (Q, 20, 2, 64, 8)
+    f1 = w1g[row1.expand(shp), col1.expand(shp)]
+    # GEMM2 A fragments [q][k-step kappa][out tile t][lane][e] (kappa-major: consecutive MFMAs use different accumulators): K position (kappa, lane half, e) is the hidden unit whose GEGLU
+    # result sits in accumulator register 8 kappa + e of that lane half
+    kap = torch.arange(2)[None, :, None, None, None]
+    t = torch.arange(10)[None, None, :, None, None]
+    q2 = torch.arange(Q)[:, None, None, None, None]
+    row2 = ff320_out_channel(t, i[None, None, None, :, None])                                     # [1,1,t,lane,1]
+    col2 = 32 * q2 + ff320_acc_row(8 * kap + e[None, None, None, None, :], hi[None, None, None, :, None])   # [q,kap,1,lane,e]
+    shp2 = (Q, 2, 10, 64, 8)
+    f2 = w2b[row2.expand(shp2), col2.expand(shp2)]
+    # b1' in accumulator order [q][kind][lane half][register r]
+    r16 = torch.arange(16)
+    rowa = (torch.arange(2)[None, :, None, None] * H + 32 * torch.arange(Q)[:, None, None, None]
+            + ff320_acc_row(r16[None, None, None, :], torch.arange(2)[None, None, :, None]))       # [q,kind,hi,16]
+    aux = b1p[rowa].contiguous()
+    # Stream chunk c = 0 .. 41 is what iteration c of the kernel's three-stage software pipeline reads: per k-step s the value
+    # and gate GEMM1 fragments of hidden chunk c and GEMM2 fragment s = (kappa, out tile) of chunk c - 2, then b1' of chunk c;
+    # the missing neighbours of the first / last two iterations stay zero.
+    frags = torch.zeros(Q + 2, 20, 3, 64, 8, dtype=torch.bfloat16)
+    frags[:Q, :, 0:2] = f1
+    frags[2:, :, 2] = f2.reshape(Q, 20, 64, 8)
+    stream = torch.zeros(Q + 2, FF320_CHUNK_BYTES, dtype=torch.uint8)
+    stream[:, : 60 * 1024] = frags.contiguous().view(torch.uint8).reshape(Q + 2, -1)
+    stream[:Q, 60 * 1024: 60 * 1024 + 256] = aux.view(torch.uint8).reshape(Q, -1)
+    tt, hh, rr = torch.meshgrid(torch.arange(10), torch.arange(2), torch.arange(16), indexing="ij")
+    b2p = b2[32 * tt + torch.where(rr < 8, 8 * hh + rr, 16 + 8 * hh + rr - 8)].reshape(-1).contiguous()
     dev = device if device is not None else torch.device("cpu")
     return PackedFF320(stream.reshape(-1).to(dev), b2p.to(dev))

@@ -117,11 +117,11 @@ int ccedit_gemm(const CcGemmDesc* desc, void* stream);
  * `x = self.ff(self.norm2(x)) + x` of BasicTransformerSingleLayerBlock._forward (:758-761), with FeedForward /
  * GEGLU as in attention.py:115-141.  One kernel: x is read once, out written once, the 1280-wide hidden activation
  * stays in registers (ff320.hip).  Replaces ccedit_layernorm + two ccedit_gemm calls.
- *   wstream: the weights as ccedit_amd/packing.py:pack_ff320 lays them out — 41 chunks of 64 KB, one per iteration of the
- *            kernel's software pipeline over the 40 groups of 32 hidden units: 40 GEMM1 A-fragments of W1 diag(gamma) for
- *            group c (bf16, lane order), 20 GEMM2 A-fragments of W2 for group c - 1, then float s1 (row sums of the bf16
- *            W1 diag(gamma) rows) and b1' (b1 + W1 beta) of the rows the iteration's two GEGLU passes touch.
- *   b2p:     b2 in accumulator order, float[20][4][4].
+ *   wstream: the weights as ccedit_amd/packing.py:pack_ff320 lays them out — 42 chunks of 64 KB, one per iteration of the
+ *            kernel's three-stage software pipeline over the 40 groups of 32 hidden units: per k-step the two GEMM1
+ *            A-fragments (value, gate rows of W1 diag(gamma), group c; bf16, v_mfma_f32_32x32x16 lane order) and one GEMM2
+ *            A-fragment of W2 (group c - 2), then float b1' = b1 + W1 beta of group c in accumulator order.
+ *   b2p:     b2 in accumulator order, float[10][2][16].
  *   ln = 0:  no normalisation (mean 0, rstd 1; the packer must then be given gamma = 1, beta = 0).
  * ------------------------------------------------------------------------------------------ */
 typedef struct CcFf320Desc {
@@ -132,8 +132,9 @@ typedef struct CcFf320Desc {
     int32_t ln;           /* 1: LayerNorm folded in (statistics computed in the kernel) */
     const void* x;        /* bf16 [M][ldx] */
     void* out;            /* bf16 [M][ldo]; may NOT alias x (other workgroups' reads are not ordered against the stores) */
-    const void* wstream;  /* packed weights, 41 * 65536 bytes */
+    const void* wstream;  /* packed weights, 42 * 65536 bytes */
     const float* b2p;     /* float[320] in accumulator order */
+    void* dbg;            /* null (tuning builds only: per-wave phase cycle counters) */
 } CcFf320Desc;
 
 int ccedit_ff320(const CcFf320Desc* desc, void* stream);
