@@ -425,7 +425,7 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         CC_UNSUPPORTED(d.N % 16 != 0 || d.res1 || d.res2 || d.group_bias || d.out_f32,
                        "ccedit_gemm: GEGLU epilogue needs N%%16==0 and no residual/group bias/f32 out");
     }
-    if (d.group_bias) CC_CHECK_ARG(d.group_rows > 0, "ccedit_gemm: group_bias without group_rows");
+    if (d.group_bias) CC_CHECK_ARG(d.group_rows > 0 && (d.ldgb == 0 || d.ldgb >= d.N), "ccedit_gemm: group_bias without group_rows / ldgb < N");
     if (d.gn_stats) {
         CC_CHECK_ARG(d.gn_rows > 0 && d.gn_rows % 128 == 0 && d.M % d.gn_rows == 0,
                      "ccedit_gemm: gn_stats needs gn_rows %% 128 == 0 dividing M (gn_rows=%d)", d.gn_rows);

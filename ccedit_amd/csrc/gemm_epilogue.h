@@ -103,7 +103,7 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
                 float v[8] = {a0[0] + bv[0], a0[1] + bv[1], a0[2] + bv[2], a0[3] + bv[3],
                               a1[0] + bv[4], a1[1] + bv[5], a1[2] + bv[6], a1[3] + bv[7]};
                 if (gbias) {
-                    const float* gb = gbias + (size_t)(m / d.group_rows) * d.N + cb;
+                    const float* gb = gbias + (size_t)(m / d.group_rows) * (d.ldgb ? d.ldgb : d.N) + cb;
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         if (full || e < 4) v[e] += gb[e];

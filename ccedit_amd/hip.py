@@ -30,6 +30,7 @@ class CcGemmDesc(C.Structure):
         ("Kpad", C.c_int32), ("act", C.c_int32), ("out_f32", C.c_int32), ("group_rows", C.c_int32),
         ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("tile", C.c_int32), ("korder", C.c_int32), ("gn_rows", C.c_int32),
         ("Tsrc", C.c_int32), ("tsrc_off", C.c_int32), ("t0", C.c_int32), ("Tglob", C.c_int32), ("cgroup", C.c_int32),
+        ("ldgb", C.c_int32), ("reserved0", C.c_int32),
         ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
         ("group_bias", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p),
         ("gn_stats", C.c_void_p),

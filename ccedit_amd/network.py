@@ -339,7 +339,7 @@ class ResBlock(nn.Module):
         n, h, w, _ = x.shape
         gn = self.in_layers[0]
         a = ops.groupnorm_spatial(x, gn.g, gn.b, gn.eps, True)
-        e = ops.linear(emb_silu, self.emb_layers[1].pw, out_f32=True)              # (B, Cout) fp32
+        e = emb_silu.of(self)                                                      # (B, Cout) fp32 = emb_layers(emb)
         hid = ops.conv2d(a, self.in_layers[2].pw, group_bias=e, group_rows=geo.t * h * w, gn=True)
         gn = self.out_layers[0]
         a = ops.groupnorm_spatial(hid, gn.g, gn.b, gn.eps, True)
@@ -374,7 +374,7 @@ class ResBlock3D(nn.Module):
         co = s.shape[-1]
         sharded = geo.shard is not None
         at = temporal_gn(s, self.in_layers_temporal[0], geo, True, ext=sharded)
-        e = ops.linear(emb_silu, self.emb_layers[1].pw, out_f32=True)
+        e = emb_silu.of(self)
         # stf output (s + conv_t) and the `+ emb_out` of openaimodel.py:762 in one epilogue
         hid = temporal_conv3(at, self.in_layers_temporal[2].pw, geo, a_is_ext=sharded, res1=s.view(-1, co), group_bias=e,
                              group_rows=geo.t * h * w, gn=True)
@@ -463,6 +463,17 @@ def _check_supported(kw: dict, who: str):
         raise NotImplementedError(f"{who}: transformer_depth must be 1")
 
 
+class EmbOut:
+    """emb_layers outputs of all ResBlocks of one network evaluation: fp32 (B, sum Cout); `of(block)` = that block's columns."""
+
+    def __init__(self, e_all: torch.Tensor, offsets: dict):
+        self.e_all, self.offsets = e_all, offsets
+
+    def of(self, block) -> torch.Tensor:
+        off, c = self.offsets[id(block)]
+        return self.e_all[:, off:off + c]
+
+
 class UNetModel(nn.Module):
     """Block wiring of sgm UNetModel.__init__ (openaimodel.py:1033-1527) for the supported options."""
 
@@ -534,13 +545,33 @@ class UNetModel(nn.Module):
             self.out = _seq(Norm(ch, GN_EPS_RES), Slot(), Conv(model_channels, out_channels, 3))
 
     # -- shared helpers --
-    def _emb_silu(self, timesteps: torch.Tensor) -> torch.Tensor:
+    def _emb_silu(self, timesteps: torch.Tensor) -> "EmbOut":
         """SiLU(time_embed(timestep_embedding(t))): (B, 4*model_channels) bf16.  Every ResBlock applies
-        nn.SiLU to emb before its own Linear (openaimodel.py:470-476), so it is hoisted here."""
+        nn.SiLU to emb before its own Linear (openaimodel.py:470-476), so it is hoisted here — and since every one of
+        those `emb_layers` Linears (22 in the UNet, 10 in a ControlNet) reads the same (B, 1280) vector, they run as ONE
+        GEMM against the row-concatenated weights; a block takes its column slice as the GEMM epilogue's row bias."""
         te = ops.timestep_embedding(timesteps, self.model_channels)
         h = ops.linear(te, self.time_embed[0].pw, act=ACT_SILU)
-        e = ops.linear(h, self.time_embed[2].pw)
-        return ops.silu(e)
+        e = ops.silu(ops.linear(h, self.time_embed[2].pw))
+        return EmbOut(ops.linear(e, self._emb_all, out_f32=True), self._emb_off)
+
+    def _pack_emb(self, device):
+        blocks = [m for m in self.modules() if isinstance(m, (ResBlock, ResBlock3D)) and self._owns(m)]
+        self._emb_off, off = {}, 0
+        for m in blocks:
+            self._emb_off[id(m)] = (off, m.emb_layers[1].cout)
+            off += m.emb_layers[1].cout
+        self._emb_all = pack_concat([m.emb_layers[1].weight for m in blocks], [m.emb_layers[1].bias for m in blocks], device=device)
+
+    def _owns(self, block) -> bool:
+        """ResBlocks of THIS network (a ControlNet nested as `.controlnet` has its own time embedding)."""
+        for name, sub in self.named_modules():
+            if sub is block:
+                return not (name.startswith("controlnet.") or name.startswith("controlnet_img."))
+        return False
+
+    def post_pack(self, device):
+        self._pack_emb(device)
 
     def pack(self, device=None):
         device = torch.device("cuda") if device is None else device
@@ -599,6 +630,7 @@ class ControlNet2D(UNetModel):
         self.middle_block_out = TimestepEmbedSequential(Conv(ch, ch, 1))
 
     def post_pack(self, device):
+        self._pack_emb(device)
         if self.control_scales != 1.0:       # `c * scale` (controlmodel.py:311-312) folded into the zero convs
             for zc in list(self.zero_convs) + [self.middle_block_out]:
                 zc[0].pack(device, scale=self.control_scales)

@@ -101,6 +101,9 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
     d.act = ACT_GEGLU if pw.geglu else act
     d.out_f32 = int(out.dtype == torch.float32)
     d.group_rows = group_rows
+    if group_bias is not None:
+        assert group_bias.dtype == torch.float32 and group_bias.stride(-1) == 1 and group_bias.shape[-1] == pw.n
+        d.ldgb = group_bias.stride(0) if group_bias.dim() == 2 else pw.n
     d.ldr1 = res1.stride(0) if res1 is not None else 0
     d.ldr2 = res2.stride(0) if res2 is not None else 0
     d.tile = tile

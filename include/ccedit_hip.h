@@ -93,6 +93,9 @@ typedef struct CcGemmDesc {
      * and local frame 0 is global keyframe t0 of Tglob; taps outside [0, Tglob) read zeros (Conv1d padding). */
     int32_t Tsrc, tsrc_off, t0, Tglob;
     int32_t cgroup;       /* internal (set by the library): block-order parameters; pass 0 */
+    int32_t ldgb;         /* row stride of group_bias in elements; 0 = N (rows of a wider matrix: all ResBlocks' emb_layers
+                           * projections of one network come out of ONE GEMM, each layer reads its column slice) */
+    int32_t reserved0;
     const void* A;        /* bf16 [rows][lda] */
     const void* A2;       /* optional second source */
     const void* W;        /* bf16 [ceil(N,256)][Kpad] (rows zero-padded to the widest block shape) */

@@ -35,7 +35,7 @@ def test_binding_matches_header(libpath):
     from ccedit_amd import hip
     assert sorted(hip.EXPORTS) == _declared()
     # descriptor layouts: sizes the C side was compiled with (kept in sync by hand; a mismatch shows up here)
-    assert ctypes.sizeof(hip.CcGemmDesc) == 8 + 32 * 4 + 9 * 8
+    assert ctypes.sizeof(hip.CcGemmDesc) == 8 + 34 * 4 + 9 * 8
     assert ctypes.sizeof(hip.CcAttnDesc) % 8 == 0
 
 
