@@ -30,6 +30,16 @@ from .hip import ACT_SILU
 from .layers import Conv, Linear, Norm, Slot, pack_tree
 from .packing import pack_concat
 
+# Per-block output capture for the parity tests (tests/test_network_gpu.py reads the reference's per-block digests):
+# set to a dict and every ControlNet / UNet block stores its output under the reference's module path.  None in production.
+TRACE: Optional[dict] = None
+
+
+def _trace(name: str, t: torch.Tensor):
+    if TRACE is not None:
+        TRACE[name] = t.detach().clone()
+
+
 GN_EPS_RES = 1e-5     # reference: normalization() = nn.GroupNorm(32, C)     diffusionmodules/util.py:296-302
 GN_EPS_ATTN = 1e-6    # reference: Normalize()                               attention.py:153-156
 
@@ -657,8 +667,13 @@ class ControlNet2D(UNetModel):
                 h = ops.conv2d(h, block[0].pw, res1=guided.view(-1, guided.shape[-1]))     # h = conv(x); h += guided_hint
             else:
                 h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
+            if TRACE is not None:
+                _trace(f"controlnet.input_blocks.{i}", h)
+                if i == 0 and not self.no_add_x:
+                    _trace("controlnet.guided_hint", guided)
             outs.append(ops.conv2d(h, zc[0].pw))
         h = self.middle_block.run(h, emb_silu, geo, ctx2d, ctx_len)
+        _trace("controlnet.middle_block", h)
         outs.append(ops.conv2d(h, self.middle_block_out[0].pw))
         return outs
 
@@ -722,6 +737,7 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
                 h = temporal_conv3(s, self.input_blocks_temporal[0].pw, geo, res1=s.view(-1, s.shape[-1]))
             else:
                 h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
+            _trace(f"input_blocks.{i}", h)
             hs.append(add_center(h))
         h = add_center(self.middle_block.run(h, emb_silu, geo, ctx2d, ctx_len))
         if control_ready is not None:      # ControlNet ran on a side stream while the encoder above was running
@@ -730,6 +746,7 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
         for block in self.output_blocks:
             h = ops.cat_add(h, hs.pop(), control.pop(), gn=True)          # cat([h, hs.pop() + control.pop()], dim=1)
             h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
+            _trace(f"output_blocks.{len(self.output_blocks) - len(hs) - 1}", h)
         gn = self.out[0]
         a = ops.groupnorm_spatial(h, gn.g, gn.b, gn.eps, True)
         n, hh, ww, _ = a.shape
@@ -828,7 +845,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         return g
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, c: Dict[str, torch.Tensor], **kwargs) -> torch.Tensor:
-        if _SPLIT_CFG and x.shape[0] == 2 and self.frame_shard is None and ops.PROFILE is None and not kwargs.get("_half"):
+        if _SPLIT_CFG and x.shape[0] == 2 and self.frame_shard is None and ops.PROFILE is None and TRACE is None and not kwargs.get("_half"):
             main = torch.cuda.current_stream()
             if OpenAIWrapperControlLDM3DTV2V._half_stream is None:
                 OpenAIWrapperControlLDM3DTV2V._half_stream = torch.cuda.Stream()
@@ -867,7 +884,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
         x8 = ops.ncthw_to_nhwc(x.float().contiguous(), 8)
         control_ready = None
-        if self.overlap_controlnet and sh is None and ops.PROFILE is None:
+        if self.overlap_controlnet and sh is None and ops.PROFILE is None and TRACE is None:
             main = torch.cuda.current_stream()
             if OpenAIWrapperControlLDM3DTV2V._side_stream is None:
                 OpenAIWrapperControlLDM3DTV2V._side_stream = {}

@@ -11,6 +11,32 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 
 
+def main_tvi2v(out_path):
+    """BASELINE.json config 3 at full size: controlnet_img on the reference latent + anchor cross-frame attention."""
+    from ccedit_amd.sgm_compat import build_network
+    from ccedit_amd.utils.synth import fill_module_
+    torch.set_grad_enabled(False)
+    dev = torch.device("cuda")
+    T, H, W = 17, 64, 96
+    w = build_network(dev, crossframe=True)
+    fill_module_(w, prefix="model.")
+    w.diffusion_model.pack(dev)
+    g = torch.Generator().manual_seed(321)
+    x = torch.randn(1, 4, T, H, W, generator=g)
+    cc, cu = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
+    hint = (torch.rand(1, 1, T, 8 * H, 8 * W, generator=g) * 2 - 1).repeat(1, 3, 1, 1, 1)
+    cf, cf2 = (torch.randn(1, 4, H, W, generator=g) * 0.18215 for _ in range(2))
+    t = torch.tensor([601, 601], dtype=torch.int64, device=dev)
+
+    def run(cfa, cfb, ca, cb):
+        c = dict(crossattn=torch.cat([ca, cb]).to(dev), control_hint=torch.cat([hint, hint]).to(dev), cond_feat=torch.cat([cfa, cfb]).to(dev))
+        return w(torch.cat([x, x]).to(dev), t, c).float().cpu().numpy()
+
+    np.savez(out_path, eps=run(cf, cf, cu, cc),        # the CFG pair: same latent / reference frame, two prompts
+             eps_same=run(cf, cf, cc, cc),             # identical halves -> identical predictions
+             eps_ref=run(cf, cf2, cu, cc))             # another reference frame in half 1: half 0 must not change, half 1 must
+
+
 def main(out_path):
     from ccedit_amd.sgm_compat import build_network, build_vae
     from ccedit_amd.utils.synth import fill_module_
@@ -45,4 +71,4 @@ def main(out_path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    (main_tvi2v if len(sys.argv) > 2 and sys.argv[2] == "tvi2v" else main)(sys.argv[1])

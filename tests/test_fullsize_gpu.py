@@ -2,7 +2,7 @@
 would need minutes per evaluation: size-independent properties instead.
 
   * the specialised kernels the full-size shapes dispatch to (LDS-halo 3x3 conv, 320-channel block shape, K rotation,
-    register-resident-weight K = 320 linears,
+    register-resident-weight K = 320 linears, the fused dim-320 feed-forward,
     channel-tile groups, persistent temporal attention, 8-wave attention blocks, fused GroupNorm statistics, two-stream
     CFG halves, ControlNet on a side stream) must reproduce the GENERIC kernels (tap-gather GEMM, flash kernel, two-pass
     GroupNorm, one stream) — the ones the small-size tests pin against the oracle and the reference goldens;
@@ -19,7 +19,8 @@ import torch
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 GENERIC = dict(CCEDIT_T6="0", CCEDIT_CONV_HALO="0", CCEDIT_ATTN_SHORT="0", CCEDIT_SPLIT_CFG="0", CCEDIT_OVERLAP_CONTROLNET="0",
-               CCEDIT_KROT="0", CCEDIT_CGROUP="0", CCEDIT_FUSE_GN_STATS="0", CCEDIT_TEMPORAL_ORDER="0", CCEDIT_LIN320="0")
+               CCEDIT_KROT="0", CCEDIT_CGROUP="0", CCEDIT_FUSE_GN_STATS="0", CCEDIT_TEMPORAL_ORDER="0", CCEDIT_LIN320="0",
+               CCEDIT_FF320="0")
 
 
 def _rel(a, b):
@@ -27,14 +28,14 @@ def _rel(a, b):
     return float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))
 
 
-def _run(tmp_path, name, extra_env):
+def _run(tmp_path, name, extra_env, workload=None):
     out = os.path.join(str(tmp_path), name + ".npz")
     env = dict(os.environ)
     for k in GENERIC:
         env.pop(k, None)
     env.update(extra_env)
-    r = subprocess.run([sys.executable, os.path.join(HERE, "_fullsize_eval.py"), out], env=env, capture_output=True, text=True,
-                       timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_fullsize_eval.py"), out] + ([workload] if workload else []), env=env,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(out)
 
@@ -63,3 +64,23 @@ def test_full_size_properties(tmp_path):
     print(f"full size: fast vs generic kernels: eps {e:.4f}, VAE frames {ev:.4f}")
     assert e < 3.5e-2, e
     assert ev < 2.5e-2, ev
+
+
+@pytest.mark.timeout(1800)
+def test_full_size_tvi2v_properties(tmp_path):
+    """BASELINE.json config 3 (TVI2V: controlnet_img + SpatialTransformer3DCA anchor attention over 2 x 6144 keys) at
+    17 x 512 x 768 — the same size-independent properties, plus: the reference frame of one CFG half reaches only that half."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    fast = _run(tmp_path, "tv_fast", {}, "tvi2v")
+    again = _run(tmp_path, "tv_again", {}, "tvi2v")
+    gen = _run(tmp_path, "tv_generic", GENERIC, "tvi2v")
+    assert fast["eps"].shape == (2, 4, 17, 64, 96) and np.isfinite(fast["eps"]).all() and np.isfinite(gen["eps"]).all()
+    for k in ("eps", "eps_same", "eps_ref"):
+        assert np.array_equal(fast[k], again[k]), f"{k}: two runs of the same evaluation differ"
+    assert np.array_equal(fast["eps_same"][0], fast["eps_same"][1])
+    assert np.array_equal(fast["eps_ref"][0], fast["eps"][0])
+    assert _rel(fast["eps_ref"][1], fast["eps"][1]) > 1e-2          # the reference latent does condition the prediction
+    e = _rel(fast["eps"], gen["eps"])
+    print(f"full size TVI2V: fast vs generic kernels: eps {e:.4f}")
+    assert e < 3.5e-2, e

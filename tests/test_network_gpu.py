@@ -74,6 +74,172 @@ def test_network_eval_vs_reference_golden(golden_dir, g160_wrapper):
     assert r < NET_TOL, f"eps rel rms err {r}"
 
 
+def _block_errors(z, wrapper, b, t):
+    """Run one traced evaluation of the golden's inputs; {reference module path: rel. error of the 256-sample digest}."""
+    from ccedit_amd import network
+    x, hint, cc, cuc = _golden_inputs(z)
+    c = dict(crossattn=torch.cat([cuc, cc]).cuda(), control_hint=torch.cat([hint, hint]).cuda())
+    network.TRACE = {}
+    try:
+        eps = wrapper(torch.cat([x, x]).cuda(), torch.from_numpy(z["t"]).cuda(), c)
+        torch.cuda.synchronize()
+        tr = network.TRACE
+    finally:
+        network.TRACE = None
+    errs = {}
+    for name in sorted({k.split("|")[0][len("trace:"):] for k in z.files if k.startswith("trace:")}):
+        short = name[len("model.diffusion_model."):]
+        got = tr[short].float()
+        if short == "controlnet.input_blocks.0":        # the reference's hook saw conv(x) BEFORE `h += guided_hint` (make_golden.py)
+            got = got - tr["controlnet.guided_hint"].float()
+        n, hh, ww, ch = got.shape
+        if short.startswith("controlnet."):
+            ref_layout = got.permute(0, 3, 1, 2)                                       # (b t) c h w
+        else:
+            ref_layout = got.view(b, t, hh, ww, ch).permute(0, 4, 1, 2, 3)            # b c t h w
+        errs[short] = _digest_rel(z, "trace:" + name, ref_layout.contiguous())
+    return eps, errs
+
+
+# Per-block budgets (relative error of the reference's 256-sample digest of each block output).  The fp32 reference against
+# bf16 storage: the error grows along the network from ~0.5e-2 after the first ControlNet block to ~2.5e-2 at the last decoder
+# block; a block whose temporal layer, zero-conv or attention branch were wrong would jump far beyond its neighbours.
+_BLOCK_BUDGET_FIRST, _BLOCK_BUDGET_LAST = 1.2e-2, 3.2e-2
+
+
+def _check_block_errors(errs):
+    order = ([f"controlnet.input_blocks.{i}" for i in range(12)] + ["controlnet.middle_block"]
+             + [f"input_blocks.{i}" for i in range(1, 12)] + [f"output_blocks.{i}" for i in range(12)])
+    assert set(order) == set(errs), sorted(set(order) ^ set(errs))
+    print("per-block rel errs:", " ".join(f"{k.replace('input_blocks', 'in').replace('output_blocks', 'out').replace('controlnet', 'cn')}={errs[k]:.4f}"
+                                            for k in order))
+    # depth of a block in the dataflow, 0 .. 1: ControlNet encoder, UNet encoder (same depth), then the decoder
+    def budget(k):
+        if k.startswith("controlnet."):
+            d = 0.5 * (12 if "middle" in k else int(k.rsplit(".", 1)[1])) / 12
+        elif k.startswith("input_blocks."):
+            d = 0.5 * int(k.rsplit(".", 1)[1]) / 12
+        else:
+            d = 0.5 + 0.5 * (int(k.rsplit(".", 1)[1]) + 1) / 12
+        return _BLOCK_BUDGET_FIRST + (_BLOCK_BUDGET_LAST - _BLOCK_BUDGET_FIRST) * d
+    bad = {k: (round(v, 4), round(budget(k), 4)) for k, v in errs.items() if v > budget(k)}
+    assert not bad, f"blocks over their bf16 budget (err, budget): {bad}"
+
+
+def test_every_block_vs_reference_golden(golden_dir, g160_wrapper):
+    """All 36 per-block digests the reference golden carries (13 ControlNet, 11 encoder, 12 decoder blocks), on the HIP path."""
+    z = np.load(os.path.join(golden_dir, "net_g160.npz"))
+    eps, errs = _block_errors(z, g160_wrapper, 2, 3)
+    assert _rel(eps, torch.from_numpy(z["eps"])) < NET_TOL
+    _check_block_errors(errs)
+
+
+def test_full_width_network_vs_reference_golden(golden_dir):
+    """The SHIPPED widths (model_channels 320, 8 heads: d = 40 / 80 / 160, context 768; the fused dim-320 feed-forward and
+    register-resident K = 320 kernels are on this path) against the reference itself: eps and all 36 block digests of
+    tests/golden/net_full.npz (T = 3, latent 16 x 24, CFG-doubled batch)."""
+    _need_gpu()
+    from ccedit_amd.sgm_compat import build_network
+    from ccedit_amd.utils.synth import fill_module_
+    z = np.load(os.path.join(golden_dir, "net_full.npz"))
+    w = build_network("cpu")
+    fill_module_(w, prefix="model.")
+    w.diffusion_model.pack("cuda")
+    eps, errs = _block_errors(z, w, 2, 3)
+    r = _rel(eps, torch.from_numpy(z["eps"]))
+    print(f"full-width network eval rel rms err vs reference golden: {r:.4f}")
+    assert torch.isfinite(eps).all() and r < NET_TOL
+    _check_block_errors(errs)
+    # the untraced evaluation (CFG halves on two streams, ControlNet on a side stream) gives the same prediction
+    x, hint, cc, cuc = _golden_inputs(z)
+    c = dict(crossattn=torch.cat([cuc, cc]).cuda(), control_hint=torch.cat([hint, hint]).cuda())
+    eps2 = w(torch.cat([x, x]).cuda(), torch.from_numpy(z["t"]).cuda(), c)
+    assert _rel(eps2, eps) < NET_TOL          # another summation order (B = 1 halves, other block shapes): the bf16 noise floor
+
+
+def _teacher_forced_block_errors(z, wrapper, cfg_kw, b, t):
+    """Every ControlNet / UNet block of the HIP path on the input the ORACLE's bf16-emulation mode feeds that block
+    (oracle/ccedit_oracle.py: the fp32 restatement pinned by the reference goldens, additionally rounding to bf16 wherever
+    this path stores a tensor), compared with the oracle's output of the block over the full tensors.  Stage by stage the
+    two agree to ~1e-5 (tools/exp/emu_diag.py); what a block accumulates is (i) the attention probabilities, whose bf16
+    rounding depends on the online-softmax tile order (1.5e-3 per attention) and (ii) the timestep-embedding row bias
+    (sin / cos of arguments up to 999 rad: a last-bit difference in the frequency flips bf16 roundings, 3e-4).  A block
+    with a wrong or missing low-energy branch (temporal layer, zero-initialised projection, text attention) lands far
+    outside this — which the 2-3e-2 end-to-end noise floor against the fp32 reference would hide."""
+    from ccedit_amd import network, ops
+    from ccedit_amd.sgm_compat import build_network_spec
+    from ccedit_amd.utils.synth import synth_state_dict
+    from oracle import ccedit_oracle as O
+    x, hint, cc, cuc = _golden_inputs(z)
+    x2, tt = torch.cat([x, x]), torch.from_numpy(z["t"])
+    c = dict(crossattn=torch.cat([cuc, cc]), control_hint=torch.cat([hint, hint]))
+    sd = synth_state_dict(build_network_spec(cfg_kw))
+    tr = {}
+    with O.bf16_emulation():
+        ref_eps = O.network_forward(sd, O.NetConfig(**cfg_kw), x2, tt, c, trace=tr)
+    net = wrapper.diffusion_model
+    geo = network.Geometry(b, t)
+    ctx2d = c["crossattn"].to(torch.bfloat16).reshape(-1, c["crossattn"].shape[-1]).contiguous().cuda()
+    ctx_len = c["crossattn"].shape[1]
+    P = "model.diffusion_model."
+
+    def to_hip(v):          # oracle layout -> (b t, h, w, c) bf16 (exact: the emulation's tensors are bf16 values)
+        v4 = v.permute(0, 2, 1, 3, 4).reshape(-1, v.shape[1], v.shape[3], v.shape[4]) if v.dim() == 5 else v
+        return v4.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+
+    def from_hip(y, five):
+        y = y.float().cpu()
+        n, hh, ww, ch = y.shape
+        return y.view(b, t, hh, ww, ch).permute(0, 4, 1, 2, 3) if five else y.permute(0, 3, 1, 2)
+
+    errs = {}
+    for sub, model, five in (("controlnet.", net.controlnet, False), ("", net, True)):
+        emb = model._emb_silu(tt.cuda())
+        blocks = [(f"input_blocks.{i}", blk) for i, blk in enumerate(model.input_blocks) if i > 0]
+        blocks.append(("middle_block", model.middle_block))
+        if five:
+            blocks += [(f"output_blocks.{i}", blk) for i, blk in enumerate(model.output_blocks)]
+        for name, blk in blocks:
+            key = P + sub + name
+            want = tr[key + ":pre"] if (five and name == "middle_block") else tr[key]
+            got = blk.run(to_hip(tr[key + ":in"]), emb, geo, ctx2d, ctx_len)
+            has_attn = any(isinstance(m, network.SpatialTransformer) for m in blk)
+            errs[sub + name] = (_rel(from_hip(got, five), want), has_attn)
+    eps = wrapper(x2.cuda(), tt.cuda(), {k: v.cuda() for k, v in c.items()})
+    return _rel(eps, ref_eps), errs
+
+
+# one block, HIP vs bf16-emulating oracle on the oracle's input (see the docstring above); measured: <= 6.7e-3 for blocks with
+# transformers (three attentions in a pseudo-3D one), <= 2.8e-3 for ResBlock / resampling-only blocks
+BLOCK_TOL_ATTN, BLOCK_TOL_PLAIN = 9e-3, 4e-3
+
+
+def _report_blocks(tag, r, errs):
+    print(f"{tag}: eps vs bf16-emulating oracle (free-running) {r:.4f}; teacher-forced blocks: "
+          + " ".join(f"{k.replace('input_blocks.', 'in').replace('output_blocks.', 'out').replace('controlnet.', 'cn.').replace('middle_block', 'mid')}={v:.4f}"
+                     for k, (v, _) in errs.items()))
+    assert len(errs) == 12 + 12 + 12 and r < NET_TOL
+    bad = {k: round(v, 4) for k, (v, attn) in errs.items() if v >= (BLOCK_TOL_ATTN if attn else BLOCK_TOL_PLAIN)}
+    assert not bad, f"blocks off the bf16-emulating oracle: {bad}"
+
+
+def test_every_block_teacher_forced_vs_bf16_emulating_oracle(golden_dir, g160_wrapper):
+    z = np.load(os.path.join(golden_dir, "net_g160.npz"))
+    _report_blocks("g160", *_teacher_forced_block_errors(z, g160_wrapper, G160, 2, 3))
+
+
+def test_full_width_teacher_forced_vs_bf16_emulating_oracle(golden_dir):
+    """Shipped widths (fused dim-320 feed-forward on the path) against the oracle's bf16-emulation mode, block by block."""
+    _need_gpu()
+    from ccedit_amd.sgm_compat import build_network
+    from ccedit_amd.utils.synth import fill_module_
+    z = np.load(os.path.join(golden_dir, "net_full.npz"))
+    w = build_network("cpu")
+    fill_module_(w, prefix="model.")
+    w.diffusion_model.pack("cuda")
+    _report_blocks("full width", *_teacher_forced_block_errors(z, w, {}, 2, 3))
+
+
 def test_control_residuals_vs_reference_golden(golden_dir, g160_wrapper):
     """ControlNet2D through its reference-signature forward (5-D in, 13 x (b c t h w) out)."""
     z = np.load(os.path.join(golden_dir, "net_g160.npz"))

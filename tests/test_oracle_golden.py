@@ -81,7 +81,7 @@ def test_network_eval_matches_reference(golden_dir, g160_sd):
     assert rel < 1e-4, f"eps rel rms err {rel}"
     # block-level digests (every hooked block of both nets)
     names = [k[len("trace:"):-len("|samp")] for k in z.files if k.startswith("trace:") and k.endswith("|samp")]
-    assert len(names) >= 12 + 1 + 11 + 12
+    assert len(names) >= 12 + 1 + 11 + 12 and all(n in trace for n in names)
     for n in names:
         if n.endswith("controlnet.input_blocks.0"):
             continue      # reference hook sees the pre-`+= guided_hint` value; covered by control:0
@@ -94,6 +94,27 @@ def test_network_eval_matches_reference(golden_dir, g160_sd):
     assert len(control) == 13
     for i, t in enumerate(control):
         _digest_cmp(z, f"control:{i}", t)
+
+
+def test_full_width_network_eval_matches_reference(golden_dir):
+    """The oracle at the SHIPPED widths (320 channels, 8 heads, context 768) against the reference's own evaluation
+    (tests/golden/net_full.npz): eps and every block digest."""
+    from ccedit_amd.sgm_compat import build_network_spec
+    z = np.load(os.path.join(golden_dir, "net_full.npz"))
+    sd = synth_state_dict(build_network_spec({}))
+    x = torch.from_numpy(z["x"])
+    hint = torch.from_numpy(z["hint1"]).repeat(1, 3, 1, 1, 1)
+    c = dict(crossattn=torch.cat([torch.from_numpy(z["cross_uc"]), torch.from_numpy(z["cross_c"])]),
+             control_hint=torch.cat([hint, hint]))
+    trace = {}
+    eps = O.network_forward(sd, O.NetConfig(), torch.cat([x, x]), torch.from_numpy(z["t"]), c, trace=trace)
+    ref = torch.from_numpy(z["eps"])
+    rel = (eps - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()
+    assert rel < 1e-4, f"eps rel rms err {rel}"
+    for n in [k[len("trace:"):-len("|samp")] for k in z.files if k.startswith("trace:") and k.endswith("|samp")]:
+        if n.endswith("controlnet.input_blocks.0") or (n.endswith("middle_block") and "controlnet" not in n):
+            continue
+        _digest_cmp(z, "trace:" + n, trace[n])
 
 
 def test_sampler_trajectory_matches_reference(golden_dir, g160_sd):
