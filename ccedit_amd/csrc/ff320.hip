@@ -70,6 +70,47 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 #define FF_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define FF_WAIT(reg, cnt) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "i"(cnt))
 
+// GEGLU as a software pipeline across the MFMA steps.  A volatile asm statement ends a scheduling region, so the VALU work
+// placed between two of them stays between them.  One step gets ONE stage of the exact-erf GELU (common.h: gelu_erf_f,
+// A&S 7.1.28) for EIGHT accumulator registers at once: eight independent instructions, each reading what the previous step
+// produced — the VALU pipe runs at issue rate instead of at the latency of a 17-deep dependent chain (which is what one
+// element per step cost: tools/exp/coexec.hip shows a wave interleaving MFMAs with 8 independent VALU chains overlaps them
+// almost completely, and the first version of this schedule spent as long in the GEGLU as in the MFMAs).
+struct GeluPipe {
+    float u[8], hv[8], ax[8], x[8], p[8];
+    // stage 0 loads (value, gate) of 8 accumulator registers; stage kStages - 1 leaves v * gelu(u) in p[]
+    static constexpr int kStages = 16;
+    // hipcc moves plain VALU instructions across volatile asm statements; an empty asm that takes the stage's live values
+    // as read-write operands pins the stage between the statements of its step
+    __device__ __forceinline__ void pin() {
+        asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+    }
+    template <int ST>
+    __device__ __forceinline__ void stage(const f32x16& accv, const f32x16& accg, int r0, bool plain) {
+        if constexpr (ST > 3) pin();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if constexpr (ST == 0) { u[i] = accg[r0 + i]; hv[i] = 0.5f * accv[r0 + i]; }
+            else if constexpr (ST == 1) ax[i] = fabsf(u[i]);
+            else if constexpr (ST == 2) x[i] = ax[i] * 0.70710678118654752440f;
+            else if constexpr (ST == 3) p[i] = fmaf(x[i], 0.0000430638f, 0.0002765672f);
+            else if constexpr (ST == 4) p[i] = fmaf(x[i], p[i], 0.0001520143f);
+            else if constexpr (ST == 5) p[i] = fmaf(x[i], p[i], 0.0092705272f);
+            else if constexpr (ST == 6) p[i] = fmaf(x[i], p[i], 0.0422820123f);
+            else if constexpr (ST == 7) p[i] = fmaf(x[i], p[i], 0.0705230784f);
+            else if constexpr (ST == 8) p[i] = fmaf(x[i], p[i], 1.0f);
+            else if constexpr (ST >= 9 && ST <= 12) p[i] = p[i] * p[i];
+            else if constexpr (ST == 13) p[i] = 1.0f - __builtin_amdgcn_rcpf(p[i]);                 // erf(|u| / sqrt 2)
+            else if constexpr (ST == 14) p[i] = fmaf(ax[i], p[i], u[i]);                             // u + |u| erf = 2 gelu(u)
+            else if constexpr (ST == 15) p[i] = plain ? 2.0f * hv[i] + u[i] : hv[i] * p[i];          // v gelu(u)
+        }
+        if constexpr (ST == 0) asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]));
+        if constexpr (ST == 1) asm volatile("" : "+v"(ax[0]), "+v"(ax[1]), "+v"(ax[2]), "+v"(ax[3]), "+v"(ax[4]), "+v"(ax[5]), "+v"(ax[6]), "+v"(ax[7]));
+        if constexpr (ST == 2) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+        if constexpr (ST >= 3) pin();
+    }
+};
+
 // ABL (tuning only, CCEDIT_FF320_ABL, bit mask): 1 = no weight stream after the first chunk; 2 = GEGLU replaced by an add; 32 = phase
 // cycle counters into d.dbg.  Results are wrong for ABL & 3.
 //
@@ -194,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
             const unsigned la = la0 + PAR * kChunkBytes, lan = la0 + (1 - PAR) * kChunkBytes;       // kIters is even: chunk c sits in buffer c & 1
             const unsigned lxn = lx0 + (1 - PAR) * kChunkBytes;
 
+            GeluPipe gp;
             auto step = [&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
                 constexpr int s = j / 3, role = j % 3;                        // k-step, (value, gate, GEMM2) fragment
@@ -235,12 +277,13 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
-                // GEGLU of chunk c - 1, one accumulator register per k-step; scalar fp32 on purpose (and -fno-slp-vectorize):
-                // beside MFMAs a v_pk_*_f32 costs several v_fma_f32
-                if constexpr (role == 2 && s >= 1 && s < 17) {
-                    constexpr int r = s - 1;
-                    const float v = acc1[1 - PAR][0][r], u = acc1[1 - PAR][1][r];
-                    hf[1 - PAR][r >> 3][r & 7] = f2bf((ABL & 2) ? v + u : v * gelu_erf_f(u));
+                // GEGLU of chunk c - 1: registers 0..7 in steps 2..17 + 18 (stages 0..15, then the bf16 pack), registers 8..15 in
+                // steps 20..35 + 36 — one stage of eight independent VALU instructions beside each step's MFMA
+                if constexpr (j >= 2 && j < 2 + GeluPipe::kStages) gp.template stage<j - 2>(acc1[1 - PAR][0], acc1[1 - PAR][1], 0, (ABL & 2) != 0);
+                if constexpr (j >= 20 && j < 20 + GeluPipe::kStages) gp.template stage<j - 20>(acc1[1 - PAR][0], acc1[1 - PAR][1], 8, (ABL & 2) != 0);
+                if constexpr (j == 18 || j == 36) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) hf[1 - PAR][j == 18 ? 0 : 1][i] = f2bf(gp.p[i]);
                 }
             };
             for_seq(step, std::make_integer_sequence<int, 60>{});
