@@ -636,3 +636,48 @@ def test_ff320_equals_unfused_path():
     wide_out = torch.full((m, 336), 7.0, dtype=BF, device="cuda")
     ops.ff320(wide_in[:, :320], pack_ff320(w1, b1, w2, b2, g, b, device="cuda"), out=wide_out[:, :320])
     assert torch.equal(wide_out[:, :320], fused) and bool((wide_out[:, 320:] == 7.0).all())
+
+
+# ------------------------------------------------------------------------------------------
+# long-sequence attention: d = 40 / 80, Lq >= 1024, Lk >= 256 (8-wave blocks, many KV tiles)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,heads,lq,lk", [(40, 8, 1536, 1536), (40, 8, 1100, 1000), (80, 4, 1536, 1536), (80, 4, 1030, 300),
+                                           (40, 2, 1024, 256), (40, 8, 2048, 321)])
+def test_attention_long_pingpong(d, heads, lq, lk):
+    """Ragged query tiles (Lq % 256), masked last KV tile (Lk % 64), odd / even tile counts."""
+    _dev()
+    from ccedit_amd import ops
+    b = 2
+    c = heads * d
+    q, k, v = _rnd(b, lq, c, seed=1), _rnd(b, lk, c, seed=2), _rnd(b, lk, c, seed=3)
+    args = (q.reshape(-1, c).to(BF).cuda(), k.reshape(-1, c).to(BF).cuda(), v.reshape(-1, c).to(BF).cuda(), heads, d)
+    o = ops.attention(*args, batches=b, lq=lq, lk=lk)
+    _close(o.reshape(b, lq, c), _sdpa_ref(q, k, v, heads), rel=2.0 ** -6, abs_=4e-3, what=f"attention (long) d={d} {lq}x{lk}")
+    assert torch.equal(o, ops.attention(*args, batches=b, lq=lq, lk=lk)), "two launches differ (LDS race?)"
+
+
+def test_attention_long_pingpong_rescale_and_anchor():
+    _dev()
+    from ccedit_amd import ops
+    # a late key with a huge score forces the rescale branch in a late vector segment (guide rule 26)
+    heads, d, lq, lk = 2, 40, 1024, 512
+    c = heads * d
+    q, k, v = _rnd(1, lq, c, seed=1), _rnd(1, lk, c, seed=2), _rnd(1, lk, c, seed=3)
+    k[0, 450] = q[0, 700] * 4.0
+    k = k.to(BF).float()
+    o = ops.attention(q.reshape(-1, c).to(BF).cuda(), k.reshape(-1, c).to(BF).cuda(), v.reshape(-1, c).to(BF).cuda(),
+                      heads, d, batches=1, lq=lq, lk=lk)
+    _close(o.reshape(1, lq, c), _sdpa_ref(q, k, v, heads), rel=2.0 ** -6, abs_=4e-3, what="long attention with spike")
+    # two-segment keys (TVI2V anchor + self) at a long sequence; the segment boundary is not a multiple of the KV tile
+    heads, d, t, clips, hw = 4, 40, 3, 2, 1064
+    c = heads * d
+    n = clips * t
+    q = _rnd(n, hw, c, seed=4)
+    kv = _rnd(n, hw, 2 * c, seed=5)
+    kvd = kv.reshape(-1, 2 * c).to(BF).cuda()
+    o = ops.attention(q.reshape(-1, c).to(BF).cuda(), kvd[:, :c], kvd[:, c:], heads, d, batches=n, lq=hw, lk=2 * hw,
+                      kv_outer_rows=hw, seg1_len=hw, seg1_div=t, seg1_mul=t, seg1_add=t // 2)
+    anchor = kv.reshape(clips, t, hw, 2 * c)[:, t // 2].repeat_interleave(t, 0)
+    ctx = torch.cat([anchor, kv], dim=1)
+    _close(o.reshape(n, hw, c), _sdpa_ref(q, ctx[..., :c], ctx[..., c:], heads), rel=2.0 ** -6, abs_=4e-3,
+           what="long anchor + self attention")
