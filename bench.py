@@ -94,9 +94,12 @@ def main():
     ap.add_argument("--no-clip", action="store_true", help="skip the whole-clip timing (30-step sampler + VAE decode, ~7 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard-frames", action="store_true",
-                    help="N>1: BASELINE.json config 4 — ONE clip, its T=17 keyframes sharded over the ranks (halo p2p, "
-                         "statistics all-reduce, RCCL all-gather of K/V at temporal attention); default N>1 mode is "
-                         "config 5 (one clip per GPU, no collective)")
+                    help="N>1: BASELINE.json config 4 — ONE clip, its T=17 keyframes sharded over the ranks; default N>1 mode "
+                         "is config 5 (one clip per GPU, no collective)")
+    ap.add_argument("--shard-mode", choices=["pair", "a2a", "halo"], default="pair",
+                    help="pair: all-to-all layout transposition around the temporal ops, the two CFG halves on mirrored "
+                         "partitions, two communicators and two streams; a2a: the same transposition, one partition; halo: "
+                         "round-1 halo p2p + statistics all-reduce + K/V all-gather")
     ap.add_argument("--workload", choices=["tv2v", "tvi2v"], default="tv2v",
                     help="tv2v = BASELINE.json config 2 (the headline metric); tvi2v = config 3 (ref-frame cfca network)")
     ap.add_argument("--no-profile-step", action="store_true", help="skip the extra HIP-event profiled step (PMC runs)")
@@ -134,9 +137,15 @@ def main():
     wrapper = build_model(device, tvi2v)
     shard = args.shard_frames and world > 1
     x, cross_c, cross_uc, hint = synth_inputs(device, seed=42 + (0 if shard else rank))
+    shards = ()
     if shard:
         from ccedit_amd.parallel import FrameShard
-        wrapper.frame_shard = FrameShard(T)
+        if args.shard_mode == "pair":               # a communicator per CFG half: their exchanges run independently
+            shards = FrameShard.cfg_pair(T, groups=(None, dist.new_group(list(range(world)))))
+            wrapper.frame_shard = shards
+        else:
+            shards = (FrameShard(T, mode=args.shard_mode),)
+            wrapper.frame_shard = shards[0]
     x2 = torch.cat([x, x]).contiguous()             # CFG-doubled batch, uc first (guiders.py:63)
     cond = dict(crossattn=torch.cat([cross_uc, cross_c]).contiguous(), control_hint=torch.cat([hint, hint]).contiguous())
     if tvi2v:
@@ -169,9 +178,42 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = (1 if shard else world) * args.steps / dt
 
-    # ---- roofline of the dominant kernel family, measured live with HIP events (one extra step) ----
+    # ---- frame-sharded: one instrumented step (bytes, exchange count, device time inside exchanges) and the same step
+    # unsharded on every rank (the single-GPU time the per-GPU efficiency is quoted against) ----
     roof = None
     extra = {}
+    if shard:
+        from ccedit_amd.parallel import cfg_pair_efficiency, sharding_efficiency
+        for s_ in shards:
+            s_.timing = []
+            s_.reset_counters()
+        step()
+        torch.cuda.synchronize()
+        mine = torch.tensor([sum(s_.bytes_sent for s_ in shards), sum(s_.n_collectives for s_ in shards),
+                             sum(s_.comm_ms() for s_ in shards), sum(s_.t_local for s_ in shards)], dtype=torch.float64)
+        for s_ in shards:
+            s_.timing = None
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather_object(allr, mine)
+        keep, wrapper.frame_shard = wrapper.frame_shard, None
+        step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        wrapper.frame_shard = keep
+        single_ms = max_over_ranks_ms(single_ms, dist, device, backend)
+        ceiling = cfg_pair_efficiency(T, world) if args.shard_mode == "pair" else sharding_efficiency(T, world)
+        extra["shard"] = dict(
+            mode=args.shard_mode, frame_instances_per_rank=[int(a[3]) * (1 if args.shard_mode == "pair" else 2) for a in allr],
+            ceiling=round(ceiling, 4), single_gpu_ms_per_step=round(single_ms, 3),
+            efficiency_per_gpu=round(single_ms / (world * ms_per_step), 4),
+            exchanges_per_step=int(allr[0][1]), bytes_sent_per_step_max_rank=int(max(a[0] for a in allr)),
+            exchange_ms_per_step_max_rank=round(max(float(a[2]) for a in allr), 3),
+            exchange_ms_note="sum of device time between issue and completion of every exchange on its stream; the two "
+                             "halves' streams overlap, so this is an upper bound on exposed communication")
     if rank == 0 and args.dump_shapes and not shard:
         ops.PROFILE = ops.LaunchProfile()
         step()
@@ -251,8 +293,9 @@ def main():
                                     "TV2V depth-midas, 17x512x768, one network evaluation = ControlNet2D + pseudo-3D UNet on "
                                     "B=2 (cfg 7.5 uncond+cond) x T=17 frames, latent 64x96, 77x768 text context; "
                                     "77.68 TFLOP/step; a 30-step DPMPP2SAncestral clip = 59 such steps + VAE decode"),
-                       "parallelism": ("one clip, T=17 keyframes sharded over the ranks (halo p2p + stats all-reduce + K/V "
-                                       "all-gather)" if shard else
+                       "parallelism": (f"one clip, T=17 keyframes sharded over the ranks (mode {args.shard_mode}: " +
+                                       ("halo p2p + stats all-reduce + K/V all-gather)" if args.shard_mode == "halo" else
+                                        "all-to-all frame<->pixel transposition around every temporal op)") if shard else
                                        "1 clip per GPU (replicas, no collective)" if world > 1 else "single GPU"),
                        "hint_stem": "recomputed every step"},
             "roofline": roof, "cpu_baseline": cpu,
@@ -264,6 +307,12 @@ def main():
     if dist is not None:
         dist.barrier()                              # rank 0 may still have been profiling: leave together
         dist.destroy_process_group()
+
+
+def max_over_ranks_ms(ms, dist, device, backend):
+    tt = torch.tensor([ms], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
 
 
 def kernel_source_hash() -> str:

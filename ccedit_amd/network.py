@@ -82,19 +82,59 @@ def _fill_halos(buf, geo: Geometry):
     return buf
 
 
-def temporal_conv3(a, pw, geo: Geometry, a_is_ext: bool = False, **kw):
-    """Conv1d k=3 over T.  Sharded: `a` is (or is copied into) the halo-extended buffer, one frame is exchanged
-    with each neighbour rank, and the GEMM gathers through the extended source (zeros outside the clip)."""
+def _a2a(geo: Geometry) -> bool:
+    return geo.shard is not None and geo.shard.mode == "a2a"
+
+
+def temporal_conv3(a, pw, geo: Geometry, a_is_ext: bool = False, res_self: bool = False, **kw):
+    """Conv1d k=3 over T (+ `a` itself when res_self: the stf identity path).
+    Sharded, mode "a2a": transpose to (all T, own pixel block), run the unsharded kernel, transpose back.
+    Sharded, mode "halo": `a` is (or is copied into) the halo-extended buffer, one frame is exchanged with each
+    neighbour rank, and the GEMM gathers through the extended source (zeros outside the clip)."""
     sh = geo.shard
     if sh is None:
+        if res_self:
+            kw["res1"] = a.view(-1, a.shape[-1])
         return ops.conv_temporal(a, geo.t, pw, **kw)
+    if sh.mode == "a2a":
+        assert not a_is_ext and "res1" not in kw, "a2a mode: residuals travel as res_self / res2"
+        n, h, w, c = a.shape
+        ap = sh.to_pixels(a.view(-1, c), geo.b, h * w)
+        kw.pop("gn", None)                     # per-frame statistics cannot be produced in the pixel layout
+        res2 = kw.pop("res2", None)
+        if res_self:
+            kw["res1"] = ap
+        if "group_rows" in kw:
+            kw["group_rows"] = sh.t_glob * sh.hw_local(h * w)
+        o = ops.conv_temporal(ap.view(geo.b * sh.t_glob, 1, -1, c), sh.t_glob, pw, **kw)
+        return sh.to_frames(o.view(-1, o.shape[-1]), geo.b, h * w, add=res2).view(n, h, w, -1)
     if not a_is_ext:
         n, h, w, c = a.shape
+        if res_self:
+            kw["res1"] = a.view(-1, c)
         buf = torch.empty((geo.b * (geo.t + 2), h, w, c), dtype=a.dtype, device=a.device)
         buf.view(geo.b, geo.t + 2, h, w, c)[:, 1:geo.t + 1].copy_(a.view(geo.b, geo.t, h, w, c))
         a = buf
     _fill_halos(a, geo)
     return ops.conv_temporal_sharded(a, geo.b, geo.t, sh.t0, sh.t_glob, pw, **kw)
+
+
+def temporal_gn_conv3(s, norm: "Norm", pw, geo: Geometry, **kw):
+    """The temporal half of an stf pair inside a ResBlock3D: s + Conv1d_T(SiLU(GroupNorm_T(s))) (+ epilogue terms)."""
+    sh = geo.shard
+    n, h, w, c = s.shape
+    if _a2a(geo):                              # one transposition carries both the normalisation and the convolution
+        sp = sh.to_pixels(s.view(-1, c), geo.b, h * w)
+        sp4 = sp.view(geo.b * sh.t_glob, 1, -1, c)
+        at = ops.groupnorm_temporal(sp4, geo.b, sh.t_glob, norm.g, norm.b, norm.eps, True)
+        kw.pop("gn", None)
+        res2 = kw.pop("res2", None)
+        if "group_rows" in kw:
+            kw["group_rows"] = sh.t_glob * sp4.shape[2]
+        o = ops.conv_temporal(at, sh.t_glob, pw, res1=sp, **kw)
+        return sh.to_frames(o.view(-1, c), geo.b, h * w, add=res2).view(n, h, w, c)
+    at = temporal_gn(s, norm, geo, True, ext=sh is not None)
+    return temporal_conv3(at, pw, geo, a_is_ext=sh is not None, res1=s.view(-1, c), **kw)
 
 
 def _seq(*mods) -> nn.Sequential:
@@ -295,6 +335,16 @@ class SpatialTransformer3D(SpatialTransformer):
     def run(self, x, geo, ctx2d, ctx_len):
         y = self.run_spatial(x, ctx2d, ctx_len, geo.t)
         n, h, w, c = y.shape
+        if _a2a(geo):       # the whole temporal branch (GroupNorm_T, projections, attention over T, FF) is per pixel:
+            sh = geo.shard  # it runs on all T frames of this rank's pixel block, between two all-to-alls
+            yp = sh.to_pixels(y.view(-1, c), geo.b, h * w)
+            hw_me = sh.hw_local(h * w)
+            nt = self.norm_temporal
+            a = ops.groupnorm_temporal(yp.view(geo.b * sh.t_glob, 1, hw_me, c), geo.b, sh.t_glob, nt.g, nt.b, nt.eps, False)
+            tok = ops.linear(a.view(-1, c), self.proj_in_temporal.pw)
+            tok = self.transformer_blocks_temporal[0].run_temporal(tok, Geometry(geo.b, sh.t_glob), hw_me)
+            z = ops.linear(tok, self.proj_out_temporal.pw, res1=yp)
+            return sh.to_frames(z, geo.b, h * w).view(n, h, w, c)
         a = temporal_gn(y, self.norm_temporal, geo, False)
         tok = ops.linear(a.view(-1, c), self.proj_in_temporal.pw)
         tok = self.transformer_blocks_temporal[0].run_temporal(tok, geo, h * w)
@@ -382,23 +432,20 @@ class ResBlock3D(nn.Module):
         a = ops.groupnorm_spatial(x, gn.g, gn.b, gn.eps, True)
         s = ops.conv2d(a, self.in_layers[2].pw)
         co = s.shape[-1]
-        sharded = geo.shard is not None
-        at = temporal_gn(s, self.in_layers_temporal[0], geo, True, ext=sharded)
         e = emb_silu.of(self)
         # stf output (s + conv_t) and the `+ emb_out` of openaimodel.py:762 in one epilogue
-        hid = temporal_conv3(at, self.in_layers_temporal[2].pw, geo, a_is_ext=sharded, res1=s.view(-1, co), group_bias=e,
-                             group_rows=geo.t * h * w, gn=True)
+        hid = temporal_gn_conv3(s, self.in_layers_temporal[0], self.in_layers_temporal[2].pw, geo, group_bias=e,
+                                group_rows=geo.t * h * w, gn=True)
         gn = self.out_layers[0]
         a = ops.groupnorm_spatial(hid, gn.g, gn.b, gn.eps, True)
         s2 = ops.conv2d(a, self.out_layers[3].pw)
-        at = temporal_gn(s2, self.out_layers_temporal[0], geo, True, ext=sharded)
         if isinstance(self.skip_connection, Slot):
             skip = x
         else:
             k = ops.conv2d(x, self.skip_connection.pw)
             skip = ops.conv_temporal(k, geo.t, self.skip_connection_temporal.pw, res1=k.view(-1, co))
-        return temporal_conv3(at, self.out_layers_temporal[3].pw, geo, a_is_ext=sharded, res1=s2.view(-1, co),
-                              res2=skip.view(-1, co), gn=True)
+        return temporal_gn_conv3(s2, self.out_layers_temporal[0], self.out_layers_temporal[3].pw, geo,
+                                 res2=skip.view(-1, co), gn=True)
 
 
 class Downsample(nn.Module):
@@ -422,7 +469,7 @@ class Downsample3D(nn.Module):
 
     def run(self, x, geo):
         s = ops.conv2d(x, self.op.pw, stride=2)
-        return temporal_conv3(s, self.conv_temporal.pw, geo, res1=s.view(-1, s.shape[-1]), gn=True)
+        return temporal_conv3(s, self.conv_temporal.pw, geo, res_self=True, gn=True)
 
 
 class Upsample3D(nn.Module):
@@ -436,7 +483,7 @@ class Upsample3D(nn.Module):
 
     def run(self, x, geo):
         s = ops.conv2d(x, self.conv.pw, upsample=True)
-        return temporal_conv3(s, self.conv_temporal.pw, geo, res1=s.view(-1, s.shape[-1]))
+        return temporal_conv3(s, self.conv_temporal.pw, geo, res_self=True)
 
 
 class TimestepEmbedSequential(nn.Sequential):
@@ -734,7 +781,7 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
         for i, block in enumerate(self.input_blocks):
             if i == 0:
                 s = ops.conv2d(h, block[0].pw)
-                h = temporal_conv3(s, self.input_blocks_temporal[0].pw, geo, res1=s.view(-1, s.shape[-1]))
+                h = temporal_conv3(s, self.input_blocks_temporal[0].pw, geo, res_self=True)
             else:
                 h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
             _trace(f"input_blocks.{i}", h)
@@ -754,6 +801,12 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
         ocp = (oc + 7) // 8 * 8
         s = torch.zeros((n * hh * ww, ocp), dtype=torch.bfloat16, device=a.device)
         ops.conv2d(a, self.out[2].pw, out=s[:, : self.out[2].pw.n])
+        if _a2a(geo):       # SiLU + Conv1d_T on this rank's pixel block; the caller all-gathers the pixel blocks
+            sh = geo.shard
+            sp = sh.to_pixels(s, geo.b, hh * ww)
+            at = ops.silu(sp)
+            return ops.conv_temporal(at.view(geo.b * sh.t_glob, 1, -1, ocp), sh.t_glob, self.out_temporal[1].pw, res1=sp,
+                                     out_f32=True)
         at = ops.silu(s)
         eps = temporal_conv3(at.view(n, hh, ww, ocp), self.out_temporal[1].pw, geo, res1=s, out_f32=True)
         return eps
@@ -845,7 +898,14 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         return g
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, c: Dict[str, torch.Tensor], **kwargs) -> torch.Tensor:
-        if _SPLIT_CFG and x.shape[0] == 2 and self.frame_shard is None and ops.PROFILE is None and TRACE is None and not kwargs.get("_half"):
+        pair = isinstance(self.frame_shard, (tuple, list)) and not kwargs.get("_half")
+        if pair and x.shape[0] != 2:
+            raise ValueError("a FrameShard.cfg_pair shards the two CFG halves of a batch-2 step")
+        if pair or (_SPLIT_CFG and x.shape[0] == 2 and self.frame_shard is None and ops.PROFILE is None and TRACE is None
+                    and not kwargs.get("_half")):
+            # the two CFG halves are independent: two streams (and, frame-sharded, two communicators with mirrored
+            # partitions — one half's exchanges overlap the other half's kernels)
+            shards = self.frame_shard if pair else (None, None)
             main = torch.cuda.current_stream()
             if OpenAIWrapperControlLDM3DTV2V._half_stream is None:
                 OpenAIWrapperControlLDM3DTV2V._half_stream = torch.cuda.Stream()
@@ -853,8 +913,8 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             hs.wait_stream(main)
             halves = [{k: (v[i:i + 1].contiguous() if torch.is_tensor(v) else v) for k, v in c.items()} for i in range(2)]
             with torch.cuda.stream(hs):
-                e1 = self.forward(x[1:2].contiguous(), t[1:2].contiguous(), halves[1], _half=True)
-            e0 = self.forward(x[0:1].contiguous(), t[0:1].contiguous(), halves[0], _half=True)
+                e1 = self.forward(x[1:2].contiguous(), t[1:2].contiguous(), halves[1], _half=True, _shard=shards[1])
+            e0 = self.forward(x[0:1].contiguous(), t[0:1].contiguous(), halves[0], _half=True, _shard=shards[0])
             main.wait_stream(hs)
             e1.record_stream(main)
             return torch.cat([e0, e1])
@@ -867,7 +927,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                              f"skips are concatenated with the 2x-upsampled decoder tensors, controlmodel.py:539-543)")
         if tuple(c["control_hint"].shape[-2:]) != (8 * lh, 8 * lw):
             raise ValueError(f"control_hint {tuple(c['control_hint'].shape)} does not match latent {lh}x{lw} (x8)")
-        sh = self.frame_shard
+        sh = kwargs.get("_shard", None) if kwargs.get("_half") else self.frame_shard
         hint5 = c["control_hint"]
         if sh is not None:             # keep this rank's keyframes of every clip; everything spatial is frame-local
             if sh.t_glob != nt:
@@ -875,9 +935,11 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             x = x[:, :, sh.t0:sh.t1]
             hint5 = hint5[:, :, sh.t0:sh.t1]
             hk = self._tensor_key(c["control_hint"]) + (sh.t0, sh.t1)
-            if not isinstance(self._hint_slices, dict) or hk not in self._hint_slices:
+            if not isinstance(self._hint_slices, dict) or len(self._hint_slices) >= 4:
+                self._hint_slices = {}
+            if hk not in self._hint_slices:
                 # a stable tensor object so the hint-stem cache can hit; the entry pins the source (see _guided_hint)
-                self._hint_slices = {hk: (c["control_hint"], hint5.contiguous())}
+                self._hint_slices[hk] = (c["control_hint"], hint5.contiguous())
             hint5 = self._hint_slices[hk][1]
         geo = Geometry(b, x.shape[2], sh)
         context = c["crossattn"]
@@ -913,5 +975,6 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             img_control = net.controlnet_img.run(None, cf8, t, None, 0, Geometry(b, 1))
         eps = net.run(x8, t, ctx2d, context.shape[1], control, geo, img_control, control_ready=control_ready)
         if sh is not None:             # all ranks get the full (B, C, T, h, w) prediction (1.6 MB at 17x64x96)
-            eps = sh.gather_frames(eps, b)
+            eps = sh.gather_pixels(eps.view(-1, eps.shape[-1]), b, lh * lw) if sh.mode == "a2a" else sh.gather_frames(eps, b)
+            eps = eps.view(b * nt, lh, lw, -1)
         return ops.nhwc_to_ncthw(eps, b, nt, net.out_channels)

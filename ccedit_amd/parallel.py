@@ -1,10 +1,16 @@
 """Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" == RCCL on ROCm, "gloo" in CPU tests).
 
-Round 1 ships the *replica* mode of BASELINE.json config 5: independent clips, one per rank, no data-path
-collective — `shard_clips` assigns clips, `max_over_ranks` produces the whole-job wall time bench.py reports.
-`frame_shards` is the partition the frame-sharded single-clip mode (config 4) will use: the 2·T CFG x frame
-instances are split contiguously, so that a rank's shard is one contiguous row range of every
-frames-outermost activation matrix (halo / all-gather exchanges are contiguous slabs).
+Two modes:
+  * replicas (BASELINE.json config 5): independent clips, one per rank, no data-path collective — `shard_clips`
+    assigns clips, `max_over_ranks` produces the whole-job wall time bench.py reports;
+  * frame sharding (config 4): ONE clip, its T keyframes split contiguously over the ranks (`FrameShard`).  Spatial
+    work is frame-local.  Temporal work (Conv1d / GroupNorm / attention over T, every pixel independent) runs in the
+    TRANSPOSED layout — all T frames of 1/world of the pixels — reached by one all-to-all and left by another
+    (mode "a2a", the default): xGMI is a full mesh, so an all-to-all drives all 7 links of a GPU at once where a
+    neighbour halo drives 2, and the temporal attention moves C values per token instead of all-gathering 2C x T.
+    Mode "halo" is the round-1 scheme (halo p2p + statistics all-reduce + K/V all-gather), kept for comparison.
+  The two CFG halves of a step can run on `cfg_pair()` shards whose uneven remainders sit at opposite ends of the
+  rank list, so 2 x 17 frame instances spread 5/4/4/4/4/4/4/5 over 8 ranks (ceiling 0.85 instead of 0.71).
 """
 from __future__ import annotations
 
@@ -37,6 +43,13 @@ def sharding_efficiency(n_instances: int, world: int) -> float:
     return (sum(sizes) / len(sizes)) / max(sizes)
 
 
+def cfg_pair_efficiency(t_glob: int, world: int) -> float:
+    """The same bound for FrameShard.cfg_pair: per rank, shard of half 0 + mirrored shard of half 1."""
+    sizes = [b - a for a, b in frame_shards(t_glob, world)]
+    both = [a + b for a, b in zip(sizes, sizes[::-1])]
+    return (sum(both) / len(both)) / max(both)
+
+
 def max_over_ranks(seconds: float, device=None) -> float:
     """MAX all-reduce of a wall-clock interval (identity when torch.distributed is not initialised)."""
     import torch.distributed as dist
@@ -59,8 +72,12 @@ class FrameShard:
     with "gloo" (CPU tests, or several ranks sharing one GPU) tensors are staged through host memory.
     """
 
-    def __init__(self, t_glob: int, rank: Optional[int] = None, world: Optional[int] = None, group=None):
+    def __init__(self, t_glob: int, rank: Optional[int] = None, world: Optional[int] = None, group=None,
+                 mode: str = "a2a", heavy_last: bool = False):
         import torch.distributed as dist
+        if mode not in ("a2a", "halo"):
+            raise ValueError(f"FrameShard mode {mode!r}: 'a2a' or 'halo'")
+        self.mode = mode
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
@@ -69,11 +86,116 @@ class FrameShard:
             raise ValueError(f"cannot shard {t_glob} keyframes over {self.world} ranks")
         self.t_glob = t_glob
         self.bounds = frame_shards(t_glob, self.world)
+        if heavy_last:                         # the ranks with one extra keyframe are the LAST ones (see cfg_pair)
+            sizes = [b - a for a, b in self.bounds][::-1]
+            self.bounds, s0 = [], 0
+            for n in sizes:
+                self.bounds.append((s0, s0 + n))
+                s0 += n
         self.t0, self.t1 = self.bounds[self.rank]
         self.t_local = self.t1 - self.t0
         self.t_max = max(b - a for a, b in self.bounds)
         self.staged = dist.get_backend(group) != "nccl"
         self.bytes_sent = 0
+        self.n_collectives = 0
+        self.timing = None                     # a list: (start, stop) device events around every exchange (bench.py)
+        self._plans = {}
+
+    # -- instrumentation ------------------------------------------------------------------------
+    def _tick(self, t: torch.Tensor):
+        self.n_collectives += 1
+        if self.timing is None or not t.is_cuda:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def _tock(self, ev):
+        if ev is not None:
+            stop = torch.cuda.Event(enable_timing=True)
+            stop.record()                      # on the stream that waits for the collective's result
+            self.timing.append((ev, stop))
+
+    def comm_ms(self) -> float:
+        """Sum of the recorded exchange durations (call after a device synchronize)."""
+        return sum(a.elapsed_time(b) for a, b in (self.timing or []))
+
+    def reset_counters(self):
+        self.bytes_sent, self.n_collectives = 0, 0
+        if self.timing is not None:
+            self.timing = []
+
+    # -- layout transposition (mode "a2a") ----------------------------------------------------------
+    def _plan(self, b: int, hw: int, device):
+        """Index plans of the frame <-> pixel transposition of a (b, t_local, hw, C) slab.
+
+        wire order of the frame-side buffer: [dest rank r][clip][local frame][pixel of r's block]
+        wire order of the pixel-side buffer: [source rank s][clip][frame of s][own pixel]
+        (for b == 1 the latter IS (T, own pixels): no reordering on that side)."""
+        key = (b, hw, str(device))
+        pl = self._plans.get(key)
+        if pl is not None:
+            return pl
+        if hw < self.world:
+            raise ValueError(f"cannot split {hw} pixels over {self.world} ranks")
+        pix = frame_shards(hw, self.world)
+        p0, p1 = pix[self.rank]
+        hw_me = p1 - p0
+        rows = torch.arange(b * self.t_local * hw, dtype=torch.int64).view(b, self.t_local, hw)
+        pack = torch.cat([rows[:, :, lo:hi].reshape(-1) for lo, hi in pix])            # wire position -> frame-layout row
+        unpack = torch.empty_like(pack)
+        unpack[pack] = torch.arange(pack.numel(), dtype=torch.int64)                  # frame-layout row -> wire position
+        frame_rows = [b * self.t_local * (hi - lo) for lo, hi in pix]
+        pixel_rows = [b * (hi - lo) * hw_me for lo, hi in self.bounds]
+        std = torch.arange(b * self.t_glob * hw_me, dtype=torch.int64).view(b, self.t_glob, hw_me)
+        wire_of_std = inv = None
+        if b > 1:
+            wire_of_std = torch.cat([std[:, lo:hi].reshape(-1) for lo, hi in self.bounds])   # wire position -> (b,T,p) row
+            inv = torch.empty_like(wire_of_std)
+            inv[wire_of_std] = torch.arange(wire_of_std.numel(), dtype=torch.int64)
+            wire_of_std, inv = wire_of_std.to(device), inv.to(device)
+        pl = dict(hw_me=hw_me, pack=pack.to(device), unpack=unpack.to(device), frame_rows=frame_rows,
+                  pixel_rows=pixel_rows, to_wire=wire_of_std, from_wire=inv)
+        self._plans[key] = pl
+        return pl
+
+    def _all_to_all(self, send: torch.Tensor, out_rows, in_rows) -> torch.Tensor:
+        out = torch.empty((sum(out_rows), send.shape[1]), dtype=send.dtype, device=send.device)
+        ev = self._tick(send)
+        if self.staged and send.is_cuda:
+            h_in = send.detach().cpu()
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_to_all_single(h_out, h_in, list(out_rows), list(in_rows), group=self.group)
+            out.copy_(h_out)
+        else:
+            self.dist.all_to_all_single(out, send, list(out_rows), list(in_rows), group=self.group)
+        self._tock(ev)
+        own = in_rows[self.rank]
+        self.bytes_sent += (send.shape[0] - own) * send.shape[1] * send.element_size()
+        return out
+
+    def hw_local(self, hw: int) -> int:
+        lo, hi = frame_shards(hw, self.world)[self.rank]
+        return hi - lo
+
+    def to_pixels(self, x2d: torch.Tensor, b: int, hw: int) -> torch.Tensor:
+        """(b * t_local * hw, C) rows of my keyframes -> (b * t_glob * hw_local, C): ALL keyframes of my pixel block."""
+        pl = self._plan(b, hw, x2d.device)
+        assert x2d.shape[0] == b * self.t_local * hw, (x2d.shape, b, self.t_local, hw)
+        send = x2d.index_select(0, pl["pack"])
+        y = self._all_to_all(send, pl["pixel_rows"], pl["frame_rows"])
+        return y if b == 1 else y.index_select(0, pl["from_wire"])
+
+    def to_frames(self, y2d: torch.Tensor, b: int, hw: int, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Inverse of to_pixels; `add` (frame layout) is summed into the result (the ResBlock skip)."""
+        pl = self._plan(b, hw, y2d.device)
+        assert y2d.shape[0] == b * self.t_glob * pl["hw_me"], (y2d.shape, b, self.t_glob, pl["hw_me"])
+        send = y2d.contiguous() if b == 1 else y2d.index_select(0, pl["to_wire"])
+        w = self._all_to_all(send, pl["frame_rows"], pl["pixel_rows"])
+        x = w.index_select(0, pl["unpack"])
+        if add is not None:
+            x.add_(add)
+        return x
 
     # -- helpers --------------------------------------------------------------------------------
     def _out(self, t: torch.Tensor) -> torch.Tensor:
@@ -81,12 +203,14 @@ class FrameShard:
 
     def allreduce(self, t: torch.Tensor) -> torch.Tensor:
         """In-place SUM over the ranks."""
+        ev = self._tick(t)
         if self.staged and t.is_cuda:
             h = t.detach().cpu()
             self.dist.all_reduce(h, group=self.group)
             t.copy_(h)
         else:
             self.dist.all_reduce(t, group=self.group)
+        self._tock(ev)
         self.bytes_sent += t.numel() * t.element_size()
         return t
 
@@ -96,6 +220,7 @@ class FrameShard:
         dist = self.dist
         dev = first.device
         ops_, prev_buf, next_buf = [], None, None
+        ev = self._tick(first)
         f_out, l_out = self._out(first), self._out(last)
         if self.rank > 0:
             prev_buf = torch.empty_like(f_out)
@@ -110,6 +235,7 @@ class FrameShard:
         if ops_:
             for r in dist.batch_isend_irecv(ops_):
                 r.wait()
+        self._tock(ev)
         self.bytes_sent += (int(self.rank > 0) + int(self.rank < self.world - 1)) * first.numel() * first.element_size()
         prev = None if prev_buf is None else prev_buf.to(dev)
         nxt = None if next_buf is None else next_buf.to(dev)
@@ -135,8 +261,34 @@ class FrameShard:
             self.bytes_sent += t.numel() * t.element_size()
         return t
 
+    @staticmethod
+    def cfg_pair(t_glob: int, groups=(None, None), mode: str = "a2a"):
+        """Shards for the two CFG halves of a step: the second one puts its longer shards on the LAST ranks, so the
+        2 x t_glob frame instances are spread as evenly as whole frames allow (17 over 8: 5,4,4,4,4,4,4,5).  `groups`:
+        one process group per half (two communicators let the halves' exchanges proceed independently on two
+        streams); (None, None) uses the default group for both."""
+        return (FrameShard(t_glob, group=groups[0], mode=mode),
+                FrameShard(t_glob, group=groups[1], mode=mode, heavy_last=True))
+
     def _global_rank(self, r: int) -> int:
         return r if self.group is None else self.dist.get_global_rank(self.group, r)
+
+    def gather_pixels(self, y2d: torch.Tensor, b: int, hw: int) -> torch.Tensor:
+        """(b * t_glob * hw_local, C) pixel-layout rows -> (b * t_glob * hw, C): every rank's pixel block, in order."""
+        pix = frame_shards(hw, self.world)
+        hw_me, hw_max = pix[self.rank][1] - pix[self.rank][0], max(hi - lo for lo, hi in pix)
+        c = y2d.shape[1]
+        yl = y2d.reshape(b * self.t_glob, hw_me, c)
+        if hw_me < hw_max:
+            yl = torch.cat([yl, yl.new_zeros((b * self.t_glob, hw_max - hw_me, c))], dim=1)
+        ev = self._tick(y2d)
+        send = self._out(yl)
+        bufs = [torch.empty_like(send) for _ in range(self.world)]
+        self.dist.all_gather(bufs, send, group=self.group)
+        self._tock(ev)
+        self.bytes_sent += send.numel() * send.element_size()
+        full = torch.cat([bufs[r][:, : hi - lo] for r, (lo, hi) in enumerate(pix)], dim=1).to(y2d.device)
+        return full.reshape(b * self.t_glob * hw, c)
 
     def gather_frames(self, x: torch.Tensor, b: int) -> torch.Tensor:
         """x: (b * t_local, ...) local frames of every clip -> (b * t_glob, ...) with all ranks' frames in order."""
@@ -145,9 +297,11 @@ class FrameShard:
         if self.t_local < self.t_max:          # equal-size all-gather: pad short shards
             pad = torch.zeros((b, self.t_max - self.t_local, *rest), dtype=x.dtype, device=x.device)
             xl = torch.cat([xl, pad], dim=1)
+        ev = self._tick(x)
         send = self._out(xl)
         bufs = [torch.empty_like(send) for _ in range(self.world)]
         self.dist.all_gather(bufs, send, group=self.group)
+        self._tock(ev)
         self.bytes_sent += send.numel() * send.element_size()
         parts = [bufs[r][:, : (hi - lo)] for r, (lo, hi) in enumerate(self.bounds)]
         full = torch.cat(parts, dim=1).to(x.device)

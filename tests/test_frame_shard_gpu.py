@@ -33,7 +33,7 @@ def _inputs(crossframe=False):
     return x2, t, c
 
 
-def _worker(rank, world, port, q, crossframe=False):
+def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -49,8 +49,10 @@ def _worker(rank, world, port, q, crossframe=False):
     x2, t, c = _inputs(crossframe)
     cc = {k: v.cuda() for k, v in c.items()}
     ref = w(x2.cuda(), t.cuda(), cc).cpu() if rank == 0 else None      # unsharded evaluation
-    w.frame_shard = FrameShard(T)
+    shards = FrameShard.cfg_pair(T) if mode == "pair" else (FrameShard(T, mode=mode),)
+    w.frame_shard = shards if mode == "pair" else shards[0]
     out = w(x2.cuda(), t.cuda(), cc).cpu()
+    torch.cuda.synchronize()
     orc = None
     if rank == 0:          # fp32 CPU oracle: the common yardstick for both execution orders
         torch.set_num_threads(16)
@@ -58,24 +60,28 @@ def _worker(rank, world, port, q, crossframe=False):
         from ccedit_amd.utils.synth import synth_state_dict
         from oracle import ccedit_oracle as O
         orc = O.network_forward(synth_state_dict(build_network_spec(cfg)), O.NetConfig(**cfg), x2, t, c)
-    q.put((rank, out.numpy(), None if ref is None else ref.numpy(), w.frame_shard.bytes_sent,
+    q.put((rank, out.numpy(), None if ref is None else ref.numpy(),
+           (sum(s.bytes_sent for s in shards), sum(s.n_collectives for s in shards)),
            None if orc is None else orc.numpy()))      # numpy: pickled by value (the child may exit before the parent reads)
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,crossframe", [(1, False), (2, False), (2, True)])
-# uneven 3-way splits: primitives in test_parallel_gloo.py (three processes time-slicing one GPU through host-staged gloo
-# take minutes).  crossframe=True: TVI2V — the centre keyframe (rank 1 of 2 at T=5) adds img_control and broadcasts its K/V
-def test_sharded_network_matches_unsharded(world, crossframe):
+@pytest.mark.parametrize("world,crossframe,mode", [(1, False, "a2a"), (2, False, "a2a"), (2, True, "a2a"), (2, False, "pair"),
+                                                   (2, True, "pair"), (2, False, "halo"), (2, True, "halo")])
+# uneven 3- and 4-way splits: primitives in test_parallel_gloo.py (several processes time-slicing one GPU through
+# host-staged gloo take minutes).  crossframe=True: TVI2V — the centre keyframe (rank 1 of 2 at T=5) adds img_control and
+# broadcasts its K/V.  mode: "a2a" = all-to-all layout transposition around the temporal ops; "pair" = the same with the two
+# CFG halves on mirrored partitions and two streams; "halo" = round-1 halo / all-reduce / all-gather exchanges
+def test_sharded_network_matches_unsharded(world, crossframe, mode):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, crossframe)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, crossframe, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=500) for _ in range(world)), key=lambda r: r[0])
@@ -94,7 +100,7 @@ def test_sharded_network_matches_unsharded(world, crossframe):
         assert out.shape == ref.shape == (2, 4, T, H, W)
         e_sh, d = rel(out, orc), rel(out, ref)
         print(f"world {world} rank {rank}: err vs fp32 oracle: unsharded {e_un:.4f}, sharded {e_sh:.4f}; "
-              f"sharded vs unsharded {d:.4f}; bytes sent {sent}")
+              f"sharded vs unsharded {d:.4f}; (bytes sent, exchanges) {sent}")
         # Both execution orders are bf16 realisations of the same fp32 computation: each must meet the stated
         # network tolerance against the oracle, and they may differ from each other by no more than the sum of
         # their errors (a different fp32 summation order in the temporal GroupNorm re-rolls the bf16 roundings).

@@ -63,6 +63,10 @@ def test_frame_shard_plan():
     assert sharding_efficiency(34, 8) == pytest.approx(0.85)
     assert sharding_efficiency(17, 8) == pytest.approx(17 / 24)
     assert sharding_efficiency(17, 2) == pytest.approx(17 / 18)
+    from ccedit_amd.parallel import cfg_pair_efficiency
+    assert cfg_pair_efficiency(17, 8) == pytest.approx(34 / 40)         # 5,4,4,4,4,4,4,5
+    assert cfg_pair_efficiency(17, 4) == pytest.approx(34 / 36)
+    assert cfg_pair_efficiency(17, 2) == pytest.approx(1.0)
 
 
 def _shard_worker(rank, world, port, t_glob, q):
@@ -96,15 +100,38 @@ def _shard_worker(rank, world, port, t_glob, q):
     anchor = local[:, centre - sh.t0].contiguous() if sh.rank == owner else torch.empty(b, hw, c)
     sh.broadcast(anchor, owner)
     ok &= torch.equal(anchor, full[:, centre])
-    q.put((rank, bool(ok), sh.t0, sh.t1))
+    # mode "a2a": frame layout <-> pixel layout (all T frames of this rank's pixel block), both CFG-pair partitions
+    for b2 in (1, 2):
+        for shp in FrameShard.cfg_pair(t_glob):
+            hw2 = 11                                                   # uneven pixel blocks too
+            fullp = (torch.arange(b2)[:, None, None] * 10000 + torch.arange(t_glob)[None, :, None] * 100
+                     + torch.arange(hw2)[None, None, :]).float()[..., None].expand(b2, t_glob, hw2, c).contiguous()
+            loc = fullp[:, shp.t0:shp.t1].reshape(-1, c).contiguous()
+            pix = shp.to_pixels(loc, b2, hw2)
+            from ccedit_amd.parallel import frame_shards as fs
+            p0, p1 = fs(hw2, world)[rank]
+            ok &= torch.equal(pix.view(b2, t_glob, p1 - p0, c), fullp[:, :, p0:p1])
+            ok &= shp.hw_local(hw2) == p1 - p0
+            skip = torch.full_like(loc, 0.5)
+            back = shp.to_frames(pix, b2, hw2, add=skip)
+            ok &= torch.equal(back, loc + 0.5)
+            allp = shp.gather_pixels(pix, b2, hw2)
+            ok &= torch.equal(allp.view(b2, t_glob, hw2, c), fullp)
+            ok &= shp.n_collectives == 3 and shp.bytes_sent > 0
+    pair = FrameShard.cfg_pair(t_glob)
+    load = torch.tensor([pair[0].t_local + pair[1].t_local])
+    loads = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(loads, load)
+    q.put((rank, bool(ok), sh.t0, sh.t1, [int(v) for v in loads]))
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("world,t_glob", [(2, 17), (3, 5)])
+@pytest.mark.parametrize("world,t_glob", [(2, 17), (3, 5), (4, 17)])
 def test_frame_shard_primitives_gloo(world, t_glob):
-    """halo exchange / statistics all-reduce / K-V all-gather / centre-frame broadcast of the frame-sharded mode, uneven
-    shards included."""
+    """halo exchange / statistics all-reduce / K-V all-gather / centre-frame broadcast of the frame-sharded mode, and the
+    all-to-all layout transposition of mode "a2a" with its mirrored CFG-pair partitions; uneven shards included
+    (17 keyframes over 4 ranks: 5,4,4,4 and 4,4,4,5)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -117,3 +144,9 @@ def test_frame_shard_primitives_gloo(world, t_glob):
         assert p.exitcode == 0
     assert all(r[1] for r in res), res
     assert res[0][2] == 0 and res[-1][3] == t_glob and all(res[i][3] == res[i + 1][2] for i in range(world - 1))
+    from ccedit_amd.parallel import cfg_pair_efficiency
+    loads = res[0][4]
+    assert sum(loads) == 2 * t_glob
+    assert (sum(loads) / world) / max(loads) == pytest.approx(cfg_pair_efficiency(t_glob, world))
+    if (world, t_glob) == (4, 17):
+        assert loads == [9, 8, 8, 9]

@@ -69,7 +69,9 @@ def test_depth_hint_normalisation():
     vmin, vmax = flat.sort(dim=1).values[:, int(0.02 * n) - 1], flat.sort(dim=1).values[:, int(0.85 * n) - 1]
     want = (((raw - vmin[:, None, None, None, None]) / (vmax - vmin)[:, None, None, None, None]).clamp(0, 1) * 2 - 1)
     assert torch.allclose(zo, want.repeat(1, 3, 1, 1, 1))
-    hint = torch.rand(1, 3, 2, 8, 8) * 2 - 1
+    hint = (torch.rand(1, 1, 2, 8, 8) * 2 - 1).repeat(1, 3, 1, 1, 1)
     assert DepthMidasEncoder()(hint) is hint                                           # finished hint: passed through
+    with pytest.raises(NotImplementedError, match="RGB"):                              # three different channels: not a hint
+        DepthMidasEncoder()(torch.rand(1, 3, 2, 8, 8) * 2 - 1)
     with pytest.raises(NotImplementedError):
         DepthMidasEncoder()(["video.mp4"])
