@@ -25,6 +25,26 @@
 bool cc_attn_short_applicable(const CcAttnDesc& a);      // attnshort.hip
 int cc_attn_short_launch(const CcAttnDesc& a, hipStream_t s);
 
+#ifndef ATTN_PRIO
+#define ATTN_PRIO 0
+#endif
+#if ATTN_PRIO == 1          // matrix segments win the issue arbitration
+#define ATTN_PRIO_MFMA() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ATTN_PRIO_VALU() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif ATTN_PRIO == 2        // vector segments win
+#define ATTN_PRIO_MFMA() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ATTN_PRIO_VALU() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif ATTN_PRIO == 3        // scheduling fences only (control)
+#define ATTN_PRIO_MFMA() __builtin_amdgcn_sched_barrier(0)
+#define ATTN_PRIO_VALU() __builtin_amdgcn_sched_barrier(0)
+#elif ATTN_PRIO == 4        // static: odd waves of a SIMD outrank even ones for the whole kernel
+#define ATTN_PRIO_MFMA() do {} while (0)
+#define ATTN_PRIO_VALU() do {} while (0)
+#else
+#define ATTN_PRIO_MFMA() do {} while (0)
+#define ATTN_PRIO_VALU() do {} while (0)
+#endif
+
 namespace {
 
 __device__ __attribute__((aligned(64))) char g_attn_zero_page[64];
@@ -176,6 +196,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
         }
     };
 
+#if ATTN_PRIO == 4
+    switch ((blockIdx.x >> 8) & 3) {
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+    }
+#endif
     f32x16 o[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -221,6 +249,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
         const char* vb = sV + buf * VB;
 
         // ---- S^T = K Q^T for the 64 kv rows of this tile ----
+        ATTN_PRIO_MFMA();
         f32x16 s[2];
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
@@ -238,6 +267,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
         // ---- online softmax (this lane: query q0 + l31, kv = 64 j + 32 t2 + 16 (r>>3) + 8 hi + (r&7)) ----
         // The running max is kept in raw-score units; p = exp2(s*sc - m*sc) is one FMA + one v_exp_f32 per
         // element (raw hardware exp2: arguments are <= 0, flush-to-zero of tiny results is what we want).
+        ATTN_PRIO_VALU();
         if (j * 64 + 64 > a.Lk) {          // wave-uniform: only the last KV tile has masked columns
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
@@ -290,6 +320,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
         if constexpr (!MFMA_ROWSUM) l_run += psum;
 
         // ---- O^T += V^T P^T ----
+        ATTN_PRIO_MFMA();
 #pragma unroll
         for (int sp = 0; sp < 4; ++sp) {
             bf16x8 pf;
@@ -304,6 +335,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
                 o[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[n], 0, 0, 0);
             }
         }
+        ATTN_PRIO_VALU();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         buf ^= 1;

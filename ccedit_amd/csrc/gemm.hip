@@ -93,12 +93,25 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
     // pixel tile back to back".
     const int Q = (d.cgroup & 0xFFFF) > 0 ? (d.cgroup & 0xFFFF) : ct_n;
     const int64_t gsz = pt_per_xcd * Q;
-    const int cg = (int)(local / gsz);
-    const int64_t rr = local - cg * gsz;
-    const int qn = min(Q, ct_n - cg * Q);
-    const int64_t pl = rr / qn;
+    int cg = (int)(local / gsz);
+    int64_t rr = local - cg * gsz;
+    int qn = min(Q, ct_n - cg * Q);
+    int64_t pl = rr / qn;
     int64_t pt = xcd * pt_per_xcd + pl;
-    if (pt >= pt_n) return;
+    if ((d.cgroup >> 18) & 1) {
+        // No channel grouping: the same walk (an XCD owns a contiguous range of pixel tiles, channel tiles back to back), but
+        // the ranges are cut at WORKGROUP granularity, so the XCDs differ by at most one workgroup.  Cutting at pixel-tile
+        // granularity leaves e.g. 51 pixel tiles x 5 channel tiles as 35,35,..,10 workgroups on 32-CU XCDs: two rounds where
+        // 255 workgroups fit the chip in one.
+        const int64_t total = pt_n * ct_n;
+        const int64_t per = (total + 7) / 8, w = xcd * per + local;
+        if (local >= per || w >= total) return;
+        pt = w / ct_n;
+        cg = 0;
+        qn = ct_n;
+        pl = 0;
+        rr = w - pt * ct_n;
+    } else if (pt >= pt_n) return;
     if constexpr (MODE == M_TEMPORAL) {
         // Conv1d over T: the three taps of pixel tile (frame t, pixel block b) read frames t-1, t, t+1 of the SAME pixel
         // block.  Walk the frames of one pixel block back to back (frame-minor order), so that the tiles sharing input
@@ -339,12 +352,11 @@ int launch(const CcGemmDesc& d, hipStream_t s) {
     if (int rc = cc_max_dynamic_lds((const void*)tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>, lds, &attr_done, "tap_gemm"))
         return rc;
     const int64_t pt_n = (d.M + BNP - 1) / BNP, ct_n = (d.N + BMC - 1) / BMC;
-    const int64_t nblk = 8 * ((pt_n + 7) / 8) * ct_n;
+    int64_t nblk = 8 * ((pt_n + 7) / 8) * ct_n;
     if (nblk > 2147483647LL) {
         cc_set_error("ccedit_gemm: grid too large");
         return CCEDIT_EUNSUPPORTED;
     }
-    dim3 grid((unsigned)nblk);
     // Channel-tile group width (see the block-order comment in the kernel).  Weights that fit in an XCD's L2 are
     // fetched once whatever the order; otherwise, with C workgroups resident per XCD as (C/Q pixel tiles) x (Q
     // channel tiles), the fabric traffic per workgroup is  wtile * Q/C + atile / Q, minimal at Q = sqrt(C*atile/wtile)
@@ -367,12 +379,22 @@ int launch(const CcGemmDesc& d, hipStream_t s) {
     if (krot_env && d.Kpad <= 640) dd.cgroup |= 1 << 16;                                         // short K only: measured neutral or -3 % at K = 1280
     static const int tord_env = getenv("CCEDIT_TEMPORAL_ORDER") ? atoi(getenv("CCEDIT_TEMPORAL_ORDER")) : 1;   // 0: frames-outermost tile order
     if (MODE == M_TEMPORAL && tord_env && d.HW % BNP == 0 && d.M % d.HW == 0) dd.cgroup |= 1 << 17;
+    static const int bal_env = getenv("CCEDIT_BALANCED") ? atoi(getenv("CCEDIT_BALANCED")) : 1;      // 0: A/B against pixel-tile cuts
+    if (bal_env && (dd.cgroup & 0xFFFF) == 0 && !((dd.cgroup >> 17) & 1)) {
+        dd.cgroup |= 1 << 18;
+        nblk = 8 * ((pt_n * ct_n + 7) / 8);
+    }
+    dim3 grid((unsigned)nblk);
     hipLaunchKernelGGL((tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>), grid, dim3(WM * WN * 64), lds, s, dd);
     return cc_launch_status("tap_gemm_kernel");
 }
 
 template <int MODE>
 int launch_tile(const CcGemmDesc& d, int tile, hipStream_t s) {
+    if constexpr (MODE == M_LINEAR) {
+        if (tile == 7) return launch<2, 2, 4, 4, 4, 32, MODE>(d, s);   // 256ch x 256pix, 4 waves of 128ch x 128pix, 4 stages of K=32
+        if (tile == 10) return launch<2, 2, 5, 4, 4, 32, MODE>(d, s);  // 320ch x 256pix, 4 waves of 160ch x 128pix, 4 stages of K=32
+    }
     if (tile == 6) return launch<2, 2, 5, 2, 2, 32, MODE>(d, s);  // 320ch x 128pix, 4 waves of 160ch x 64pix, 2 stages of K=32, 2 WG/CU
     if (tile == 5) return launch<2, 4, 2, 4, 4, 32, MODE>(d, s);  // 128ch x 512pix, 8 waves of 64ch x 128pix, 4 stages of K=32
     if (tile == 4) return launch<2, 4, 4, 2, 4, 32, MODE>(d, s);  // 256ch x 256pix, 8 waves of 128ch x 64pix, 4 stages of K=32
@@ -472,6 +494,14 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         if (t6_env && d.N % 320 == 0 && !d.gn_stats && d.M >= 8192 &&
             ((d.mode == CCEDIT_GEMM_LINEAR && d.Kpad >= 1280) || (d.mode == CCEDIT_GEMM_TEMPORAL && d.Kpad >= 3840)))
             tile = 6;
+        //   16x24-level Linears onto 1280 channels: 256ch x 256pix (t4).  With the workgroup-granular XCD cut (cgroup bit 18)
+        //   13056 pixels x 1280 channels is 255 workgroups = one round of the chip: 706 / 906 / 954 TF/s at K = 1280 / 5120 /
+        //   11520 against 644 / 817 / 846 for t6 (tools/exp/gemm_vs_vendor.py; the same shapes cut at pixel-tile granularity
+        //   ran 374 / 540 / 591).  CCEDIT_T4=0 switches it off for A/B.
+        static const int t4_env = getenv("CCEDIT_T4") ? atoi(getenv("CCEDIT_T4")) : 1;
+        if (t4_env && d.mode == CCEDIT_GEMM_LINEAR && d.N % 256 == 0 && d.N <= 2560 && d.act != CCEDIT_ACT_GEGLU && !d.gn_stats &&
+            d.Kpad >= 1280 && d.M >= 6000 && d.M <= 16384)
+            tile = 4;
         if (d.gn_stats && d.gn_rows % 256 != 0) tile = 1;     // a block must not straddle two frames
     }
     const int mode = d.mode == CCEDIT_GEMM_CONV2D ? (d.upsample ? M_CONV_UP : M_CONV)

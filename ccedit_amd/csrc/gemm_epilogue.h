@@ -12,6 +12,14 @@ constexpr int epi_lds_total(int bmc, int bnp, int tj, int lds_main) {
     return lds_main >= one_tile ? lds_main : one_col;      // wide channel tiles: stage 32 pixels at a time
 }
 
+// Largest whole number of `unit`-pixel groups that fits `cap` staged rows and divides the block's pixel count.
+constexpr int epi_chunk_pixels(int cap, int unit, int bnp) {
+    int best = 0;
+    for (int e = unit; e <= bnp && e <= cap; e += unit)
+        if (bnp % e == 0) best = e;
+    return best;
+}
+
 // In the MFMA layout a lane owns 4 channels of 32 different pixels, i.e. 8-byte pieces of 32 different output rows
 // per store.  Staging the tile through LDS turns that into 16-byte-per-lane accesses that walk each pixel row
 // contiguously (bias / timestep-embedding / activation / residual reads use the same coalesced pattern).
@@ -33,7 +41,7 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
     constexpr int LDS_TOTAL = epi_lds_total(BMC, BNP, TJ, LDS_MAIN);
     // pixels staged per chunk: whole wave columns, or single 32-pixel MFMA tile columns when a wave column does not fit
     constexpr int EGR = LDS_TOTAL / EROW >= WPIX ? WPIX : 32;
-    constexpr int ECH = (LDS_TOTAL / EROW / EGR) * EGR < BNP ? (LDS_TOTAL / EROW / EGR) * EGR : BNP;
+    constexpr int ECH = epi_chunk_pixels(LDS_TOTAL / EROW, EGR, BNP);
     static_assert(ECH >= EGR && BNP % ECH == 0, "epilogue chunking");
     char* const sE = smem;
     const float* __restrict__ bias = d.bias;

@@ -150,3 +150,48 @@ def test_frame_shard_primitives_gloo(world, t_glob):
     assert (sum(loads) / world) / max(loads) == pytest.approx(cfg_pair_efficiency(t_glob, world))
     if (world, t_glob) == (4, 17):
         assert loads == [9, 8, 8, 9]
+
+
+def _subgroup_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ccedit_amd.parallel import FrameShard
+    members = [1, 2]
+    g = dist.new_group(members)                       # every rank creates the group; only its members use it
+    ok = True
+    if rank in members:
+        t_glob, hw, c = 4, 6, 3
+        full = torch.arange(t_glob * hw * c, dtype=torch.float32).view(1, t_glob, hw, c)
+        for mode in ("halo", "a2a"):
+            sh = FrameShard(t_glob, group=g, mode=mode)
+            ok &= sh.rank == members.index(rank) and sh.world == 2
+            local = full[:, sh.t0:sh.t1].contiguous()
+            prev, nxt = sh.halo(local[:, 0].contiguous(), local[:, -1].contiguous())      # peers are GLOBAL ranks 1 and 2
+            ok &= (prev is None) if sh.rank == 0 else torch.equal(prev, full[:, sh.t0 - 1])
+            ok &= (nxt is None) if sh.rank == 1 else torch.equal(nxt, full[:, sh.t1])
+            pix = sh.to_pixels(local.reshape(-1, c), 1, hw)
+            ok &= torch.equal(sh.to_frames(pix, 1, hw), local.reshape(-1, c))
+            anchor = local[:, 0].contiguous() if sh.rank == 1 else torch.empty(1, hw, c)
+            sh.broadcast(anchor, 1)                                                        # group rank 1 = global rank 2
+            ok &= torch.equal(anchor, full[:, 2])
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_frame_shard_inside_a_subgroup_gloo():
+    """A FrameShard built on a process sub-group addresses its point-to-point peers and broadcast sources by GLOBAL rank
+    (torch.distributed's P2POp / broadcast convention): group {1, 2} of a 3-rank world."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
