@@ -1,3 +1,11 @@
+// EXPERIMENT, NOT BUILT INTO THE LIBRARY (round 2; numbers in DESIGN.md §3.1): attention.hip with two tuning variants —
+//   * PIPE = true: software-pipelined long-sequence loop, the QK^T MFMAs of tile j+1 interleaved (sched_group_barrier) with
+//     the exp / convert instructions of tile j.  Bit-correct (passed every attention test while dispatched), the ISA shows
+//     one MFMA per ~10 VALU as intended — and it is SLOWER: 3.14-3.26 ms (8 waves per workgroup) / 2.91-2.96 ms (4 waves)
+//     against 2.65-2.71 ms for the plain loop on the 34 x 8 x 6144^2, d = 40 launch.  The second score tile costs 24-30 VGPRs
+//     (121 -> 145-151): three waves per SIMD instead of four, and that loses more than the interleave gains.  Forcing 128
+//     VGPRs spills inside the loop (4.9-7.0 ms).
+//   * ATTN_PRIO = 1..4: s_setprio around the matrix / vector segments, or static per workgroup: 2.66-2.76 ms, no effect.
 // Flash-style attention on bf16 MFMA (v_mfma_f32_32x32x16_bf16) for gfx950.
 //
 // Serves the three attention shapes of the CCEdit hot path (reference: CrossAttention.forward,
@@ -25,6 +33,34 @@
 bool cc_attn_short_applicable(const CcAttnDesc& a);      // attnshort.hip
 int cc_attn_short_launch(const CcAttnDesc& a, hipStream_t s);
 
+#ifndef ATTN_PRIO
+#define ATTN_PRIO 0
+#endif
+#ifndef ATTN_PIPE_VAR
+#define ATTN_PIPE_VAR 0
+#endif
+#if ATTN_PIPE_VAR & 2
+#define ATTN_WAVES_MIN 4
+#else
+#define ATTN_WAVES_MIN 2
+#endif
+#if ATTN_PRIO == 1          // matrix segments win the issue arbitration
+#define ATTN_PRIO_MFMA() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ATTN_PRIO_VALU() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif ATTN_PRIO == 2        // vector segments win
+#define ATTN_PRIO_MFMA() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ATTN_PRIO_VALU() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif ATTN_PRIO == 3        // scheduling fences only (control)
+#define ATTN_PRIO_MFMA() __builtin_amdgcn_sched_barrier(0)
+#define ATTN_PRIO_VALU() __builtin_amdgcn_sched_barrier(0)
+#elif ATTN_PRIO == 4        // static: odd waves of a SIMD outrank even ones for the whole kernel
+#define ATTN_PRIO_MFMA() do {} while (0)
+#define ATTN_PRIO_VALU() do {} while (0)
+#else
+#define ATTN_PRIO_MFMA() do {} while (0)
+#define ATTN_PRIO_VALU() do {} while (0)
+#endif
+
 namespace {
 
 __device__ __attribute__((aligned(64))) char g_attn_zero_page[64];
@@ -40,8 +76,8 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p, int second_off) {
 // amdgpu_waves_per_eu(2, 8): with a 1-wave lower bound hipcc parks part of the S^T / O^T accumulators in AGPRs and
 // pays ~150 v_accvgpr_read/write per KV tile to run the softmax on them (the kernel is VALU-bound: 20 VALU per
 // MFMA measured); with >= 2 waves/EU it keeps everything in arch VGPRs (0 moves).
-template <int D, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8))) void attn_kernel(const CcAttnDesc a) {
+template <int D, int NW, bool PIPE = false>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(PIPE ? ATTN_WAVES_MIN : 2, 8))) void attn_kernel(const CcAttnDesc a) {
     constexpr int KS = (D + 15) / 16;         // QK^T k-steps
     constexpr int NT = (D + 31) / 32;         // O^T row tiles
     // LDS row widths.  For d <= 128 rows are padded to a power of two so that an XOR swizzle of the 16-byte
@@ -132,13 +168,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
         seg1base = (int64_t)(sb / a.kv_inner) * a.kv_outer_rows + (int64_t)(sb % a.kv_inner) * a.kv_inner_rows;
     }
 
-    auto stage = [&](int j, int buf) {
+    // which: 1 = K tile, 2 = V tile, 3 = both (each tile index must be staged once and in order: the pointers advance)
+    auto stage = [&](int j, int buf, int which = 3) {
         const int rows_left = a.Lk - j * 64;        // rows >= rows_left of this tile come from the zero page
         if (a.seg1_len > 0) {
             // two-segment keys: recompute the row address per slot (the running pointers assume one segment)
 #pragma unroll
             for (int it = 0; it < ITK; ++it) {
-                if (krw[it] >= 0) {
+                if (krw[it] >= 0 && (which & 1)) {
                     const int kv = j * 64 + krw[it];
                     const int64_t r = (kv < a.seg1_len) ? seg1base + (int64_t)kv * a.kv_seq_rows
                                                         : kvbase + (int64_t)(kv - a.seg1_len) * a.kv_seq_rows;
@@ -148,7 +185,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
             }
 #pragma unroll
             for (int it = 0; it < ITV; ++it) {
-                if (vrw[it] >= 0) {
+                if (vrw[it] >= 0 && (which & 2)) {
                     const int kv = j * 64 + vrw[it];
                     const int64_t r = (kv < a.seg1_len) ? seg1base + (int64_t)kv * a.kv_seq_rows
                                                         : kvbase + (int64_t)(kv - a.seg1_len) * a.kv_seq_rows;
@@ -158,24 +195,36 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
             }
             return;
         }
+        if (which & 1) {
 #pragma unroll
-        for (int it = 0; it < ITK; ++it) {
-            if (krw[it] >= 0) {
-                const bf16* src = (krw[it] < rows_left) ? kp[it] : zp;
-                glds16(src, sK + buf * KB + (it * NTHR + wave * 64) * 16);
+            for (int it = 0; it < ITK; ++it) {
+                if (krw[it] >= 0) {
+                    const bf16* src = (krw[it] < rows_left) ? kp[it] : zp;
+                    glds16(src, sK + buf * KB + (it * NTHR + wave * 64) * 16);
+                }
+                kp[it] += kstep;
             }
-            kp[it] += kstep;
         }
+        if (which & 2) {
 #pragma unroll
-        for (int it = 0; it < ITV; ++it) {
-            if (vrw[it] >= 0) {
-                const bf16* src = (vrw[it] < rows_left) ? vp[it] : zp;
-                glds16(src, sV + buf * VB + (it * NTHR + wave * 64) * 16);
+            for (int it = 0; it < ITV; ++it) {
+                if (vrw[it] >= 0) {
+                    const bf16* src = (vrw[it] < rows_left) ? vp[it] : zp;
+                    glds16(src, sV + buf * VB + (it * NTHR + wave * 64) * 16);
+                }
+                vp[it] += vstep;
             }
-            vp[it] += vstep;
         }
     };
 
+#if ATTN_PRIO == 4
+    switch ((blockIdx.x >> 8) & 3) {
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+    }
+#endif
     f32x16 o[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -211,6 +260,135 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
             *(u32x4*)(sV + b * VB + row * (DV * 2) + slot * 16) = u32x4{0x00003F80u, 0u, 0u, 0u};   // bf16 {1,0,0,...}
         }
     }
+    if constexpr (PIPE) {
+    // ---- software-pipelined loop (long key sequences, d <= 80) ----
+    // tools/exp/coexec.hip: an MFMA stream and a VALU stream on one SIMD — from two waves or interleaved in one — take the
+    // VALU time plus ~30 % of the MFMA time; attn_kernel's plain loop ran at VALU + MFMA - 42 % of MFMA (PMC: the waves of a
+    // SIMD drift into the same phase).  Here iteration j issues the QK^T MFMAs of tile j+1 INSIDE the exp / convert
+    // instructions of tile j (one MFMA per ~10 VALU, sched_group_barrier), so the overlap no longer depends on what the
+    // other waves happen to be doing.  Arithmetic and its order per tile are unchanged: results are bit-identical.
+    //   K ring: iteration j reads K(j+1) from slot (j+1)&1 while K(j+2) lands in slot j&1 (last read in iteration j-1);
+    //   V ring: reads V(j) from slot j&1 while V(j+1) lands in slot (j+1)&1.  One barrier per tile, as before.
+    auto qk_tile = [&](const char* kb, f32x16 (&sn)[2]) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sn[t2][r] = 0.f;
+            const int krow = t2 * 32 + krow_l;
+            const char* kr = kb + krow * (DK * 2);
+            const int ksw = SWZ ? ((GK == 8) ? ((krow >> 1) & 7) : (krow & 15)) : 0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kr + (((ks * 2 + hi) ^ ksw) << 4));
+                sn[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sn[t2], 0, 0, 0);
+            }
+        }
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ntiles > 1) stage(1, 1, 1);
+    f32x16 s[2];
+    qk_tile(sK, s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int j = 0; j < ntiles; ++j) {
+        const bool more = j + 1 < ntiles;
+        if (j + 2 < ntiles) stage(j + 2, j & 1, 1);
+        if (more) stage(j + 1, (j + 1) & 1, 2);
+        const char* vb = sV + (j & 1) * VB;
+        if (j * 64 + 64 > a.Lk) {          // wave-uniform: only the last KV tile has masked columns
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = j * 64 + 32 * t2 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    if (kv >= a.Lk) s[t2][r] = -INFINITY;
+                }
+        }
+        if (a.causal && j * 64 + 63 > q0) {
+            const int qi_c = q0 + l31;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = j * 64 + 32 * t2 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    if (kv > qi_c) s[t2][r] = -INFINITY;
+                }
+        }
+        float mt = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[1][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+            l_run *= alpha;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+            m_run = m_new;
+        }
+        const float msc = -m_run * sc;
+        bf16x8 pf[4];
+        f32x16 sn[2];
+        auto exp_part = [&]() {
+            float psum = 0.f;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 e = {s[t2][r], s[t2][r + 1]};
+                    e = __builtin_elementwise_fma(e, f32x2{sc, sc}, f32x2{msc, msc});      // v_pk_fma_f32
+                    const float p0 = __builtin_amdgcn_exp2f(e[0]), p1 = __builtin_amdgcn_exp2f(e[1]);
+                    pf[t2 * 2 + (r >> 3)][r & 7] = f2bf(p0);
+                    pf[t2 * 2 + (r >> 3)][(r & 7) + 1] = f2bf(p1);
+                    if constexpr (!MFMA_ROWSUM) psum += p0 + p1;
+                }
+            if constexpr (!MFMA_ROWSUM) l_run += psum;
+        };
+        if (more) {
+            qk_tile(sK + ((j + 1) & 1) * KB, sn);
+            exp_part();
+            // 2 KS-chains of KS MFMAs among ~64-100 VALU: fragments first, then one MFMA per slice of the vector work
+#if !(ATTN_PIPE_VAR & 1)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * KS, 0);
+#endif
+#pragma unroll
+            for (int g = 0; g < 2 * KS; ++g) {
+#if ATTN_PIPE_VAR & 1
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#endif
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (MFMA_ROWSUM ? 64 : 96) / (2 * KS), 0);
+            }
+        } else {
+            exp_part();
+        }
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+            const int vrow = 16 * sp + 8 * hi + (i16 >> 2);
+            const char* vr = vb + vrow * (DV * 2) + (dvhalf * 16 + (i16 & 3) * 4) * 2;
+            const int vsw = SWZ ? (((vrow >> 1) & 1) << 6) : 0;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const bf16x8 vf = tr_pair(vr + ((n * 64) ^ vsw), 4 * DV * 2);
+                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sp], o[n], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (more) {
+            s[0] = sn[0];
+            s[1] = sn[1];
+        }
+    }
+    } else {
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -221,6 +399,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
         const char* vb = sV + buf * VB;
 
         // ---- S^T = K Q^T for the 64 kv rows of this tile ----
+        ATTN_PRIO_MFMA();
         f32x16 s[2];
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
@@ -238,6 +417,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
         // ---- online softmax (this lane: query q0 + l31, kv = 64 j + 32 t2 + 16 (r>>3) + 8 hi + (r&7)) ----
         // The running max is kept in raw-score units; p = exp2(s*sc - m*sc) is one FMA + one v_exp_f32 per
         // element (raw hardware exp2: arguments are <= 0, flush-to-zero of tiny results is what we want).
+        ATTN_PRIO_VALU();
         if (j * 64 + 64 > a.Lk) {          // wave-uniform: only the last KV tile has masked columns
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
@@ -290,6 +470,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
         if constexpr (!MFMA_ROWSUM) l_run += psum;
 
         // ---- O^T += V^T P^T ----
+        ATTN_PRIO_MFMA();
 #pragma unroll
         for (int sp = 0; sp < 4; ++sp) {
             bf16x8 pf;
@@ -304,9 +485,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
                 o[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[n], 0, 0, 0);
             }
         }
+        ATTN_PRIO_VALU();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         buf ^= 1;
+    }
+
     }
 
     // ---- normalise and store: lane holds O^T[dv = 32 n + (r&3) + 8 (r>>2) + 4 hi][q = l31] ----
@@ -335,18 +519,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
     }
 }
 
-template <int D, int NW>
+template <int D, int NW, bool PIPE = false>
 int launch_attn(const CcAttnDesc& a, hipStream_t s) {
     constexpr bool SWZ = (D <= 128);
     constexpr int DK = SWZ ? (D <= 64 ? 64 : 128) : (D + 15) / 16 * 16;
     constexpr int DV = SWZ ? (D <= 64 ? 64 : 128) : (D + 31) / 32 * 32;
     constexpr int lds = 2 * 64 * DK * 2 + 2 * 64 * DV * 2;
     static unsigned long long attr_done = 0;
-    if (int rc = cc_max_dynamic_lds((const void*)attn_kernel<D, NW>, lds, &attr_done, "attn")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)attn_kernel<D, NW, PIPE>, lds, &attr_done, "attn")) return rc;
     const int64_t qtiles = (a.Lq + NW * 32 - 1) / (NW * 32);
     const int64_t groups = ((int64_t)a.batches * a.heads + 7) / 8 * 8;
     dim3 grid((unsigned)(qtiles * groups));
-    hipLaunchKernelGGL((attn_kernel<D, NW>), grid, dim3(NW * 64), a.Lk <= 64 ? lds / 2 : lds, s, a);
+    hipLaunchKernelGGL((attn_kernel<D, NW, PIPE>), grid, dim3(NW * 64), a.Lk <= 64 ? lds / 2 : lds, s, a);
     return cc_launch_status("attn_kernel");
 }
 
@@ -354,7 +538,12 @@ template <int D>
 int dispatch_nw(const CcAttnDesc& a, hipStream_t s) {
     if (a.Lq <= 32) return launch_attn<D, 1>(a, s);
     if constexpr (D <= 80) {
-        if (a.Lq >= 1024) return launch_attn<D, 8>(a, s);     // 256 query rows per K/V tile load: -2.5 % attention time
+        static const int pipe_env = getenv("CCEDIT_ATTN_PIPE") ? atoi(getenv("CCEDIT_ATTN_PIPE")) : 1;   // 0: A/B against the plain loop
+        if (a.Lq >= 1024) {                                  // 256 query rows per K/V tile load: -2.5 % attention time
+            if (pipe_env == 4 && a.Lk >= 256) return launch_attn<D, 4, true>(a, s);
+            if (pipe_env && a.Lk >= 256) return launch_attn<D, 8, true>(a, s);
+            return launch_attn<D, 8>(a, s);
+        }
     }
     return launch_attn<D, 4>(a, s);
 }

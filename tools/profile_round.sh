@@ -1,0 +1,24 @@
+#!/bin/bash
+# Everything profiles/ holds for one round, in one call on the GPU box:  tools/profile_round.sh <tag>   (e.g. r02)
+#   <tag>_bench_line_default.json       python bench.py                                   (the driver's command, clip included)
+#   <tag>_bench_line_tvi2v.json         python bench.py --workload tvi2v
+#   <tag>_bench_line_under_rocprof.json + <tag>_bench_kernel_stats.txt        rocprofv3 --kernel-trace --stats, batched single stream
+#   <tag>_bench_line_under_rocprof_streams.json + <tag>_bench_kernel_stats_streams.txt   the same, default multi-stream execution
+#   <tag>_pmc_traffic.json / .txt       FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh), tagged with the kernel-source hash
+# Outputs land in gpurun_out/; copy what is to be judged into profiles/.
+tag=${1:-rXX}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py 2>/dev/null | tail -1 > $O/${tag}_bench_line_default.json
+python $R/bench.py --workload tvi2v --no-cpu-baseline 2>/dev/null | tail -1 > $O/${tag}_bench_line_tvi2v.json
+for mode in single streams; do
+  rm -rf /tmp/pf_$mode
+  if [ $mode = single ]; then export CCEDIT_SPLIT_CFG=0 CCEDIT_OVERLAP_CONTROLNET=0; sfx=""; else unset CCEDIT_SPLIT_CFG CCEDIT_OVERLAP_CONTROLNET; sfx="_streams"; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_$mode -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-clip 2>/dev/null | tail -1 > $O/${tag}_bench_line_under_rocprof$sfx.json
+  python $R/tools/prof_summary.py /tmp/pf_$mode $O/${tag}_bench_kernel_stats$sfx.txt > /dev/null 2>&1
+done
+unset CCEDIT_SPLIT_CFG CCEDIT_OVERLAP_CONTROLNET
+PMC_JSON=$O/${tag}_pmc_traffic.json bash $R/tools/pmc_traffic.sh > $O/${tag}_pmc_traffic.txt 2>&1
+ls -la $O/${tag}_*
