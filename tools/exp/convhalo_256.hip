@@ -1,0 +1,288 @@
+// EXPERIMENT, NOT BUILT INTO THE LIBRARY (round 2): convhalo.hip with a second block shape — 16 x 16 pixel
+// rectangles, eight waves, one workgroup per CU (the weight tile of a tap staged once per 256 pixels: L2 -> LDS bytes per
+// FLOP 20 instead of 37 B/clk at MFMA peak) — and a three-slot weight ring with counted vmcnt (WS = 3).  Bit-correct (the
+// conv tests passed while it was dispatched).  Same-box timings, 34 frames: 320->320 at 64x96 492 us (2 slots) / 525 us
+// (3 slots, slower box) against 482 / 541 us for the 8 x 16 shape; 640->640 at 32x48 425 / 458 against 406 / 431.  PMC:
+// the DMA instruction count drops 38 % and the LDS wait halves, but the waves' total wait grows (one 8-wave barrier domain
+// per CU instead of two independent 4-wave workgroups) — neither the weight stream nor its latency is what limits this
+// kernel.
+// 3x3 stride-1 convolution with the input tile staged ONCE per 64-channel chunk (halo included) and the nine taps read
+// from LDS at shifted rows.
+//
+// Why a second conv kernel: tap_gemm_kernel gathers every tap's activation tile from global memory again (9 x per
+// chunk).  PMC on the 64x96-level 320->320 conv: 124 M L1 accesses, 46 % of them missing to L2 (3.6 GB through the
+// TCP->TCC path per launch).  A CU sustains only ~20 B/clk of L1-miss traffic (outstanding-miss queue x L2 latency,
+// measured with tools/exp/readpat.hip), so that traffic — not MFMA, not HBM — bounded the convs at 30-38 % of peak.
+// Here a workgroup owns a TH x TW pixel rectangle (128 pixels) of one frame and 128 output channels:
+//   per chunk  : (TH+2) x (TW+2) halo rows x 128 B  -> LDS once           (23 KB instead of 9 x 16 KB)
+//   per tap    : only the 128 x 64 weight tile streams (2-deep ring), the B fragments are ds_read_b128 at
+//                halo row (ty+dy)*(TW+2) + tx+dx with the same XOR swizzle as everywhere else
+// K order of the packed weights is [Cin/64][tap][64] (korder 1), i.e. k-tile c*9 + t.  Epilogue: gemm_epilogue.h with
+// a 2-D row map.  Shapes that do not qualify (stride 2, fused upsample, Cin % 64 != 0, frames not divisible into
+// 8x16 / 16x8 rectangles) stay on tap_gemm_kernel.
+#include "common.h"
+#include "gemm_epilogue.h"
+#include <stdlib.h>
+
+namespace {
+
+__device__ __attribute__((aligned(64))) char g_zero_page_h[64];     // source of out-of-image halo rows
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_h() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// halo geometry of a BNP-pixel rectangle: 128 pixels = 8 x 16 or 16 x 8 (180 halo rows), 256 pixels = 16 x 16 (324)
+constexpr int halo_rows(int bnp) { return bnp == 128 ? 180 : 324; }
+constexpr int halo_rows_padded(int bnp) { return (halo_rows(bnp) + 7) / 8 * 8; }      // whole 8-row DMA groups
+constexpr int halo_bytes(int bnp) { return halo_rows_padded(bnp) * 128; }
+
+template <int WM, int WN, int TI, int TJ, int WS>
+__global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc d, int tw_log2) {
+    static_assert(WS == 2 || WS == 3, "weight ring depth");
+    constexpr int NT = WM * WN * 64;
+    constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
+    static_assert((NT == 256 && BNP == 128) || (NT == 512 && BNP == 256), "tile geometry");
+    constexpr int RPI = NT / 8;                    // rows per DMA issue (8 granules of 16 B per 128-byte row)
+    constexpr int kHaloRows = halo_rows(BNP), kHaloRowsPad = halo_rows_padded(BNP), kHaloBytes = halo_bytes(BNP);
+    constexpr int kHaloIssues = (kHaloRowsPad + RPI - 1) / RPI;
+    constexpr int W_ISSUES = BMC / RPI;
+    constexpr int W_BYTES = BMC * 128;
+    constexpr int LDS_MAIN = WS * W_BYTES + 2 * kHaloBytes;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sW = smem;                         // [WS][W_BYTES]
+    char* const sH = smem + WS * W_BYTES;          // [2][kHaloBytes]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int TW = 1 << tw_log2, TH = BNP >> tw_log2, HW_ = TW + 2;
+    const int tiles_x = (d.Wout + TW - 1) >> tw_log2, tiles_y = d.Hout / TH;      // the last column of rectangles may be ragged
+    const int tpf = tiles_x * tiles_y;
+
+    // XCD-aware block order, same scheme as tap_gemm_kernel (pixel tiles contiguous per XCD, channel tiles in groups)
+    const int ct_n = (d.N + BMC - 1) / BMC;
+    const int64_t pt_n = (int64_t)(d.M / (d.Hout * d.Wout)) * tpf;
+    const int64_t pt_per_xcd = (pt_n + 7) / 8;
+    const int64_t bid = blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const int64_t local = bid >> 3;
+    const int Q = d.cgroup > 0 ? d.cgroup : ct_n;
+    const int64_t gsz = pt_per_xcd * Q;
+    const int cg = (int)(local / gsz);
+    const int64_t rr = local - cg * gsz;
+    const int qn = min(Q, ct_n - cg * Q);
+    const int64_t pl = rr / qn;
+    const int64_t pt = xcd * pt_per_xcd + pl;
+    if (pt >= pt_n) return;
+    const int ch0 = (cg * Q + (int)(rr - pl * qn)) * BMC;
+    const int frame = (int)(pt / tpf);
+    const int tr = (int)(pt - (int64_t)frame * tpf);
+    const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) << tw_log2;
+
+    const bf16* __restrict__ Ap = (const bf16*)d.A;
+    const bf16* __restrict__ Wp = (const bf16*)d.W;
+    const bf16* zp = (const bf16*)g_zero_page_h;
+    const int nc = d.Cin >> 6, nk = nc * 9;
+
+    // ---- staging coordinates ----
+    // Halo swizzle: LDS slot s of halo entry (hy, hx) holds source granule s ^ f(hy, hx),
+    //   f = (hx >> 1) & 7                     for 8 x 16 rectangles,
+    //   f = ((hx >> 1) + 4 * (hy & 1)) & 7    for 16 x 8 rectangles.
+    // ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (MI355X_MICROARCH.md); with
+    // the halo pitch TW+2 a swizzle keyed on the linear row index (as in tap_gemm_kernel) is 2-way conflicted for every
+    // tap, this one puts the 16 lanes of a group on 16 distinct 16-byte slots of the 256-byte bank row for all nine
+    // shifts (checked exhaustively; PMC: SQ_LDS_BANK_CONFLICT 28.2 M -> ~0 per launch).
+    const int f_hy = (tw_log2 == 3) ? 1 : 0;
+    const int p = tid & 7, rsub = tid >> 3;
+    const int gcol_w = p ^ ((rsub >> 1) & 7);              // weight rows rsub + 32 i: (row >> 1) & 7 is i-independent
+    // halo: issue i stages halo rows i*32 + rsub; source element offset (without the chunk) or -1
+    int64_t hoff[kHaloIssues];
+#pragma unroll
+    for (int i = 0; i < kHaloIssues; ++i) {
+        const int hrow = i * RPI + rsub;
+        const int hy = hrow / HW_, hx = hrow - hy * HW_;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const bool v = hrow < kHaloRows && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+        const int gsrc = p ^ (((hx >> 1) + ((hy & 1) << 2) * f_hy) & 7);     // halo swizzle, see compute()
+        hoff[i] = v ? (((int64_t)frame * d.Hin + iy) * d.Win + ix) * d.lda + gsrc * 8 : (hrow < kHaloRowsPad ? -1 : -2);
+    }
+
+    auto stageW = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < W_ISSUES; ++i)
+            glds16(Wp + (size_t)(ch0 + i * RPI + rsub) * d.Kpad + kt * 64 + gcol_w * 8, sW + buf * W_BYTES + i * (RPI * 128) + wave * 1024);
+    };
+    auto stageH = [&](int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < kHaloIssues; ++i) {
+            if (hoff[i] != -2) {                            // rows past the padded halo of the last issue do not exist
+                const bf16* src = hoff[i] >= 0 ? Ap + hoff[i] + c * 64 : zp;
+                glds16(src, sH + buf * kHaloBytes + i * (RPI * 128) + wave * 1024);
+            }
+        }
+    };
+
+    // ---- fragment coordinates ----
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sw_w = (l31 >> 1) & 7;
+    const char* fa = sW + (wm * TI * 32 + l31) * 128;
+    int hb[TJ], pty[TJ], ptx[TJ];                           // halo row of this lane's pixel for tap (0, 0); its (ty, tx)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int px = (wn * TJ + j) * 32 + l31;
+        pty[j] = px >> tw_log2;
+        ptx[j] = px & (TW - 1);
+        hb[j] = pty[j] * HW_ + ptx[j];
+    }
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int wbuf, int hbuf, int tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int shift = dy * HW_ + dx;
+        const char* pa = fa + wbuf * W_BYTES;
+        const char* ph = sH + hbuf * kHaloBytes;
+        int hr[TJ], hsw[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            hr[j] = hb[j] + shift;
+            hsw[j] = (((ptx[j] + dx) >> 1) + (((pty[j] + dy) & 1) << 2) * f_hy) & 7;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[TI], bfr[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8*)(pa + i * 32 * 128 + (((ks * 2 + hi) ^ sw_w) << 4));
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8*)(ph + hr[j] * 128 + (((ks * 2 + hi) ^ hsw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: weight ring per k-tile, halo 2-deep ring per chunk ----
+    if constexpr (WS == 2) {
+        stageW(0, 0);
+        stageH(0, 0);
+        wait_vmcnt_h<0>();
+        __syncthreads();
+        int kt = 0;
+        for (int c = 0; c < nc; ++c) {
+            for (int t = 0; t < 9; ++t, ++kt) {
+                if (kt + 1 < nk) stageW(kt + 1, (kt + 1) & 1);
+                const bool pre = (t == 0) && (c + 1 < nc);
+                if (pre) stageH(c + 1, (c + 1) & 1);            // issued AFTER the weight tile: loads complete in order
+                compute(kt & 1, c & 1, t);
+                // the next weight tile must have landed; the next halo (needed 8 k-tiles from now) may stay in flight.
+                // A wave issues kHaloIssues or kHaloIssues - 1 halo loads (the last issue is partial): count conservatively.
+                if (pre) wait_vmcnt_h<kHaloIssues - 1>(); else wait_vmcnt_h<0>();
+                __syncthreads();
+            }
+        }
+    } else {
+        // Three weight slots: tile kt + 2 is issued while tile kt is consumed, so a tile has two k-tiles of MFMA time
+        // (instead of one) to arrive before anybody waits for it — PMC on the 2-slot loop with one 8-wave workgroup per CU:
+        // waves wait 42 % of their cycles.  The barrier is a bare s_barrier: __syncthreads() would drain the queue.
+        stageW(0, 0);
+        stageH(0, 0);
+        if (nk > 1) stageW(1, 1);
+        if (nk > 1) wait_vmcnt_h<W_ISSUES>(); else wait_vmcnt_h<0>();
+        __builtin_amdgcn_s_barrier();
+        int kt = 0, cur = 0;
+        for (int c = 0; c < nc; ++c) {
+            for (int t = 0; t < 9; ++t, ++kt) {
+                const bool ahead = kt + 2 < nk;
+                if (ahead) stageW(kt + 2, cur == 0 ? 2 : cur - 1);     // (cur + 2) % 3: the slot of tile kt - 1
+                const bool pre = (t == 0) && (c + 1 < nc);
+                if (pre) stageH(c + 1, (c + 1) & 1);
+                compute(cur, c & 1, t);
+                // tile kt + 1 (issued one iteration ago) must have landed; what this iteration issued may stay in flight
+                if (pre) wait_vmcnt_h<W_ISSUES + kHaloIssues - 1>();
+                else if (ahead) wait_vmcnt_h<W_ISSUES>();
+                else wait_vmcnt_h<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                cur = cur == 2 ? 0 : cur + 1;
+            }
+        }
+    }
+
+    // ---- epilogue ----
+    const int64_t row_base = ((int64_t)frame * d.Hout + y0) * d.Wout + x0;
+    __syncthreads();                               // (WS == 3 leaves the loop through a bare barrier)
+    gemm_epilogue<WM, WN, TI, TJ, LDS_MAIN>(
+        d, acc, smem, ch0,
+        [&](int px) -> int64_t {
+            const int tx = px & (TW - 1);
+            return x0 + tx < d.Wout ? row_base + (int64_t)(px >> tw_log2) * d.Wout + tx : -1;
+        },
+        (int64_t)frame);
+}
+
+}  // namespace
+
+bool cc_conv_halo_applicable(const CcGemmDesc& d) {
+    if (!(d.mode == CCEDIT_GEMM_CONV2D && d.taps == 9 && d.ksize == 3 && d.stride == 1 && d.pad == 1 && !d.upsample &&
+          !d.A2 && d.korder == 1 && d.Cin % 64 == 0 && d.Cin1 == d.Cin && d.Hout == d.Hin && d.Wout == d.Win && d.N >= 64 &&
+          d.act != CCEDIT_ACT_GEGLU))
+        return false;
+    if (d.M % ((int64_t)d.Hout * d.Wout) != 0) return false;
+    if (d.gn_stats && d.gn_rows != d.Hout * d.Wout) return false;
+    // whole rectangles vertically; a ragged last column (8x12 frames: 12 of 16 columns used) is masked
+    return d.Hout % 8 == 0 || (d.Wout % 8 == 0 && d.Hout % 16 == 0);
+}
+
+template <int WM, int WN, int WS>
+static int conv_halo_launch_shape(const CcGemmDesc& d, hipStream_t s) {
+    constexpr int TI = 2, TJ = 2;
+    constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
+    constexpr int lds = epi_lds_total(BMC, BNP, TJ, WS * BMC * 128 + 2 * halo_bytes(BNP));
+    static unsigned long long attr_done = 0;
+    if (int rc = cc_max_dynamic_lds((const void*)conv_halo_kernel<WM, WN, TI, TJ, WS>, lds, &attr_done, "conv_halo")) return rc;
+    int tw_log2 = 4;
+    if (BNP == 128) {
+        // orientation with the least padding: 8 x 16 needs Hout % 8 == 0, 16 x 8 needs Hout % 16 == 0
+        const int pad16 = (d.Hout % 8 == 0) ? (d.Wout + 15) / 16 * 16 : 1 << 30;
+        const int pad8 = (d.Hout % 16 == 0) ? (d.Wout + 7) / 8 * 8 : 1 << 30;
+        tw_log2 = pad16 <= pad8 ? 4 : 3;
+    }
+    const int TWh = 1 << tw_log2, THh = BNP >> tw_log2;
+    const int64_t frames = d.M / ((int64_t)d.Hout * d.Wout);
+    const int64_t pt_n = frames * ((d.Wout + TWh - 1) / TWh) * (d.Hout / THh), ct_n = (d.N + BMC - 1) / BMC;
+    const int64_t nblk = 8 * ((pt_n + 7) / 8) * ct_n;
+    if (nblk > 2147483647LL) {
+        cc_set_error("ccedit_gemm: grid too large");
+        return CCEDIT_EUNSUPPORTED;
+    }
+    CcGemmDesc dd = d;
+    dd.cgroup = 0;                                // weights of these convs exceed L2: share a weight tile among the
+    if (ct_n > 3) {                               // resident workgroups (see the block-order note in gemm.hip)
+        const int q = 3;
+        const int ng = (int)((ct_n + q - 1) / q);
+        dd.cgroup = (int)((ct_n + ng - 1) / ng);
+    }
+    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, TI, TJ, WS>), dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, dd, tw_log2);
+    return cc_launch_status("conv_halo_kernel");
+}
+
+int cc_conv_halo_launch(const CcGemmDesc& d, hipStream_t s) {
+    // 16 x 16 rectangles, eight waves, one workgroup per CU: the weight tile of a tap is staged once per 256 pixels instead
+    // of once per 128 (L2 -> LDS bytes per FLOP: 20 B/clk at MFMA peak against 37).  CCEDIT_HALO256=0: A/B.
+    static const int h256_env = getenv("CCEDIT_HALO256") ? atoi(getenv("CCEDIT_HALO256")) : 1;
+    const int64_t frames = d.M / ((int64_t)d.Hout * d.Wout);
+    if (h256_env && d.Hout % 16 == 0 && d.Wout % 16 == 0 && frames * (d.Hout / 16) * (d.Wout / 16) * ((d.N + 127) / 128) >= 512)
+        return conv_halo_launch_shape<2, 4, 3>(d, s);
+    return conv_halo_launch_shape<2, 2, 2>(d, s);
+}
