@@ -14,6 +14,7 @@
 // 8x16 / 16x8 rectangles) stay on tap_gemm_kernel.
 #include "common.h"
 #include "gemm_epilogue.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -29,7 +30,8 @@ constexpr int kHaloBytes = 184 * 128;          // rounded to whole 8-row DMA gro
 constexpr int kHaloIssues = 6;                 // ceil(184 rows / 32 rows per 256-thread issue)
 
 template <int WM, int WN, int TI, int TJ>
-__global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc d, int tw_log2) {
+__global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc d, int tw_log2_flags) {
+    const int tw_log2 = tw_log2_flags & 0xFF;      // bit 8: narrow last channel tile allowed
     constexpr int NT = WM * WN * 64;
     constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
     static_assert(NT == 256 && BNP == 128, "tile geometry");
@@ -73,6 +75,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc
     const bf16* __restrict__ Wp = (const bf16*)d.W;
     const bf16* zp = (const bf16*)g_zero_page_h;
     const int nc = d.Cin >> 6, nk = nc * 9;
+    // Last channel tile of a Cout that is not a multiple of 128 (320 = 128 + 128 + 64): only WM x 32 channels are real.
+    // The block then stages half the weight tile and every wave keeps ONE of its two MFMA row tiles (wave row wm takes
+    // channels 32 wm .. 32 wm + 31) — half the matrix work instead of multiplying 64 rows of padding (17 % of the MFMA
+    // energy of a 320-channel conv on a part that runs these kernels at its power limit).
+    const bool narrow = (TI == 2) && ((tw_log2_flags >> 8) & 1) && (d.N - ch0 <= WM * 32);
 
     // ---- staging coordinates ----
     // Halo swizzle: LDS slot s of halo entry (hy, hx) holds source granule s ^ f(hy, hx),
@@ -100,7 +107,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc
     auto stageW = [&](int kt, int buf) {
 #pragma unroll
         for (int i = 0; i < W_ISSUES; ++i)
-            glds16(Wp + (size_t)(ch0 + i * RPI + rsub) * d.Kpad + kt * 64 + gcol_w * 8, sW + buf * W_BYTES + i * (RPI * 128) + wave * 1024);
+            if (!narrow || i * RPI < WM * 32)
+                glds16(Wp + (size_t)(ch0 + i * RPI + rsub) * d.Kpad + kt * 64 + gcol_w * 8, sW + buf * W_BYTES + i * (RPI * 128) + wave * 1024);
     };
     auto stageH = [&](int c, int buf) {
 #pragma unroll
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc
     // ---- fragment coordinates ----
     const int l31 = lane & 31, hi = lane >> 5;
     const int sw_w = (l31 >> 1) & 7;
-    const char* fa = sW + (wm * TI * 32 + l31) * 128;
+    const char* fa = sW + ((narrow ? wm * 32 : wm * TI * 32) + l31) * 128;
     int hb[TJ], pty[TJ], ptx[TJ];                           // halo row of this lane's pixel for tap (0, 0); its (ty, tx)
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
@@ -148,14 +156,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 af[TI], bfr[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8*)(pa + i * 32 * 128 + (((ks * 2 + hi) ^ sw_w) << 4));
+            for (int i = 0; i < TI; ++i)
+                if (i == 0 || !narrow) af[i] = *(const bf16x8*)(pa + i * 32 * 128 + (((ks * 2 + hi) ^ sw_w) << 4));
 #pragma unroll
             for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8*)(ph + hr[j] * 128 + (((ks * 2 + hi) ^ hsw[j]) << 4));
 #pragma unroll
             for (int i = 0; i < TI; ++i)
+                if (i == 0 || !narrow) {
 #pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
         }
     };
 
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc
             const int tx = px & (TW - 1);
             return x0 + tx < d.Wout ? row_base + (int64_t)(px >> tw_log2) * d.Wout + tx : -1;
         },
-        (int64_t)frame);
+        (int64_t)frame, narrow);
 }
 
 }  // namespace
@@ -227,6 +238,8 @@ int cc_conv_halo_launch(const CcGemmDesc& d, hipStream_t s) {
         const int ng = (int)((ct_n + q - 1) / q);
         dd.cgroup = (int)((ct_n + ng - 1) / ng);
     }
-    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, TI, TJ>), dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, dd, tw_log2);
+    static const int narrow_env = getenv("CCEDIT_CONV_NARROW") ? atoi(getenv("CCEDIT_CONV_NARROW")) : 1;     // 0: A/B with the padded tile
+    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, TI, TJ>), dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, dd,
+                       tw_log2 | (narrow_env ? 1 << 8 : 0));
     return cc_launch_status("conv_halo_kernel");
 }

@@ -25,9 +25,12 @@ constexpr int epi_chunk_pixels(int cap, int unit, int bnp) {
 // contiguously (bias / timestep-embedding / activation / residual reads use the same coalesced pattern).
 //   rowmap(p): output row (pixel index into out / residuals / group_bias) of tile pixel p in [0, BNP), or -1 when the
 //              tile pixel lies outside the tensor; stat_frame: frame index for the GroupNorm statistics.
+//   narrow: the block computed only its first WM x 32 channels, one MFMA row tile per wave row (conv_halo_kernel's last
+//           channel tile when fewer than BMC / 2 channels are left): accumulator row tile 0 of wave row wm is channels
+//           wm * 32 .. + 31 and the other row tiles are not staged.
 template <int WM, int WN, int TI, int TJ, int LDS_MAIN, class RowMap>
 __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)[TI][TJ], char* smem, int ch0,
-                                              RowMap rowmap, int64_t stat_frame) {
+                                              RowMap rowmap, int64_t stat_frame, bool narrow = false) {
     constexpr int NT = WM * WN * 64;
     constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
     const int tid = threadIdx.x;
@@ -58,12 +61,15 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
         const int pb = wn * WPIX + tj * 32;       // first tile pixel of this wave's MFMA tile column tj
         if (pb >= ec * ECH && pb < (ec + 1) * ECH) {
 #pragma unroll
-            for (int ti = 0; ti < TI; ++ti)
+            for (int ti = 0; ti < TI; ++ti) {
+                if (narrow && ti > 0) break;
+                const int row0 = narrow ? wm * 32 : wm * TI * 32 + ti * 32;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x4 v = {acc[ti][tj][q * 4 + 0], acc[ti][tj][q * 4 + 1], acc[ti][tj][q * 4 + 2], acc[ti][tj][q * 4 + 3]};
-                    *(f32x4*)(sE + (pb - ec * ECH + l31) * EROW + (wm * TI * 32 + ti * 32 + q * 8 + hi * 4) * 4) = v;
+                    *(f32x4*)(sE + (pb - ec * ECH + l31) * EROW + (row0 + q * 8 + hi * 4) * 4) = v;
                 }
+            }
         }
     }
     __syncthreads();

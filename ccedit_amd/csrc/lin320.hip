@@ -179,7 +179,9 @@ __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int 
         for (int ks = 0; ks < kKS / 2; ++ks) {
             const bf16x8 x0 = *(const bf16x8*)(xb + ks * 32);
 #pragma unroll
-            for (int ti = 0; ti < 3; ++ti) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ti][ks], x0, acc[ti], 0, 0, 0);
+            for (int ti = 0; ti < 3; ++ti)
+                if (ti == 0 || grp < 3)        // 320 = 3 * 96 + 32: the last wave group has one real row tile, do not multiply padding
+                    acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ti][ks], x0, acc[ti], 0, 0, 0);
         }
         // Tile pt+1 (staged one iteration ago) must have landed before the next loop-top barrier.  Waited for HERE, before
         // this iteration's stores are issued: loads complete in order, so once at most `my_issues` operations (the DMA just

@@ -36,8 +36,13 @@ def _inputs(crossframe=False):
 def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
+    rccl = mode.endswith("-rccl")          # world 1 only: the un-staged (device tensor) code path through RCCL itself
+    mode = mode.replace("-rccl", "")
+    if rccl:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_grad_enabled(False)
     from ccedit_amd.parallel import FrameShard
     from ccedit_amd.sgm_compat import build_network
@@ -49,7 +54,9 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     x2, t, c = _inputs(crossframe)
     cc = {k: v.cuda() for k, v in c.items()}
     ref = w(x2.cuda(), t.cuda(), cc).cpu() if rank == 0 else None      # unsharded evaluation
-    shards = FrameShard.cfg_pair(T) if mode == "pair" else (FrameShard(T, mode=mode),)
+    groups = (None, dist.new_group([0])) if rccl else (None, None)      # bench.py's two-communicator arrangement
+    shards = FrameShard.cfg_pair(T, groups=groups) if mode == "pair" else (FrameShard(T, mode=mode),)
+    assert all(s.staged != rccl for s in shards)
     w.frame_shard = shards if mode == "pair" else shards[0]
     out = w(x2.cuda(), t.cuda(), cc).cpu()
     torch.cuda.synchronize()
@@ -68,11 +75,12 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,crossframe,mode", [(1, False, "a2a"), (2, False, "a2a"), (2, True, "a2a"), (2, False, "pair"),
+@pytest.mark.parametrize("world,crossframe,mode", [(1, False, "a2a"), (1, True, "pair-rccl"), (1, False, "halo-rccl"), (2, False, "a2a"), (2, True, "a2a"), (2, False, "pair"),
                                                    (2, True, "pair"), (2, False, "halo"), (2, True, "halo")])
 # uneven 3- and 4-way splits: primitives in test_parallel_gloo.py (several processes time-slicing one GPU through
 # host-staged gloo take minutes).  crossframe=True: TVI2V — the centre keyframe (rank 1 of 2 at T=5) adds img_control and
-# broadcasts its K/V.  mode: "a2a" = all-to-all layout transposition around the temporal ops; "pair" = the same with the two
+# broadcasts its K/V.  "-rccl": one rank on the nccl (= RCCL) backend — every exchange degenerates to a self-exchange, but the
+# calls, tensor placement and communicator set-up are the ones the multi-GPU run makes.  mode: "a2a" = all-to-all layout transposition around the temporal ops; "pair" = the same with the two
 # CFG halves on mirrored partitions and two streams; "halo" = round-1 halo / all-reduce / all-gather exchanges
 def test_sharded_network_matches_unsharded(world, crossframe, mode):
     if not torch.cuda.is_available():
