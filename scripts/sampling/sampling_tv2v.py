@@ -47,6 +47,10 @@ def add_common_args(p: argparse.ArgumentParser) -> None:
     p.add_argument("--prompt", type=str, default="")
     p.add_argument("--negative_prompt", type=str, default="ugly, low quality")
     p.add_argument("--add_prompt", type=str, default="masterpiece, high quality")
+    p.add_argument("--tokenizer_path", type=str, default="",
+                   help="directory with the CLIP tokenizer files (vocab.json, merges.txt) of openai/clip-vit-large-patch14: with it "
+                        "--prompt / --negative_prompt / --add_prompt are tokenised here as in the reference script; without it the "
+                        "conditioning tensors must carry token ids or embeddings (--cond_path)")
     p.add_argument("--sample_steps", type=int, default=50)
     p.add_argument("--sampler_name", type=str, default="EulerEDMSampler")       # the reference script's default
     p.add_argument("--discretization_name", type=str, default="LegacyDDPMDiscretization")
@@ -66,6 +70,8 @@ def build_model(args):
         raise SystemExit("--config_path is required (e.g. configs/inference_ccedit/keyframe_no2ndca_depthmidas.yaml)")
     dev = torch.device("cuda")
     from scripts.sampling.util import load_lora_file, load_vae_file, model_load_ckpt
+    if getattr(args, "tokenizer_path", ""):
+        os.environ["CCEDIT_CLIP_TOKENIZER"] = args.tokenizer_path      # read by FrozenCLIPEmbedder when the yaml builds it
     model = create_model(args.config_path, dev)
     if args.ckpt_path:
         model_load_ckpt(model, path=args.ckpt_path)
@@ -118,9 +124,13 @@ def conditioning_tensors(args, g: torch.Generator, need_frames: bool, need_ref: 
     return cond
 
 
-def text_inputs(cond, dev):
-    """batch['txt'] for prompt / negative prompt: token ids (`tokens`, `tokens_uc`: (1,77) int64 -> CLIP text encoder
-    on the GPU) or precomputed embeddings (`crossattn`, `crossattn_uc`)."""
+def text_inputs(cond, dev, args=None):
+    """batch['txt'] for prompt / negative prompt: the strings themselves when --tokenizer_path is given (composed as
+    sampling_tv2v.py:334-347: add_prompt + ", " + prompt; the negative prompt alone), else token ids (`tokens`, `tokens_uc`:
+    (1,77) int64 -> CLIP text encoder on the GPU) or precomputed embeddings (`crossattn`, `crossattn_uc`)."""
+    if args is not None and getattr(args, "tokenizer_path", ""):
+        prompt = args.add_prompt + ", " + args.prompt if args.add_prompt else args.prompt
+        return [prompt], [args.negative_prompt]
     if "tokens" in cond:
         return cond["tokens"].to(dev), cond["tokens_uc"].to(dev)
     return cond["crossattn"].to(dev), cond["crossattn_uc"].to(dev)
@@ -176,7 +186,7 @@ def main():
     need_frames = args.prior_coefficient_x != 0.0 or args.sdedit_denoise_strength != 0.0
     cond = conditioning_tensors(args, g, need_frames)
     hint = cond["control_hint"].to(dev)
-    txt, txt_uc = text_inputs(cond, dev)
+    txt, txt_uc = text_inputs(cond, dev, args)
     batch = {"txt": txt, "control_hint": hint}
     batch_uc = {"txt": txt_uc, "control_hint": hint.clone()}                              # uc keeps the SAME hint (:339-344)
     c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=batch_uc)

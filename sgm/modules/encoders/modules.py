@@ -20,6 +20,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -65,13 +67,16 @@ class FrozenCLIPEmbedder(AbstractEmbModel):
     LAYERS = ["last", "pooled", "hidden"]
 
     def __init__(self, version="openai/clip-vit-large-patch14", device="cuda", max_length=77, freeze=True, layer="last",
-                 layer_idx=None, always_return_pooled=False):
+                 layer_idx=None, always_return_pooled=False, tokenizer_path=None):
         super().__init__()
         assert layer in self.LAYERS
         if layer != "last" or always_return_pooled:
             raise NotImplementedError("FrozenCLIPEmbedder: the CCEdit configs use layer='last' without the pooled output")
         from ccedit_amd.clip import CLIPTextModel
         self.version, self.max_length, self.layer = version, max_length, layer
+        # where the tokenizer files live: an explicit directory (ctor / CCEDIT_CLIP_TOKENIZER / the scripts' --tokenizer_path),
+        # else `version` as the reference passes it to CLIPTokenizer.from_pretrained (a hub id needs a populated local cache)
+        self.tokenizer_path = tokenizer_path or os.environ.get("CCEDIT_CLIP_TOKENIZER") or version
         self.transformer = CLIPTextModel()
         self._tokenizer = None
 
@@ -88,14 +93,14 @@ class FrozenCLIPEmbedder(AbstractEmbModel):
         if self._tokenizer is None:
             try:
                 from transformers import CLIPTokenizer
-                tok = CLIPTokenizer.from_pretrained(self.version, local_files_only=True)
-                if len(tok) < 49408:        # recent transformers build an EMPTY tokenizer when the files are missing
-                    raise FileNotFoundError(f"vocabulary of {self.version} not found locally ({len(tok)} entries)")
+                tok = CLIPTokenizer.from_pretrained(self.tokenizer_path, local_files_only=True)
+                if len(tok) < 256:          # recent transformers build an EMPTY tokenizer when the files are missing
+                    raise FileNotFoundError(f"vocabulary of {self.tokenizer_path} not found locally ({len(tok)} entries)")
                 self._tokenizer = tok
             except Exception as e:          # no vocabulary files offline
                 raise NotImplementedError(
-                    f"FrozenCLIPEmbedder: the tokenizer files of {self.version!r} are not on this machine ({type(e).__name__}); "
-                    f"pass token ids (B,{self.max_length}) int64 or a precomputed (B,{self.max_length},768) embedding as batch['txt']")
+                    f"FrozenCLIPEmbedder: the tokenizer files of {self.tokenizer_path!r} are not on this machine "
+                    f"({type(e).__name__}); point tokenizer_path / CCEDIT_CLIP_TOKENIZER / --tokenizer_path at them, or pass token ids (B,{self.max_length}) int64 or a precomputed (B,{self.max_length},768) embedding as batch['txt']")
         enc = self._tokenizer(text, truncation=True, max_length=self.max_length, return_length=True,
                               return_overflowing_tokens=False, padding="max_length", return_tensors="pt")
         return enc["input_ids"]

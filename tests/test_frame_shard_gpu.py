@@ -36,11 +36,15 @@ def _inputs(crossframe=False):
 def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
-    rccl = mode.endswith("-rccl")          # world 1 only: the un-staged (device tensor) code path through RCCL itself
+    # one GPU per rank and RCCL whenever the box has enough devices; otherwise every rank shares cuda:0 and gloo stages
+    # the exchanges through host memory ("-rccl": world 1 on the nccl backend — the un-staged code path on a one-GPU box)
+    multi = world > 1 and torch.cuda.device_count() >= world
+    dev = rank if multi else 0
+    torch.cuda.set_device(dev)
+    rccl = mode.endswith("-rccl") or multi
     mode = mode.replace("-rccl", "")
     if rccl:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_grad_enabled(False)
@@ -54,7 +58,7 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     x2, t, c = _inputs(crossframe)
     cc = {k: v.cuda() for k, v in c.items()}
     ref = w(x2.cuda(), t.cuda(), cc).cpu() if rank == 0 else None      # unsharded evaluation
-    groups = (None, dist.new_group([0])) if rccl else (None, None)      # bench.py's two-communicator arrangement
+    groups = (None, dist.new_group(list(range(world)))) if rccl else (None, None)      # bench.py's two-communicator arrangement
     shards = FrameShard.cfg_pair(T, groups=groups) if mode == "pair" else (FrameShard(T, mode=mode),)
     assert all(s.staged != rccl for s in shards)
     w.frame_shard = shards if mode == "pair" else shards[0]
