@@ -31,9 +31,13 @@ constexpr int kNT = 512;
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool GEGLU, bool RES>
+// LN: the rows of A are LayerNorm-normalised ((x - mean) * rstd over the 320 channels, rounded to bf16) on their way through
+// LDS — `q = to_q(norm(x))` without the normalised tensor ever existing in memory.  gamma / beta are folded into W / bias by
+// the packer (W' = W diag(gamma), b' = b + W beta), d.ln_eps carries the epsilon.
+template <bool GEGLU, bool RES, bool LN>
 __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int nslice, int pt_n) {
     static_assert(!(GEGLU && RES), "the GEGLU projection has no residual");
+    static_assert(!LN || (!GEGLU && !RES), "the normalised projections are plain Linears");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sS = smem;                      // [2][kStage] fp32 staging tiles
     char* const sX = smem + 2 * kStage;         // [3][kXBuf]: tile i is consumed while tiles i+1 and i+2 are in flight
@@ -168,6 +172,50 @@ __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int 
         }
         const bool more = pt + 2 * lanes < pt_hi;
         if (more) stage(pt + 2 * lanes, buf == 0 ? 2 : buf - 1);      // (buf + 2) % 3
+        if constexpr (LN) {
+            // 16 threads per pixel row: granules sub, sub + 16, sub + 32 (< 40) of the row; two-pass statistics in fp32 as in
+            // layernorm_kernel (norm.hip), the normalised row written back in place
+            char* const rowp = sX + buf * kXBuf + (tid >> 4) * kRS;
+            const int sub = tid & 15;
+            bf16x8 t[3];
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int g = sub + 16 * k;
+                if (g < kK / 8) {
+                    t[k] = *(const bf16x8*)(rowp + g * 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sm += bf2f(t[k][e]);
+                }
+            }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) sm += __shfl_xor(sm, m, 16);
+            const float mean = sm * (1.0f / kK);
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (sub + 16 * k < kK / 8) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float dv = bf2f(t[k][e]) - mean;
+                        q += dv * dv;
+                    }
+                }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) q += __shfl_xor(q, m, 16);
+            const float rstd = rsqrtf(q * (1.0f / kK) + d.ln_eps);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int g = sub + 16 * k;
+                if (g < kK / 8) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = f2bf((bf2f(t[k][e]) - mean) * rstd);
+                    *(bf16x8*)(rowp + g * 16) = o;
+                }
+            }
+            lds_barrier();
+        }
 
         f32x16 acc[3];
 #pragma unroll
@@ -233,23 +281,25 @@ bool cc_lin320_applicable(const CcGemmDesc& d) {
     return d.mode == CCEDIT_GEMM_LINEAR && d.taps == 1 && d.A2 == nullptr && d.Cin == kK && d.Kpad == kK &&
            d.N % kSlice == 0 && d.N / kSlice <= 8 && d.gn_stats == nullptr && d.res2 == nullptr && d.group_bias == nullptr && !d.out_f32 &&
            (d.act == CCEDIT_ACT_NONE || (d.act == CCEDIT_ACT_GEGLU && d.res1 == nullptr)) && d.ldc % 8 == 0 &&
-           (d.res1 == nullptr || d.ldr1 % 8 == 0);
+           (d.res1 == nullptr || d.ldr1 % 8 == 0) && (d.ln_eps == 0.f || (d.act == CCEDIT_ACT_NONE && d.res1 == nullptr));
 }
 
 int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s) {
     const int lds = 2 * kStage + 3 * kXBuf + kSlice * 4;
     const bool geglu = d.act == CCEDIT_ACT_GEGLU;
-    static unsigned long long attr_done[3] = {0, 0, 0};
-    if (int rc = cc_max_dynamic_lds((const void*)lin320_kernel<false, false>, lds, &attr_done[0], "lin320")) return rc;
-    if (int rc = cc_max_dynamic_lds((const void*)lin320_kernel<false, true>, lds, &attr_done[1], "lin320")) return rc;
-    if (int rc = cc_max_dynamic_lds((const void*)lin320_kernel<true, false>, lds, &attr_done[2], "lin320")) return rc;
+    static unsigned long long attr_done[4] = {0, 0, 0, 0};
+    if (int rc = cc_max_dynamic_lds((const void*)lin320_kernel<false, false, false>, lds, &attr_done[0], "lin320")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)lin320_kernel<false, true, false>, lds, &attr_done[1], "lin320")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)lin320_kernel<true, false, false>, lds, &attr_done[2], "lin320")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)lin320_kernel<false, false, true>, lds, &attr_done[3], "lin320")) return rc;
     const int64_t pt_n = (d.M + kP - 1) / kP;
     if (pt_n > 2147483647LL) {
         cc_set_error("ccedit_gemm: grid too large");
         return CCEDIT_EUNSUPPORTED;
     }
-    if (geglu) hipLaunchKernelGGL((lin320_kernel<true, false>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
-    else if (d.res1) hipLaunchKernelGGL((lin320_kernel<false, true>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
-    else hipLaunchKernelGGL((lin320_kernel<false, false>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
+    if (geglu) hipLaunchKernelGGL((lin320_kernel<true, false, false>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
+    else if (d.res1) hipLaunchKernelGGL((lin320_kernel<false, true, false>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
+    else if (d.ln_eps != 0.f) hipLaunchKernelGGL((lin320_kernel<false, false, true>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
+    else hipLaunchKernelGGL((lin320_kernel<false, false, false>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
     return cc_launch_status("lin320_kernel");
 }

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the library is loaded: to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCEDIT_HIP_LIB") or os.path.join(_HERE, "libccedit_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 GEMM_LINEAR, GEMM_CONV2D, GEMM_TEMPORAL = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
@@ -30,7 +30,7 @@ class CcGemmDesc(C.Structure):
         ("Kpad", C.c_int32), ("act", C.c_int32), ("out_f32", C.c_int32), ("group_rows", C.c_int32),
         ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("tile", C.c_int32), ("korder", C.c_int32), ("gn_rows", C.c_int32),
         ("Tsrc", C.c_int32), ("tsrc_off", C.c_int32), ("t0", C.c_int32), ("Tglob", C.c_int32), ("cgroup", C.c_int32),
-        ("ldgb", C.c_int32), ("reserved0", C.c_int32),
+        ("ldgb", C.c_int32), ("ln_eps", C.c_float),
         ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
         ("group_bias", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p),
         ("gn_stats", C.c_void_p),

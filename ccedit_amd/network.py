@@ -166,6 +166,22 @@ class CrossAttention(nn.Module):
         self.kv = pack_concat([self.to_k.weight, self.to_v.weight], device=device)
 
 
+def ln_linear(tok, norm: "Norm", pw, pw_ln):
+    """linear(LayerNorm(tok)).  With a folded weight (packing.fold_layernorm) and the K = 320 register-resident-weight
+    shape the rows are normalised inside the GEMM (CcGemmDesc.ln_eps): the normalised tensor never exists in memory."""
+    if pw_ln is not None and ops.ln320_applicable(tok.shape[0], pw_ln):
+        return ops.linear(tok, pw_ln, ln_eps=norm.eps)
+    return ops.linear(ops.layernorm(tok, norm.g, norm.b, norm.eps), pw)
+
+
+def _fold_ln(weights, norm: "Norm", device):
+    """Folded projection of LayerNorm(x) for dim 320 (None elsewhere: only lin320 normalises its rows)."""
+    if weights[0].shape[1] != 320:
+        return None
+    from .packing import fold_layernorm
+    return fold_layernorm(weights, None, norm.weight, norm.bias, device=device)
+
+
 class FeedForward(nn.Module):
     """FeedForward(glu=True): net.0 = GEGLU(proj), net.1 = Dropout, net.2 = Linear (attention.py:115-141)."""
 
@@ -208,20 +224,21 @@ class BasicTransformerBlock(nn.Module):
     def run(self, tok, frames: int, hw: int, ctx_kv_src, ctx_len: int, frames_per_clip: int):
         a1, a2 = self.attn1, self.attn2
         c = a1.inner
-        n1 = ops.layernorm(tok, self.norm1.g, self.norm1.b)
-        qkv = ops.linear(n1, a1.qkv)
+        qkv = ops.linear(ops.layernorm(tok, self.norm1.g, self.norm1.b), a1.qkv)      # 3 slices: folding the norm does not pay
         o = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], a1.heads, a1.dim_head, batches=frames, lq=hw, lk=hw)
         tok = ops.linear(o, a1.to_out[0].pw, res1=tok)
-        n2 = ops.layernorm(tok, self.norm2.g, self.norm2.b)
-        q = ops.linear(n2, a2.to_q.pw)
+        q = ln_linear(tok, self.norm2, a2.to_q.pw, self.q2_ln)
         kv = ops.linear(ctx_kv_src, a2.kv)                     # [B*L, 2C]: once per clip, shared by its T frames
         o = ops.attention(q, kv[:, :c], kv[:, c:], a2.heads, a2.dim_head, batches=frames, lq=hw, lk=ctx_len,
                           kv_div=frames_per_clip)
         tok = ops.linear(o, a2.to_out[0].pw, res1=tok)
         return self.ff.run(tok, self.norm3)
 
+    q2_ln = None
+
     def post_pack(self, device):
         self.ff.pack_fused(self.norm3, device)
+        self.q2_ln = _fold_ln([self.attn2.to_q.weight], self.norm2, device)
 
 
 class BasicTransformerSingleLayerBlock(nn.Module):
@@ -239,8 +256,7 @@ class BasicTransformerSingleLayerBlock(nn.Module):
         [tokens of frame anchor_t of the same clip ; own tokens] — SpatialTransformer3DCA 'center_self'."""
         a = self.attn1
         c = a.inner
-        n1 = ops.layernorm(tok, self.norm1.g, self.norm1.b)
-        q = ops.linear(n1, a.to_q.pw)
+        q = ln_linear(tok, self.norm1, a.to_q.pw, self.q_ln)
         kv = ops.linear(tok, a.kv)
         if anchor_t is None:
             o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=frames, lq=hw, lk=hw)
@@ -266,14 +282,16 @@ class BasicTransformerSingleLayerBlock(nn.Module):
         tok = ops.linear(o, a.to_out[0].pw, res1=tok)
         return self.ff.run(tok, self.norm2)
 
+    q_ln = None
+
     def post_pack(self, device):
         self.ff.pack_fused(self.norm2, device)
+        self.q_ln = _fold_ln([self.attn1.to_q.weight], self.norm1, device)
 
     def run_temporal(self, tok, geo: Geometry, hw: int):
         a = self.attn1
         c = a.inner
-        n1 = ops.layernorm(tok, self.norm1.g, self.norm1.b)
-        q = ops.linear(n1, a.to_q.pw)
+        q = ln_linear(tok, self.norm1, a.to_q.pw, self.q_ln)
         kv = ops.linear(tok, a.kv)
         t = tk = geo.t
         if geo.shard is not None:      # all-gather the K/V rows of the other ranks' keyframes (RCCL over xGMI)

@@ -73,7 +73,7 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
          group_bias: Optional[torch.Tensor] = None, group_rows: int = 0,
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, out_f32: bool = False, use_bias: bool = True, tile: int = 0,
-         gn_rows: int = 0) -> torch.Tensor:
+         gn_rows: int = 0, ln_eps: float = 0.0) -> torch.Tensor:
     """out[m, :] = epilogue(sum_taps W . A[src(m, tap)]).  a2d: [rows, lda] bf16 (last dim contiguous).
 
     gn_rows > 0 (= H*W of the output frames) asks the epilogue to also accumulate the GroupNorm(32) statistics of
@@ -107,6 +107,10 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
     d.ldr1 = res1.stride(0) if res1 is not None else 0
     d.ldr2 = res2.stride(0) if res2 is not None else 0
     d.tile = tile
+    if ln_eps:          # rows of A normalised on the way in (lin320 only): the weight must come from packing.fold_layernorm
+        if not ln320_applicable(m, pw, act, res1, res2, group_bias, out_f32, gn_rows):
+            raise ValueError("gemm: ln_eps needs the K = 320 register-resident-weight shape (>= 32768 rows, plain Linear)")
+        d.ln_eps, d.tile = ln_eps, 9
     d.korder = pw.korder
     d.A, d.A2, d.W = a2d.data_ptr(), _ptr(a2), pw.w.data_ptr()
     d.bias = _ptr(pw.bias) if use_bias else None
@@ -138,6 +142,18 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
 
 def linear(x2d, pw, **kw):
     return gemm(x2d, pw, mode=GEMM_LINEAR, **kw)
+
+
+LN320 = os.environ.get("CCEDIT_LN320", "1") != "0"      # 0: separate LayerNorm pass in front of the K = 320 projections
+
+
+def ln320_applicable(m, pw, act=ACT_NONE, res1=None, res2=None, group_bias=None, out_f32=False, gn_rows=0) -> bool:
+    """Can `linear(layernorm(x), pw)` run as ONE lin320 launch that normalises the rows in LDS?  Only single-slice layers
+    (N = 320: to_q): every 320-channel slice of a wider layer is its own workgroup and would normalise the tile again — measured
+    114 us against 153 us for LayerNorm + lin320 at N = 320, but 301 against 292 at N = 960 (tools/exp/ln320_time.py)."""
+    return (LN320 and m >= 32768 and pw.cin == 320 and pw.taps == 1 and pw.kpad == 320 and pw.n == 320
+            and not pw.geglu and act == ACT_NONE and res1 is None and res2 is None and group_bias is None and not out_f32
+            and gn_rows == 0)
 
 
 FF320 = os.environ.get("CCEDIT_FF320", "1") != "0"      # 0: LayerNorm + two GEMMs instead of the fused dim-320 feed-forward

@@ -104,6 +104,19 @@ def pack_concat(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optio
     return pack_weight(w, b, device=device)
 
 
+def fold_layernorm(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optional[torch.Tensor]]], gamma: torch.Tensor,
+                   beta: torch.Tensor, device: Optional[torch.device] = None) -> PackedWeight:
+    """Projections of a LayerNorm output, Linear(gamma * xhat + beta) = (W diag(gamma)) xhat + (b + W beta), packed for the
+    GEMM that normalises its rows itself (CcGemmDesc.ln_eps): the affine half of the LayerNorm lives in the weights."""
+    ws = [w.detach().float() for w in weights]
+    g, bt = gamma.detach().float().to(ws[0].device), beta.detach().float().to(ws[0].device)
+    bs = [None] * len(ws) if biases is None else list(biases)
+    wf = torch.cat([w * g[None, :] for w in ws], dim=0)
+    bf = torch.cat([(torch.zeros(w.shape[0], device=w.device) if b is None else b.detach().float().to(w.device)) + w @ bt
+                    for w, b in zip(ws, bs)])
+    return pack_weight(wf, bf, device=device)
+
+
 # ------------------------------------------------------------------------------------------
 # fused feed-forward (dim 320): the weight stream of csrc/ff320.hip
 # ------------------------------------------------------------------------------------------

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCEDIT_ABI_VERSION 5
+#define CCEDIT_ABI_VERSION 6
 
 #define CCEDIT_OK 0
 #define CCEDIT_EINVAL (-1)       /* null pointer / bad size */
@@ -95,7 +95,10 @@ typedef struct CcGemmDesc {
     int32_t cgroup;       /* internal (set by the library): block-order parameters; pass 0 */
     int32_t ldgb;         /* row stride of group_bias in elements; 0 = N (rows of a wider matrix: all ResBlocks' emb_layers
                            * projections of one network come out of ONE GEMM, each layer reads its column slice) */
-    int32_t reserved0;
+    float ln_eps;         /* 0 = off.  > 0 (Linear, K = 320, >= 32k rows, no activation / residual: block shape 9 only): every row of
+                           * A is LayerNorm-normalised WITHOUT affine, (x - mean) * rsqrt(var + ln_eps) rounded to bf16, before the
+                           * product — `to_q(norm(x))` of attention.py:695-716 with gamma / beta folded into W / bias by the caller
+                           * (W diag(gamma), b + W beta: ccedit_amd/packing.py:fold_layernorm) */
     const void* A;        /* bf16 [rows][lda] */
     const void* A2;       /* optional second source */
     const void* W;        /* bf16 [ceil(N,256)][Kpad] (rows zero-padded to the widest block shape) */

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 GENERIC = dict(CCEDIT_T6="0", CCEDIT_CONV_HALO="0", CCEDIT_ATTN_SHORT="0", CCEDIT_SPLIT_CFG="0", CCEDIT_OVERLAP_CONTROLNET="0",
                CCEDIT_KROT="0", CCEDIT_CGROUP="0", CCEDIT_FUSE_GN_STATS="0", CCEDIT_TEMPORAL_ORDER="0", CCEDIT_LIN320="0",
-               CCEDIT_FF320="0")
+               CCEDIT_FF320="0", CCEDIT_LN320="0", CCEDIT_T4="0", CCEDIT_BALANCED="0", CCEDIT_CONV_NARROW="0")
 
 
 def _rel(a, b):

@@ -638,6 +638,33 @@ def test_ff320_equals_unfused_path():
     assert torch.equal(wide_out[:, :320], fused) and bool((wide_out[:, 320:] == 7.0).all())
 
 
+@pytest.mark.parametrize("m,n", [(32768, 320), (40000 + 13, 320)])
+def test_layernorm_folded_into_k320_linear(m, n):
+    """`to_q(norm(x))` of attention.py:695-716 / 758-761 as ONE launch: lin320 normalises the rows in LDS
+    (CcGemmDesc.ln_eps), gamma / beta folded into the weights (packing.fold_layernorm).  Against the fp32 formula on
+    bf16-representable inputs (rel RMS <= 1e-2: bf16 activations and weights, fp32 accumulation) and against the two-launch
+    HIP path it replaces (LayerNorm kernel + lin320; they differ by where gamma is rounded in: <= 6e-3)."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import fold_layernorm, pack_weight
+    x = (_rnd(m, 320, seed=31, scale=1.7) + 0.4).to(BF)
+    w = _rnd(n, 320, seed=32, scale=320 ** -0.5)
+    g, b = 1.0 + _rnd(320, seed=33, scale=0.2), _rnd(320, seed=34, scale=0.2)
+    pw_ln = fold_layernorm([w], None, g, b, device="cuda")
+    assert ops.ln320_applicable(m, pw_ln)
+    xc = x.cuda()
+    y = ops.linear(xc, pw_ln, ln_eps=1e-5)
+    ref = torch.nn.functional.layer_norm(x.float(), (320,), g, b, 1e-5) @ w.t()
+    got = y.float().cpu()
+    e_ref = ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    two = ops.linear(ops.layernorm(xc, g.cuda(), b.cuda(), 1e-5), pack_weight(w, None).to("cuda")).float().cpu()
+    e_two = ((got - two).pow(2).mean().sqrt() / two.pow(2).mean().sqrt()).item()
+    print(f"ln320 m={m} n={n}: vs fp32 {e_ref:.4f}, vs LayerNorm + lin320 {e_two:.4f}")
+    assert torch.isfinite(got).all() and e_ref < 1e-2 and e_two < 6e-3
+    with pytest.raises(ValueError, match="ln_eps"):        # only the K = 320 register-resident-weight shape normalises its rows
+        ops.linear(xc[:1000], pw_ln, ln_eps=1e-5)
+
+
 # ------------------------------------------------------------------------------------------
 # long-sequence attention: d = 40 / 80, Lq >= 1024, Lk >= 256 (8-wave blocks, many KV tiles)
 # ------------------------------------------------------------------------------------------

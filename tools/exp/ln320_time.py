@@ -1,0 +1,23 @@
+import sys, os
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
+import torch
+from ccedit_amd import ops
+from ccedit_amd.packing import pack_weight, fold_layernorm
+m, k = 208896, 320
+g, b = torch.ones(320), torch.zeros(320)
+gc, bc = g.cuda(), b.cuda()
+for n in (320, 960):
+    w = torch.randn(n, k) * k ** -0.5
+    pw, pwl = pack_weight(w, None).to("cuda"), fold_layernorm([w], None, g, b, device="cuda")
+    a = [torch.randn(m, k, device="cuda").to(torch.bfloat16) for _ in range(4)]
+    def t(f):
+        for x in a: f(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for rep in range(5):
+            for x in a: f(x)
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 20 * 1e3
+    print(f"n={n}: lin320 {t(lambda x: ops.linear(x, pw)):.1f} us, layernorm {t(lambda x: ops.layernorm(x, gc, bc, 1e-5)):.1f} us, "
+          f"layernorm + lin320 {t(lambda x: ops.linear(ops.layernorm(x, gc, bc, 1e-5), pw)):.1f} us, folded {t(lambda x: ops.linear(x, pwl, ln_eps=1e-5)):.1f} us")
