@@ -498,9 +498,11 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         //   13056 pixels x 1280 channels is 255 workgroups = one round of the chip: 706 / 906 / 954 TF/s at K = 1280 / 5120 /
         //   11520 against 644 / 817 / 846 for t6 (tools/exp/gemm_vs_vendor.py; the same shapes cut at pixel-tile granularity
         //   ran 374 / 540 / 591).  CCEDIT_T4=0 switches it off for A/B.
+        //   Only with BOTH CFG halves in the launch: at 6528 pixels (one half, the default two-stream execution) it is 130
+        //   workgroups and loses to t1 (383 / 544 against 454 / 577 TF/s at K = 1280 / 5120; -0.6 ms per step in the A/B).
         static const int t4_env = getenv("CCEDIT_T4") ? atoi(getenv("CCEDIT_T4")) : 1;
         if (t4_env && d.mode == CCEDIT_GEMM_LINEAR && d.N % 256 == 0 && d.N <= 2560 && d.act != CCEDIT_ACT_GEGLU && !d.gn_stats &&
-            d.Kpad >= 1280 && d.M >= 6000 && d.M <= 16384)
+            d.Kpad >= 1280 && d.M >= 12000 && d.M <= 16384)
             tile = 4;
         if (d.gn_stats && d.gn_rows % 256 != 0) tile = 1;     // a block must not straddle two frames
     }
