@@ -63,13 +63,19 @@ def max_over_ranks(seconds: float, device=None) -> float:
 class FrameShard:
     """One clip's T keyframes split contiguously over the ranks of a process group (BASELINE.json config 4).
 
-    Every rank holds frames [t0, t1) of EVERY clip of the (CFG-doubled) batch, i.e. a (B, t_local, H, W, C) slab of
-    each frames-outermost activation.  Spatial work is frame-local.  The three kinds of temporal work exchange:
-      * Conv1d k=3 over T     -> `halo`: one boundary frame to/from each neighbour rank (point-to-point)
-      * GroupNorm over (C/32 x T) -> `allreduce`: per-(clip, pixel, group) sum / sum-of-squares (fp32)
-      * temporal attention    -> `gather_frames`: all-gather of the K/V rows (RCCL all-gather over xGMI)
-    Collectives go through torch.distributed: backend "nccl" (= RCCL on ROCm) moves device tensors directly;
-    with "gloo" (CPU tests, or several ranks sharing one GPU) tensors are staged through host memory.
+    Every rank holds frames [t0, t1) of EVERY clip of the batch, i.e. a (B, t_local, H, W, C) slab of each
+    frames-outermost activation.  Spatial work is frame-local.  Temporal work (Conv1d k3 over T, GroupNorm over
+    C/32 x T, temporal attention — every pixel independent) depends on `mode`:
+      * "a2a" (default): `to_pixels` transposes the slab with one all-to-all into (all T frames x this rank's 1/world of
+        the pixels), the UNSHARDED temporal kernels run on it, `to_frames` transposes back; `gather_pixels` collects the
+        final prediction.  Nothing else is exchanged.
+      * "halo" (round 1): `halo` (one boundary frame to / from each neighbour, point-to-point) for the convolutions,
+        `allreduce` (per-(clip, pixel, group) sum / sum of squares, fp32) for the normalisations, `gather_frames`
+        (all-gather of the K/V rows) for the attention.
+    `broadcast` serves the TVI2V anchor frame in both modes.  Collectives go through torch.distributed: backend "nccl"
+    (= RCCL on ROCm) moves device tensors directly; with "gloo" (CPU tests, or several ranks sharing one GPU) tensors are
+    staged through host memory.  `bytes_sent`, `n_collectives` and (with `timing = []`) device events around every
+    exchange are what `bench.py --shard-frames` reports.
     """
 
     def __init__(self, t_glob: int, rank: Optional[int] = None, world: Optional[int] = None, group=None,
