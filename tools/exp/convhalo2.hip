@@ -1,0 +1,448 @@
+// EXPERIMENT, NOT BUILT INTO THE LIBRARY (round 2): convhalo.hip plus conv_halo2_kernel — 16 x 16 pixel rectangles,
+// 64 channels x 128 pixels per wave (2 x 4 MFMA tiles: six ds_read_b128 per eight MFMAs instead of eight), both operands
+// staged in 32-channel pieces with 64-byte LDS rows (new conflict-free halo swizzle, found by exhaustive search), two
+// workgroups per CU by LDS.  Bit-compatible with conv_halo_kernel up to the fp32 summation order (checksums agree to 1e-7).
+// SLOWER: 549 / 940 / 513 / 934 us against 490 / 851 / 432 / 774 us (34 x 64x96 320->320, 640->320; 34 x 32x48 640->640,
+// 1280->640).  The 128 accumulator registers push the kernel to 288 VGPRs (one wave per SIMD); capped at 256 it spills 33
+// and runs the same (536 us).  The ablation that motivated it (weight / halo DMA alone 267 us, LDS reads + MFMAs alone 335 us,
+// together 488 us; 1254 measured against 1290 LDS-limited cycles per k-tile pair) still stands as a description of
+// conv_halo_kernel; this was not the way to spend the LDS bandwidth it frees.
+// 3x3 stride-1 convolution with the input tile staged ONCE per 64-channel chunk (halo included) and the nine taps read
+// from LDS at shifted rows.
+//
+// Why a second conv kernel: tap_gemm_kernel gathers every tap's activation tile from global memory again (9 x per
+// chunk).  PMC on the 64x96-level 320->320 conv: 124 M L1 accesses, 46 % of them missing to L2 (3.6 GB through the
+// TCP->TCC path per launch).  A CU sustains only ~20 B/clk of L1-miss traffic (outstanding-miss queue x L2 latency,
+// measured with tools/exp/readpat.hip), so that traffic — not MFMA, not HBM — bounded the convs at 30-38 % of peak.
+// Here a workgroup owns a TH x TW pixel rectangle (128 pixels) of one frame and 128 output channels:
+//   per chunk  : (TH+2) x (TW+2) halo rows x 128 B  -> LDS once           (23 KB instead of 9 x 16 KB)
+//   per tap    : only the 128 x 64 weight tile streams (2-deep ring), the B fragments are ds_read_b128 at
+//                halo row (ty+dy)*(TW+2) + tx+dx with the same XOR swizzle as everywhere else
+// K order of the packed weights is [Cin/64][tap][64] (korder 1), i.e. k-tile c*9 + t.  Epilogue: gemm_epilogue.h with
+// a 2-D row map.  Shapes that do not qualify (stride 2, fused upsample, Cin % 64 != 0, frames not divisible into
+// 8x16 / 16x8 rectangles) stay on tap_gemm_kernel.
+#include "common.h"
+#include "gemm_epilogue.h"
+#include <stdlib.h>
+
+namespace {
+
+__device__ __attribute__((aligned(64))) char g_zero_page_h[64];     // source of out-of-image halo rows
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_h() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int kHaloRows = 180;                 // (8+2) x (16+2) = (16+2) x (8+2)
+constexpr int kHaloBytes = 184 * 128;          // rounded to whole 8-row DMA groups
+constexpr int kHaloIssues = 6;                 // ceil(184 rows / 32 rows per 256-thread issue)
+
+template <int WM, int WN, int TI, int TJ>
+__global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc d, int tw_log2_flags) {
+    const int tw_log2 = tw_log2_flags & 0xFF;      // bit 8: narrow last channel tile allowed
+    constexpr int NT = WM * WN * 64;
+    constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
+    static_assert(NT == 256 && BNP == 128, "tile geometry");
+    constexpr int RPI = NT / 8;                    // rows per DMA issue (8 granules of 16 B per 128-byte row)
+    constexpr int W_ISSUES = BMC / RPI;
+    constexpr int W_BYTES = BMC * 128;
+    constexpr int LDS_MAIN = 2 * W_BYTES + 2 * kHaloBytes;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sW = smem;                         // [2][W_BYTES]
+    char* const sH = smem + 2 * W_BYTES;           // [2][kHaloBytes]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int TW = 1 << tw_log2, TH = BNP >> tw_log2, HW_ = TW + 2;
+    const int tiles_x = (d.Wout + TW - 1) >> tw_log2, tiles_y = d.Hout / TH;      // the last column of rectangles may be ragged
+    const int tpf = tiles_x * tiles_y;
+
+    // XCD-aware block order, same scheme as tap_gemm_kernel (pixel tiles contiguous per XCD, channel tiles in groups)
+    const int ct_n = (d.N + BMC - 1) / BMC;
+    const int64_t pt_n = (int64_t)(d.M / (d.Hout * d.Wout)) * tpf;
+    const int64_t pt_per_xcd = (pt_n + 7) / 8;
+    const int64_t bid = blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const int64_t local = bid >> 3;
+    const int Q = d.cgroup > 0 ? d.cgroup : ct_n;
+    const int64_t gsz = pt_per_xcd * Q;
+    const int cg = (int)(local / gsz);
+    const int64_t rr = local - cg * gsz;
+    const int qn = min(Q, ct_n - cg * Q);
+    const int64_t pl = rr / qn;
+    const int64_t pt = xcd * pt_per_xcd + pl;
+    if (pt >= pt_n) return;
+    const int ch0 = (cg * Q + (int)(rr - pl * qn)) * BMC;
+    const int frame = (int)(pt / tpf);
+    const int tr = (int)(pt - (int64_t)frame * tpf);
+    const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) << tw_log2;
+
+    const bf16* __restrict__ Ap = (const bf16*)d.A;
+    const bf16* __restrict__ Wp = (const bf16*)d.W;
+    const bf16* zp = (const bf16*)g_zero_page_h;
+    const int nc = d.Cin >> 6, nk = nc * 9;
+    // Last channel tile of a Cout that is not a multiple of 128 (320 = 128 + 128 + 64): only WM x 32 channels are real.
+    // The block then stages half the weight tile and every wave keeps ONE of its two MFMA row tiles (wave row wm takes
+    // channels 32 wm .. 32 wm + 31) — half the matrix work instead of multiplying 64 rows of padding (17 % of the MFMA
+    // energy of a 320-channel conv on a part that runs these kernels at its power limit).
+    const bool narrow = (TI == 2) && ((tw_log2_flags >> 8) & 1) && (d.N - ch0 <= WM * 32);
+
+    // ---- staging coordinates ----
+    // Halo swizzle: LDS slot s of halo entry (hy, hx) holds source granule s ^ f(hy, hx),
+    //   f = (hx >> 1) & 7                     for 8 x 16 rectangles,
+    //   f = ((hx >> 1) + 4 * (hy & 1)) & 7    for 16 x 8 rectangles.
+    // ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (MI355X_MICROARCH.md); with
+    // the halo pitch TW+2 a swizzle keyed on the linear row index (as in tap_gemm_kernel) is 2-way conflicted for every
+    // tap, this one puts the 16 lanes of a group on 16 distinct 16-byte slots of the 256-byte bank row for all nine
+    // shifts (checked exhaustively; PMC: SQ_LDS_BANK_CONFLICT 28.2 M -> ~0 per launch).
+    const int f_hy = (tw_log2 == 3) ? 1 : 0;
+    const int p = tid & 7, rsub = tid >> 3;
+    const int gcol_w = p ^ ((rsub >> 1) & 7);              // weight rows rsub + 32 i: (row >> 1) & 7 is i-independent
+    // halo: issue i stages halo rows i*32 + rsub; source element offset (without the chunk) or -1
+    int64_t hoff[kHaloIssues];
+#pragma unroll
+    for (int i = 0; i < kHaloIssues; ++i) {
+        const int hrow = i * 32 + rsub;
+        const int hy = hrow / HW_, hx = hrow - hy * HW_;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const bool v = hrow < kHaloRows && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+        const int gsrc = p ^ (((hx >> 1) + ((hy & 1) << 2) * f_hy) & 7);     // halo swizzle, see compute()
+        hoff[i] = v ? (((int64_t)frame * d.Hin + iy) * d.Win + ix) * d.lda + gsrc * 8 : (hrow < 184 ? -1 : -2);
+    }
+
+    auto stageW = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < W_ISSUES; ++i)
+            if (!narrow || i * RPI < WM * 32)
+                glds16(Wp + (size_t)(ch0 + i * RPI + rsub) * d.Kpad + kt * 64 + gcol_w * 8, sW + buf * W_BYTES + i * (RPI * 128) + wave * 1024);
+    };
+    auto stageH = [&](int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < kHaloIssues; ++i) {
+            if (hoff[i] != -2) {                            // rows 184..191 of the last issue do not exist
+                const bf16* src = hoff[i] >= 0 ? Ap + hoff[i] + c * 64 : zp;
+                glds16(src, sH + buf * kHaloBytes + i * (32 * 128) + wave * 1024);
+            }
+        }
+    };
+
+    // ---- fragment coordinates ----
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sw_w = (l31 >> 1) & 7;
+    const char* fa = sW + ((narrow ? wm * 32 : wm * TI * 32) + l31) * 128;
+    int hb[TJ], pty[TJ], ptx[TJ];                           // halo row of this lane's pixel for tap (0, 0); its (ty, tx)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int px = (wn * TJ + j) * 32 + l31;
+        pty[j] = px >> tw_log2;
+        ptx[j] = px & (TW - 1);
+        hb[j] = pty[j] * HW_ + ptx[j];
+    }
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int wbuf, int hbuf, int tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int shift = dy * HW_ + dx;
+        const char* pa = fa + wbuf * W_BYTES;
+        const char* ph = sH + hbuf * kHaloBytes;
+        int hr[TJ], hsw[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            hr[j] = hb[j] + shift;
+            hsw[j] = (((ptx[j] + dx) >> 1) + (((pty[j] + dy) & 1) << 2) * f_hy) & 7;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[TI], bfr[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                if (i == 0 || !narrow) af[i] = *(const bf16x8*)(pa + i * 32 * 128 + (((ks * 2 + hi) ^ sw_w) << 4));
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8*)(ph + hr[j] * 128 + (((ks * 2 + hi) ^ hsw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                if (i == 0 || !narrow) {
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // ---- main loop: weights 2-deep ring per k-tile, halo 2-deep ring per chunk ----
+    stageW(0, 0);
+    stageH(0, 0);
+    wait_vmcnt_h<0>();
+    __syncthreads();
+    int kt = 0;
+    for (int c = 0; c < nc; ++c) {
+        for (int t = 0; t < 9; ++t, ++kt) {
+            if (kt + 1 < nk) stageW(kt + 1, (kt + 1) & 1);
+            const bool pre = (t == 0) && (c + 1 < nc);
+            if (pre) stageH(c + 1, (c + 1) & 1);            // issued AFTER the weight tile: loads complete in order
+            compute(kt & 1, c & 1, t);
+            // the next weight tile must have landed; the next halo (needed 8 k-tiles from now) may stay in flight.
+            // A wave issues 5 or 6 halo loads (the last issue covers rows 160..183 only): count conservatively.
+            if (pre) wait_vmcnt_h<kHaloIssues - 1>(); else wait_vmcnt_h<0>();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ----
+    const int64_t row_base = ((int64_t)frame * d.Hout + y0) * d.Wout + x0;
+    gemm_epilogue<WM, WN, TI, TJ, LDS_MAIN>(
+        d, acc, smem, ch0,
+        [&](int px) -> int64_t {
+            const int tx = px & (TW - 1);
+            return x0 + tx < d.Wout ? row_base + (int64_t)(px >> tw_log2) * d.Wout + tx : -1;
+        },
+        (int64_t)frame, narrow);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// 16 x 16 rectangles, 64 channels x 128 pixels per wave (round 2).
+//
+// Ablation of conv_halo_kernel on the 64x96 320 -> 320 launch (tools/exp: DMA only 267 us, LDS reads + MFMAs only 335 us,
+// together 488 us) and its insensitivity to rectangle size, ring depth and DMA issue placement all point at one resource:
+// LDS bandwidth.  With 64 x 64 per wave every MFMA costs one ds_read_b128 (1 KB), i.e. 64 KB of reads + 18.6 KB of DMA
+// writes per k-tile and workgroup = 645 LDS cycles against 512 MFMA cycles — the kernel runs at the LDS rate (1254
+// measured vs 1290 predicted cycles per k-tile pair and CU).  Here a wave owns 2 x 4 MFMA tiles (six reads per eight
+// MFMAs), the workgroup 128 channels x 256 pixels, and both operands are staged in 32-channel pieces (64-byte LDS rows) so
+// that two workgroups still fit a CU: 58 KB of LDS traffic per 16 MFMAs of a wave instead of 83.
+//   halo: 18 x 18 rows x 64 B per 32-channel chunk, two buffers; swizzle slot = g ^ ((hy + (row >> 1)) & 3), row = 18 hy + hx
+//         (searched exhaustively: conflict-free for the ds_read_b128 lane groups at all nine shifts and tile rows)
+//   W:    128 rows x 64 B per (chunk, tap), two slots; slot = g ^ ((row >> 2) & 3) as in tap_gemm_kernel's K = 32 tiles
+// K order of the packed weights stays [Cin/64][tap][64]: chunk c32 = (c64, half) reads columns (9 c64 + tap) 64 + 32 half.
+constexpr int kH2Rows = 324, kH2Pitch = 18;
+constexpr int kH2Issues = 6;                   // 64 halo rows per 256-thread issue; the sixth covers rows 320..323 (wave 0 only)
+constexpr int kH2Bytes = kH2Issues * 64 * 64;  // 24,576 B per buffer
+constexpr int kW2Bytes = 128 * 64;             // 8 KB per slot
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_halo2_kernel(const CcGemmDesc d, int flags) {
+    constexpr int WM = 2, WN = 2, TI = 2, TJ = 4;
+    constexpr int BMC = 128, BNP = 256, TW = 16, TH = 16;
+    constexpr int LDS_MAIN = 2 * kW2Bytes + 2 * kH2Bytes;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sW = smem;                         // [2][kW2Bytes]
+    char* const sH = smem + 2 * kW2Bytes;          // [2][kH2Bytes]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_x = d.Wout / TW, tiles_y = d.Hout / TH;
+    const int tpf = tiles_x * tiles_y;
+
+    // XCD-aware block order, as conv_halo_kernel
+    const int ct_n = (d.N + BMC - 1) / BMC;
+    const int64_t pt_n = (int64_t)(d.M / (d.Hout * d.Wout)) * tpf;
+    const int64_t pt_per_xcd = (pt_n + 7) / 8;
+    const int64_t bid = blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const int64_t local = bid >> 3;
+    const int Q = d.cgroup > 0 ? d.cgroup : ct_n;
+    const int64_t gsz = pt_per_xcd * Q;
+    const int cg = (int)(local / gsz);
+    const int64_t rr = local - cg * gsz;
+    const int qn = min(Q, ct_n - cg * Q);
+    const int64_t pl = rr / qn;
+    const int64_t pt = xcd * pt_per_xcd + pl;
+    if (pt >= pt_n) return;
+    const int ch0 = (cg * Q + (int)(rr - pl * qn)) * BMC;
+    const int frame = (int)(pt / tpf);
+    const int tr = (int)(pt - (int64_t)frame * tpf);
+    const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
+
+    const bf16* __restrict__ Ap = (const bf16*)d.A;
+    const bf16* __restrict__ Wp = (const bf16*)d.W;
+    const bf16* zp = (const bf16*)g_zero_page_h;
+    const int nc = d.Cin >> 5;                     // 32-channel chunks
+    const bool narrow = ((flags >> 8) & 1) && (d.N - ch0 <= WM * 32);       // see conv_halo_kernel
+
+    // ---- staging plan: thread -> (row r4 + 64 i, LDS slot p4) ----
+    const int p4 = tid & 3, r4 = tid >> 2;
+    const int gcol_w = p4 ^ ((r4 >> 2) & 3);
+    int64_t hoff[kH2Issues];                       // source element offset (without the chunk), -1 = zero page, -2 = no such row
+#pragma unroll
+    for (int i = 0; i < kH2Issues; ++i) {
+        const int hrow = i * 64 + r4;
+        const int hy = hrow / kH2Pitch, hx = hrow - hy * kH2Pitch;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const bool v = hrow < kH2Rows && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+        const int gsrc = p4 ^ ((hy + (hrow >> 1)) & 3);
+        hoff[i] = v ? (((int64_t)frame * d.Hin + iy) * d.Win + ix) * d.lda + gsrc * 8 : (hrow < 336 ? -1 : -2);
+    }
+    auto stageW = [&](int c32, int tap, int slot) {
+        const int col = ((c32 >> 1) * 9 + tap) * 64 + (c32 & 1) * 32 + gcol_w * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (!narrow || i == 0)
+                glds16(Wp + (size_t)(ch0 + i * 64 + r4) * d.Kpad + col, sW + slot * kW2Bytes + i * (64 * 64) + wave * 1024);
+    };
+    auto stageH = [&](int c32, int buf) {
+#pragma unroll
+        for (int i = 0; i < kH2Issues; ++i) {
+            if (hoff[i] != -2) {                            // rows 336.. of the last issue do not exist (waves 1-3 skip it)
+                const bf16* src = hoff[i] >= 0 ? Ap + hoff[i] + c32 * 32 : zp;
+                glds16(src, sH + buf * kH2Bytes + i * (64 * 64) + wave * 1024);
+            }
+        }
+    };
+
+    // ---- fragment coordinates ----
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sw_w = (l31 >> 2) & 3;
+    const char* fa = sW + ((narrow ? wm * 32 : wm * TI * 32) + l31) * 64;
+    int hb[TJ], pty[TJ];                            // halo row of this lane's pixel for tap (0, 0); its tile row
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int px = (wn * TJ + j) * 32 + l31;
+        pty[j] = px >> 4;
+        hb[j] = pty[j] * kH2Pitch + (px & 15);
+    }
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int slot, int hbuf, int tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int shift = dy * kH2Pitch + dx;
+        const char* pa = fa + slot * kW2Bytes;
+        const char* ph = sH + hbuf * kH2Bytes;
+        const char* pb[TJ];
+        int hsw[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int hr = hb[j] + shift;
+            hsw[j] = ((pty[j] + dy) + (hr >> 1)) & 3;
+            pb[j] = ph + hr * 64;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TI], bfr[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                if (i == 0 || !narrow) af[i] = *(const bf16x8*)(pa + i * 32 * 64 + (((ks * 2 + hi) ^ sw_w) << 4));
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8*)(pb[j] + (((ks * 2 + hi) ^ hsw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                if (i == 0 || !narrow) {
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // ---- main loop: one (chunk, tap) per iteration; weights 2 slots, halo 2 buffers per chunk ----
+    stageW(0, 0, 0);
+    stageH(0, 0);
+    wait_vmcnt_h<0>();
+    __syncthreads();
+    int q = 0;
+    for (int c = 0; c < nc; ++c) {
+        for (int t = 0; t < 9; ++t, ++q) {
+            const bool last = (c + 1 == nc) && (t == 8);
+            if (!last) stageW(t == 8 ? c + 1 : c, t == 8 ? 0 : t + 1, (q + 1) & 1);
+            if (t == 0 && c + 1 < nc) stageH(c + 1, (c + 1) & 1);
+            compute(q & 1, c & 1, t);
+            wait_vmcnt_h<0>();
+            __syncthreads();
+        }
+    }
+
+    const int64_t row_base = ((int64_t)frame * d.Hout + y0) * d.Wout + x0;
+    gemm_epilogue<WM, WN, TI, TJ, LDS_MAIN>(
+        d, acc, smem, ch0, [&](int px) -> int64_t { return row_base + (int64_t)(px >> 4) * d.Wout + (px & 15); }, (int64_t)frame,
+        narrow);
+}
+
+}  // namespace
+
+bool cc_conv_halo_applicable(const CcGemmDesc& d) {
+    if (!(d.mode == CCEDIT_GEMM_CONV2D && d.taps == 9 && d.ksize == 3 && d.stride == 1 && d.pad == 1 && !d.upsample &&
+          !d.A2 && d.korder == 1 && d.Cin % 64 == 0 && d.Cin1 == d.Cin && d.Hout == d.Hin && d.Wout == d.Win && d.N >= 64 &&
+          d.act != CCEDIT_ACT_GEGLU))
+        return false;
+    if (d.M % ((int64_t)d.Hout * d.Wout) != 0) return false;
+    if (d.gn_stats && d.gn_rows != d.Hout * d.Wout) return false;
+    // whole rectangles vertically; a ragged last column (8x12 frames: 12 of 16 columns used) is masked
+    return d.Hout % 8 == 0 || (d.Wout % 8 == 0 && d.Hout % 16 == 0);
+}
+
+static int conv_halo2_launch(const CcGemmDesc& d, hipStream_t s) {
+    constexpr int BMC = 128, BNP = 256;
+    constexpr int lds = epi_lds_total(BMC, BNP, 4, 2 * kW2Bytes + 2 * kH2Bytes);
+    static unsigned long long attr_done = 0;
+    if (int rc = cc_max_dynamic_lds((const void*)conv_halo2_kernel, lds, &attr_done, "conv_halo2")) return rc;
+    const int64_t frames = d.M / ((int64_t)d.Hout * d.Wout);
+    const int64_t pt_n = frames * (d.Wout / 16) * (d.Hout / 16), ct_n = (d.N + BMC - 1) / BMC;
+    const int64_t nblk = 8 * ((pt_n + 7) / 8) * ct_n;
+    if (nblk > 2147483647LL) {
+        cc_set_error("ccedit_gemm: grid too large");
+        return CCEDIT_EUNSUPPORTED;
+    }
+    CcGemmDesc dd = d;
+    dd.cgroup = 0;
+    if (ct_n > 3) {
+        const int q = 3;
+        const int ng = (int)((ct_n + q - 1) / q);
+        dd.cgroup = (int)((ct_n + ng - 1) / ng);
+    }
+    static const int narrow_env = getenv("CCEDIT_CONV_NARROW") ? atoi(getenv("CCEDIT_CONV_NARROW")) : 1;
+    hipLaunchKernelGGL(conv_halo2_kernel, dim3((unsigned)nblk), dim3(256), lds, s, dd, narrow_env ? 1 << 8 : 0);
+    return cc_launch_status("conv_halo2_kernel");
+}
+
+int cc_conv_halo_launch(const CcGemmDesc& d, hipStream_t s) {
+    // frames that divide into 16 x 16 rectangles with enough of them to fill the chip: the 64-channel x 128-pixel wave tile
+    static const int h2_env = getenv("CCEDIT_CONV_HALO2") ? atoi(getenv("CCEDIT_CONV_HALO2")) : 1;     // 0: A/B with conv_halo_kernel
+    if (h2_env && d.Hout % 16 == 0 && d.Wout % 16 == 0 &&
+        (d.M / ((int64_t)d.Hout * d.Wout)) * (d.Hout / 16) * (d.Wout / 16) * ((d.N + 127) / 128) >= 512)
+        return conv_halo2_launch(d, s);
+    constexpr int WM = 2, WN = 2, TI = 2, TJ = 2;
+    constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
+    constexpr int lds = epi_lds_total(BMC, BNP, TJ, 2 * BMC * 128 + 2 * kHaloBytes);
+    static unsigned long long attr_done = 0;
+    if (int rc = cc_max_dynamic_lds((const void*)conv_halo_kernel<WM, WN, TI, TJ>, lds, &attr_done, "conv_halo")) return rc;
+    // orientation with the least padding: 8 x 16 needs Hout % 8 == 0, 16 x 8 needs Hout % 16 == 0
+    const int pad16 = (d.Hout % 8 == 0) ? (d.Wout + 15) / 16 * 16 : 1 << 30;
+    const int pad8 = (d.Hout % 16 == 0) ? (d.Wout + 7) / 8 * 8 : 1 << 30;
+    const int tw_log2 = pad16 <= pad8 ? 4 : 3;
+    const int TWh = 1 << tw_log2, THh = BNP >> tw_log2;
+    const int64_t frames = d.M / ((int64_t)d.Hout * d.Wout);
+    const int64_t pt_n = frames * ((d.Wout + TWh - 1) / TWh) * (d.Hout / THh), ct_n = (d.N + BMC - 1) / BMC;
+    const int64_t nblk = 8 * ((pt_n + 7) / 8) * ct_n;
+    if (nblk > 2147483647LL) {
+        cc_set_error("ccedit_gemm: grid too large");
+        return CCEDIT_EUNSUPPORTED;
+    }
+    CcGemmDesc dd = d;
+    dd.cgroup = 0;                                // weights of these convs exceed L2: share a weight tile among the
+    if (ct_n > 3) {                               // resident workgroups (see the block-order note in gemm.hip)
+        const int q = 3;
+        const int ng = (int)((ct_n + q - 1) / q);
+        dd.cgroup = (int)((ct_n + ng - 1) / ng);
+    }
+    static const int narrow_env = getenv("CCEDIT_CONV_NARROW") ? atoi(getenv("CCEDIT_CONV_NARROW")) : 1;     // 0: A/B with the padded tile
+    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, TI, TJ>), dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, dd,
+                       tw_log2 | (narrow_env ? 1 << 8 : 0));
+    return cc_launch_status("conv_halo_kernel");
+}
