@@ -1,0 +1,298 @@
+// EXPERIMENT, NOT BUILT INTO THE LIBRARY (round 2): convhalo.hip with warp specialisation (SPEC) — four MFMA
+// waves plus four DMA waves per workgroup; the DMA waves issue the whole weight / halo stream of the next k-tile and leave
+// before the epilogue.  Bit-correct (conv tests passed while dispatched).  34 frames, same box, SPEC vs shipped loop:
+//     184 VGPRs, ONE workgroup per CU (1 MFMA wave + 1 DMA wave per SIMD): 570 / 966 / 468 / 838 / 509 us
+//     shipped: 164 VGPRs, TWO workgroups per CU (2 waves per SIMD doing both):  492 / 860 / 446 / 836 / 483 us
+//     (64x96 320->320, 640->320; 32x48 640->640, 1280->640; 16x24 1280->1280)
+// i.e. one specialised MFMA wave per SIMD does what two unspecialised ones do on the long-K shapes.  Capped at 128 VGPRs
+// (two workgroups of eight waves per CU) hipcc spills 56 registers in the loop: 702 us.  The lead for round 3: get the MFMA
+// waves' path (64 accumulators + fragments + fragment addressing) and a slim epilogue under 128 registers.
+// 3x3 stride-1 convolution with the input tile staged ONCE per 64-channel chunk (halo included) and the nine taps read
+// from LDS at shifted rows.
+//
+// Why a second conv kernel: tap_gemm_kernel gathers every tap's activation tile from global memory again (9 x per
+// chunk).  PMC on the 64x96-level 320->320 conv: 124 M L1 accesses, 46 % of them missing to L2 (3.6 GB through the
+// TCP->TCC path per launch).  A CU sustains only ~20 B/clk of L1-miss traffic (outstanding-miss queue x L2 latency,
+// measured with tools/exp/readpat.hip), so that traffic — not MFMA, not HBM — bounded the convs at 30-38 % of peak.
+// Here a workgroup owns a TH x TW pixel rectangle (128 pixels) of one frame and 128 output channels:
+//   per chunk  : (TH+2) x (TW+2) halo rows x 128 B  -> LDS once           (23 KB instead of 9 x 16 KB)
+//   per tap    : only the 128 x 64 weight tile streams (2-deep ring), the B fragments are ds_read_b128 at
+//                halo row (ty+dy)*(TW+2) + tx+dx with the same XOR swizzle as everywhere else
+// K order of the packed weights is [Cin/64][tap][64] (korder 1), i.e. k-tile c*9 + t.  Epilogue: gemm_epilogue.h with
+// a 2-D row map.  Shapes that do not qualify (stride 2, fused upsample, Cin % 64 != 0, frames not divisible into
+// 8x16 / 16x8 rectangles) stay on tap_gemm_kernel.
+#include "common.h"
+#include "gemm_epilogue.h"
+#include <stdlib.h>
+
+namespace {
+
+__device__ __attribute__((aligned(64))) char g_zero_page_h[64];     // source of out-of-image halo rows
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_h() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int kHaloRows = 180;                 // (8+2) x (16+2) = (16+2) x (8+2)
+constexpr int kHaloBytes = 184 * 128;          // rounded to whole 8-row DMA groups
+constexpr int kHaloIssues = 6;                 // ceil(184 rows / 32 rows per 256-thread issue)
+
+// SPEC: the workgroup has WM x WN MFMA waves plus as many DMA waves (warp specialisation).  A global_load_lds costs the
+// issuing wave ~65 cycles; in the unspecialised loop every wave spends ~300 cycles per k-tile issuing its share of the
+// weight / halo stream in front of 16 MFMAs that execute in 512 — the in-order instruction stream of the wave, not a pipe,
+// is what is full (ablation: DMA alone 267 us, fragment reads + MFMAs alone 335 us, together 488 us on the 64x96 320 -> 320
+// launch; tools/exp/lds_mfma.hip: the fragment loop alone sustains 1725 TF/s).  Here waves WM*WN .. 2*WM*WN-1 issue ALL the
+// DMA of the next k-tile, wait for it and meet the MFMA waves at the per-tile barrier; the MFMA waves only read fragments and
+// multiply.  The DMA waves leave before the epilogue (a finished wave no longer counts at s_barrier).
+template <int WM, int WN, int TI, int TJ, bool SPEC>
+__global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), SPEC ? 2 : 1) void conv_halo_kernel(const CcGemmDesc d, int tw_log2_flags) {
+    const int tw_log2 = tw_log2_flags & 0xFF;      // bit 8: narrow last channel tile allowed
+    constexpr int NT = WM * WN * 64;               // threads of one role
+    constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
+    static_assert(NT == 256 && BNP == 128, "tile geometry");
+    constexpr int RPI = NT / 8;                    // rows per DMA issue (8 granules of 16 B per 128-byte row)
+    constexpr int W_ISSUES = BMC / RPI;
+    constexpr int W_BYTES = BMC * 128;
+    constexpr int LDS_MAIN = 2 * W_BYTES + 2 * kHaloBytes;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sW = smem;                         // [2][W_BYTES]
+    char* const sH = smem + 2 * W_BYTES;           // [2][kHaloBytes]
+
+    const bool producer = SPEC && threadIdx.x >= NT;          // wave-uniform
+    const int tid = threadIdx.x & (NT - 1);                    // both roles use the same thread -> tile-row mapping
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int TW = 1 << tw_log2, TH = BNP >> tw_log2, HW_ = TW + 2;
+    const int tiles_x = (d.Wout + TW - 1) >> tw_log2, tiles_y = d.Hout / TH;      // the last column of rectangles may be ragged
+    const int tpf = tiles_x * tiles_y;
+
+    // XCD-aware block order, same scheme as tap_gemm_kernel (pixel tiles contiguous per XCD, channel tiles in groups)
+    const int ct_n = (d.N + BMC - 1) / BMC;
+    const int64_t pt_n = (int64_t)(d.M / (d.Hout * d.Wout)) * tpf;
+    const int64_t pt_per_xcd = (pt_n + 7) / 8;
+    const int64_t bid = blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const int64_t local = bid >> 3;
+    const int Q = d.cgroup > 0 ? d.cgroup : ct_n;
+    const int64_t gsz = pt_per_xcd * Q;
+    const int cg = (int)(local / gsz);
+    const int64_t rr = local - cg * gsz;
+    const int qn = min(Q, ct_n - cg * Q);
+    const int64_t pl = rr / qn;
+    const int64_t pt = xcd * pt_per_xcd + pl;
+    if (pt >= pt_n) return;
+    const int ch0 = (cg * Q + (int)(rr - pl * qn)) * BMC;
+    const int frame = (int)(pt / tpf);
+    const int tr = (int)(pt - (int64_t)frame * tpf);
+    const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) << tw_log2;
+
+    const bf16* __restrict__ Ap = (const bf16*)d.A;
+    const bf16* __restrict__ Wp = (const bf16*)d.W;
+    const bf16* zp = (const bf16*)g_zero_page_h;
+    const int nc = d.Cin >> 6, nk = nc * 9;
+    // Last channel tile of a Cout that is not a multiple of 128 (320 = 128 + 128 + 64): only WM x 32 channels are real.
+    // The block then stages half the weight tile and every wave keeps ONE of its two MFMA row tiles (wave row wm takes
+    // channels 32 wm .. 32 wm + 31) — half the matrix work instead of multiplying 64 rows of padding (17 % of the MFMA
+    // energy of a 320-channel conv on a part that runs these kernels at its power limit).
+    const bool narrow = (TI == 2) && ((tw_log2_flags >> 8) & 1) && (d.N - ch0 <= WM * 32);
+
+    // ---- staging coordinates ----
+    // Halo swizzle: LDS slot s of halo entry (hy, hx) holds source granule s ^ f(hy, hx),
+    //   f = (hx >> 1) & 7                     for 8 x 16 rectangles,
+    //   f = ((hx >> 1) + 4 * (hy & 1)) & 7    for 16 x 8 rectangles.
+    // ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (MI355X_MICROARCH.md); with
+    // the halo pitch TW+2 a swizzle keyed on the linear row index (as in tap_gemm_kernel) is 2-way conflicted for every
+    // tap, this one puts the 16 lanes of a group on 16 distinct 16-byte slots of the 256-byte bank row for all nine
+    // shifts (checked exhaustively; PMC: SQ_LDS_BANK_CONFLICT 28.2 M -> ~0 per launch).
+    const int f_hy = (tw_log2 == 3) ? 1 : 0;
+    const int p = tid & 7, rsub = tid >> 3;
+    const int gcol_w = p ^ ((rsub >> 1) & 7);              // weight rows rsub + 32 i: (row >> 1) & 7 is i-independent
+    // halo: issue i stages halo rows i*32 + rsub; source element offset (without the chunk) or -1
+    int64_t hoff[kHaloIssues];
+#pragma unroll
+    for (int i = 0; i < kHaloIssues; ++i) {
+        const int hrow = i * 32 + rsub;
+        const int hy = hrow / HW_, hx = hrow - hy * HW_;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const bool v = hrow < kHaloRows && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+        const int gsrc = p ^ (((hx >> 1) + ((hy & 1) << 2) * f_hy) & 7);     // halo swizzle, see compute()
+        hoff[i] = v ? (((int64_t)frame * d.Hin + iy) * d.Win + ix) * d.lda + gsrc * 8 : (hrow < 184 ? -1 : -2);
+    }
+
+    auto stageW = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < W_ISSUES; ++i)
+            if (!narrow || i * RPI < WM * 32)
+                glds16(Wp + (size_t)(ch0 + i * RPI + rsub) * d.Kpad + kt * 64 + gcol_w * 8, sW + buf * W_BYTES + i * (RPI * 128) + wave * 1024);
+    };
+    auto stageH = [&](int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < kHaloIssues; ++i) {
+            if (hoff[i] != -2) {                            // rows 184..191 of the last issue do not exist
+                const bf16* src = hoff[i] >= 0 ? Ap + hoff[i] + c * 64 : zp;
+                glds16(src, sH + buf * kHaloBytes + i * (32 * 128) + wave * 1024);
+            }
+        }
+    };
+
+    // ---- fragment coordinates ----
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sw_w = (l31 >> 1) & 7;
+    const char* fa = sW + ((narrow ? wm * 32 : wm * TI * 32) + l31) * 128;
+    int hb[TJ], pty[TJ], ptx[TJ];                           // halo row of this lane's pixel for tap (0, 0); its (ty, tx)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int px = (wn * TJ + j) * 32 + l31;
+        pty[j] = px >> tw_log2;
+        ptx[j] = px & (TW - 1);
+        hb[j] = pty[j] * HW_ + ptx[j];
+    }
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int wbuf, int hbuf, int tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int shift = dy * HW_ + dx;
+        const char* pa = fa + wbuf * W_BYTES;
+        const char* ph = sH + hbuf * kHaloBytes;
+        int hr[TJ], hsw[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            hr[j] = hb[j] + shift;
+            hsw[j] = (((ptx[j] + dx) >> 1) + (((pty[j] + dy) & 1) << 2) * f_hy) & 7;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[TI], bfr[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                if (i == 0 || !narrow) af[i] = *(const bf16x8*)(pa + i * 32 * 128 + (((ks * 2 + hi) ^ sw_w) << 4));
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8*)(ph + hr[j] * 128 + (((ks * 2 + hi) ^ hsw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                if (i == 0 || !narrow) {
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    if constexpr (SPEC) {
+        // ---- main loop, specialised: one s_barrier per k-tile shared by both roles ----
+        if (producer) {
+            stageW(0, 0);
+            stageH(0, 0);
+            wait_vmcnt_h<0>();
+            __builtin_amdgcn_s_barrier();
+            int kt = 0;
+            for (int c = 0; c < nc; ++c) {
+                for (int t = 0; t < 9; ++t, ++kt) {
+                    if (kt + 1 < nk) stageW(kt + 1, (kt + 1) & 1);
+                    if (t == 0 && c + 1 < nc) stageH(c + 1, (c + 1) & 1);
+                    wait_vmcnt_h<0>();           // (the next halo is needed 8 k-tiles from now, but this wave has nothing else to do)
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            return;
+        }
+        __builtin_amdgcn_s_barrier();            // k-tile 0 and the first halo have landed
+        int kt = 0;
+        for (int c = 0; c < nc; ++c) {
+            for (int t = 0; t < 9; ++t, ++kt) {
+                compute(kt & 1, c & 1, t);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment reads are done: the slot may be refilled
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    } else {
+    // ---- main loop: weights 2-deep ring per k-tile, halo 2-deep ring per chunk ----
+    stageW(0, 0);
+    stageH(0, 0);
+    wait_vmcnt_h<0>();
+    __syncthreads();
+    int kt = 0;
+    for (int c = 0; c < nc; ++c) {
+        for (int t = 0; t < 9; ++t, ++kt) {
+            if (kt + 1 < nk) stageW(kt + 1, (kt + 1) & 1);
+            const bool pre = (t == 0) && (c + 1 < nc);
+            if (pre) stageH(c + 1, (c + 1) & 1);            // issued AFTER the weight tile: loads complete in order
+            compute(kt & 1, c & 1, t);
+            // the next weight tile must have landed; the next halo (needed 8 k-tiles from now) may stay in flight.
+            // A wave issues 5 or 6 halo loads (the last issue covers rows 160..183 only): count conservatively.
+            if (pre) wait_vmcnt_h<kHaloIssues - 1>(); else wait_vmcnt_h<0>();
+            __syncthreads();
+        }
+    }
+
+    }
+
+    // ---- epilogue ----
+    const int64_t row_base = ((int64_t)frame * d.Hout + y0) * d.Wout + x0;
+    gemm_epilogue<WM, WN, TI, TJ, LDS_MAIN>(
+        d, acc, smem, ch0,
+        [&](int px) -> int64_t {
+            const int tx = px & (TW - 1);
+            return x0 + tx < d.Wout ? row_base + (int64_t)(px >> tw_log2) * d.Wout + tx : -1;
+        },
+        (int64_t)frame, narrow);
+}
+
+}  // namespace
+
+bool cc_conv_halo_applicable(const CcGemmDesc& d) {
+    if (!(d.mode == CCEDIT_GEMM_CONV2D && d.taps == 9 && d.ksize == 3 && d.stride == 1 && d.pad == 1 && !d.upsample &&
+          !d.A2 && d.korder == 1 && d.Cin % 64 == 0 && d.Cin1 == d.Cin && d.Hout == d.Hin && d.Wout == d.Win && d.N >= 64 &&
+          d.act != CCEDIT_ACT_GEGLU))
+        return false;
+    if (d.M % ((int64_t)d.Hout * d.Wout) != 0) return false;
+    if (d.gn_stats && d.gn_rows != d.Hout * d.Wout) return false;
+    // whole rectangles vertically; a ragged last column (8x12 frames: 12 of 16 columns used) is masked
+    return d.Hout % 8 == 0 || (d.Wout % 8 == 0 && d.Hout % 16 == 0);
+}
+
+template <bool SPEC>
+static int conv_halo_launch_variant(const CcGemmDesc& d, hipStream_t s) {
+    constexpr int WM = 2, WN = 2, TI = 2, TJ = 2;
+    constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
+    constexpr int lds = epi_lds_total(BMC, BNP, TJ, 2 * BMC * 128 + 2 * kHaloBytes);
+    static unsigned long long attr_done = 0;
+    if (int rc = cc_max_dynamic_lds((const void*)conv_halo_kernel<WM, WN, TI, TJ, SPEC>, lds, &attr_done, "conv_halo")) return rc;
+    // orientation with the least padding: 8 x 16 needs Hout % 8 == 0, 16 x 8 needs Hout % 16 == 0
+    const int pad16 = (d.Hout % 8 == 0) ? (d.Wout + 15) / 16 * 16 : 1 << 30;
+    const int pad8 = (d.Hout % 16 == 0) ? (d.Wout + 7) / 8 * 8 : 1 << 30;
+    const int tw_log2 = pad16 <= pad8 ? 4 : 3;
+    const int TWh = 1 << tw_log2, THh = BNP >> tw_log2;
+    const int64_t frames = d.M / ((int64_t)d.Hout * d.Wout);
+    const int64_t pt_n = frames * ((d.Wout + TWh - 1) / TWh) * (d.Hout / THh), ct_n = (d.N + BMC - 1) / BMC;
+    const int64_t nblk = 8 * ((pt_n + 7) / 8) * ct_n;
+    if (nblk > 2147483647LL) {
+        cc_set_error("ccedit_gemm: grid too large");
+        return CCEDIT_EUNSUPPORTED;
+    }
+    CcGemmDesc dd = d;
+    dd.cgroup = 0;                                // weights of these convs exceed L2: share a weight tile among the
+    if (ct_n > 3) {                               // resident workgroups (see the block-order note in gemm.hip)
+        const int q = 3;
+        const int ng = (int)((ct_n + q - 1) / q);
+        dd.cgroup = (int)((ct_n + ng - 1) / ng);
+    }
+    static const int narrow_env = getenv("CCEDIT_CONV_NARROW") ? atoi(getenv("CCEDIT_CONV_NARROW")) : 1;     // 0: A/B with the padded tile
+    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, TI, TJ, SPEC>), dim3((unsigned)nblk), dim3(WM * WN * 64 * (SPEC ? 2 : 1)), lds, s, dd,
+                       tw_log2 | (narrow_env ? 1 << 8 : 0));
+    return cc_launch_status("conv_halo_kernel");
+}
+
+int cc_conv_halo_launch(const CcGemmDesc& d, hipStream_t s) {
+    static const int spec_env = getenv("CCEDIT_CONV_SPEC") ? atoi(getenv("CCEDIT_CONV_SPEC")) : 1;      // 0: every wave stages and multiplies
+    return spec_env ? conv_halo_launch_variant<true>(d, s) : conv_halo_launch_variant<false>(d, s);
+}
