@@ -1,15 +1,15 @@
-// EXPERIMENT, NOT BUILT INTO THE LIBRARY (round 2): convhalo.hip with warp specialisation (SPEC) — four MFMA
-// waves plus four DMA waves per workgroup; the DMA waves issue the whole weight / halo stream of the next k-tile and leave
-// before the epilogue.  Bit-correct (conv tests passed while dispatched).  34 frames, same box, SPEC vs shipped loop:
-//     184 VGPRs, ONE workgroup per CU (1 MFMA wave + 1 DMA wave per SIMD): 570 / 966 / 468 / 838 / 509 us
-//     shipped: 164 VGPRs, TWO workgroups per CU (2 waves per SIMD doing both):  492 / 860 / 446 / 836 / 483 us
+// EXPERIMENT, NOT BUILT INTO THE LIBRARY (round 2): convhalo.hip with warp specialisation (SPEC) — four MFMA waves
+// plus four DMA waves per workgroup; the DMA waves issue the whole weight / halo stream of the next k-tile and leave before the
+// epilogue.  Bit-correct (conv tests passed while dispatched).  34 frames, same box, SPEC vs shipped loop, us:
+//     first version, 184 VGPRs, ONE workgroup per CU (1 MFMA + 1 DMA wave per SIMD):   570 / 966 / 468 / 838 / 509
+//     with the per-tap fragment rows recomputed instead of hoisted (asm pin below): 103 VGPRs, no spills, TWO workgroups per
+//     CU (2 MFMA + 2 DMA waves per SIMD):                                              478 / 841 / 438 / 778 / 466
+//     shipped: 164 VGPRs, two workgroups per CU, every wave stages and multiplies:      486 / 847 / 443 / 770 / 472
 //     (64x96 320->320, 640->320; 32x48 640->640, 1280->640; 16x24 1280->1280)
-// i.e. one specialised MFMA wave per SIMD does what two unspecialised ones do on the long-K shapes.  Capped at 128 VGPRs
-// (two workgroups of eight waves per CU) hipcc spills 56 registers in the loop: 702 us.  The lead for round 3: get the MFMA
-// waves' path (64 accumulators + fragments + fragment addressing) and a slim epilogue under 128 registers.
-// 3x3 stride-1 convolution with the input tile staged ONCE per 64-channel chunk (halo included) and the nine taps read
-// from LDS at shifted rows.
-//
+// Equal within 2 %: taking the DMA issue out of the MFMA waves' instruction streams does not speed the kernel up, so the
+// per-wave issue stream is NOT the limiter either.  What the ablation (DMA alone 267 us, fragment reads + MFMAs alone 335 us,
+// together 488 us) and the byte count agree on is LDS bandwidth: 128 KB of fragment reads + 37 KB of DMA writes per k-tile pair
+// and CU = 1290 cycles at 128 B/clk against 1254 measured.
 // Why a second conv kernel: tap_gemm_kernel gathers every tap's activation tile from global memory again (9 x per
 // chunk).  PMC on the 64x96-level 320->320 conv: 124 M L1 accesses, 46 % of them missing to L2 (3.6 GB through the
 // TCP->TCC path per launch).  A CU sustains only ~20 B/clk of L1-miss traffic (outstanding-miss queue x L2 latency,
@@ -46,7 +46,7 @@ constexpr int kHaloIssues = 6;                 // ceil(184 rows / 32 rows per 25
 // DMA of the next k-tile, wait for it and meet the MFMA waves at the per-tile barrier; the MFMA waves only read fragments and
 // multiply.  The DMA waves leave before the epilogue (a finished wave no longer counts at s_barrier).
 template <int WM, int WN, int TI, int TJ, bool SPEC>
-__global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), SPEC ? 2 : 1) void conv_halo_kernel(const CcGemmDesc d, int tw_log2_flags) {
+__global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), SPEC ? 4 : 1) void conv_halo_kernel(const CcGemmDesc d, int tw_log2_flags) {
     const int tw_log2 = tw_log2_flags & 0xFF;      // bit 8: narrow last channel tile allowed
     constexpr int NT = WM * WN * 64;               // threads of one role
     constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
@@ -166,8 +166,10 @@ __global__ __launch_bounds__(WM* WN * 64 * (SPEC ? 2 : 1), SPEC ? 2 : 1) void co
         int hr[TJ], hsw[TJ];
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-            hr[j] = hb[j] + shift;
-            hsw[j] = (((ptx[j] + dx) >> 1) + (((pty[j] + dy) & 1) << 2) * f_hy) & 7;
+            int hbj = hb[j], txj = ptx[j], tyj = pty[j];
+            if constexpr (SPEC) asm volatile("" : "+v"(hbj), "+v"(txj), "+v"(tyj));      // recompute per tap: hoisting all nine taps' rows out of the chunk loop costs 36+ VGPRs
+            hr[j] = hbj + shift;
+            hsw[j] = (((txj + dx) >> 1) + (((tyj + dy) & 1) << 2) * f_hy) & 7;
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
