@@ -1,15 +1,13 @@
 // EXPERIMENT, NOT BUILT INTO THE LIBRARY (round 2): convhalo.hip plus conv_halo2_kernel — 16 x 16 pixel rectangles,
 // 64 channels x 128 pixels per wave (2 x 4 MFMA tiles: six ds_read_b128 per eight MFMAs instead of eight), both operands
 // staged in 32-channel pieces with 64-byte LDS rows (new conflict-free halo swizzle, found by exhaustive search), two
-// workgroups per CU by LDS.  Bit-compatible with conv_halo_kernel up to the fp32 summation order (checksums agree to 1e-7).
-// SLOWER: 549 / 940 / 513 / 934 us against 490 / 851 / 432 / 774 us (34 x 64x96 320->320, 640->320; 34 x 32x48 640->640,
-// 1280->640).  The 128 accumulator registers push the kernel to 288 VGPRs (one wave per SIMD); capped at 256 it spills 33
-// and runs the same (536 us).  The ablation that motivated it (weight / halo DMA alone 267 us, LDS reads + MFMAs alone 335 us,
-// together 488 us; 1254 measured against 1290 LDS-limited cycles per k-tile pair) still stands as a description of
-// conv_halo_kernel; this was not the way to spend the LDS bandwidth it frees.
-// 3x3 stride-1 convolution with the input tile staged ONCE per 64-channel chunk (halo included) and the nine taps read
-// from LDS at shifted rows.
-//
+// workgroups per CU.  Bit-compatible with conv_halo_kernel up to the fp32 summation order (checksums agree to 1e-7).
+//   first version: 288 VGPRs (one wave per SIMD): 549 / 940 / 513 / 934 us against 490 / 851 / 432 / 774 us for the shipped kernel
+//                  (34 x 64x96 320->320, 640->320; 34 x 32x48 640->640, 1280->640); capped at 256 it spilled 33 (536 us)
+//   this version:  per-tap fragment rows recomputed instead of hoisted (asm pin in compute()), 32-bit halo offsets:
+//                  233 VGPRs, no spills, two waves per SIMD: 477 / 839 / 467 / 885 us against 487 / 854 / 445 / 809 us —
+//                  -2 % at 64x96, +5...9 % at 32x48.  29 % less LDS traffic per MFMA buys nothing measurable.
+//   with DMA waves on top (warp specialisation, 232 VGPRs, one workgroup per CU): 570 / 959 / 533 / 961 us.
 // Why a second conv kernel: tap_gemm_kernel gathers every tap's activation tile from global memory again (9 x per
 // chunk).  PMC on the 64x96-level 320->320 conv: 124 M L1 accesses, 46 % of them missing to L2 (3.6 GB through the
 // TCP->TCC path per launch).  A CU sustains only ~20 B/clk of L1-miss traffic (outstanding-miss queue x L2 latency,
@@ -273,7 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- staging plan: thread -> (row r4 + 64 i, LDS slot p4) ----
     const int p4 = tid & 3, r4 = tid >> 2;
     const int gcol_w = p4 ^ ((r4 >> 2) & 3);
-    int64_t hoff[kH2Issues];                       // source element offset (without the chunk), -1 = zero page, -2 = no such row
+    int hoff[kH2Issues];                           // source element offset (without the chunk), -1 = zero page, -2 = no such row
 #pragma unroll
     for (int i = 0; i < kH2Issues; ++i) {
         const int hrow = i * 64 + r4;
@@ -281,7 +279,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int iy = y0 + hy - 1, ix = x0 + hx - 1;
         const bool v = hrow < kH2Rows && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
         const int gsrc = p4 ^ ((hy + (hrow >> 1)) & 3);
-        hoff[i] = v ? (((int64_t)frame * d.Hin + iy) * d.Win + ix) * d.lda + gsrc * 8 : (hrow < 336 ? -1 : -2);
+        hoff[i] = v ? (int)((((int64_t)frame * d.Hin + iy) * d.Win + ix) * d.lda + gsrc * 8) : (hrow < 336 ? -1 : -2);
     }
     auto stageW = [&](int c32, int tap, int slot) {
         const int col = ((c32 >> 1) * 9 + tap) * 64 + (c32 & 1) * 32 + gcol_w * 8;
@@ -329,8 +327,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int hsw[TJ];
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-            const int hr = hb[j] + shift;
-            hsw[j] = ((pty[j] + dy) + (hr >> 1)) & 3;
+            int hbj = hb[j], tyj = pty[j];
+            asm volatile("" : "+v"(hbj), "+v"(tyj));
+            const int hr = hbj + shift;
+            hsw[j] = ((tyj + dy) + (hr >> 1)) & 3;
             pb[j] = ph + hr * 64;
         }
 #pragma unroll
