@@ -152,21 +152,29 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc
             hr[j] = hb[j] + shift;
             hsw[j] = (((ptx[j] + dx) >> 1) + (((pty[j] + dy) & 1) << 2) * f_hy) & 7;
         }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[TI], bfr[TJ];
+        // The fragments of k-step ks + 1 are requested before the MFMAs of k-step ks are issued (hipcc on its own reads, waits,
+        // multiplies, then reads again: the LDS latency of every k-step sat between two MFMA groups): -1.2 ... -2.6 % per conv.
+        bf16x8 af[2][TI], bfr[2][TJ];
+        auto load = [&](int ks, int b) {
 #pragma unroll
             for (int i = 0; i < TI; ++i)
-                if (i == 0 || !narrow) af[i] = *(const bf16x8*)(pa + i * 32 * 128 + (((ks * 2 + hi) ^ sw_w) << 4));
+                if (i == 0 || !narrow) af[b][i] = *(const bf16x8*)(pa + i * 32 * 128 + (((ks * 2 + hi) ^ sw_w) << 4));
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8*)(ph + hr[j] * 128 + (((ks * 2 + hi) ^ hsw[j]) << 4));
+            for (int j = 0; j < TJ; ++j) bfr[b][j] = *(const bf16x8*)(ph + hr[j] * 128 + (((ks * 2 + hi) ^ hsw[j]) << 4));
+        };
+        load(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) load(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
                 if (i == 0 || !narrow) {
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
