@@ -223,13 +223,20 @@ __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
         const char* xb = sX + buf * kXBuf + l31 * kRS + khalf * kK + hi * 16;
+        // the activation fragment of k-step ks + 2 is requested before the MFMAs of k-step ks are issued (hipcc on its own
+        // reads, waits, multiplies, reads again)
+        bf16x8 xq[3];
+        xq[0] = *(const bf16x8*)(xb);
+        xq[1] = *(const bf16x8*)(xb + 32);
 #pragma unroll
         for (int ks = 0; ks < kKS / 2; ++ks) {
-            const bf16x8 x0 = *(const bf16x8*)(xb + ks * 32);
+            if (ks + 2 < kKS / 2) xq[(ks + 2) % 3] = *(const bf16x8*)(xb + (ks + 2) * 32);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ti = 0; ti < 3; ++ti)
                 if (ti == 0 || grp < 3)        // 320 = 3 * 96 + 32: the last wave group has one real row tile, do not multiply padding
-                    acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ti][ks], x0, acc[ti], 0, 0, 0);
+                    acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ti][ks], xq[ks % 3], acc[ti], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // Tile pt+1 (staged one iteration ago) must have landed before the next loop-top barrier.  Waited for HERE, before
         // this iteration's stores are issued: loads complete in order, so once at most `my_issues` operations (the DMA just
