@@ -27,8 +27,8 @@ def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"),
-                                                      os.path.join(HERE, "..", "..", "include", "ccedit_hip.h")]
+    deps = ([os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")]
+            + [os.path.join(HERE, "..", "..", "include", "ccedit_hip.h")])
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -109,7 +109,37 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
             float bv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) bv[e] = (bias && (full || e < 4)) ? bias[cb + e] : 0.f;
+            // Rows of this thread in the chunk: r0, r0 + NT / CPR, ...  Their residual and per-clip-bias rows are REQUESTED FIRST, for
+            // all rows at once (the accumulators are in LDS by now, registers are free): left inside the row loop, every row
+            // paid one global-memory round trip before its store (hipcc: load, s_waitcnt vmcnt(0), add, store, next row) — the
+            // "store phase" of the short-K Linears and temporal convs was a chain of 4-8 such round trips per workgroup.
+            constexpr int RSTEP = NT / CPR;
+            constexpr int RPT = (ECH + RSTEP - 1) / RSTEP;           // rows per thread and chunk (compile time)
+            constexpr bool PREFETCH = (ECH == BNP) && RPT <= 8;      // whole tile staged: the accumulators are dead, registers are free
+                                                                   // (the chunked shapes t3 / t4 / t6 still hold theirs: +96 VGPRs cost them 30-120 %)
+            bf16x8 pr1[PREFETCH ? RPT : 1], pr2[PREFETCH ? RPT : 1];
+            f32x4 pg0[PREFETCH ? RPT : 1], pg1[PREFETCH ? RPT : 1];
+            if constexpr (PREFETCH) {
+                if (full && (r1 || r2 || gbias)) {
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k) {
+                        const int row = r0 + k * RSTEP;
+                        const int64_t m = row < ECH ? rowmap(ec * ECH + row) : -1;
+                        if (m >= 0) {
+                            if (r1) pr1[k] = *(const bf16x8*)(r1 + (size_t)m * d.ldr1 + cb);
+                            if (r2) pr2[k] = *(const bf16x8*)(r2 + (size_t)m * d.ldr2 + cb);
+                            if (gbias) {
+                                const float* gb = gbias + (size_t)(m / d.group_rows) * (d.ldgb ? d.ldgb : d.N) + cb;
+                                pg0[k] = *(const f32x4*)gb;
+                                pg1[k] = *(const f32x4*)(gb + 4);
+                            }
+                        }
+                    }
+                }
+            }
+            int kk = -1;
             for (int row = r0; row < ECH; row += NT / CPR) {
+                ++kk;
                 const int64_t m = rowmap(ec * ECH + row);
                 if (m < 0) continue;
                 const char* src = sE + row * EROW + g * 32;
@@ -117,10 +147,22 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
                 float v[8] = {a0[0] + bv[0], a0[1] + bv[1], a0[2] + bv[2], a0[3] + bv[3],
                               a1[0] + bv[4], a1[1] + bv[5], a1[2] + bv[6], a1[3] + bv[7]};
                 if (gbias) {
-                    const float* gb = gbias + (size_t)(m / d.group_rows) * (d.ldgb ? d.ldgb : d.N) + cb;
+                    if (PREFETCH && full) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (full || e < 4) v[e] += gb[e];
+                        for (int k = 0; k < RPT; ++k)
+                            if (k == kk) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    v[e] += pg0[k][e];
+                                    v[4 + e] += pg1[k][e];
+                                }
+                            }
+                    } else {
+                        const float* gb = gbias + (size_t)(m / d.group_rows) * (d.ldgb ? d.ldgb : d.N) + cb;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (full || e < 4) v[e] += gb[e];
+                    }
                 }
                 if (d.act == CCEDIT_ACT_SILU) {
 #pragma unroll
@@ -131,12 +173,26 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
                 }
                 if (full) {
                     if (r1) {
-                        const bf16x8 rv = *(const bf16x8*)(r1 + (size_t)m * d.ldr1 + cb);
+                        bf16x8 rv;
+                        if constexpr (PREFETCH) {
+#pragma unroll
+                            for (int k = 0; k < RPT; ++k)
+                                if (k == kk) rv = pr1[k];
+                        } else {
+                            rv = *(const bf16x8*)(r1 + (size_t)m * d.ldr1 + cb);
+                        }
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
                     }
                     if (r2) {
-                        const bf16x8 rv = *(const bf16x8*)(r2 + (size_t)m * d.ldr2 + cb);
+                        bf16x8 rv;
+                        if constexpr (PREFETCH) {
+#pragma unroll
+                            for (int k = 0; k < RPT; ++k)
+                                if (k == kk) rv = pr2[k];
+                        } else {
+                            rv = *(const bf16x8*)(r2 + (size_t)m * d.ldr2 + cb);
+                        }
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
                     }
