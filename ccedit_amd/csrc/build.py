@@ -10,7 +10,7 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.abspath(os.path.join(HERE, "..", "libccedit_hip.so"))
-SOURCES = ["gemm.hip", "convhalo.hip", "smallconv.hip", "lin320.hip", "ff320.hip", "norm.hip", "attention.hip", "attnshort.hip", "elementwise.hip", "core.cpp"]
+SOURCES = ["gemm.hip", "gemm8p.hip", "convhalo.hip", "smallconv.hip", "lin320.hip", "ff320.hip", "norm.hip", "attention.hip", "attnshort.hip", "elementwise.hip", "core.cpp"]
 ARCH = "gfx950"
 # per-file flags: ff320's GEGLU must stay scalar fp32 (packed fp32 VALU is several times slower beside MFMAs, see the file)
 EXTRA_FLAGS = {"ff320.hip": ["-fno-slp-vectorize"]}

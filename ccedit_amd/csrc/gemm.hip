@@ -39,6 +39,8 @@ bool cc_lin320_applicable(const CcGemmDesc& d);           // lin320.hip
 int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s);
 bool cc_small_conv_applicable(const CcGemmDesc& d);       // smallconv.hip
 int cc_small_conv_launch(const CcGemmDesc& d, hipStream_t s);
+bool cc_g8_applicable(const CcGemmDesc& d);               // gemm8p.hip
+int cc_g8_launch(const CcGemmDesc& d, hipStream_t s);
 
 namespace {
 
@@ -469,6 +471,11 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     if ((d.tile == 0 && l320_env && d.M >= 32768) || d.tile == 9) {
         if (cc_lin320_applicable(d)) return cc_lin320_launch(d, s);
         CC_UNSUPPORTED(d.tile == 9, "ccedit_gemm: tile 9 (register-resident weights, K = 320) does not apply to this descriptor");
+    }
+    // plain long Linear: persistent 256ch x 256pix eight-phase kernel (gemm8p.hip)
+    if (d.tile == 11) {
+        CC_UNSUPPORTED(!cc_g8_applicable(d), "ccedit_gemm: tile 11 (persistent 256 x 256 Linear) does not apply to this descriptor");
+        return cc_g8_launch(d, s);
     }
     CC_UNSUPPORTED(d.tile == 6 && d.N % 320 != 0, "ccedit_gemm: tile 6 (320-channel block shape) needs N %% 320 == 0 (N=%d)", d.N);
     int tile = d.tile;
