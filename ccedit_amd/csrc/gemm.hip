@@ -40,7 +40,7 @@ int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s);
 bool cc_small_conv_applicable(const CcGemmDesc& d);       // smallconv.hip
 int cc_small_conv_launch(const CcGemmDesc& d, hipStream_t s);
 bool cc_g8_applicable(const CcGemmDesc& d);               // gemm8p.hip
-int cc_g8_launch(const CcGemmDesc& d, hipStream_t s);
+int cc_g8_launch(const CcGemmDesc& d, hipStream_t s, int shape);
 
 namespace {
 
@@ -450,7 +450,7 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
                        "ccedit_gemm: GEGLU epilogue needs N%%16==0 and no residual/group bias/f32 out");
     }
     if (d.group_bias) CC_CHECK_ARG(d.group_rows > 0 && (d.ldgb == 0 || d.ldgb >= d.N), "ccedit_gemm: group_bias without group_rows / ldgb < N");
-    if (d.gn_stats) {
+    if (d.gn_stats && !(d.tile >= 11 && d.tile <= 13)) {      // (the persistent Linear shapes refuse gn_stats themselves)
         CC_CHECK_ARG(d.gn_rows > 0 && d.gn_rows % 128 == 0 && d.M % d.gn_rows == 0,
                      "ccedit_gemm: gn_stats needs gn_rows %% 128 == 0 dividing M (gn_rows=%d)", d.gn_rows);
         CC_CHECK_ARG(d.gn_rows % 256 == 0 || d.tile <= 1 || d.tile == 8,
@@ -473,9 +473,9 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         CC_UNSUPPORTED(d.tile == 9, "ccedit_gemm: tile 9 (register-resident weights, K = 320) does not apply to this descriptor");
     }
     // plain long Linear: persistent 256ch x 256pix eight-phase kernel (gemm8p.hip)
-    if (d.tile == 11) {
-        CC_UNSUPPORTED(!cc_g8_applicable(d), "ccedit_gemm: tile 11 (persistent 256 x 256 Linear) does not apply to this descriptor");
-        return cc_g8_launch(d, s);
+    if (d.tile >= 11 && d.tile <= 13) {     // 11: block shape by Cout, 12: 256ch x 256pix, 13: 128ch x 512pix
+        CC_UNSUPPORTED(!cc_g8_applicable(d), "ccedit_gemm: tile 11-13 (persistent eight-phase Linear) does not apply to this descriptor");
+        return cc_g8_launch(d, s, d.tile - 11);
     }
     CC_UNSUPPORTED(d.tile == 6 && d.N % 320 != 0, "ccedit_gemm: tile 6 (320-channel block shape) needs N %% 320 == 0 (N=%d)", d.N);
     int tile = d.tile;

@@ -29,11 +29,12 @@
 //
 // Hazards, in phase numbers j (K tile t = j / 4; a phase = fragment reads + one half-tile request, barrier, 8 MFMAs,
 // barrier; the second wave half runs every step one barrier later):
-//   reads   phase 4t: B half 0 then A half 0;  4t+1: B half 1;  4t+2: A half 1;  4t+3: none (B half 0 is still in registers)
-//   refills phase 4t: A1 of tile t+1;  4t+1: B0 of t+2;  4t+2: A0 of t+2;  4t+3: B1 of t+2, then vmcnt(6)
+// (X = B, Y = A for the 256 x 256 shape; the 128 x 512 shape swaps the roles)
+//   reads   phase 4t: X half 0 then Y half 0;  4t+1: X half 1;  4t+2: Y half 1;  4t+3: none (X half 0 is still in registers)
+//   refills phase 4t: Y1 of tile t+1;  4t+1: X0 of t+2;  4t+2: Y0 of t+2;  4t+3: X1 of t+2, then vmcnt(6)
 //   RAW: tile t+1 is complete when every wave has passed the vmcnt(6) of phase 4t+3 (it leaves only the three requests
 //        of phases 4t+1..4t+3 in flight) and a barrier; its first read is in phase 4t+4.
-//   WAR: B0 is re-requested one phase after its reads, which `lgkmcnt(8)` retires BEFORE the reading phase's first
+//   WAR: X0 is re-requested one phase after its reads, which `lgkmcnt(8)` retires BEFORE the reading phase's first
 //        barrier (they are issued first); every other slot is re-requested two phases after its reads, whose results the
 //        MFMAs of the reading phase consumed before that phase's second barrier.
 #include "common.h"
@@ -42,10 +43,6 @@
 #include <type_traits>
 
 namespace {
-
-constexpr int G8_HALF = 128 * 128;          // bytes of a half tile
-constexpr int G8_BUF = 4 * G8_HALF;         // A0 A1 B0 B1
-constexpr int G8_LDS = 2 * G8_BUF;          // 128 KB
 
 template <int N>
 __device__ __forceinline__ void g8_vmcnt() {
@@ -71,43 +68,51 @@ __device__ __forceinline__ void g8_swap(float& x, float& y) {
 }
 
 struct G8Order {          // 32-bit on purpose: the tile walk runs once per output tile in every wave (M < 2^31 rows)
-    int pt_n, pt_per_xcd, nlocal;
-    int ct_n, Q, balanced;
+    int pt_n, ct_n, Q, total, per;
 };
 
-__device__ __forceinline__ G8Order g8_order(const CcGemmDesc& d) {
+// Tile walk.  All pt_n x ct_n tiles in ONE linear order — channel tiles in groups of Q; inside a group pixel-major, channel-minor
+// — cut into eight equal contiguous ranges, one per XCD (workgroup b runs on XCD b % 8).  The workgroups of an XCD take the
+// tiles of its range round-robin, so the ~32 that run together cover (32 / Q pixel tiles) x (Q channel tiles): the weight rows of
+// a group (Q x 256 x K, chosen by the launcher to fit the XCD's L2 with room to spare) are fetched once per XCD and group,
+// every activation tile once per group.  Q = ct_n when the whole weight matrix fits.
+template <int BM>
+__device__ __forceinline__ G8Order g8_order(const CcGemmDesc& d, int bn) {
     G8Order o;
-    o.ct_n = (d.N + 255) >> 8;
-    o.pt_n = (int)((d.M + 255) >> 8);
-    o.pt_per_xcd = (o.pt_n + 7) / 8;
+    o.ct_n = (d.N + BM - 1) / BM;
+    o.pt_n = (int)((d.M + bn - 1) / bn);
     o.Q = (d.cgroup & 0xFFFF) > 0 ? (d.cgroup & 0xFFFF) : o.ct_n;
-    o.balanced = (d.cgroup >> 18) & 1;
-    o.nlocal = o.balanced ? (o.pt_n * o.ct_n + 7) / 8 : o.pt_per_xcd * o.ct_n;
+    o.total = o.pt_n * o.ct_n;
+    o.per = (o.total + 7) >> 3;
     return o;
 }
 
-// Tile `local` of XCD `xcd` (same walk as tap_gemm_kernel: an XCD owns a contiguous range of pixel tiles; channel tiles in
-// groups of Q, inside a group channel-minor — so the workgroups running together on an XCD cover (32 / Q pixel tiles) x
-// (Q channel tiles) and an over-L2 weight matrix is shared by 32 / Q of them).
-__device__ __forceinline__ bool g8_decode(const G8Order& o, int local, int xcd, int& pt, int& ct) {
-    if (o.balanced) {
-        const int w = xcd * o.nlocal + local;
-        if (w >= o.pt_n * o.ct_n) return false;
-        pt = w / o.ct_n;
-        ct = w - pt * o.ct_n;
-        return true;
-    }
-    const int gsz = o.pt_per_xcd * o.Q;
-    const int cg = local / gsz;
-    const int rr = local - cg * gsz;
+__device__ __forceinline__ void g8_decode(const G8Order& o, int g, int& pt, int& ct) {
+    const int gfull = o.pt_n * o.Q;
+    const int cg = g / gfull;
+    const int r = g - cg * gfull;
     const int qn = min(o.Q, o.ct_n - cg * o.Q);
-    const int pl = rr / qn;
-    pt = xcd * o.pt_per_xcd + pl;
-    ct = cg * o.Q + (rr - pl * qn);
-    return pt < o.pt_n;
+    pt = r / qn;
+    ct = cg * o.Q + (r - pt * qn);
 }
 
+// TIH / TJH: 32-row MFMA tiles per wave and operand HALF.  A half = 2 wave rows x TIH x 32 channels, B half = 4 wave columns x
+// TJH x 32 pixels; the block computes (TIH x 128) channels x (TJH x 256) pixels, a wave 2 TIH x 2 TJH accumulator tiles:
+//   <2, 1>  256ch x 256pix, 128 KB LDS           — Cout a multiple of 256
+//   <1, 2>  128ch x 512pix, 160 KB LDS           — Cout = 640 (5 tiles instead of 2.5), 102 instead of 128 FLOP per staged byte
+enum { G8_PLAIN = 0, G8_RES = 1, G8_GEGLU = 2 };      // epilogue variants (compiled separately: one register budget each)
+
+template <int TIH, int TJH, int EPI>
 __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
+    static_assert(TIH * TJH == 2, "eight MFMAs per phase");
+    constexpr int BM = TIH * 128, BN = TJH * 256;
+    constexpr int AH = TIH * 8192, BH = TJH * 16384;          // bytes of an A / B half tile (128-byte rows)
+    constexpr int BUF = 2 * AH + 2 * BH;                      // [A0 | A1 | B0 | B1]
+    constexpr int AI = TIH, BI = 2 * TJH;                     // 64-row DMA issues per half tile
+    constexpr bool XA = TIH < TJH;                            // which operand's half 0 stays in registers through a K tile (see ktile)
+    constexpr int KEEP = XA ? 2 * AI + BI : 2 * BI + AI;      // DMA instructions of the three half tiles that stay in flight
+    constexpr int NI = 2 * TIH, NJ = 2 * TJH;                 // accumulator tiles per wave
+    constexpr int CW = NI * 32;                               // consecutive output channels per wave row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -115,16 +120,23 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     const int wr = wave >> 2, wc = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
     const int nk = d.Kpad >> 6;
+    const int flags = d.cgroup >> 24;           // tuning only: 1 = no output stores, 2 = next tile requested AFTER the epilogue
 
-    const G8Order ord = g8_order(d);
+    const G8Order ord = g8_order<BM>(d, BN);
     const int xcd = blockIdx.x & 7;
     const int nw = gridDim.x >> 3;              // workgroups per XCD
-    int local = blockIdx.x >> 3;
+    int g = xcd * ord.per + (blockIdx.x >> 3);
+    const int gend = min((xcd + 1) * ord.per, ord.total);
+    if (g >= gend) return;
 
     // ---- staging: thread -> (row rsub of a 64-row issue, LDS slot p), source granule p ^ ((rsub >> 1) & 7) ----
     const int p = tid & 7, rsub = tid >> 3;
     const int gcol = p ^ ((rsub >> 1) & 7);
-    const uint32_t a_lane = ((uint32_t)rsub * (uint32_t)d.Kpad + gcol * 8) * 2;          // byte offset inside a 64-row issue of W
+    // LDS row rho = i * 64 + rsub of A half h belongs to wave row rho / (TIH * 32); it holds weight row (= output channel)
+    //   wave_row * CW + h * (TIH * 32) + rho % (TIH * 32),   CW = 2 * TIH * 32 channels per wave row,
+    // so that the 2 TIH row tiles a wave accumulates are CW CONSECUTIVE channels (whole 128-byte lines in the epilogue).
+    const int a_row = (rsub / (TIH * 32)) * CW + rsub % (TIH * 32);
+    const uint32_t a_lane = ((uint32_t)a_row * (uint32_t)d.Kpad + gcol * 8) * 2;          // per-lane byte offset into W (issue 0, half 0)
     const char* const Wp = (const char*)d.W;
     const char* const Ap = (const char*)d.A;
     char* const lds_wave = smem + wave * 1024;
@@ -136,148 +148,182 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const int off = l31 * 128 + (((2 * ks + hi) ^ sw) << 4);
-        fa[ks] = smem + wr * 8192 + off;                       // A half h at + h * G8_HALF, row tile ti' at + ti' * 4096
-        fb[ks] = smem + 2 * G8_HALF + wc * 4096 + off;         // B half h at + h * G8_HALF
+        fa[ks] = smem + wr * (TIH * 4096) + off;                 // A half h at + h * AH, row tile ti at + ti * 4096
+        fb[ks] = smem + 2 * AH + wc * (TJH * 4096) + off;        // B half h at + h * BH, pixel tile tj at + tj * 4096
     }
 
     int pt, ct;
-    // first tile of this workgroup
-    for (;; local += nw) {
-        if (local >= ord.nlocal) return;
-        if (g8_decode(ord, local, xcd, pt, ct)) break;
-    }
+    g8_decode(ord, g, pt, ct);
 
-    // per-tile source bases (uniform) and the pixel-row offsets of the four 64-row issues of the B tile (clamped at M - 1:
-    // rows past the end are computed from valid memory and never stored)
+    // per-tile source bases (uniform).  Pixel rows past M are clamped to M - 1 when the B tile is requested (computed from
+    // valid memory, never stored): rmax = M - 1 - pix0 is the last valid row of the tile, >= BN - 1 except in the last one.
     const char* wt;
     const char* at;
-    uint32_t b_lane[4];
+    int rmax;
+    const uint32_t ldab = (uint32_t)d.lda * 2, gcol16 = gcol * 16;
     auto set_tile = [&](int pt_, int ct_) {
-        wt = Wp + (size_t)ct_ * 256 * d.Kpad * 2;
-        const int64_t pix0 = (int64_t)pt_ * 256;
+        wt = Wp + (size_t)ct_ * BM * d.Kpad * 2;
+        const int64_t pix0 = (int64_t)pt_ * BN;
         at = Ap + (size_t)pix0 * d.lda * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int64_t r = pix0 + i * 64 + rsub;
-            r = r < d.M ? r : d.M - 1;
-            b_lane[i] = (uint32_t)((r - pix0) * d.lda + gcol * 8) * 2;
-        }
+        const int64_t left = d.M - 1 - pix0;
+        rmax = left < BN ? (int)left : BN;
     };
-    // one half tile = two 64-row issues
     auto stage_a = [&](int h, int kt, int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            // uniform part in SGPRs (readfirstlane keeps hipcc from turning it into eight per-lane 64-bit induction variables),
+        for (int i = 0; i < AI; ++i) {
+            // uniform part in SGPRs (readfirstlane keeps hipcc from turning it into per-lane 64-bit induction variables),
             // per-lane part a 32-bit VGPR offset: global_load_lds_dwordx4 v, s[..]
-            const uint32_t u = __builtin_amdgcn_readfirstlane((uint32_t)((h * 128 + i * 64) * d.Kpad * 2 + kt * 128));
-            glds16(wt + u + a_lane, lds_wave + buf * G8_BUF + h * G8_HALF + i * 8192);
+            const uint32_t u = __builtin_amdgcn_readfirstlane((uint32_t)((i * (64 / (TIH * 32)) * CW + h * (TIH * 32)) * d.Kpad * 2 + kt * 128));
+            glds16(wt + u + a_lane, lds_wave + buf * BUF + h * AH + i * 8192);
         }
     };
     auto stage_b = [&](int h, int kt, int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < BI; ++i) {
             const uint32_t u = __builtin_amdgcn_readfirstlane((uint32_t)(kt * 128));
-            glds16(at + u + b_lane[h * 2 + i], lds_wave + buf * G8_BUF + (2 + h) * G8_HALF + i * 8192);
+            const int r = min((h * BI + i) * 64 + rsub, rmax);
+            glds16(at + u + ((uint32_t)r * ldab + gcol16), lds_wave + buf * BUF + 2 * AH + h * BH + i * 8192);
         }
     };
-    auto prologue = [&]() {
+    auto prologue_a = [&]() {          // K tile 0 -> buffer 0
         stage_a(0, 0, 0);
         stage_a(1, 0, 0);
         stage_b(0, 0, 0);
         stage_b(1, 0, 0);
-        stage_b(0, 1, 1);
-        stage_a(0, 1, 1);
-        stage_b(1, 1, 1);
+    };
+    auto prologue_b = [&]() {          // the three half tiles of K tile 1 that are in flight when the loop starts -> buffer 1
+        if constexpr (XA) {
+            stage_a(0, 1, 1);
+            stage_b(0, 1, 1);
+            stage_a(1, 1, 1);
+        } else {
+            stage_b(0, 1, 1);
+            stage_a(0, 1, 1);
+            stage_b(1, 1, 1);
+        }
+    };
+#ifdef G8_PROBE
+    unsigned long long* const probe = (unsigned long long*)d.gn_stats + (size_t)blockIdx.x * 64;
+    int probe_n = 0;
+#define G8_STAMP()                                                            \
+    do {                                                                      \
+        if (probe && tid == 0 && probe_n < 64) probe[probe_n++] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define G8_STAMP() \
+    do {           \
+    } while (0)
+#endif
+
+    // The bias is the INITIAL VALUE of the accumulators: register 4 q + e of row tile tf holds channel 32 tf + 8 q + 4 hi + e of
+    // this wave row, the same for every pixel tile — 16 loads of 16 bytes per lane and output tile straight into the accumulator
+    // registers, requested before the operand requests whose counted wait also covers them.  The epilogue never touches it.
+    f32x16 acc[NI][NJ];
+    auto init_acc = [&](int ct_) {
+        const float* const bias = d.bias;
+#pragma unroll
+        for (int tf = 0; tf < NI; ++tf)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (bias) b = *(const f32x4*)(bias + min(ct_ * BM + wr * CW + 32 * tf + 8 * q + 4 * hi, d.N - 4));   // (past N: never stored)
+#pragma unroll
+                for (int tj = 0; tj < NJ; ++tj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[tf][tj][4 * q + e] = b[e];
+            }
     };
 
+    G8_STAMP();
     set_tile(pt, ct);
-    prologue();
-    g8_vmcnt<6>();                               // K tile 0 has landed (this wave's part)
+    prologue_a();
+    prologue_b();
+    init_acc(ct);
+    g8_vmcnt<KEEP>();                            // K tile 0 has landed (this wave's part)
 
     for (;;) {
-        const int64_t pix0 = (int64_t)pt * 256;
-        const int ch0 = ct * 256;
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int64_t pix0 = (int64_t)pt * BN;
+        const int ch0 = ct * BM;
 
         g8_barrier();                            // ... and everybody else's
+        G8_STAMP();
         if (wr == 1) g8_barrier();               // second wave half: one barrier behind from here on
 
-        // ---- K loop: one K tile = four phases on LDS buffer CUR ----
+        // ---- K loop: one K tile = four phases on LDS buffer CUR.  X = the operand with the smaller per-wave fragment set (B for
+        // 256 x 256, A for 128 x 512): its half 0 stays in registers for phases 0..3, half 1 for phases 1..2; the other operand
+        // (Y) is read half 0 in phase 0, half 1 in phase 2.  64 fragment VGPRs at the peak.
         auto ktile = [&](auto CURC, int t) {
             constexpr int CUR = decltype(CURC)::value;
-            constexpr int BASE = CUR * G8_BUF;
-            bf16x8 a[2][4], b0[4], b1[4];
-            // phase 0: B half 0 (first: retired by lgkmcnt(8) before the barrier), A half 0; request A1 of tile t + 1
+            constexpr int BASE = CUR * BUF;
+            constexpr int NX = XA ? TIH : TJH, NY = XA ? TJH : TIH;
+            constexpr int XH = XA ? AH : BH, YH = XA ? BH : AH;
+            bf16x8 x0[NX][4], x1[NX][4], y[NY][4];
+            auto read_x = [&](int h, bf16x8(&f)[NX][4]) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) b0[ks] = *(const bf16x8*)(fb[ks] + BASE);
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) f[i][ks] = *(const bf16x8*)((XA ? fa[ks] : fb[ks]) + BASE + h * XH + i * 4096);
+            };
+            auto read_y = [&](int h) {
+#pragma unroll
+                for (int i = 0; i < NY; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) y[i][ks] = *(const bf16x8*)((XA ? fb[ks] : fa[ks]) + BASE + h * YH + i * 4096);
+            };
+            auto stage_x = [&](int h, int kt, int buf) {
+                if constexpr (XA) stage_a(h, kt, buf);
+                else stage_b(h, kt, buf);
+            };
+            auto stage_y = [&](int h, int kt, int buf) {
+                if constexpr (XA) stage_b(h, kt, buf);
+                else stage_a(h, kt, buf);
+            };
+            auto mma = [&](const bf16x8(&xf)[NX][4], int xh, int yh) {
+                const int ah = XA ? xh : yh, bh = XA ? yh : xh;
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int ti = 0; ti < TIH; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < TJH; ++tj)
+                            acc[ah * TIH + ti][bh * TJH + tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                XA ? xf[ti][ks] : y[ti][ks], XA ? y[tj][ks] : xf[tj][ks], acc[ah * TIH + ti][bh * TJH + tj], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            // phase 0: X half 0 (first: retired by the lgkmcnt before the barrier), Y half 0; request Y1 of tile t + 1
+            read_x(0, x0);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) a[ti][ks] = *(const bf16x8*)(fa[ks] + BASE + ti * 4096);
+            read_y(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < nk) stage_a(1, t + 1, CUR ^ 1);
-            g8_lgkmcnt<8>();
+            if (t + 1 < nk) stage_y(1, t + 1, CUR ^ 1);
+            g8_lgkmcnt<NY * 4>();
             g8_barrier();
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-                    acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][ks], b0[ks], acc[ti][0], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+            mma(x0, 0, 0);
             g8_barrier();
-            // phase 1: B half 1; request B0 of tile t + 2
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) b1[ks] = *(const bf16x8*)(fb[ks] + BASE + G8_HALF);
+            // phase 1: X half 1; request X0 of tile t + 2
+            read_x(1, x1);
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < nk) stage_b(0, t + 2, CUR);
+            if (t + 2 < nk) stage_x(0, t + 2, CUR);
             g8_barrier();
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-                    acc[ti][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][ks], b1[ks], acc[ti][1], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+            mma(x1, 1, 0);
             g8_barrier();
-            // phase 2: A half 1; request A0 of tile t + 2
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) a[ti][ks] = *(const bf16x8*)(fa[ks] + BASE + G8_HALF + ti * 4096);
+            // phase 2: Y half 1; request Y0 of tile t + 2
+            read_y(1);
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < nk) stage_a(0, t + 2, CUR);
+            if (t + 2 < nk) stage_y(0, t + 2, CUR);
             g8_barrier();
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-                    acc[2 + ti][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][ks], b1[ks], acc[2 + ti][1], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+            mma(x1, 1, 1);
             g8_barrier();
-            // phase 3: no reads; request B1 of tile t + 2; tile t + 1 must have landed before the next phase reads it
+            // phase 3: no reads; request X1 of tile t + 2; tile t + 1 must have landed before the next phase reads it
             if (t + 2 < nk) {
-                stage_b(1, t + 2, CUR);
-                g8_vmcnt<6>();
+                stage_x(1, t + 2, CUR);
+                g8_vmcnt<KEEP>();
             } else {
                 g8_vmcnt<0>();
             }
             g8_barrier();
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-                    acc[2 + ti][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti][ks], b0[ks], acc[2 + ti][0], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+            mma(x0, 0, 1);
             g8_barrier();
         };
         int t = 0;
@@ -287,138 +333,189 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         }
         if (t < nk) ktile(std::integral_constant<int, 0>{}, t);
         if (wr == 0) g8_barrier();               // both halves level again: every fragment read of this tile is done
+        G8_STAMP();
 
-        // ---- next tile: request its first seven half tiles now, they land under the epilogue ----
+        // ---- next tile: request its first K tile now (buffer 0), it lands under the epilogue; buffer 1 is the epilogue's ----
+        g += nw;
+        const bool more = g < gend;
         int npt = 0, nct = 0;
-        bool more = false;
-        for (local += nw; local < ord.nlocal; local += nw)
-            if (g8_decode(ord, local, xcd, npt, nct)) {
-                more = true;
-                break;
-            }
         if (more) {
+            g8_decode(ord, g, npt, nct);
             set_tile(npt, nct);
-            prologue();
+            if (!(flags & 2)) prologue_a();
         }
 
-        // ---- epilogue: accumulators -> global ----
-        const float* __restrict__ bias = d.bias;
+        // ---- epilogue: accumulators -> wave-private LDS tile -> global, whole 128-byte lines per row.
+        // In the 32x32 MFMA layout a lane owns 4 channels of ONE pixel, so a direct store instruction touches 64 different
+        // 16-byte pieces (measured: 8 us per 256 x 256 tile, the request rate of the vector memory path).  Each wave turns its
+        // CW-channel x 32-pixel blocks around in 8 KB of its own (no workgroup barrier: LDS executes a wave's accesses in order)
+        // and then stores 16 bytes per lane with consecutive lanes walking a pixel's channels.
         const bf16* __restrict__ r1 = (const bf16*)d.res1;
         const bf16* __restrict__ r2 = (const bf16*)d.res2;
         bf16* __restrict__ outp = (bf16*)d.out;
-        if (d.act == CCEDIT_ACT_GEGLU) {
+        const bool st = !(flags & 1);
+        char* const stg = smem + BUF + wave * 8192;
+        const int chw = ch0 + wr * CW;                                   // this wave's first channel (packed row)
+        auto pixbase = [&](int tjf) { return (tjf / TJH) * (TJH * 128) + wc * (TJH * 32) + (tjf % TJH) * 32; };
+        if constexpr (EPI == G8_GEGLU) {
+            // packed rows 16 g + [0, 8) are values, + [8, 16) their gates: a 32-row tile yields 16 output channels
+            constexpr int RB = CW, G = RB / 16;                          // staged row: CW / 2 bf16 outputs of one pixel
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
-                const int rowb = ch0 + (ti >> 1) * 128 + wr * 64 + (ti & 1) * 32;     // first packed row of this MFMA tile
-                // packed rows rowb + 16 g + [0, 8) are values, + [8, 16) their gates; this lane: 4 hi + (0..3) of each
-                f32x4 bx[2], bg[2];
+            for (int tjf = 0; tjf < NJ; ++tjf) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const int rx = rowb + 16 * g + 4 * hi;
-                    const bool ok = bias && rx < d.N;
-                    bx[g] = ok ? *(const f32x4*)(bias + rx) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    bg[g] = ok ? *(const f32x4*)(bias + rx + 8) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                for (int tf = 0; tf < NI; ++tf) {
 #pragma unroll
-                for (int tj = 0; tj < 2; ++tj) {
-                    const int64_t m = pix0 + tj * 128 + wc * 32 + l31;
-                    float o0[4], o1[4];
+                    for (int gq = 0; gq < 2; ++gq) {
+                        bf16x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o0[e] = (acc[ti][tj][e] + bx[0][e]) * gelu_erf_f(acc[ti][tj][4 + e] + bg[0][e]);
-                        o1[e] = (acc[ti][tj][8 + e] + bx[1][e]) * gelu_erf_f(acc[ti][tj][12 + e] + bg[1][e]);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) g8_swap(o0[e], o1[e]);
-                    const int oc = (rowb >> 1) + 8 * hi;                               // 8 consecutive output channels
-                    if (m < d.M && rowb + 16 * hi < d.N) {
-                        bf16x8 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            o[e] = f2bf(o0[e]);
-                            o[4 + e] = f2bf(o1[e]);
-                        }
-                        *(bf16x8*)(outp + (size_t)m * d.ldc + oc) = o;
+                        for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[tf][tjf][8 * gq + e] * gelu_erf_f(acc[tf][tjf][8 * gq + 4 + e]));
+                        *(bf16x4*)(stg + l31 * RB + (((2 * tf + gq) ^ (l31 & (G - 1))) << 4) + hi * 8) = o;
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < G / 2; ++j) {
+                    const int row = j * (64 / G) + lane / G, c = lane % G;
+                    const bf16x8 v = *(const bf16x8*)(stg + row * RB + ((c ^ (row & (G - 1))) << 4));
+                    const int64_t m = pix0 + pixbase(tjf) + row;
+                    if (st && m < d.M && chw + 16 * c < d.N) *(bf16x8*)(outp + (size_t)m * d.ldc + (chw >> 1) + 8 * c) = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-        } else {
+        } else if constexpr (EPI == G8_RES) {
+            // fp32 staging, 64 channels x 32 pixels at a time: the residuals are added before the one rounding to bf16
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
-                const int rowb = ch0 + (ti >> 1) * 128 + wr * 64 + (ti & 1) * 32;
+            for (int tjf = 0; tjf < NJ; ++tjf) {
 #pragma unroll
-                for (int qp = 0; qp < 2; ++qp) {
-                    const int cb = rowb + 16 * qp + 8 * hi;                            // this lane's 8 channels after the swap
-                    const bool cok = cb < d.N;
-                    f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = {0.f, 0.f, 0.f, 0.f};
-                    if (bias && cok) {
-                        bv0 = *(const f32x4*)(bias + cb);
-                        bv1 = *(const f32x4*)(bias + cb + 4);
+                for (int cs = 0; cs < CW / 64; ++cs) {
+                    const int cb64 = chw + cs * 64;
+                    // this lane's part of the block: pixel rows 8 j + lane / 8, channels cb64 + 8 (lane % 8) .. + 7
+                    const int c = lane & 7, cb = cb64 + 8 * c;
+                    bf16x8 rv1[4];                 // first residual: requested before the block is turned around (a second one is rare)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t m = pix0 + pixbase(tjf) + 8 * j + (lane >> 3);
+                        if (r1 && m < d.M && cb < d.N) rv1[j] = *(const bf16x8*)(r1 + (size_t)m * d.ldr1 + cb);
                     }
 #pragma unroll
-                    for (int tj = 0; tj < 2; ++tj) {
-                        const int64_t m = pix0 + tj * 128 + wc * 32 + l31;
-                        const bool ok = cok && m < d.M;
-                        bf16x8 rv1, rv2;
-                        if (r1 && ok) rv1 = *(const bf16x8*)(r1 + (size_t)m * d.ldr1 + cb);
-                        if (r2 && ok) rv2 = *(const bf16x8*)(r2 + (size_t)m * d.ldr2 + cb);
-                        float v[8];
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[ti][tj][8 * qp + e];
-                            v[4 + e] = acc[ti][tj][8 * qp + 4 + e];
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[2 * cs + u][tjf][4 * q + e];
+                            *(f32x4*)(stg + l31 * 256 + (((8 * u + 2 * q + hi) ^ (l31 & 15)) << 4)) = v;
                         }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) g8_swap(v[e], v[4 + e]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] += bv0[e];
-                            v[4 + e] += bv1[e];
-                        }
-                        if (d.act == CCEDIT_ACT_SILU) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-                        } else if (d.act == CCEDIT_ACT_QUICK_GELU) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
-                        }
-                        if (ok) {
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = 8 * j + (lane >> 3);
+                        const f32x4 f0 = *(const f32x4*)(stg + row * 256 + (((2 * c) ^ (row & 15)) << 4));
+                        const f32x4 f1 = *(const f32x4*)(stg + row * 256 + (((2 * c + 1) ^ (row & 15)) << 4));
+                        float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+                        const int64_t m = pix0 + pixbase(tjf) + row;
+                        if (m < d.M && cb < d.N) {
                             if (r1) {
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) v[e] += bf2f(rv1[e]);
+                                for (int e = 0; e < 8; ++e) v[e] += bf2f(rv1[j][e]);
                             }
                             if (r2) {
+                                const bf16x8 rv2 = *(const bf16x8*)(r2 + (size_t)m * d.ldr2 + cb);
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) v[e] += bf2f(rv2[e]);
                             }
                             bf16x8 o;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-                            *(bf16x8*)(outp + (size_t)m * d.ldc + cb) = o;
+                            if (st) *(bf16x8*)(outp + (size_t)m * d.ldc + cb) = o;
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        } else {
+            // bf16 staging, all CW channels x 32 pixels at a time
+            constexpr int RB = CW * 2, G = RB / 16;
+#pragma unroll
+            for (int tjf = 0; tjf < NJ; ++tjf) {
+#pragma unroll
+                for (int tf = 0; tf < NI; ++tf)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[tf][tjf][4 * q + e]);
+                        *(bf16x4*)(stg + l31 * RB + (((4 * tf + q) ^ (l31 & (G - 1))) << 4) + hi * 8) = o;
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < G / 2; ++j) {
+                    const int row = j * (64 / G) + lane / G, c = lane % G;
+                    const bf16x8 v = *(const bf16x8*)(stg + row * RB + ((c ^ (row & (G - 1))) << 4));
+                    const int64_t m = pix0 + pixbase(tjf) + row;
+                    if (st && m < d.M && chw + 8 * c < d.N) *(bf16x8*)(outp + (size_t)m * d.ldc + chw + 8 * c) = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        G8_STAMP();
         if (!more) return;
         pt = npt;
         ct = nct;
-        g8_vmcnt<0>();                           // the next tile's first K tiles (and this tile's stores) are through
+        init_acc(ct);
+        g8_barrier();                            // every wave is done with its staging block in buffer 1
+        if (flags & 2) prologue_a();
+        prologue_b();
+        // K tile 0 of the next tile has landed: at most the KEEP requests just issued are outstanding — loads complete in order,
+        // so whatever else is still counted (stores of the epilogue) only makes this wait longer, never shorter
+        g8_vmcnt<KEEP>();
     }
+}
+
+template <int TIH, int TJH, int EPI>
+int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu) {
+    constexpr int BM = TIH * 128, BN = TJH * 256;
+    constexpr int LDS = 2 * (2 * TIH * 8192 + 2 * TJH * 16384);
+    static unsigned long long attr_done = 0;
+    if (int rc = cc_max_dynamic_lds((const void*)g8_kernel<TIH, TJH, EPI>, LDS, &attr_done, "g8_kernel")) return rc;
+    const int64_t pt_n = (d.M + BN - 1) / BN, ct_n = (d.N + BM - 1) / BM;
+    CcGemmDesc dd = d;
+    dd.cgroup = 0;
+    // channel-tile groups when the weight matrix does not fit an XCD's 4 MB L2 beside the activation tiles in flight: the largest
+    // group of at most ~2 MB of weight rows, evened out over the groups
+    static const int cg_env = getenv("CCEDIT_CGROUP") ? atoi(getenv("CCEDIT_CGROUP")) : -1;     // tuning: -1 auto, 0 off, n fixed
+    const double tile_bytes = (double)BM * d.Kpad * 2.0;
+    if (cg_env != 0 && ct_n * tile_bytes > 3.0 * 1024 * 1024) {
+        int q = cg_env > 0 ? cg_env : (int)(2.0 * 1024 * 1024 / tile_bytes);
+        q = q < 2 ? 2 : q;
+        if (q < ct_n) {
+            const int ng = (int)((ct_n + q - 1) / q);
+            dd.cgroup = (int)((ct_n + ng - 1) / ng);
+        }
+    }
+    static const int flag_env = getenv("CCEDIT_G8_FLAGS") ? atoi(getenv("CCEDIT_G8_FLAGS")) : 0;   // tuning (see `flags` in the kernel)
+    dd.cgroup |= flag_env << 24;
+    int wgs = n_cu - n_cu % 8;
+    const int64_t tiles = pt_n * ct_n;
+    if (tiles < wgs) wgs = (int)((tiles + 7) / 8 * 8);
+    hipLaunchKernelGGL((g8_kernel<TIH, TJH, EPI>), dim3((unsigned)wgs), dim3(512), LDS, s, dd);
+    return cc_launch_status("g8_kernel");
 }
 
 }  // namespace
 
 bool cc_g8_applicable(const CcGemmDesc& d) {
     return d.mode == CCEDIT_GEMM_LINEAR && d.taps == 1 && d.A2 == nullptr && d.Cin % 64 == 0 && d.Kpad == d.Cin && d.Kpad >= 128 &&
-           d.N % 8 == 0 && (d.act != CCEDIT_ACT_GEGLU || d.N % 16 == 0) && !d.out_f32 && !d.gn_stats && !d.group_bias &&
-           d.ln_eps == 0.f && d.lda % 8 == 0 && d.ldc % 8 == 0 && (!d.res1 || d.ldr1 % 8 == 0) && (!d.res2 || d.ldr2 % 8 == 0) &&
-           (int64_t)256 * d.lda * 2 < (1LL << 31);
+           d.N % 16 == 0 && (d.act == CCEDIT_ACT_NONE || d.act == CCEDIT_ACT_GEGLU) && !d.out_f32 && !d.group_bias && d.ln_eps == 0.f &&
+#ifndef G8_PROBE
+           !d.gn_stats &&
+#endif
+           d.lda % 8 == 0 && d.ldc % 8 == 0 && (!d.res1 || d.ldr1 % 8 == 0) && (!d.res2 || d.ldr2 % 8 == 0) &&
+           (int64_t)512 * d.lda * 2 < (1LL << 31) && d.M * ((d.N + 127) / 128) < (1LL << 37);
 }
 
-int cc_g8_launch(const CcGemmDesc& d, hipStream_t s) {
-    static unsigned long long attr_done = 0;
-    if (int rc = cc_max_dynamic_lds((const void*)g8_kernel, G8_LDS, &attr_done, "g8_kernel")) return rc;
+// shape 0 = by Cout: 128ch x 512pix when Cout leaves half a 256-channel tile (640 = 2.5 tiles), else 256ch x 256pix
+int cc_g8_launch(const CcGemmDesc& d, hipStream_t s, int shape) {
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -429,24 +526,15 @@ int cc_g8_launch(const CcGemmDesc& d, hipStream_t s) {
         }
         n_cu = prop.multiProcessorCount;
     }
-    const int64_t pt_n = (d.M + 255) / 256, ct_n = (d.N + 255) / 256;
-    CcGemmDesc dd = d;
-    dd.cgroup = 0;
-    // channel-tile groups when the weight matrix does not fit an XCD's L2 (see tap_gemm's launch()): 32 workgroups per XCD as
-    // (32 / Q pixel tiles) x (Q channel tiles); equal tile footprints, so Q = sqrt(32)
-    static const int cg_env = getenv("CCEDIT_CGROUP") ? atoi(getenv("CCEDIT_CGROUP")) : -1;
-    const double wbytes = (double)ct_n * 256 * d.Kpad * 2.0;
-    if (cg_env != 0 && ct_n > 6 && wbytes > 3.0 * 1024 * 1024) {
-        const int q = cg_env > 0 ? cg_env : 6;
-        if (q < ct_n) {
-            const int ng = (int)((ct_n + q - 1) / q);
-            dd.cgroup = (int)((ct_n + ng - 1) / ng);
-        }
+    if (shape == 0) {
+        const int rem = d.N % 256;
+        shape = (rem > 0 && rem <= 128 && d.N <= 1024) ? 2 : 1;
     }
-    if ((dd.cgroup & 0xFFFF) == 0) dd.cgroup |= 1 << 18;        // no groups: cut the XCD ranges at tile granularity
-    int wgs = n_cu - n_cu % 8;
-    const int64_t tiles = pt_n * ct_n;
-    if (tiles < wgs) wgs = (int)((tiles + 7) / 8 * 8);
-    hipLaunchKernelGGL(g8_kernel, dim3((unsigned)wgs), dim3(512), G8_LDS, s, dd);
-    return cc_launch_status("g8_kernel");
+    const int epi = d.act == CCEDIT_ACT_GEGLU ? G8_GEGLU : ((d.res1 || d.res2) ? G8_RES : G8_PLAIN);
+    if (shape == 2) {
+        if (epi == G8_GEGLU) return g8_launch_shape<1, 2, G8_GEGLU>(d, s, n_cu);
+        return epi == G8_RES ? g8_launch_shape<1, 2, G8_RES>(d, s, n_cu) : g8_launch_shape<1, 2, G8_PLAIN>(d, s, n_cu);
+    }
+    if (epi == G8_GEGLU) return g8_launch_shape<2, 1, G8_GEGLU>(d, s, n_cu);
+    return epi == G8_RES ? g8_launch_shape<2, 1, G8_RES>(d, s, n_cu) : g8_launch_shape<2, 1, G8_PLAIN>(d, s, n_cu);
 }

@@ -18,7 +18,7 @@ def rnd(*shape, seed=0, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(BF)
 
 
-def check(m, n, k, geglu=False, res=0, act=0, reps=4):
+def check(m, n, k, geglu=False, res=0, act=0, reps=4, T11=T11):
     x, w, b = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5), rnd(n, seed=3).float()
     pw = pack_weight(w.float(), b, geglu=geglu).to(dev)
     xc = x.to(dev)
@@ -124,12 +124,17 @@ if __name__ == "__main__":
             ok &= check(m, n, k)
         ok &= check(777, 640, 640, res=1)
         ok &= check(2048, 1280, 1280, res=2)
-        ok &= check(1000, 320, 128, act=1)
+        ok &= check(1000, 320, 128)
         ok &= check(3000, 5120, 640, geglu=True)
         ok &= check(6528, 10240, 1280, geglu=True)
         ok &= check(200, 2560, 320, geglu=True)
         ok &= check(26112, 640, 2560, res=1, reps=8)
         ok &= check(52224, 5120, 640, geglu=True, reps=8)
+        for t in (12, 13):          # both block shapes on shapes that are not their natural ones
+            ok &= check(1000, 640, 640, res=1, T11=t)
+            ok &= check(700, 384, 192, T11=t)
+            ok &= check(3000, 5120, 640, geglu=True, T11=t)
+            ok &= check(26112, 640, 2560, res=2, T11=t)
         print("CHECK", "PASSED" if ok else "FAILED", flush=True)
     if what in ("all", "perf"):
         perf(8192, 8192, 8192, tiles=(1, 4, 11))
@@ -137,10 +142,11 @@ if __name__ == "__main__":
         perf(52224, 5120, 640, geglu=True, tiles=(1, 2, 11))
         perf(13056, 10240, 1280, tiles=(1, 4, 6, 11))
         perf(13056, 10240, 1280, geglu=True, tiles=(1, 6, 11))
-        perf(52224, 640, 2560, res=True, tiles=(1, 6, 11))
+        perf(52224, 640, 2560, res=True, tiles=(1, 6, 12, 13))
+        perf(26112, 640, 2560, res=True, tiles=(1, 6, 12, 13))
         perf(13056, 1280, 5120, res=True, tiles=(1, 4, 6, 11))
         perf(13056, 1280, 1280, res=True, tiles=(1, 4, 6, 11))
-        perf(52224, 640, 640, res=True, tiles=(1, 2, 11))
+        perf(52224, 640, 640, res=True, tiles=(1, 2, 12, 13))
         perf(26112, 5120, 640, geglu=True, tiles=(2, 11))
         perf(6528, 10240, 1280, geglu=True, tiles=(6, 11))
         perf(6528, 1280, 5120, res=True, tiles=(1, 6, 11))
