@@ -477,6 +477,14 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         CC_UNSUPPORTED(!cc_g8_applicable(d), "ccedit_gemm: tile 11-13 (persistent eight-phase Linear) does not apply to this descriptor");
         return cc_g8_launch(d, s, d.tile - 11);
     }
+    // Long plain Linears (FF / GEGLU projections and the C -> C projections of the 32x48 and 16x24 levels): the persistent
+    // eight-phase kernel (gemm8p.hip).  Cold-operand sweep (tools/exp/g8_check.py), TF/s against the best older block shape:
+    //   52224 x 5120 <- 640 GEGLU 1030 / 713    13056 x 10240 <- 1280 GEGLU 1176 / 818    52224 x 640 <- 2560 + res 858 / 752
+    //   13056 x 1280 <- 5120 + res 1171 / 904   13056 x 1280 <- 1280 + res 814 / 553      52224 x 640 <- 640 + res 582 / 525
+    // and the single CFG halves (two-stream execution): 26112 x 5120 <- 640 GEGLU 945 / 588, 6528 x 10240 <- 1280 GEGLU 964 / 677.
+    // Not below 4096 rows (fewer than ~100 tiles: most CUs idle) and not for K = 320 (lin320 / ff320 own those).
+    static const int g8_env = getenv("CCEDIT_G8") ? atoi(getenv("CCEDIT_G8")) : 1;      // 0: A/B against the older block shapes
+    if (d.tile == 0 && g8_env && d.M >= 4096 && d.Kpad >= 640 && d.N >= 640 && cc_g8_applicable(d)) return cc_g8_launch(d, s, 0);
     CC_UNSUPPORTED(d.tile == 6 && d.N % 320 != 0, "ccedit_gemm: tile 6 (320-channel block shape) needs N %% 320 == 0 (N=%d)", d.N);
     int tile = d.tile;
     if (tile == 0) {

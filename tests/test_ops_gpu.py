@@ -60,6 +60,56 @@ def test_linear(m, n, k, tile):
     _close(y, F.linear(x, w, b), what=f"linear {m}x{n}x{k} tile{tile}")
 
 
+@pytest.mark.parametrize("tile", [11, 12, 13])
+@pytest.mark.parametrize("m,n,k,res,geglu", [(256, 256, 128, 0, False), (700, 384, 192, 0, False), (1000, 640, 640, 1, False),
+                                             (257, 1280, 2560, 2, False), (3000, 5120, 640, 0, True), (6528, 1280, 1280, 1, False),
+                                             (4200, 2560, 320, 0, True), (513, 656, 704, 1, False)])
+def test_linear_persistent_eight_phase(m, n, k, res, geglu, tile):
+    """tile 11-13 = g8_kernel (gemm8p.hip): persistent 256ch x 256pix / 128ch x 512pix workgroups, eight-phase K loop with counted
+    vmcnt, bias as accumulator init, wave-private LDS transposition in the epilogue.  Ragged M / N tiles, odd and even K tile
+    counts, several output tiles per workgroup (the prefetch of the next tile under the epilogue), all three epilogues — and the
+    same launch five times (a misplaced wait shows up as run-to-run differences long before it shows up as a wrong mean)."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    x, w, b = _rnd(m, k, seed=1), _rnd(n, k, seed=2, scale=k ** -0.5), _rnd(n, seed=3)
+    r1 = _rnd(m, n, seed=4) if res >= 1 else None
+    r2 = _rnd(m, n, seed=5) if res >= 2 else None
+    pw = pack_weight(w, b, geglu=geglu).to("cuda")
+    ref = F.linear(x, w, b)
+    if geglu:
+        a, g = ref.chunk(2, dim=-1)
+        ref = a * F.gelu(g)
+    for r in (r1, r2):
+        if r is not None:
+            ref = ref + r
+    kw = dict(res1=None if r1 is None else r1.to(BF).cuda(), res2=None if r2 is None else r2.to(BF).cuda(), tile=tile)
+    xc = x.to(BF).cuda()
+    y = ops.linear(xc, pw, **kw)
+    _close(y, ref, what=f"g8 {m}x{n}x{k} res{res} geglu{int(geglu)} tile{tile}")
+    for _ in range(4):
+        assert torch.equal(ops.linear(xc, pw, **kw), y), "g8: run-to-run difference"
+
+
+def test_linear_persistent_auto_dispatch_and_refusals():
+    """The automatic policy routes long Linears to the persistent kernel (same numbers as forcing it); epilogues it does not
+    implement are refused when forced, and fall back to the tiled kernel when not."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.hip import HipLibraryError
+    from ccedit_amd.packing import pack_weight
+    m, n, k = 4608, 1280, 1280
+    x, w, b = _rnd(m, k, seed=1), _rnd(n, k, seed=2, scale=k ** -0.5), _rnd(n, seed=3)
+    pw = pack_weight(w, b).to("cuda")
+    xc = x.to(BF).cuda()
+    assert torch.equal(ops.linear(xc, pw), ops.linear(xc, pw, tile=11))
+    _close(ops.linear(xc, pw, act=1), F.silu(F.linear(x, w, b)), what="SiLU epilogue falls back to the tiled kernel")
+    with pytest.raises(HipLibraryError):
+        ops.linear(xc, pw, act=1, tile=11)
+    with pytest.raises(HipLibraryError):
+        ops.linear(xc, pw, out_f32=True, tile=12)
+
+
 def test_linear_asymmetric_identity():
     """A = I against an asymmetric B catches a transposed C-write (guide rule 16)."""
     _dev()
