@@ -335,6 +335,28 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         if (wr == 0) g8_barrier();               // both halves level again: every fragment read of this tile is done
         G8_STAMP();
 
+        // ---- residual epilogue: the first residual's rows of the first two 64-channel x 32-pixel blocks are requested NOW —
+        // ahead of the next tile's operand requests in the memory queue; the other blocks two blocks ahead of their use ----
+        const bf16* __restrict__ r1 = (const bf16*)d.res1;
+        const bf16* __restrict__ r2 = (const bf16*)d.res2;
+        auto pixbase = [&](int tjf) { return (tjf / TJH) * (TJH * 128) + wc * (TJH * 32) + (tjf % TJH) * 32; };
+        constexpr int NSB = NJ * (CW / 64);                  // blocks: sb = tjf * (CW / 64) + cs
+        bf16x8 rv1[EPI == G8_RES ? NSB : 1][4];
+        auto load_r1 = [&](int sb) {          // unconditional (rows / channels clamped into the tensor): a conditional load would keep the
+            const int tjf = sb / (CW / 64), cs = sb % (CW / 64);      // registers alive around the whole persistent loop.  r1 != null here
+#pragma unroll                                                        // (the launcher moves a lone second residual into the first slot)
+            for (int j = 0; j < 4; ++j) {
+                const int64_t m = min(pix0 + pixbase(tjf) + 8 * j + (lane >> 3), d.M - 1);
+                const int cb = min(ch0 + wr * CW + cs * 64 + 8 * (lane & 7), d.N - 8);
+                rv1[sb][j] = *(const bf16x8*)(r1 + (size_t)m * d.ldr1 + cb);
+            }
+        };
+        if constexpr (EPI == G8_RES) {
+            load_r1(0);
+            load_r1(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
         // ---- next tile: request its first K tile now (buffer 0), it lands under the epilogue; buffer 1 is the epilogue's ----
         g += nw;
         const bool more = g < gend;
@@ -350,13 +372,10 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         // 16-byte pieces (measured: 8 us per 256 x 256 tile, the request rate of the vector memory path).  Each wave turns its
         // CW-channel x 32-pixel blocks around in 8 KB of its own (no workgroup barrier: LDS executes a wave's accesses in order)
         // and then stores 16 bytes per lane with consecutive lanes walking a pixel's channels.
-        const bf16* __restrict__ r1 = (const bf16*)d.res1;
-        const bf16* __restrict__ r2 = (const bf16*)d.res2;
         bf16* __restrict__ outp = (bf16*)d.out;
         const bool st = !(flags & 1);
         char* const stg = smem + BUF + wave * 8192;
         const int chw = ch0 + wr * CW;                                   // this wave's first channel (packed row)
-        auto pixbase = [&](int tjf) { return (tjf / TJH) * (TJH * 128) + wc * (TJH * 32) + (tjf % TJH) * 32; };
         if constexpr (EPI == G8_GEGLU) {
             // packed rows 16 g + [0, 8) are values, + [8, 16) their gates: a 32-row tile yields 16 output channels
             constexpr int RB = CW, G = RB / 16;                          // staged row: CW / 2 bf16 outputs of one pixel
@@ -391,12 +410,6 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                     const int cb64 = chw + cs * 64;
                     // this lane's part of the block: pixel rows 8 j + lane / 8, channels cb64 + 8 (lane % 8) .. + 7
                     const int c = lane & 7, cb = cb64 + 8 * c;
-                    bf16x8 rv1[4];                 // first residual: requested before the block is turned around (a second one is rare)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int64_t m = pix0 + pixbase(tjf) + 8 * j + (lane >> 3);
-                        if (r1 && m < d.M && cb < d.N) rv1[j] = *(const bf16x8*)(r1 + (size_t)m * d.ldr1 + cb);
-                    }
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -415,10 +428,8 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                         float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
                         const int64_t m = pix0 + pixbase(tjf) + row;
                         if (m < d.M && cb < d.N) {
-                            if (r1) {
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) v[e] += bf2f(rv1[j][e]);
-                            }
+                            for (int e = 0; e < 8; ++e) v[e] += bf2f(rv1[tjf * (CW / 64) + cs][j][e]);
                             if (r2) {
                                 const bf16x8 rv2 = *(const bf16x8*)(r2 + (size_t)m * d.ldr2 + cb);
 #pragma unroll
@@ -430,6 +441,8 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                             if (st) *(bf16x8*)(outp + (size_t)m * d.ldc + cb) = o;
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tjf * (CW / 64) + cs + 2 < NSB) load_r1(tjf * (CW / 64) + cs + 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -466,9 +479,14 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         g8_barrier();                            // every wave is done with its staging block in buffer 1
         if (flags & 2) prologue_a();
         prologue_b();
-        // K tile 0 of the next tile has landed: at most the KEEP requests just issued are outstanding — loads complete in order,
-        // so whatever else is still counted (stores of the epilogue) only makes this wait longer, never shorter
-        g8_vmcnt<KEEP>();
+        // K tile 0 of the next tile has landed.  Loads complete in order among themselves (stores are counted by vmcnt too, but
+        // may be acknowledged in any order relative to loads).  K tile 0 was requested BEFORE the epilogue; younger loads are the
+        // 16 bias loads of init_acc and the KEEP requests just issued.  If any K-tile-0 request were still outstanding, all of
+        // those would be too, i.e. more than KEEP + 16 operations — so a count of at most KEEP + 12 (margin: the compiler may merge
+        // bias loads) proves it has landed WITHOUT waiting for the epilogue's stores to be acknowledged (measured: ~1.5 us per tile).
+        // Without a bias there is no such padding and the count is KEEP.
+        if (d.bias) g8_vmcnt<KEEP + 12>();
+        else g8_vmcnt<KEEP>();
     }
 }
 
@@ -481,6 +499,11 @@ int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu) {
     const int64_t pt_n = (d.M + BN - 1) / BN, ct_n = (d.N + BM - 1) / BM;
     CcGemmDesc dd = d;
     dd.cgroup = 0;
+    if (!dd.res1 && dd.res2) {          // the residual epilogue always has a FIRST residual
+        dd.res1 = dd.res2;
+        dd.ldr1 = dd.ldr2;
+        dd.res2 = nullptr;
+    }
     // channel-tile groups when the weight matrix does not fit an XCD's 4 MB L2 beside the activation tiles in flight: the largest
     // group of at most ~2 MB of weight rows, evened out over the groups
     static const int cg_env = getenv("CCEDIT_CGROUP") ? atoi(getenv("CCEDIT_CGROUP")) : -1;     // tuning: -1 auto, 0 off, n fixed

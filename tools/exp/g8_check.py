@@ -137,16 +137,17 @@ if __name__ == "__main__":
             ok &= check(26112, 640, 2560, res=2, T11=t)
         print("CHECK", "PASSED" if ok else "FAILED", flush=True)
     if what in ("all", "perf"):
-        perf(8192, 8192, 8192, tiles=(1, 4, 11))
-        perf(52224, 5120, 640, tiles=(1, 2, 4, 11))
-        perf(52224, 5120, 640, geglu=True, tiles=(1, 2, 11))
-        perf(13056, 10240, 1280, tiles=(1, 4, 6, 11))
-        perf(13056, 10240, 1280, geglu=True, tiles=(1, 6, 11))
-        perf(52224, 640, 2560, res=True, tiles=(1, 6, 12, 13))
-        perf(26112, 640, 2560, res=True, tiles=(1, 6, 12, 13))
-        perf(13056, 1280, 5120, res=True, tiles=(1, 4, 6, 11))
-        perf(13056, 1280, 1280, res=True, tiles=(1, 4, 6, 11))
-        perf(52224, 640, 640, res=True, tiles=(1, 2, 12, 13))
+        perf(8192, 8192, 8192, tiles=(4, 11))
+        perf(52224, 5120, 640, tiles=(1, 11))
+        perf(52224, 5120, 640, geglu=True, tiles=(2, 11))
+        perf(13056, 10240, 1280, tiles=(6, 11))
+        perf(13056, 10240, 1280, geglu=True, tiles=(6, 11))
+        perf(52224, 640, 2560, res=True, tiles=(1, 12, 13))
+        perf(26112, 640, 2560, res=True, tiles=(1, 13))
+        perf(13056, 1280, 5120, res=True, tiles=(4, 11))
+        perf(13056, 1280, 1280, res=True, tiles=(4, 11))
+        perf(13056, 1280, 1280, tiles=(4, 11))
+        perf(52224, 640, 640, res=True, tiles=(1, 13))
         perf(26112, 5120, 640, geglu=True, tiles=(2, 11))
         perf(6528, 10240, 1280, geglu=True, tiles=(6, 11))
-        perf(6528, 1280, 5120, res=True, tiles=(1, 6, 11))
+        perf(6528, 1280, 5120, res=True, tiles=(1, 11))
