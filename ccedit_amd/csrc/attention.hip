@@ -346,6 +346,7 @@ int launch_attn(const CcAttnDesc& a, hipStream_t s) {
     const int64_t qtiles = (a.Lq + NW * 32 - 1) / (NW * 32);
     const int64_t groups = ((int64_t)a.batches * a.heads + 7) / 8 * 8;
     dim3 grid((unsigned)(qtiles * groups));
+    cc_note_kernel("attn_kernel d=%d", D);
     hipLaunchKernelGGL((attn_kernel<D, NW>), grid, dim3(NW * 64), a.Lk <= 64 ? lds / 2 : lds, s, a);
     return cc_launch_status("attn_kernel");
 }

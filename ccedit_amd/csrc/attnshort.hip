@@ -228,6 +228,7 @@ int launch_short(const CcAttnDesc& a, hipStream_t s) {
     const int lds = (2 * a.Lq + 2 * a.Lk) * RS;
     const int per_cu = 160 * 1024 / lds < 4 ? 160 * 1024 / lds : 4;          // resident workgroups per CU (LDS / 16 waves)
     const int64_t grid = nblk < 256 * per_cu ? nblk : 256 * per_cu;
+    cc_note_kernel("attn_short_kernel d=%d", D);
     hipLaunchKernelGGL((attn_short_kernel<D>), dim3((unsigned)grid), dim3(256), lds, s, a, (int)nblk);
     return cc_launch_status("attn_short_kernel");
 }

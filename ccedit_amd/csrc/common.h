@@ -56,6 +56,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 void cc_set_error(const char* fmt, ...);
+void cc_note_kernel(const char* fmt, ...);      // which kernel template the entry point dispatched to (ccedit_last_kernel)
 
 #define CC_CHECK_ARG(cond, ...)          \
     do {                                 \

@@ -15,6 +15,18 @@ void cc_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local char g_kernel[96] = "";
+
+// Name of the kernel template a GEMM / attention entry point dispatched to (for per-kernel roofline accounting in bench.py)
+void cc_note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* ccedit_last_kernel(void) { return g_kernel; }
+
 extern "C" int ccedit_abi_version(void) { return CCEDIT_ABI_VERSION; }
 
 extern "C" const char* ccedit_last_error(void) { return g_err; }

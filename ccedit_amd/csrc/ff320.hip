@@ -361,6 +361,7 @@ extern "C" int ccedit_ff320(const CcFf320Desc* desc, void* stream) {
         }
     }
     const int grid = (int)(rounds < cus ? rounds : cus);
+    cc_note_kernel("ff320_kernel");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 2 * kChunkBytes, (hipStream_t)stream, d, (int)rounds);
     return cc_launch_status("ff320_kernel");
 }

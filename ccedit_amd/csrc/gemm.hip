@@ -387,6 +387,7 @@ int launch(const CcGemmDesc& d, hipStream_t s) {
         nblk = 8 * ((pt_n * ct_n + 7) / 8);
     }
     dim3 grid((unsigned)nblk);
+    cc_note_kernel("tap_gemm_kernel %dch x %dpix, %d stages of K=%d", BMC, BNP, STAGES, BKE);
     hipLaunchKernelGGL((tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>), grid, dim3(WM * WN * 64), lds, s, dd);
     return cc_launch_status("tap_gemm_kernel");
 }
@@ -460,6 +461,14 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
                        "ccedit_gemm: gn_stats needs N%%32==0, N>=256, bf16 output, no GEGLU (N=%d)", d.N);
     }
     hipStream_t s = (hipStream_t)stream;
+    // ln_eps: only lin320_kernel normalises its rows; every other kernel would multiply the gamma / beta-folded weights with
+    // un-normalised rows.  Whatever block shape the caller asked for: that kernel, or a refusal — never a silently wrong product.
+    if (d.ln_eps != 0.f) {
+        CC_UNSUPPORTED(!(d.tile == 0 || d.tile == 9) || !cc_lin320_applicable(d),
+                       "ccedit_gemm: ln_eps needs the register-resident K = 320 kernel (block shape 0 / 9, plain Linear with K = 320 "
+                       "and N %% 320 == 0, no activation / residual): not applicable to this descriptor");
+        return cc_lin320_launch(d, s);
+    }
     if (d.tile == 0 && cc_small_conv_applicable(d)) return cc_small_conv_launch(d, s);     // few-channel 3x3 (hint stem top)
     static const int halo_env = getenv("CCEDIT_CONV_HALO") ? atoi(getenv("CCEDIT_CONV_HALO")) : 1;   // 0: A/B against the gather path
     if ((d.tile == 0 && halo_env) || d.tile == 8) {

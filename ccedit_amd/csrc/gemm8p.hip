@@ -521,6 +521,7 @@ int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu) {
     int wgs = n_cu - n_cu % 8;
     const int64_t tiles = pt_n * ct_n;
     if (tiles < wgs) wgs = (int)((tiles + 7) / 8 * 8);
+    cc_note_kernel("g8_kernel %dch x %dpix", BM, BN);
     hipLaunchKernelGGL((g8_kernel<TIH, TJH, EPI>), dim3((unsigned)wgs), dim3(512), LDS, s, dd);
     return cc_launch_status("g8_kernel");
 }

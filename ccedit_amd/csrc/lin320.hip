@@ -304,6 +304,7 @@ int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s) {
         cc_set_error("ccedit_gemm: grid too large");
         return CCEDIT_EUNSUPPORTED;
     }
+    cc_note_kernel("lin320_kernel");
     if (geglu) hipLaunchKernelGGL((lin320_kernel<true, false, false>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
     else if (d.res1) hipLaunchKernelGGL((lin320_kernel<false, true, false>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
     else if (d.ln_eps != 0.f) hipLaunchKernelGGL((lin320_kernel<false, false, true>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);

@@ -103,6 +103,7 @@ int cc_small_conv_launch(const CcGemmDesc& d, hipStream_t s) {
     while (gpw > 1 && groups / (4 * gpw) < 4096) gpw >>= 1;
     const int64_t blocks = (groups + 4 * gpw - 1) / (4 * gpw);
     dim3 grid((unsigned)blocks);
+    cc_note_kernel("small_conv3x3_kernel");
     if (d.Cin == 8) hipLaunchKernelGGL(small_conv3x3_kernel<8>, grid, dim3(256), 0, s, d, gpw);
     else if (d.Cin == 16) hipLaunchKernelGGL(small_conv3x3_kernel<16>, grid, dim3(256), 0, s, d, gpw);
     else hipLaunchKernelGGL(small_conv3x3_kernel<32>, grid, dim3(256), 0, s, d, gpw);

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the library is loaded: to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCEDIT_HIP_LIB") or os.path.join(_HERE, "libccedit_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 GEMM_LINEAR, GEMM_CONV2D, GEMM_TEMPORAL = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
@@ -67,6 +67,7 @@ _lib: Optional[C.CDLL] = None
 _SIGS = {
     "ccedit_abi_version": (C.c_int, []),
     "ccedit_last_error": (C.c_char_p, []),
+    "ccedit_last_kernel": (C.c_char_p, []),
     "ccedit_device_info": (C.c_int, [C.c_char_p, C.c_int]),
     "ccedit_gemm": (C.c_int, [C.POINTER(CcGemmDesc), C.c_void_p]),
     "ccedit_ff320": (C.c_int, [C.POINTER(CcFf320Desc), C.c_void_p]),

@@ -539,14 +539,18 @@ def _check_supported(kw: dict, who: str):
 
 
 class EmbOut:
-    """emb_layers outputs of all ResBlocks of one network evaluation: fp32 (B, sum Cout); `of(block)` = that block's columns."""
+    """emb_layers outputs of all ResBlocks of one network evaluation: fp32 (B, sum Cout); `of(block)` = that block's columns.
+    The column slice lives ON the block (`_emb_slice`, written by `_pack_emb`): copies of a packed model keep working, and a
+    block that was never packed into the batched projection is an error, not a stale lookup."""
 
-    def __init__(self, e_all: torch.Tensor, offsets: dict):
-        self.e_all, self.offsets = e_all, offsets
+    def __init__(self, e_all: torch.Tensor, owner=None):
+        self.e_all, self.owner = e_all, owner
 
     def of(self, block) -> torch.Tensor:
-        off, c = self.offsets[id(block)]
-        return self.e_all[:, off:off + c]
+        sl = getattr(block, "_emb_slice", None)
+        if sl is None or sl[0] + sl[1] > self.e_all.shape[1]:
+            raise RuntimeError("ResBlock is not part of the packed timestep-embedding projection: call pack() after changing modules")
+        return self.e_all[:, sl[0]:sl[0] + sl[1]]
 
 
 class UNetModel(nn.Module):
@@ -628,14 +632,16 @@ class UNetModel(nn.Module):
         te = ops.timestep_embedding(timesteps, self.model_channels)
         h = ops.linear(te, self.time_embed[0].pw, act=ACT_SILU)
         e = ops.silu(ops.linear(h, self.time_embed[2].pw))
-        return EmbOut(ops.linear(e, self._emb_all, out_f32=True), self._emb_off)
+        return EmbOut(ops.linear(e, self._emb_all, out_f32=True), self)
 
     def _pack_emb(self, device):
         blocks = [m for m in self.modules() if isinstance(m, (ResBlock, ResBlock3D)) and self._owns(m)]
-        self._emb_off, off = {}, 0
+        off = 0
         for m in blocks:
-            self._emb_off[id(m)] = (off, m.emb_layers[1].cout)
-            off += m.emb_layers[1].cout
+            c = m.emb_layers[1].cout
+            assert c % 8 == 0, "the conv epilogue reads the per-clip bias rows as 16-byte pieces"
+            m._emb_slice = (off, c)
+            off += c
         self._emb_all = pack_concat([m.emb_layers[1].weight for m in blocks], [m.emb_layers[1].bias for m in blocks], device=device)
 
     def _owns(self, block) -> bool:

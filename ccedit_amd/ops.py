@@ -29,13 +29,25 @@ class LaunchProfile:
         self.records = {}          # family -> list of (start_event, end_event, algorithmic_flops, algorithmic_bytes)
 
     def add(self, family, e0, e1, flops, nbytes, shape=None):
-        self.records.setdefault(family, []).append((e0, e1, flops, nbytes, shape))
+        k = hip.lib().ccedit_last_kernel()           # the kernel template the entry point just dispatched to
+        self.records.setdefault(family, []).append((e0, e1, flops, nbytes, shape, k.decode() if k else "?"))
+
+    def by_kernel(self, families=("tap_gemm", "attention")):
+        """[{kernel, launches, ms, tflops}] over the given families, sorted by time."""
+        torch.cuda.synchronize()
+        acc = {}
+        for fam in families:
+            for a, b, fl, _, _, k in self.records.get(fam, []):
+                n, ms, f = acc.get(k, (0, 0.0, 0.0))
+                acc[k] = (n + 1, ms + a.elapsed_time(b), f + fl)
+        return sorted(({"kernel": k, "launches": n, "ms": ms, "tflops": f / (ms * 1e-3) / 1e12} for k, (n, ms, f) in acc.items()),
+                      key=lambda r: -r["ms"])
 
     def by_shape(self, family):
         """{shape: (launches, total_ms, tflops)} sorted by time."""
         torch.cuda.synchronize()
         acc = {}
-        for a, b, fl, _, shape in self.records.get(family, []):
+        for a, b, fl, _, shape, _k in self.records.get(family, []):
             n, ms, f = acc.get(shape, (0, 0.0, 0.0))
             acc[shape] = (n + 1, ms + a.elapsed_time(b), f + fl)
         return sorted(((k, n, ms, f / (ms * 1e-3) / 1e12) for k, (n, ms, f) in acc.items()), key=lambda r: -r[2])

@@ -271,10 +271,17 @@ class FrameShard:
     def cfg_pair(t_glob: int, groups=(None, None), mode: str = "a2a"):
         """Shards for the two CFG halves of a step: the second one puts its longer shards on the LAST ranks, so the
         2 x t_glob frame instances are spread as evenly as whole frames allow (17 over 8: 5,4,4,4,4,4,4,5).  `groups`:
-        one process group per half (two communicators let the halves' exchanges proceed independently on two
-        streams); (None, None) uses the default group for both."""
-        return (FrameShard(t_glob, group=groups[0], mode=mode),
-                FrameShard(t_glob, group=groups[1], mode=mode, heavy_last=True))
+        one process group per half — the halves run on two streams, and on ONE communicator the exchanges of half 1 would
+        queue behind all of half 0's (correct, but serialised: the advertised overlap needs two).  When the second group is not
+        given and torch.distributed is initialised with more than one rank, it is created here over the same ranks
+        (`dist.new_group` is collective: every rank calls cfg_pair at the same point, as bench.py and the tests do)."""
+        g0, g1 = groups
+        if g1 is None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(g0) > 1:
+                ranks = list(range(dist.get_world_size())) if g0 is None else dist.get_process_group_ranks(g0)
+                g1 = dist.new_group(ranks)
+        return (FrameShard(t_glob, group=g0, mode=mode), FrameShard(t_glob, group=g1, mode=mode, heavy_last=True))
 
     def _global_rank(self, r: int) -> int:
         return r if self.group is None else self.dist.get_global_rank(self.group, r)

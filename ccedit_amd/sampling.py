@@ -117,10 +117,9 @@ class Img2ImgDiscretizationWrapper:
         assert 0.0 <= self.strength <= 1.0
 
     def __call__(self, *args, **kwargs):
-        sigmas = self.discretization(*args, **kwargs)
-        sigmas = torch.flip(sigmas, (0,))
-        sigmas = sigmas[: max(int(self.strength * len(sigmas)), 1)]
-        return torch.flip(sigmas, (0,))
+        full = self.discretization(*args, **kwargs)                 # descending, trailing zero included
+        keep = max(int(self.strength * len(full)), 1)
+        return full[len(full) - keep:]                              # the `keep` smallest sigmas, order unchanged
 
 
 class EpsWeighting:
@@ -159,11 +158,7 @@ class Denoiser(nn.Module):
     def __call__(self, network, input, sigma, cond):
         sigma = self.possibly_quantize_sigma(sigma.detach().to("cpu", torch.float32))
         c_skip, c_out, c_in, c_noise = self.scaling(sigma)
-        c_noise = self.possibly_quantize_c_noise(c_noise)
-        if c_noise.dtype == torch.int64:
-            c_noise_dev = c_noise.to(input.device)
-        else:
-            c_noise_dev = c_noise.to(input.device)
+        c_noise_dev = self.possibly_quantize_c_noise(c_noise).to(input.device)     # int64 table indices (discrete) or sigmas
         b = input.shape[0]
         x = input.float().contiguous()
         xs = torch.empty_like(x)
@@ -310,18 +305,32 @@ class BaseDiffusionSampler:
         return self.guider(denoised, sigma)
 
     def get_sigma_gen(self, num_sigmas):
-        gen = range(num_sigmas - 1)
-        if self.verbose:
-            print("#" * 30, " Sampling setting ", "#" * 30)
-            print(f"Sampler: {self.__class__.__name__}")
-            print(f"Discretization: {self.discretization.__class__.__name__}")
-            print(f"Guider: {self.guider.__class__.__name__}")
-            try:
-                from tqdm import tqdm
-                gen = tqdm(gen, total=num_sigmas, desc=f"Sampling with {self.__class__.__name__} for {num_sigmas} steps")
-            except ImportError:      # pragma: no cover
-                pass
-        return gen
+        """Step indices 0 .. num_sigmas - 2 (name kept: reference scripts call it); verbose wraps them in a progress bar."""
+        steps = range(num_sigmas - 1)
+        if not self.verbose:
+            return steps
+        what = f"{type(self).__name__} / {type(self.discretization).__name__} / {type(self.guider).__name__}"
+        try:
+            from tqdm import tqdm
+        except ImportError:      # pragma: no cover
+            print(f"[sampler] {what}: {num_sigmas - 1} steps")
+            return steps
+        return tqdm(steps, total=num_sigmas - 1, desc=what)
+
+    def _walk(self, denoiser, x, cond, uc, num_steps, before_step=None, first_step=0, step_kwargs=None):
+        """The loop every sampler entry point shares: (sigma_i, sigma_{i+1}) pairs of the schedule into `sampler_step`.
+        before_step(x, i, sigmas) -> x edits the latent ahead of a step (inpainting / blending variants); first_step(num_sigmas)
+        skips the head of the schedule (SDEdit); step_kwargs(i, sigmas, num_sigmas) adds per-step arguments (EDM churn)."""
+        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        start = first_step(num_sigmas) if callable(first_step) else first_step
+        for i in self.get_sigma_gen(num_sigmas):
+            if i < start:
+                continue
+            if before_step is not None:
+                x = before_step(x, i, sigmas)
+            extra = step_kwargs(i, sigmas, num_sigmas) if step_kwargs is not None else {}
+            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, **extra)
+        return x
 
 
 class SingleStepDiffusionSampler(BaseDiffusionSampler):
@@ -363,37 +372,23 @@ class AncestralSampler(SingleStepDiffusionSampler):
         return x
 
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None):
-        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
-        for i in self.get_sigma_gen(num_sigmas):
-            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc)
-        return x
+        return self._walk(denoiser, x, cond, uc, num_steps)
 
     def sample_inpainting(self, denoiser, x, cond, x0, mask, uc=None, num_steps=None):
         """sampling.py:206-225: before every step the region with mask == 0 is reset to the noised original."""
-        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
-        for i in self.get_sigma_gen(num_sigmas):
-            x = self._inpaint_blend(x, x0, mask, sigmas[i])
-            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc)
-        return x
+        return self._walk(denoiser, x, cond, uc, num_steps, before_step=lambda x, i, sig: self._inpaint_blend(x, x0, mask, sig[i]))
 
     def sampling_blending(self, denoiser, x, cond, x0, uc=None, num_steps=None):
         """sampling.py:227-249: the first T//2 frames are overwritten with the noised LAST T//2 frames of x0."""
-        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
-        t = x.shape[2]
-        for i in self.get_sigma_gen(num_sigmas):
-            img_orig = self._noised_original(x0, sigmas[i])
-            x[:, :, : t // 2] = img_orig[:, :, t // 2 + 1:]
-            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc)
-        return x
+        def overwrite_head(x, i, sig):
+            half = x.shape[2] // 2
+            x[:, :, :half] = self._noised_original(x0, sig[i])[:, :, half + 1:]
+            return x
+        return self._walk(denoiser, x, cond, uc, num_steps, before_step=overwrite_head)
 
     def sdedit(self, denoise_steps, denoiser, x, cond, uc=None, num_steps=None):
         """sampling.py:251-266: run only the last `denoise_steps` steps of the schedule."""
-        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
-        for i in self.get_sigma_gen(num_sigmas):
-            if i < num_sigmas - 1 - denoise_steps:
-                continue
-            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc)
-        return x
+        return self._walk(denoiser, x, cond, uc, num_steps, first_step=lambda n: n - 1 - denoise_steps)
 
 
 class EulerAncestralSampler(AncestralSampler):
@@ -459,21 +454,18 @@ class EDMSampler(SingleStepDiffusionSampler):
     def possible_correction_step(self, euler_step, x, denoised, sigma_hat, dt, next_sigma, denoiser, cond, uc):
         raise NotImplementedError
 
+    def _churn(self, i, sigmas, num_sigmas):
+        """gamma of step i: s_churn spread over the steps (capped at sqrt(2) - 1) while sigma_i lies in [s_tmin, s_tmax], else 0."""
+        inside = self.s_tmin <= sigmas[i] <= self.s_tmax
+        return dict(gamma=min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if inside else 0.0)
+
     def __call__(self, denoiser, x, cond, uc=None, num_steps=None):
-        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
-        for i in self.get_sigma_gen(num_sigmas):
-            gamma = min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if self.s_tmin <= sigmas[i] <= self.s_tmax else 0.0
-            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, gamma)
-        return x
+        return self._walk(denoiser, x, cond, uc, num_steps, step_kwargs=self._churn)
 
     def sample_inpainting(self, denoiser, x, cond, x0, mask, uc=None, num_steps=None):
         """sampling.py:138-166."""
-        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
-        for i in self.get_sigma_gen(num_sigmas):
-            gamma = min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if self.s_tmin <= sigmas[i] <= self.s_tmax else 0.0
-            x = self._inpaint_blend(x, x0, mask, sigmas[i])
-            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, gamma)
-        return x
+        return self._walk(denoiser, x, cond, uc, num_steps, step_kwargs=self._churn,
+                          before_step=lambda x, i, sig: self._inpaint_blend(x, x0, mask, sig[i]))
 
 
 class EulerEDMSampler(EDMSampler):

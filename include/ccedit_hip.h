@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCEDIT_ABI_VERSION 6
+#define CCEDIT_ABI_VERSION 7
 
 #define CCEDIT_OK 0
 #define CCEDIT_EINVAL (-1)       /* null pointer / bad size */
@@ -37,6 +37,9 @@ extern "C" {
 
 int ccedit_abi_version(void);
 const char* ccedit_last_error(void);
+/* name of the kernel template the last ccedit_gemm / ccedit_ff320 / ccedit_attention call of this thread dispatched to
+ * ("g8_kernel 256x256", "conv_halo_kernel", "tap_gemm_kernel 128x128 s2", ...): bench.py's per-kernel roofline table */
+const char* ccedit_last_kernel(void);
 /* fills name with hipDeviceProp_t.gcnArchName of the current device; returns CU count or <0 */
 int ccedit_device_info(char* name, int name_len);
 
@@ -95,7 +98,8 @@ typedef struct CcGemmDesc {
     int32_t cgroup;       /* internal (set by the library): block-order parameters; pass 0 */
     int32_t ldgb;         /* row stride of group_bias in elements; 0 = N (rows of a wider matrix: all ResBlocks' emb_layers
                            * projections of one network come out of ONE GEMM, each layer reads its column slice) */
-    float ln_eps;         /* 0 = off.  > 0 (Linear, K = 320, >= 32k rows, no activation / residual: block shape 9 only): every row of
+    float ln_eps;         /* 0 = off.  > 0 (Linear, K = 320, N % 320 == 0, no activation / residual; tile 0 or 9 — the call always runs the
+                           * register-resident-weights kernel and is REFUSED with CCEDIT_EUNSUPPORTED otherwise): every row of
                            * A is LayerNorm-normalised WITHOUT affine, (x - mean) * rsqrt(var + ln_eps) rounded to bf16, before the
                            * product — `to_q(norm(x))` of attention.py:695-716 with gamma / beta folded into W / bias by the caller
                            * (W diag(gamma), b + W beta: ccedit_amd/packing.py:fold_layernorm) */

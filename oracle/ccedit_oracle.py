@@ -273,9 +273,14 @@ def _sdpa(q, k, v):
         return F.scaled_dot_product_attention(q, k, v)
     # HIP kernels: fp32 scores, probabilities rounded to bf16 where they enter the P.V MFMA, the row sum taken from those
     # rounded values (a ones column in the same MFMA), the normalised output stored as bf16
-    s = (q @ k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
-    pb = _R(torch.exp(s - s.amax(dim=-1, keepdim=True)))
-    return _R((pb @ v) / pb.sum(dim=-1, keepdim=True))
+    def one(q, k, v):
+        s = (q @ k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
+        pb = _R(torch.exp(s - s.amax(dim=-1, keepdim=True)))
+        return _R((pb @ v) / pb.sum(dim=-1, keepdim=True))
+    # rows are independent: long sequences go one batch entry at a time (a 17-frame 6144 x 6144 score tensor is 41 GB)
+    if q.shape[0] > 1 and q.shape[0] * q.shape[1] * q.shape[2] * k.shape[2] > (1 << 29):
+        return torch.cat([one(q[i:i + 1], k[i:i + 1], v[i:i + 1]) for i in range(q.shape[0])])
+    return one(q, k, v)
 
 
 def cross_attention(sd: SD, p: str, x, context, heads: int, res=None):

@@ -80,6 +80,8 @@ class FrozenCLIPEmbedder(AbstractEmbModel):
         self.transformer = CLIPTextModel()
         self._tokenizer = None
 
+    _expected_vocab = (49408, 49406, 49407)      # (entries, <|startoftext|>, <|endoftext|>) of openai/clip-vit-large-patch14
+
     def freeze(self):
         self.transformer = self.transformer.eval()
         for p in self.parameters():
@@ -94,8 +96,15 @@ class FrozenCLIPEmbedder(AbstractEmbModel):
             try:
                 from transformers import CLIPTokenizer
                 tok = CLIPTokenizer.from_pretrained(self.tokenizer_path, local_files_only=True)
-                if len(tok) < 256:          # recent transformers build an EMPTY tokenizer when the files are missing
+                # The ids index the 49408-row CLIP ViT-L/14 embedding table: only THAT vocabulary is accepted (recent transformers
+                # build an empty tokenizer when the files are missing; a different or truncated BPE table would condition on the
+                # wrong rows or run past the table).  Tests swap the expectation through _expected_vocab.
+                want = self._expected_vocab
+                if len(tok) < 16:
                     raise FileNotFoundError(f"vocabulary of {self.tokenizer_path} not found locally ({len(tok)} entries)")
+                if want is not None and (len(tok) != want[0] or tok.bos_token_id != want[1] or tok.eos_token_id != want[2]):
+                    raise FileNotFoundError(f"{self.tokenizer_path}: {len(tok)} entries, bos {tok.bos_token_id}, eos {tok.eos_token_id} — "
+                                            f"not the CLIP ViT-L/14 vocabulary (expected {want})")
                 self._tokenizer = tok
             except Exception as e:          # no vocabulary files offline
                 raise NotImplementedError(

@@ -28,7 +28,7 @@ def test_header_symbols_exported(libpath):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ccedit_hip.h but not exported"
     lib.ccedit_abi_version.restype = ctypes.c_int
-    assert lib.ccedit_abi_version() == 6
+    assert lib.ccedit_abi_version() == 7
 
 
 def test_binding_matches_header(libpath):
@@ -53,6 +53,27 @@ def test_invalid_arguments_are_reported_not_crashing(libpath):
     assert rc == -2 and b"multiple of 4" in lib.ccedit_last_error()
     a = hip.CcAttnDesc()
     assert lib.ccedit_attention(ctypes.byref(a), None) == -1
+
+
+def test_ln_eps_is_refused_where_no_kernel_normalises(libpath):
+    """CcGemmDesc.ln_eps folds a LayerNorm into the GEMM; only the K = 320 register-resident kernel implements it.  Any other
+    block shape or geometry must be refused — a kernel that ignored the field would multiply gamma / beta-folded weights with
+    un-normalised rows and return a plausible, wrong tensor."""
+    from ccedit_amd import hip
+    lib = hip.lib()
+
+    def desc(cin, n, tile):
+        d = hip.CcGemmDesc()
+        d.M, d.N, d.Cin, d.Cin1, d.taps, d.Kpad = 4096, n, cin, cin, 1, cin
+        d.A = d.W = d.out = 1
+        d.lda, d.ldc, d.tile, d.ln_eps = cin, n, tile, 1e-5
+        return d
+    for cin, n, tile in ((320, 320, 1), (320, 320, 2), (320, 320, 11), (640, 320, 0), (320, 256, 0), (320, 320, 6)):
+        rc = lib.ccedit_gemm(ctypes.byref(desc(cin, n, tile)), None)
+        assert rc == -2 and b"ln_eps" in lib.ccedit_last_error(), (cin, n, tile, rc, lib.ccedit_last_error())
+    d = desc(320, 320, 0)
+    d.res1, d.ldr1 = 1, 320                     # a residual epilogue is not available together with the normalisation either
+    assert lib.ccedit_gemm(ctypes.byref(d), None) == -2
 
 
 def test_product_never_imports_oracle():

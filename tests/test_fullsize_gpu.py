@@ -84,3 +84,66 @@ def test_full_size_tvi2v_properties(tmp_path):
     e = _rel(fast["eps"], gen["eps"])
     print(f"full size TVI2V: fast vs generic kernels: eps {e:.4f}")
     assert e < 3.5e-2, e
+
+
+# ------------------------------------------------------------------------------------------
+# Full-size shapes tied to the ORACLE.  The properties above compare HIP kernels with HIP kernels; here single
+# blocks of the network run at the production geometry — one CFG half, T = 17 keyframes, latent 64x96 / 32x48 / 16x24, shipped
+# widths — on a generated input, teacher-forced against the bf16-emulating oracle (oracle/ccedit_oracle.py, the restatement the
+# reference goldens pin).  These are the launches the 17x512x768 step really makes: conv_halo at 64x96 and 32x48, the persistent
+# eight-phase Linears (gemm8p) at M = 26112, lin320 / ff320 at M = 104448, attn_kernel<40,8> at 6144^2, attn_short at T = 17, the
+# temporal convs and GroupNorms at 17 rows.  One level-0 block is ~1.8 TFLOP on the host: tens of seconds on the box's cores.
+# ------------------------------------------------------------------------------------------
+def _oracle_block(O, sd, cfg, name, x5, emb, ctx):
+    """The oracle's statements for one UNet block (unet3d_forward, controlmodel.py:471-550), input already concatenated."""
+    inputs, _, outputs = O.unet_topology(cfg)
+    kind, i = name.rsplit(".", 1)
+    spec = (inputs if kind == "input_blocks" else outputs)[int(i)]
+    bp = f"model.diffusion_model.{name}"
+    assert spec.kind == "res" and not spec.up
+    h = O.resblock3d(sd, bp + ".0", x5, emb)
+    if spec.attn:
+        h = O.spatial_transformer3d(sd, bp + ".1", h, ctx, cfg.num_heads)
+    return h
+
+
+@pytest.mark.timeout(3000)
+@pytest.mark.parametrize("name,cin,hh,ww", [("input_blocks.1", 320, 64, 96), ("input_blocks.4", 320, 32, 48),
+                                            ("input_blocks.7", 640, 16, 24), ("output_blocks.11", 640, 64, 96)])
+def test_full_size_block_teacher_forced_vs_bf16_emulating_oracle(name, cin, hh, ww):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from ccedit_amd import network
+    from ccedit_amd.sgm_compat import build_network, build_network_spec
+    from ccedit_amd.utils.synth import fill_module_, synth_state_dict
+    from oracle import ccedit_oracle as O
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    b, t = 1, 17
+    g = torch.Generator().manual_seed(100 + hh)
+    bf = lambda v: v.to(torch.bfloat16).float()
+    x5 = bf(torch.randn(b, cin, t, hh, ww, generator=g))
+    ctx = bf(torch.randn(b, 77, 768, generator=g))
+    tt = torch.tensor([601], dtype=torch.int64)
+    cfg = O.NetConfig()
+    sd_all = synth_state_dict(build_network_spec({}))
+    pref = f"model.diffusion_model.{name}."
+    sd = {k: v for k, v in sd_all.items() if k.startswith(pref) or k.startswith("model.diffusion_model.time_embed.")}
+    with torch.no_grad(), O.bf16_emulation():
+        emb = O.time_embed(sd, "model.diffusion_model.time_embed", tt, cfg.model_channels)
+        want = _oracle_block(O, sd, cfg, name, x5, emb, ctx)
+    del sd_all
+    w = build_network("cpu")
+    fill_module_(w, prefix="model.")
+    net = w.diffusion_model
+    net.pack("cuda")
+    kind, i = name.rsplit(".", 1)
+    blk = getattr(net, kind)[int(i)]
+    x_hip = x5.permute(0, 2, 3, 4, 1).reshape(b * t, hh, ww, cin).contiguous().to(torch.bfloat16).cuda()
+    ctx2d = ctx.to(torch.bfloat16).reshape(-1, 768).contiguous().cuda()
+    got = blk.run(x_hip, net._emb_silu(tt.cuda()), network.Geometry(b, t), ctx2d, 77)
+    torch.cuda.synchronize()
+    got5 = got.float().cpu().view(b, t, hh, ww, -1).permute(0, 4, 1, 2, 3)
+    assert got5.shape == want.shape
+    r = _rel(got5.numpy(), want.numpy())
+    print(f"full-size {name} ({cin} ch in, T=17, {hh}x{ww}): HIP vs bf16-emulating oracle, teacher-forced: {r:.4f}")
+    assert np.isfinite(r) and r < 9e-3, f"{name}: {r}"       # the small-size budget for blocks with attention (test_network_gpu.py)

@@ -336,6 +336,9 @@ def test_clip_tokenizer_path_plumbing(tmp_path, monkeypatch):
     pytest.importorskip("transformers")
     from sgm.modules.encoders.modules import FrozenCLIPEmbedder
     vocab = _write_toy_clip_tokenizer(str(tmp_path))
+    with pytest.raises(NotImplementedError, match="tokenizer_path"):       # production guard: only the real 49408-entry vocabulary
+        FrozenCLIPEmbedder(tokenizer_path=str(tmp_path)).tokenize(["a cat"])
+    monkeypatch.setattr(FrozenCLIPEmbedder, "_expected_vocab", None)        # the toy vocabulary stands in from here on
     emb = FrozenCLIPEmbedder(tokenizer_path=str(tmp_path))
     ids = emb.tokenize(["a cat", "cat " * 100])
     assert ids.shape == (2, 77) and ids.dtype == torch.int64

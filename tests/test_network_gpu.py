@@ -134,6 +134,19 @@ def test_every_block_vs_reference_golden(golden_dir, g160_wrapper):
     _check_block_errors(errs)
 
 
+def test_t17_network_vs_reference_golden(golden_dir, g160_wrapper):
+    """T = 17 keyframes through a whole network evaluation against the REFERENCE (tests/golden/net_g160_t17.npz): the temporal
+    kernels' 17-row register-resident paths (GroupNorm over T, Conv1d k3, the 17-key temporal attention) inside the network,
+    eps and all 36 block digests."""
+    z = np.load(os.path.join(golden_dir, "net_g160_t17.npz"))
+    eps, errs = _block_errors(z, g160_wrapper, 2, 17)
+    assert eps.shape == (2, 4, 17, 8, 16)
+    r = _rel(eps, torch.from_numpy(z["eps"]))
+    print(f"T=17 network eval rel rms err vs reference golden: {r:.4f}")
+    assert r < NET_TOL
+    _check_block_errors(errs)
+
+
 def test_full_width_network_vs_reference_golden(golden_dir):
     """The SHIPPED widths (model_channels 320, 8 heads: d = 40 / 80 / 160, context 768; the fused dim-320 feed-forward and
     register-resident K = 320 kernels are on this path) against the reference itself: eps and all 36 block digests of
@@ -386,6 +399,25 @@ def test_vae_decode_vs_reference_golden(golden_dir):
     assert dec.shape == (1, 3, 3, 64, 96)
     r = _rel(dec, torch.from_numpy(z["dec"]))
     print(f"vae decode rel rms err vs reference golden: {r:.4f}")
+    assert r < VAE_TOL
+
+
+def test_vae_decode_shipped_width_vs_reference_golden(golden_dir):
+    """The ch = 128 decoder the clip actually runs (bf16 here, fp32 in the reference: diffusion.py:151-156 disables autocast) against
+    the reference's decode of 3 frames at 64x96 — the stated tolerance on the shipped width, not on the ch = 32 toy."""
+    _need_gpu()
+    from ccedit_amd import ops
+    from ccedit_amd.sgm_compat import build_vae
+    from ccedit_amd.utils.synth import fill_module_
+    z = np.load(os.path.join(golden_dir, "vae_ch128.npz"))
+    vae = build_vae("cpu")
+    fill_module_(vae, prefix="first_stage_model.")
+    vae.pack("cuda")
+    lat = torch.from_numpy(z["z"]).cuda()
+    dec = vae.decode(ops.axpby(lat.contiguous(), lat.contiguous(), 1.0 / 0.18215, 0.0))
+    assert dec.shape == (1, 3, 3, 64, 96)
+    r = _rel(dec, torch.from_numpy(z["dec"]))
+    print(f"vae decode (ch=128) rel rms err vs reference golden: {r:.4f}")
     assert r < VAE_TOL
 
 

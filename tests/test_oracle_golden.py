@@ -117,6 +117,26 @@ def test_full_width_network_eval_matches_reference(golden_dir):
         _digest_cmp(z, "trace:" + n, trace[n])
 
 
+def test_t17_network_eval_matches_reference(golden_dir, g160_sd):
+    """T = 17 keyframes (the production clip length) on an 8x16 latent at the G160 width: eps and every block digest of the
+    reference's own evaluation (tests/golden/net_g160_t17.npz)."""
+    z = np.load(os.path.join(golden_dir, "net_g160_t17.npz"))
+    x = torch.from_numpy(z["x"])
+    assert x.shape == (1, 4, 17, 8, 16)
+    hint = torch.from_numpy(z["hint1"]).repeat(1, 3, 1, 1, 1)
+    c = dict(crossattn=torch.cat([torch.from_numpy(z["cross_uc"]), torch.from_numpy(z["cross_c"])]),
+             control_hint=torch.cat([hint, hint]))
+    trace = {}
+    eps = O.network_forward(g160_sd, g160_cfg(), torch.cat([x, x]), torch.from_numpy(z["t"]), c, trace=trace)
+    ref = torch.from_numpy(z["eps"])
+    rel = (eps - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()
+    assert rel < 1e-4, f"eps rel rms err {rel}"
+    for n in [k[len("trace:"):-len("|samp")] for k in z.files if k.startswith("trace:") and k.endswith("|samp")]:
+        if n.endswith("controlnet.input_blocks.0") or (n.endswith("middle_block") and "controlnet" not in n):
+            continue
+        _digest_cmp(z, "trace:" + n, trace[n])
+
+
 def test_sampler_trajectory_matches_reference(golden_dir, g160_sd):
     z = np.load(os.path.join(golden_dir, "sampler_g160.npz"))
     cfg = g160_cfg()
@@ -150,6 +170,19 @@ def test_vae_decode_matches_reference(golden_dir):
     from ccedit_amd.sgm_compat import build_vae_spec
     z = np.load(os.path.join(golden_dir, "vae_g32.npz"))
     vcfg = O.VAEConfig(ch=32)
+    sd = synth_state_dict(build_vae_spec(vcfg.__dict__))
+    dec = O.vae_decode(sd, "first_stage_model", vcfg, torch.from_numpy(z["z"]))
+    ref = torch.from_numpy(z["dec"])
+    rel = (dec - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()
+    assert rel < 1e-4, f"vae decode rel rms err {rel}"
+
+
+def test_vae_decode_shipped_width_matches_reference(golden_dir):
+    """ch = 128 (the shipped ddconfig) decode of 3 frames at 64x96 against the reference's own (tests/golden/vae_ch128.npz)."""
+    from ccedit_amd.sgm_compat import build_vae_spec
+    z = np.load(os.path.join(golden_dir, "vae_ch128.npz"))
+    vcfg = O.VAEConfig()
+    assert vcfg.ch == 128
     sd = synth_state_dict(build_vae_spec(vcfg.__dict__))
     dec = O.vae_decode(sd, "first_stage_model", vcfg, torch.from_numpy(z["z"]))
     ref = torch.from_numpy(z["dec"])
