@@ -39,7 +39,7 @@ bool cc_lin320_applicable(const CcGemmDesc& d);           // lin320.hip
 int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s);
 bool cc_small_conv_applicable(const CcGemmDesc& d);       // smallconv.hip
 int cc_small_conv_launch(const CcGemmDesc& d, hipStream_t s);
-bool cc_g8_applicable(const CcGemmDesc& d);               // gemm8p.hip
+bool cc_g8_applicable(const CcGemmDesc& d, int shape);    // gemm8p.hip
 int cc_g8_launch(const CcGemmDesc& d, hipStream_t s, int shape);
 
 namespace {
@@ -483,7 +483,7 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     }
     // plain long Linear: persistent 256ch x 256pix eight-phase kernel (gemm8p.hip)
     if (d.tile >= 11 && d.tile <= 13) {     // 11: block shape by Cout, 12: 256ch x 256pix, 13: 128ch x 512pix
-        CC_UNSUPPORTED(!cc_g8_applicable(d), "ccedit_gemm: tile 11-13 (persistent eight-phase Linear) does not apply to this descriptor");
+        CC_UNSUPPORTED(!cc_g8_applicable(d, d.tile - 11), "ccedit_gemm: tile 11-13 (persistent eight-phase GEMM) does not apply to this descriptor");
         return cc_g8_launch(d, s, d.tile - 11);
     }
     // Long plain Linears (FF / GEGLU projections and the C -> C projections of the 32x48 and 16x24 levels): the persistent
@@ -493,7 +493,14 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     // and the single CFG halves (two-stream execution): 26112 x 5120 <- 640 GEGLU 945 / 588, 6528 x 10240 <- 1280 GEGLU 964 / 677.
     // Not below 4096 rows (fewer than ~100 tiles: most CUs idle) and not for K = 320 (lin320 / ff320 own those).
     static const int g8_env = getenv("CCEDIT_G8") ? atoi(getenv("CCEDIT_G8")) : 1;      // 0: A/B against the older block shapes
-    if (d.tile == 0 && g8_env && d.M >= 4096 && d.Kpad >= 640 && d.N >= 640 && cc_g8_applicable(d)) return cc_g8_launch(d, s, 0);
+    if (d.tile == 0 && g8_env && d.M >= 4096 && d.Kpad >= 640 && d.N >= 640 && cc_g8_applicable(d, 0)) {
+        // Conv1d k3 over T: the same K loop with the activation rows gathered HW rows away (cold sweep, + residual, against the
+        // best older shape: 32x48 640->640 746 / 703, 1280->1280 1034 / 883; 16x24 1280->1280 981 / 917; 64x96 640->640 801 / 692 —
+        // and 507 / 519 at 320->320, where three 128-channel tiles re-read every activation row: those stay on tap_gemm, N >= 640 above).
+        // Below ~200 tiles the persistent grid is mostly idle: the 8x12 level (3264 rows) and single CFG halves of 16x24 stay too.
+        static const int g8t_env = getenv("CCEDIT_G8_TEMPORAL") ? atoi(getenv("CCEDIT_G8_TEMPORAL")) : 1;      // 0: A/B
+        if (d.mode == CCEDIT_GEMM_LINEAR || (g8t_env && d.M >= 12000)) return cc_g8_launch(d, s, 0);
+    }
     CC_UNSUPPORTED(d.tile == 6 && d.N % 320 != 0, "ccedit_gemm: tile 6 (320-channel block shape) needs N %% 320 == 0 (N=%d)", d.N);
     int tile = d.tile;
     if (tile == 0) {

@@ -102,7 +102,45 @@ __device__ __forceinline__ void g8_decode(const G8Order& o, int g, int& pt, int&
 //   <1, 2>  128ch x 512pix, 160 KB LDS           — Cout = 640 (5 tiles instead of 2.5), 102 instead of 128 FLOP per staged byte
 enum { G8_PLAIN = 0, G8_RES = 1, G8_GEGLU = 2 };      // epilogue variants (compiled separately: one register budget each)
 
-template <int TIH, int TJH, int EPI>
+__device__ __attribute__((aligned(64))) const char g8_zero_page[64] = {0};
+
+// GroupNorm(32, N) statistics of the tensor being written (CcGemmDesc.gn_stats): gs / gq = this lane's sums / sums of squares of
+// the bf16-rounded outputs of channels cb .. cb + 7 over its rows.  Lanes with the same channels sit `G` apart: butterfly over
+// those, then the first G lanes add their (at most two) groups' shares to the frame's double-precision slots — the arrival
+// order of double adds cannot move the fp32 mean / rstd taken from them (same argument as gemm_epilogue.h).
+template <int G>
+__device__ __forceinline__ void g8_flush_stats(float (&gs)[8], float (&gq)[8], int lane, int cb, int N, double* slots) {
+#pragma unroll
+    for (int off = G; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            gs[e] += __shfl_xor(gs[e], off);
+            gq[e] += __shfl_xor(gq[e], off);
+        }
+    if (lane < G && cb < N) {
+        const int cpg = N >> 5, g0 = cb / cpg;
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool first = cb + e < (g0 + 1) * cpg;
+            s0 += first ? gs[e] : 0.f;
+            q0 += first ? gq[e] : 0.f;
+            s1 += first ? 0.f : gs[e];
+            q1 += first ? 0.f : gq[e];
+        }
+        unsafeAtomicAdd(slots + 2 * g0, (double)s0);
+        unsafeAtomicAdd(slots + 2 * g0 + 1, (double)q0);
+        if (g0 < 31 && (cb + 7) / cpg > g0) {
+            unsafeAtomicAdd(slots + 2 * g0 + 2, (double)s1);
+            unsafeAtomicAdd(slots + 2 * g0 + 3, (double)q1);
+        }
+    }
+}
+
+// TEMPORAL: Conv1d k3 over the T keyframes of a clip (openaimodel.py:617-629, 674-687): K = [Cin / 64][3 taps][64]; K tile kt reads
+// channel chunk kt / 3 of the pixel's row in frame t + kt % 3 - 1 — the same row HW rows earlier / later — or the zero page when
+// that frame is outside the clip (Conv1d padding).  Only the activation request changes: one select per 16-byte piece.
+template <int TIH, int TJH, int EPI, bool TEMPORAL>
 __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     static_assert(TIH * TJH == 2, "eight MFMAs per phase");
     constexpr int BM = TIH * 128, BN = TJH * 256;
@@ -161,12 +199,23 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     const char* at;
     int rmax;
     const uint32_t ldab = (uint32_t)d.lda * 2, gcol16 = gcol * 16;
+    uint32_t prev_ok = 0, next_ok = 0;           // TEMPORAL: bit j = row j * 64 + rsub of the tile has a frame before / after it in its clip
+    const int64_t hw_bytes = (int64_t)d.HW * d.lda * 2;
     auto set_tile = [&](int pt_, int ct_) {
         wt = Wp + (size_t)ct_ * BM * d.Kpad * 2;
         const int64_t pix0 = (int64_t)pt_ * BN;
         at = Ap + (size_t)pix0 * d.lda * 2;
         const int64_t left = d.M - 1 - pix0;
         rmax = left < BN ? (int)left : BN;
+        if constexpr (TEMPORAL) {
+            prev_ok = next_ok = 0;
+#pragma unroll
+            for (int j = 0; j < 2 * BI; ++j) {
+                const int fr = (int)((pix0 + min(j * 64 + rsub, rmax)) / d.HW) % d.T;      // keyframe index inside the clip
+                prev_ok |= (uint32_t)(fr > 0) << j;
+                next_ok |= (uint32_t)(fr < d.T - 1) << j;
+            }
+        }
     };
     auto stage_a = [&](int h, int kt, int buf) {
 #pragma unroll
@@ -178,11 +227,24 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         }
     };
     auto stage_b = [&](int h, int kt, int buf) {
+        if constexpr (TEMPORAL) {
+            const int chunk = kt / 3, tap = kt - 3 * chunk;                        // uniform
+            const char* const base = at + (int64_t)(tap - 1) * hw_bytes + chunk * 128;
+            const uint32_t okm = tap == 1 ? 0xFFFFFFFFu : (tap == 0 ? prev_ok : next_ok);
 #pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const uint32_t u = __builtin_amdgcn_readfirstlane((uint32_t)(kt * 128));
-            const int r = min((h * BI + i) * 64 + rsub, rmax);
-            glds16(at + u + ((uint32_t)r * ldab + gcol16), lds_wave + buf * BUF + 2 * AH + h * BH + i * 8192);
+            for (int i = 0; i < BI; ++i) {
+                const int r = min((h * BI + i) * 64 + rsub, rmax);
+                const char* src = base + ((uint32_t)r * ldab + gcol16);
+                src = ((okm >> (h * BI + i)) & 1) ? src : g8_zero_page;
+                glds16(src, lds_wave + buf * BUF + 2 * AH + h * BH + i * 8192);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BI; ++i) {
+                const uint32_t u = __builtin_amdgcn_readfirstlane((uint32_t)(kt * 128));
+                const int r = min((h * BI + i) * 64 + rsub, rmax);
+                glds16(at + u + ((uint32_t)r * ldab + gcol16), lds_wave + buf * BUF + 2 * AH + h * BH + i * 8192);
+            }
         }
     };
     auto prologue_a = [&]() {          // K tile 0 -> buffer 0
@@ -219,18 +281,32 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     // this wave row, the same for every pixel tile — 16 loads of 16 bytes per lane and output tile straight into the accumulator
     // registers, requested before the operand requests whose counted wait also covers them.  The epilogue never touches it.
     f32x16 acc[NI][NJ];
-    auto init_acc = [&](int ct_) {
+    auto pixbase = [&](int tjf) { return (tjf / TJH) * (TJH * 128) + wc * (TJH * 32) + (tjf % TJH) * 32; };
+    auto init_acc = [&](int pt_, int ct_) {
         const float* const bias = d.bias;
+        const float* const gbias = d.group_bias;       // + per-clip row bias (ResBlock: h + emb_out): a 32-pixel tile lies in ONE clip
+        const int ldgb = d.ldgb ? d.ldgb : d.N;
 #pragma unroll
         for (int tf = 0; tf < NI; ++tf)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                const int c = min(ct_ * BM + wr * CW + 32 * tf + 8 * q + 4 * hi, d.N - 4);          // (past N: never stored)
                 f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (bias) b = *(const f32x4*)(bias + min(ct_ * BM + wr * CW + 32 * tf + 8 * q + 4 * hi, d.N - 4));   // (past N: never stored)
+                if (bias) b = *(const f32x4*)(bias + c);
+                if (gbias) {
 #pragma unroll
-                for (int tj = 0; tj < NJ; ++tj)
+                    for (int tj = 0; tj < NJ; ++tj) {
+                        const int64_t m = min((int64_t)pt_ * BN + pixbase(tj), d.M - 1);
+                        const f32x4 gb = *(const f32x4*)(gbias + (size_t)(m / d.group_rows) * ldgb + c);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[tf][tj][4 * q + e] = b[e];
+                        for (int e = 0; e < 4; ++e) acc[tf][tj][4 * q + e] = b[e] + gb[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int tj = 0; tj < NJ; ++tj)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[tf][tj][4 * q + e] = b[e];
+                }
             }
     };
 
@@ -238,7 +314,7 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     set_tile(pt, ct);
     prologue_a();
     prologue_b();
-    init_acc(ct);
+    init_acc(pt, ct);
     g8_vmcnt<KEEP>();                            // K tile 0 has landed (this wave's part)
 
     for (;;) {
@@ -339,7 +415,6 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         // ahead of the next tile's operand requests in the memory queue; the other blocks two blocks ahead of their use ----
         const bf16* __restrict__ r1 = (const bf16*)d.res1;
         const bf16* __restrict__ r2 = (const bf16*)d.res2;
-        auto pixbase = [&](int tjf) { return (tjf / TJH) * (TJH * 128) + wc * (TJH * 32) + (tjf % TJH) * 32; };
         constexpr int NSB = NJ * (CW / 64);                  // blocks: sb = tjf * (CW / 64) + cs
         bf16x8 rv1[EPI == G8_RES ? NSB : 1][4];
         auto load_r1 = [&](int sb) {          // unconditional (rows / channels clamped into the tensor): a conditional load would keep the
@@ -376,6 +451,8 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         const bool st = !(flags & 1);
         char* const stg = smem + BUF + wave * 8192;
         const int chw = ch0 + wr * CW;                                   // this wave's first channel (packed row)
+        const bool gn = d.gn_stats != nullptr;                           // (the launcher admits it only when a tile lies inside one frame)
+        double* const gn_slots = gn ? d.gn_stats + (size_t)(pix0 / d.gn_rows) * 64 : nullptr;
         if constexpr (EPI == G8_GEGLU) {
             // packed rows 16 g + [0, 8) are values, + [8, 16) their gates: a 32-row tile yields 16 output channels
             constexpr int RB = CW, G = RB / 16;                          // staged row: CW / 2 bf16 outputs of one pixel
@@ -403,6 +480,11 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
             }
         } else if constexpr (EPI == G8_RES) {
             // fp32 staging, 64 channels x 32 pixels at a time: the residuals are added before the one rounding to bf16
+            float gs[CW / 64][8], gq[CW / 64][8];
+#pragma unroll
+            for (int cs = 0; cs < CW / 64; ++cs)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gs[cs][e] = gq[cs][e] = 0.f;
 #pragma unroll
             for (int tjf = 0; tjf < NJ; ++tjf) {
 #pragma unroll
@@ -439,6 +521,14 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
                             if (st) *(bf16x8*)(outp + (size_t)m * d.ldc + cb) = o;
+                            if (gn) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    const float f = bf2f(o[e]);      // statistics of what the consumer will read
+                                    gs[cs][e] += f;
+                                    gq[cs][e] += f * f;
+                                }
+                            }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -446,9 +536,16 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (gn) {
+#pragma unroll
+                for (int cs = 0; cs < CW / 64; ++cs) g8_flush_stats<8>(gs[cs], gq[cs], lane, chw + cs * 64 + 8 * (lane & 7), d.N, gn_slots);
+            }
         } else {
             // bf16 staging, all CW channels x 32 pixels at a time
             constexpr int RB = CW * 2, G = RB / 16;
+            float gs[8], gq[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
 #pragma unroll
             for (int tjf = 0; tjf < NJ; ++tjf) {
 #pragma unroll
@@ -467,15 +564,24 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                     const bf16x8 v = *(const bf16x8*)(stg + row * RB + ((c ^ (row & (G - 1))) << 4));
                     const int64_t m = pix0 + pixbase(tjf) + row;
                     if (st && m < d.M && chw + 8 * c < d.N) *(bf16x8*)(outp + (size_t)m * d.ldc + chw + 8 * c) = v;
+                    if (gn && m < d.M) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = bf2f(v[e]);
+                            gs[e] += f;
+                            gq[e] += f * f;
+                        }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (gn) g8_flush_stats<G>(gs, gq, lane, chw + 8 * (lane % G), d.N, gn_slots);
         }
         G8_STAMP();
         if (!more) return;
         pt = npt;
         ct = nct;
-        init_acc(ct);
+        init_acc(pt, ct);
         g8_barrier();                            // every wave is done with its staging block in buffer 1
         if (flags & 2) prologue_a();
         prologue_b();
@@ -485,17 +591,17 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         // those would be too, i.e. more than KEEP + 16 operations — so a count of at most KEEP + 12 (margin: the compiler may merge
         // bias loads) proves it has landed WITHOUT waiting for the epilogue's stores to be acknowledged (measured: ~1.5 us per tile).
         // Without a bias there is no such padding and the count is KEEP.
-        if (d.bias) g8_vmcnt<KEEP + 12>();
+        if (d.bias || d.group_bias) g8_vmcnt<KEEP + 12>();
         else g8_vmcnt<KEEP>();
     }
 }
 
-template <int TIH, int TJH, int EPI>
+template <int TIH, int TJH, int EPI, bool TEMPORAL>
 int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu) {
     constexpr int BM = TIH * 128, BN = TJH * 256;
     constexpr int LDS = 2 * (2 * TIH * 8192 + 2 * TJH * 16384);
     static unsigned long long attr_done = 0;
-    if (int rc = cc_max_dynamic_lds((const void*)g8_kernel<TIH, TJH, EPI>, LDS, &attr_done, "g8_kernel")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)g8_kernel<TIH, TJH, EPI, TEMPORAL>, LDS, &attr_done, "g8_kernel")) return rc;
     const int64_t pt_n = (d.M + BN - 1) / BN, ct_n = (d.N + BM - 1) / BM;
     CcGemmDesc dd = d;
     dd.cgroup = 0;
@@ -521,24 +627,39 @@ int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu) {
     int wgs = n_cu - n_cu % 8;
     const int64_t tiles = pt_n * ct_n;
     if (tiles < wgs) wgs = (int)((tiles + 7) / 8 * 8);
-    cc_note_kernel("g8_kernel %dch x %dpix", BM, BN);
-    hipLaunchKernelGGL((g8_kernel<TIH, TJH, EPI>), dim3((unsigned)wgs), dim3(512), LDS, s, dd);
+    cc_note_kernel(TEMPORAL ? "g8_kernel %dch x %dpix, temporal taps" : "g8_kernel %dch x %dpix", BM, BN);
+    hipLaunchKernelGGL((g8_kernel<TIH, TJH, EPI, TEMPORAL>), dim3((unsigned)wgs), dim3(512), LDS, s, dd);
     return cc_launch_status("g8_kernel");
 }
 
 }  // namespace
 
-bool cc_g8_applicable(const CcGemmDesc& d) {
-    return d.mode == CCEDIT_GEMM_LINEAR && d.taps == 1 && d.A2 == nullptr && d.Cin % 64 == 0 && d.Kpad == d.Cin && d.Kpad >= 128 &&
-           d.N % 16 == 0 && (d.act == CCEDIT_ACT_NONE || d.act == CCEDIT_ACT_GEGLU) && !d.out_f32 && !d.group_bias && d.ln_eps == 0.f &&
+// Pixels per tile of the block shape cc_g8_launch picks for this Cout (shape 0): 128ch x 512pix when Cout leaves half a 256-channel
+// tile (640 = 2.5 tiles), else 256ch x 256pix
+static int g8_auto_shape(const CcGemmDesc& d) {
+    const int rem = d.N % 256;
+    return (rem > 0 && rem <= 128 && d.N <= 1024) ? 2 : 1;
+}
+
+// shape: 0 = by Cout, 1 = 256ch x 256pix, 2 = 128ch x 512pix
+bool cc_g8_applicable(const CcGemmDesc& d, int shape) {
+    if (shape == 0) shape = g8_auto_shape(d);
+    const int bn = shape == 2 ? 512 : 256;
+    const bool geo = d.mode == CCEDIT_GEMM_LINEAR
+                         ? (d.taps == 1 && d.Kpad == d.Cin)
+                         : (d.mode == CCEDIT_GEMM_TEMPORAL && d.taps == 3 && d.korder == 1 && d.Kpad == 3 * d.Cin && d.T > 0 && d.HW > 0 &&
+                            (d.Tsrc == 0 || (d.Tsrc == d.T && d.tsrc_off == 0 && d.t0 == 0 && d.Tglob == d.T)) &&      // unsharded clips only
+                            d.act == CCEDIT_ACT_NONE && (int64_t)d.HW * d.lda * 2 < (1LL << 40));
+    return geo && d.A2 == nullptr && d.Cin % 64 == 0 && d.Kpad >= 128 && d.N % 16 == 0 &&
+           (d.act == CCEDIT_ACT_NONE || d.act == CCEDIT_ACT_GEGLU) && !d.out_f32 && d.ln_eps == 0.f &&
+           (!d.group_bias || (d.act == CCEDIT_ACT_NONE && d.group_rows > 0 && d.group_rows % 32 == 0 && (d.ldgb == 0 || d.ldgb % 4 == 0))) &&
 #ifndef G8_PROBE
-           !d.gn_stats &&
+           (!d.gn_stats || (d.act == CCEDIT_ACT_NONE && d.gn_rows > 0 && d.gn_rows % bn == 0 && d.N % 32 == 0 && d.N >= 256)) &&
 #endif
            d.lda % 8 == 0 && d.ldc % 8 == 0 && (!d.res1 || d.ldr1 % 8 == 0) && (!d.res2 || d.ldr2 % 8 == 0) &&
            (int64_t)512 * d.lda * 2 < (1LL << 31) && d.M * ((d.N + 127) / 128) < (1LL << 37);
 }
 
-// shape 0 = by Cout: 128ch x 512pix when Cout leaves half a 256-channel tile (640 = 2.5 tiles), else 256ch x 256pix
 int cc_g8_launch(const CcGemmDesc& d, hipStream_t s, int shape) {
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -550,15 +671,15 @@ int cc_g8_launch(const CcGemmDesc& d, hipStream_t s, int shape) {
         }
         n_cu = prop.multiProcessorCount;
     }
-    if (shape == 0) {
-        const int rem = d.N % 256;
-        shape = (rem > 0 && rem <= 128 && d.N <= 1024) ? 2 : 1;
-    }
+    if (shape == 0) shape = g8_auto_shape(d);
     const int epi = d.act == CCEDIT_ACT_GEGLU ? G8_GEGLU : ((d.res1 || d.res2) ? G8_RES : G8_PLAIN);
+    const bool temporal = d.mode == CCEDIT_GEMM_TEMPORAL;
+#define G8_GO(TI, TJ, EP) (temporal ? g8_launch_shape<TI, TJ, EP, true>(d, s, n_cu) : g8_launch_shape<TI, TJ, EP, false>(d, s, n_cu))
     if (shape == 2) {
-        if (epi == G8_GEGLU) return g8_launch_shape<1, 2, G8_GEGLU>(d, s, n_cu);
-        return epi == G8_RES ? g8_launch_shape<1, 2, G8_RES>(d, s, n_cu) : g8_launch_shape<1, 2, G8_PLAIN>(d, s, n_cu);
+        if (epi == G8_GEGLU) return g8_launch_shape<1, 2, G8_GEGLU, false>(d, s, n_cu);
+        return epi == G8_RES ? G8_GO(1, 2, G8_RES) : G8_GO(1, 2, G8_PLAIN);
     }
-    if (epi == G8_GEGLU) return g8_launch_shape<2, 1, G8_GEGLU>(d, s, n_cu);
-    return epi == G8_RES ? g8_launch_shape<2, 1, G8_RES>(d, s, n_cu) : g8_launch_shape<2, 1, G8_PLAIN>(d, s, n_cu);
+    if (epi == G8_GEGLU) return g8_launch_shape<2, 1, G8_GEGLU, false>(d, s, n_cu);
+    return epi == G8_RES ? G8_GO(2, 1, G8_RES) : G8_GO(2, 1, G8_PLAIN);
+#undef G8_GO
 }

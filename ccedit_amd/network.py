@@ -868,10 +868,12 @@ class IdentityWrapper(nn.Module):
         return self.diffusion_model(*args, **kwargs)
 
 
-# The two CFG halves (uncond / cond clip of the doubled batch) are independent: evaluated as two B = 1 passes on two
-# HIP streams (each with its own ControlNet side stream) they fill each other's launch tails for the whole step, not
-# only during the encoder: another -1.5...2.5 % per step.  CCEDIT_SPLIT_CFG=0 keeps the single batched pass.
-_SPLIT_CFG = os.environ.get("CCEDIT_SPLIT_CFG", "1") == "1"
+# The two CFG halves (uncond / cond clip of the doubled batch) are independent and CAN be evaluated as two B = 1 passes on two
+# HIP streams (each with its own ControlNet side stream), filling each other's launch tails.  Rounds 1-2: -1.5...2.5 % per step
+# and the default.  Round 3: the persistent eight-phase GEMM (gemm8p.hip) owns every CU while it runs (128-160 KB of LDS per
+# workgroup), so there is little left to overlap, and the batched pass gives it twice the tiles per launch — same-box A/B
+# 115.2 (batched) vs 116.3 ms (two streams).  Batched is the default now; CCEDIT_SPLIT_CFG=1 restores the two-stream halves.
+_SPLIT_CFG = os.environ.get("CCEDIT_SPLIT_CFG", "0") == "1"
 
 
 class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 GENERIC = dict(CCEDIT_T6="0", CCEDIT_CONV_HALO="0", CCEDIT_ATTN_SHORT="0", CCEDIT_SPLIT_CFG="0", CCEDIT_OVERLAP_CONTROLNET="0",
                CCEDIT_KROT="0", CCEDIT_CGROUP="0", CCEDIT_FUSE_GN_STATS="0", CCEDIT_TEMPORAL_ORDER="0", CCEDIT_LIN320="0",
-               CCEDIT_FF320="0", CCEDIT_LN320="0", CCEDIT_T4="0", CCEDIT_BALANCED="0", CCEDIT_CONV_NARROW="0")
+               CCEDIT_FF320="0", CCEDIT_LN320="0", CCEDIT_T4="0", CCEDIT_BALANCED="0", CCEDIT_CONV_NARROW="0", CCEDIT_G8="0")
 
 
 def _rel(a, b):
@@ -53,9 +53,15 @@ def test_full_size_properties(tmp_path):
     #     arrival order cannot move the fp32 mean / rstd; everything else has a fixed summation order)
     for k in ("eps", "eps_same", "eps_other", "frames"):
         assert np.array_equal(fast[k], again[k]), f"{k}: two runs of the same evaluation differ"
-    # (2) identical CFG halves (each on its own stream) give identical predictions; (3) clips do not interact
-    assert np.array_equal(fast["eps_same"][0], fast["eps_same"][1])
-    assert np.array_equal(fast["eps_other"][0], fast["eps"][0])
+    # (2) identical CFG halves give identical predictions: bit for bit when each half is its own launch sequence (two streams,
+    #     CCEDIT_SPLIT_CFG=1); in the batched default the halves are different tiles of one launch and the short-K Linears start
+    #     their K loops at tile-dependent positions, so there they agree to the summation-order noise floor.  (3) clips do not
+    #     interact: half 0 does not change when half 1 is another clip (same tiles, same order: bit-exact in both modes).
+    split = _run(tmp_path, "split", dict(CCEDIT_SPLIT_CFG="1"))
+    assert np.array_equal(split["eps_same"][0], split["eps_same"][1])
+    assert _rel(fast["eps_same"][0], fast["eps_same"][1]) < 3.5e-2
+    assert np.array_equal(fast["eps_other"][0], fast["eps"][0]) and np.array_equal(split["eps_other"][0], split["eps"][0])
+    assert _rel(fast["eps"], split["eps"]) < 3.5e-2
     # (4) specialised kernels == generic kernels, up to the bf16 noise floor: both are bf16 realisations of the same fp32
     #     computation with different summation orders, and a single flipped bf16 rounding spreads to that floor within a
     #     few layers (measured 2.0e-2 on eps, 1.1e-2 on decoded frames — the distance between ANY two summation orders);
@@ -78,7 +84,7 @@ def test_full_size_tvi2v_properties(tmp_path):
     assert fast["eps"].shape == (2, 4, 17, 64, 96) and np.isfinite(fast["eps"]).all() and np.isfinite(gen["eps"]).all()
     for k in ("eps", "eps_same", "eps_ref"):
         assert np.array_equal(fast[k], again[k]), f"{k}: two runs of the same evaluation differ"
-    assert np.array_equal(fast["eps_same"][0], fast["eps_same"][1])
+    assert _rel(fast["eps_same"][0], fast["eps_same"][1]) < 3.5e-2          # (bit-equal with CCEDIT_SPLIT_CFG=1, see above)
     assert np.array_equal(fast["eps_ref"][0], fast["eps"][0])
     assert _rel(fast["eps_ref"][1], fast["eps"][1]) > 1e-2          # the reference latent does condition the prediction
     e = _rel(fast["eps"], gen["eps"])

@@ -110,6 +110,63 @@ def test_linear_persistent_auto_dispatch_and_refusals():
         ops.linear(xc, pw, out_f32=True, tile=12)
 
 
+@pytest.mark.parametrize("tile", [12, 13])
+@pytest.mark.parametrize("b_,t,c,cout,h,w", [(1, 5, 64, 256, 16, 32), (2, 17, 128, 320, 8, 16), (1, 3, 192, 640, 16, 16)])
+def test_temporal_conv_persistent_eight_phase(b_, t, c, cout, h, w, tile):
+    """Conv1d k3 over T through g8_kernel's temporal mode (tile 12 / 13): neighbouring frames HW rows away, zero padding at the
+    clip ends (also between the clips of a batch), + bias + per-clip row bias (timestep embedding) + two residuals + the fused
+    GroupNorm statistics of what it writes — against F.conv1d on the '(b h w) c t' view; same launch repeated (race screen)."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    n = b_ * t
+    x = _rnd(n, c, h, w, seed=1)
+    wt, bt = _rnd(cout, c, 3, seed=4, scale=(3 * c) ** -0.5), _rnd(cout, seed=5)
+    xp = x.reshape(b_, t, c, h, w).permute(0, 3, 4, 2, 1).reshape(b_ * h * w, c, t)
+    ref = F.conv1d(xp, wt, bt, padding=1).reshape(b_, h, w, cout, t).permute(0, 4, 3, 1, 2).reshape(n, cout, h, w)
+    r1, r2 = _rnd(n, cout, h, w, seed=6), _rnd(n, cout, h, w, seed=7)
+    gb = _rnd(b_, cout, seed=8)
+    pw = pack_weight(wt, bt).to("cuda")
+    with_stats = (h * w) % (512 if tile == 13 else 256) == 0 and cout % 32 == 0       # a pixel tile must lie inside one frame
+    kw = dict(res1=_nhwc(r1).reshape(-1, cout), res2=_nhwc(r2).reshape(-1, cout), group_bias=gb.cuda(), group_rows=t * h * w,
+              gn=with_stats, tile=tile)
+    y = ops.conv_temporal(_nhwc(x), t, pw, **kw)
+    full = ref + r1 + r2 + gb.repeat_interleave(t, 0)[:, :, None, None]
+    _close(_nchw(y), full, what=f"g8 temporal conv {c}->{cout} T={t} {h}x{w} tile{tile}")
+    if with_stats:
+        st = ops.gn_stats_of(y, h * w)
+        assert st is not None
+        yf = y.float().view(n, h * w, 32, cout // 32)
+        assert torch.allclose(st[..., 0].float(), yf.sum(dim=(1, 3)), rtol=1e-4, atol=2e-2)
+        assert torch.allclose(st[..., 1].float(), (yf * yf).sum(dim=(1, 3)), rtol=1e-4, atol=2e-2)
+    for _ in range(3):
+        assert torch.equal(ops.conv_temporal(_nhwc(x), t, pw, **kw), y), "g8 temporal: run-to-run difference"
+    y0 = ops.conv_temporal(_nhwc(x), t, pw, tile=tile)                  # plain epilogue, no statistics
+    _close(_nchw(y0), ref, what="g8 temporal conv, plain")
+    _close(_nchw(ops.conv_temporal(_nhwc(x), t, pw, tile=1)), ref, what="tap_gemm temporal (same reference)")
+
+
+def test_linear_persistent_groupnorm_statistics_and_row_bias():
+    """tile 11: Linear + per-group row bias + fused GroupNorm statistics (the 1x1 projections in front of a GroupNorm)."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    n, hw, k, cout = 3, 512, 256, 640
+    x, w, b = _rnd(n * hw, k, seed=1), _rnd(cout, k, seed=2, scale=k ** -0.5), _rnd(cout, seed=3)
+    gb, r1 = _rnd(n, cout, seed=4), _rnd(n * hw, cout, seed=5)
+    pw = pack_weight(w, b).to("cuda")
+    for tile in (12, 13):
+        y = ops.linear(x.to(BF).cuda(), pw, group_bias=gb.cuda(), group_rows=hw, res1=r1.to(BF).cuda(), gn_rows=hw, tile=tile)
+        _close(y, F.linear(x, w, b) + gb.repeat_interleave(hw, 0) + r1, what=f"g8 linear + row bias + residual tile{tile}")
+        st = ops.gn_stats_of(y, hw)
+        yf = y.float().view(n, hw, 32, cout // 32)
+        assert torch.allclose(st[..., 0].float(), yf.sum(dim=(1, 3)), rtol=1e-4, atol=2e-2)
+        assert torch.allclose(st[..., 1].float(), (yf * yf).sum(dim=(1, 3)), rtol=1e-4, atol=2e-2)
+        g, be = (_rnd(cout, seed=6) * 0.1 + 1).cuda(), (_rnd(cout, seed=7) * 0.1).cuda()
+        _close(ops.groupnorm_spatial(y.view(n, 16, 32, cout), g, be, 1e-5, True),
+               ops.groupnorm_spatial(y.clone().view(n, 16, 32, cout), g, be, 1e-5, True).float(), rel=2.0 ** -8, what="GN through g8 statistics")
+
+
 def test_linear_asymmetric_identity():
     """A = I against an asymmetric B catches a transposed C-write (guide rule 16)."""
     _dev()

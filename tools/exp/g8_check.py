@@ -115,6 +115,36 @@ def perf(m, n, k, geglu=False, res=False, tiles=(1, 3, 4, 6, 11)):
     print(f"M={m:6d} N={n:5d} K={k:5d} geglu={int(geglu)} res={int(res)} | hot: " + "  ".join(row) + " | cold: " + "  ".join(cold), flush=True)
 
 
+def perf_temporal(b_, t, h, w, c, cout, res=1, tiles=(0, 1, 2, 12, 13)):
+    """Conv1d k3 over T (temporal mode), cold operands, + residual(s): TF/s per block shape."""
+    n = b_ * t
+    pw = pack_weight(torch.randn(cout, c, 3) * (3 * c) ** -0.5, torch.randn(cout)).to(dev)
+    NB = 4
+    src = [torch.randn(n * h * w, c, device=dev).to(BF) for _ in range(NB)]
+    act = [torch.empty_like(x) for x in src]
+    rs = [torch.randn(n * h * w, cout, device=dev).to(BF) for _ in range(NB)]
+    g1, b1 = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+    fl = 2.0 * n * h * w * cout * c * 3
+    row = []
+    for tl in tiles:
+        try:
+            evs = []
+            for rep in range(3):
+                for i in range(NB):
+                    hip_ln(src[i], act[i], g1, b1)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ops.conv_temporal(act[i].view(n, h, w, c), t, pw, res1=rs[i], res2=rs[(i + 1) % NB] if res > 1 else None, tile=tl)
+                    e1.record()
+                    if rep:
+                        evs.append((e0, e1))
+            torch.cuda.synchronize()
+            row.append(f"t{tl} {fl / (sum(x.elapsed_time(y) for x, y in evs) / len(evs)) / 1e9:5.0f}")
+        except Exception as e:
+            row.append(f"t{tl} err")
+    print(f"temporal B={b_} T={t} {h}x{w} {c}->{cout} res={res}: " + "  ".join(row), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     ok = True
@@ -136,6 +166,16 @@ if __name__ == "__main__":
             ok &= check(3000, 5120, 640, geglu=True, T11=t)
             ok &= check(26112, 640, 2560, res=2, T11=t)
         print("CHECK", "PASSED" if ok else "FAILED", flush=True)
+    if what in ("all", "temporal"):
+        perf_temporal(2, 17, 64, 96, 320, 320)
+        perf_temporal(1, 17, 64, 96, 320, 320)
+        perf_temporal(2, 17, 32, 48, 640, 640)
+        perf_temporal(1, 17, 32, 48, 640, 640)
+        perf_temporal(2, 17, 16, 24, 1280, 1280)
+        perf_temporal(1, 17, 16, 24, 1280, 1280)
+        perf_temporal(2, 17, 8, 12, 1280, 1280)
+        perf_temporal(2, 17, 64, 96, 640, 640)
+        perf_temporal(2, 17, 32, 48, 1280, 1280)
     if what in ("all", "perf"):
         perf(8192, 8192, 8192, tiles=(4, 11))
         perf(52224, 5120, 640, tiles=(1, 11))
