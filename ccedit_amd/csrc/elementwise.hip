@@ -259,6 +259,31 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     }
 }
 
+// Row-block copy: block s moves `rows` whole rows (row_bytes each) from row src_row of `src` to row dst_row of `dst`, optionally
+// adding the rows of `add` that sit where the DESTINATION rows sit (bf16: fp32 add, one rounding — x.add_(skip)).  The pack /
+// unpack halves of the frame <-> pixel layout transposition of a frame-sharded clip (parallel.FrameShard): for every (peer rank,
+// clip, keyframe) one block, 16 bytes per lane, rows walked contiguously.
+__global__ __launch_bounds__(256) void copy_row_blocks_kernel(const char* __restrict__ src, char* __restrict__ dst,
+                                                              const bf16* __restrict__ add, const int64_t* __restrict__ blocks,
+                                                              int row_gran) {
+    const int64_t src_row = blocks[3 * blockIdx.y], dst_row = blocks[3 * blockIdx.y + 1], rows = blocks[3 * blockIdx.y + 2];
+    const int64_t total = rows * row_gran;                       // 16-byte granules of this block (rows are contiguous on both sides)
+    const u32x4* s = (const u32x4*)(src + src_row * row_gran * 16);
+    u32x4* o = (u32x4*)(dst + dst_row * row_gran * 16);
+    const bf16x8* a = add ? (const bf16x8*)((const char*)add + dst_row * row_gran * 16) : nullptr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        u32x4 v = s[i];
+        if (a) {
+            bf16x8 x = *(bf16x8*)&v;
+            const bf16x8 y = a[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = f2bf(bf2f(x[e]) + bf2f(y[e]));
+            v = *(u32x4*)&x;
+        }
+        o[i] = v;
+    }
+}
+
 inline unsigned grid_for(int64_t n, int threads) {
     int64_t g = (n + threads - 1) / threads;
     return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -286,6 +311,19 @@ extern "C" int ccedit_nhwc_to_ncthw(const void* x, int32_t x_is_f32, int32_t ld,
         hipLaunchKernelGGL(nhwc_to_ncthw_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
                            ld, y, B, C, T, H, W);
     return cc_launch_status("nhwc_to_ncthw");
+}
+
+extern "C" int ccedit_copy_row_blocks(const void* src, void* dst, const void* add, const int64_t* blocks, int32_t n_blocks,
+                                      int64_t max_rows, int32_t row_bytes, void* stream) {
+    CC_CHECK_ARG(src && dst && blocks && n_blocks > 0 && max_rows > 0 && row_bytes > 0, "ccedit_copy_row_blocks: bad args");
+    CC_UNSUPPORTED(row_bytes % 16 != 0 || n_blocks > 65535, "ccedit_copy_row_blocks: row_bytes=%d must be a multiple of 16 (n_blocks=%d <= 65535)",
+                   row_bytes, n_blocks);
+    const int row_gran = row_bytes / 16;
+    int64_t gx = (max_rows * row_gran + 256 * 8 - 1) / (256 * 8);       // ~8 granules per thread in the longest block
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(copy_row_blocks_kernel, dim3((unsigned)gx, (unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const char*)src, (char*)dst, (const bf16*)add, blocks, row_gran);
+    return cc_launch_status("copy_row_blocks");
 }
 
 extern "C" int ccedit_cat_add(const void* a, const void* b, const void* c, void* out, int64_t rows, int32_t C1, int32_t C2,

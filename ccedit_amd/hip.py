@@ -88,6 +88,7 @@ _SIGS = {
                                        C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
     "ccedit_nhwc_to_ncthw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_void_p]),
+    "ccedit_copy_row_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "ccedit_cat_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                  C.c_void_p]),
     "ccedit_cat_add_gn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

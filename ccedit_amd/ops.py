@@ -425,6 +425,18 @@ def cat_add(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor], gn: boo
     return out
 
 
+def copy_row_blocks(src: torch.Tensor, dst: torch.Tensor, blocks: torch.Tensor, max_rows: int, add: Optional[torch.Tensor] = None):
+    """dst[blocks[s,1] : +blocks[s,2]] = src[blocks[s,0] : +blocks[s,2]] (+ add at the destination rows) for every block s.
+    src / dst / add: 2-D row-major with the same row width; blocks: int64 (n, 3) on the device."""
+    assert src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.shape[1] == dst.shape[1]
+    assert blocks.dtype == torch.int64 and blocks.is_cuda and blocks.is_contiguous() and blocks.shape[1] == 3
+    if add is not None:
+        assert add.dtype == BF16 and dst.dtype == BF16 and add.is_contiguous() and add.shape == dst.shape
+    hip.check(hip.lib().ccedit_copy_row_blocks(src.data_ptr(), dst.data_ptr(), _ptr(add), blocks.data_ptr(), blocks.shape[0], max_rows,
+                                               src.shape[1] * src.element_size(), _stream()), "ccedit_copy_row_blocks")
+    return dst
+
+
 def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk_act(a, "add.a"), _chk_act(b, "add.b")
     y = torch.empty_like(a) if out is None else out

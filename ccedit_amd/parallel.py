@@ -106,10 +106,17 @@ class FrameShard:
         self.n_collectives = 0
         self.timing = None                     # a list: (start, stop) device events around every exchange (bench.py)
         self._plans = {}
+        self._slabs = {}
 
     # -- instrumentation ------------------------------------------------------------------------
-    def _tick(self, t: torch.Tensor):
+    issue_log = None       # class-wide: a list collects (partition, kind, elements) of every collective in HOST ISSUE ORDER — all
+    #                        shards of the process append to the same list, so the interleaving of two communicators is visible.
+    #                        Ranks whose logs differ would deadlock on real links; tests compare them across ranks.
+
+    def _tick(self, t: torch.Tensor, kind: str = "a2a"):
         self.n_collectives += 1
+        if FrameShard.issue_log is not None:
+            FrameShard.issue_log.append((int(self.bounds[0][1] - self.bounds[0][0] != self.t_max), kind, int(t.numel())))
         if self.timing is None or not t.is_cuda:
             return None
         ev = torch.cuda.Event(enable_timing=True)
@@ -162,11 +169,47 @@ class FrameShard:
             wire_of_std, inv = wire_of_std.to(device), inv.to(device)
         pl = dict(hw_me=hw_me, pack=pack.to(device), unpack=unpack.to(device), frame_rows=frame_rows,
                   pixel_rows=pixel_rows, to_wire=wire_of_std, from_wire=inv)
+        if torch.device(device).type == "cuda":
+            # The same two permutations as ROW BLOCKS for ccedit_copy_row_blocks (one HIP kernel per pack / unpack instead of an
+            # ATen index_select over every row + a separate add): the wire order only permutes whole runs of rows.
+            #   frame side: block (peer r, clip, local frame) = the pixels of r's block, contiguous on both sides
+            #   pixel side (b > 1): block (peer s, clip) = s's keyframes of that clip x my pixels, contiguous on both sides
+            fb, wpos = [], 0
+            for lo, hi in pix:
+                for bi in range(b):
+                    for tl in range(self.t_local):
+                        fb.append(((bi * self.t_local + tl) * hw + lo, wpos, hi - lo))
+                        wpos += hi - lo
+            pl["frame_blocks"] = torch.tensor(fb, dtype=torch.int64, device=device)                       # (frame row, wire row, rows)
+            pl["frame_blocks_inv"] = torch.tensor([(w_, f_, n_) for f_, w_, n_ in fb], dtype=torch.int64, device=device)
+            pl["frame_max"] = max(n_ for _, _, n_ in fb)
+            if b > 1:
+                pb, wpos = [], 0
+                for lo, hi in self.bounds:
+                    for bi in range(b):
+                        pb.append(((bi * self.t_glob + lo) * hw_me, wpos, (hi - lo) * hw_me))
+                        wpos += (hi - lo) * hw_me
+                pl["pixel_blocks"] = torch.tensor(pb, dtype=torch.int64, device=device)                   # (std row, wire row, rows)
+                pl["pixel_blocks_inv"] = torch.tensor([(w_, s_, n_) for s_, w_, n_ in pb], dtype=torch.int64, device=device)
+                pl["pixel_max"] = max(n_ for _, _, n_ in pb)
         self._plans[key] = pl
         return pl
 
-    def _all_to_all(self, send: torch.Tensor, out_rows, in_rows) -> torch.Tensor:
-        out = torch.empty((sum(out_rows), send.shape[1]), dtype=send.dtype, device=send.device)
+    def _slab(self, tag: str, rows: int, like: torch.Tensor) -> torch.Tensor:
+        """Wire-side scratch (pack output, unpack input): two alternating slabs per role instead of an allocation per exchange.
+        Safe to recycle: a slab is next written by a kernel on the stream that already waited for the collective that read /
+        wrote it (all_to_all_single returns with that stream dependency in place); results handed to the caller are never slabs."""
+        key = (tag, rows, like.shape[1], like.dtype, str(like.device))
+        ent = self._slabs.get(key)
+        if ent is None:
+            ent = [[torch.empty((rows, like.shape[1]), dtype=like.dtype, device=like.device) for _ in range(2)], 0]
+            self._slabs[key] = ent
+        ent[1] ^= 1
+        return ent[0][ent[1]]
+
+    def _all_to_all(self, send: torch.Tensor, out_rows, in_rows, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty((sum(out_rows), send.shape[1]), dtype=send.dtype, device=send.device)
         ev = self._tick(send)
         if self.staged and send.is_cuda:
             h_in = send.detach().cpu()
@@ -188,20 +231,37 @@ class FrameShard:
         """(b * t_local * hw, C) rows of my keyframes -> (b * t_glob * hw_local, C): ALL keyframes of my pixel block."""
         pl = self._plan(b, hw, x2d.device)
         assert x2d.shape[0] == b * self.t_local * hw, (x2d.shape, b, self.t_local, hw)
-        send = x2d.index_select(0, pl["pack"])
-        y = self._all_to_all(send, pl["pixel_rows"], pl["frame_rows"])
-        return y if b == 1 else y.index_select(0, pl["from_wire"])
+        if not x2d.is_cuda:                    # CPU tensors (gloo tests of the collective pattern): ATen
+            send = x2d.index_select(0, pl["pack"])
+            y = self._all_to_all(send, pl["pixel_rows"], pl["frame_rows"])
+            return y if b == 1 else y.index_select(0, pl["from_wire"])
+        from . import ops
+        send = ops.copy_row_blocks(x2d.contiguous(), self._slab("send_f", x2d.shape[0], x2d), pl["frame_blocks"], pl["frame_max"])
+        n_out = sum(pl["pixel_rows"])
+        if b == 1:                             # the wire order IS (T, own pixels): the received buffer is the result
+            return self._all_to_all(send, pl["pixel_rows"], pl["frame_rows"])
+        w = self._all_to_all(send, pl["pixel_rows"], pl["frame_rows"], out=self._slab("recv_p", n_out, x2d))
+        return ops.copy_row_blocks(w, torch.empty_like(w), pl["pixel_blocks_inv"], pl["pixel_max"])
 
     def to_frames(self, y2d: torch.Tensor, b: int, hw: int, add: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Inverse of to_pixels; `add` (frame layout) is summed into the result (the ResBlock skip)."""
         pl = self._plan(b, hw, y2d.device)
         assert y2d.shape[0] == b * self.t_glob * pl["hw_me"], (y2d.shape, b, self.t_glob, pl["hw_me"])
-        send = y2d.contiguous() if b == 1 else y2d.index_select(0, pl["to_wire"])
-        w = self._all_to_all(send, pl["frame_rows"], pl["pixel_rows"])
-        x = w.index_select(0, pl["unpack"])
-        if add is not None:
-            x.add_(add)
-        return x
+        if not y2d.is_cuda:
+            send = y2d.contiguous() if b == 1 else y2d.index_select(0, pl["to_wire"])
+            w = self._all_to_all(send, pl["frame_rows"], pl["pixel_rows"])
+            x = w.index_select(0, pl["unpack"])
+            if add is not None:
+                x.add_(add)
+            return x
+        from . import ops
+        y2d = y2d.contiguous()
+        send = y2d if b == 1 else ops.copy_row_blocks(y2d, self._slab("send_p", y2d.shape[0], y2d), pl["pixel_blocks"], pl["pixel_max"])
+        n_out = sum(pl["frame_rows"])
+        w = self._all_to_all(send, pl["frame_rows"], pl["pixel_rows"], out=self._slab("recv_f", n_out, y2d))
+        # unpack + the ResBlock skip in ONE pass: x = w[wire order] + add, fp32 add, one rounding (== x.add_(add))
+        return ops.copy_row_blocks(w, torch.empty_like(w), pl["frame_blocks_inv"], pl["frame_max"],
+                                   add=None if add is None else add.contiguous())
 
     # -- helpers --------------------------------------------------------------------------------
     def _out(self, t: torch.Tensor) -> torch.Tensor:
@@ -209,7 +269,7 @@ class FrameShard:
 
     def allreduce(self, t: torch.Tensor) -> torch.Tensor:
         """In-place SUM over the ranks."""
-        ev = self._tick(t)
+        ev = self._tick(t, "allreduce")
         if self.staged and t.is_cuda:
             h = t.detach().cpu()
             self.dist.all_reduce(h, group=self.group)
@@ -226,7 +286,7 @@ class FrameShard:
         dist = self.dist
         dev = first.device
         ops_, prev_buf, next_buf = [], None, None
-        ev = self._tick(first)
+        ev = self._tick(first, "halo")
         f_out, l_out = self._out(first), self._out(last)
         if self.rank > 0:
             prev_buf = torch.empty_like(f_out)
@@ -294,7 +354,7 @@ class FrameShard:
         yl = y2d.reshape(b * self.t_glob, hw_me, c)
         if hw_me < hw_max:
             yl = torch.cat([yl, yl.new_zeros((b * self.t_glob, hw_max - hw_me, c))], dim=1)
-        ev = self._tick(y2d)
+        ev = self._tick(y2d, "gather_pixels")
         send = self._out(yl)
         bufs = [torch.empty_like(send) for _ in range(self.world)]
         self.dist.all_gather(bufs, send, group=self.group)
@@ -310,7 +370,7 @@ class FrameShard:
         if self.t_local < self.t_max:          # equal-size all-gather: pad short shards
             pad = torch.zeros((b, self.t_max - self.t_local, *rest), dtype=x.dtype, device=x.device)
             xl = torch.cat([xl, pad], dim=1)
-        ev = self._tick(x)
+        ev = self._tick(x, "gather_frames")
         send = self._out(xl)
         bufs = [torch.empty_like(send) for _ in range(self.world)]
         self.dist.all_gather(bufs, send, group=self.group)

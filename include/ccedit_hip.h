@@ -232,6 +232,13 @@ int ccedit_cat_add(const void* a, const void* b, const void* c, void* out, int64
  * the decoder ResBlock's in_layers.0 (openaimodel.py:441-444) then does not re-read the concatenation. */
 int ccedit_cat_add_gn(const void* a, const void* b, const void* c, void* out, double* stats, int32_t frames,
                       int32_t hw, int32_t C1, int32_t C2, void* stream);
+/* Row-block copy for the layout transposition of a frame-sharded clip (ccedit_amd/parallel.py: FrameShard.to_pixels / to_frames;
+ * BASELINE.json config 4 — the reference has no multi-GPU path, scripts/sampling/sampling_tv2v.py:106 is a single .to("cuda")):
+ * for s < n_blocks, rows [blocks[3s], + blocks[3s+2]) of src go to rows [blocks[3s+1], ...) of dst; with `add` (bf16 rows laid out
+ * like dst) dst = src + add in fp32 with one rounding — the unpack of an all-to-all with the ResBlock skip folded in.
+ * blocks: int64 [n_blocks][3] in DEVICE memory; max_rows = the largest block (grid sizing); row_bytes % 16 == 0. */
+int ccedit_copy_row_blocks(const void* src, void* dst, const void* add, const int64_t* blocks, int32_t n_blocks,
+                           int64_t max_rows, int32_t row_bytes, void* stream);
 /* y = a + b (bf16), n elements — `h = h + control.pop()` (controlmodel.py:537), `h += guided_hint` (:300) */
 int ccedit_add(const void* a, const void* b, void* y, int64_t n, void* stream);
 /* y = silu(x), bf16 elementwise (out_temporal's leading nn.SiLU, openaimodel.py:1627-1632) */

@@ -62,8 +62,18 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     shards = FrameShard.cfg_pair(T, groups=groups) if mode == "pair" else (FrameShard(T, mode=mode),)
     assert all(s.staged != rccl for s in shards)
     w.frame_shard = shards if mode == "pair" else shards[0]
+    FrameShard.issue_log = []
     out = w(x2.cuda(), t.cuda(), cc).cpu()
     torch.cuda.synchronize()
+    # Every rank must have issued the SAME sequence of collectives (kind, size class, communicator) from its host thread — with
+    # two communicators on two streams ("pair") a rank-dependent order is the classic RCCL deadlock.  Element counts differ
+    # between ranks only through the shard sizes, so the comparable part is (partition, kind).
+    mine = [(p_, k_) for p_, k_, _ in FrameShard.issue_log]
+    FrameShard.issue_log = None
+    logs = [None] * world
+    dist.all_gather_object(logs, mine)
+    assert all(l == logs[0] for l in logs), "ranks issued their collectives in different orders"
+    assert len(mine) == sum(s.n_collectives for s in shards)
     orc = None
     if rank == 0:          # fp32 CPU oracle: the common yardstick for both execution orders
         torch.set_num_threads(16)

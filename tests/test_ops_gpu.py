@@ -815,3 +815,30 @@ def test_attention_long_pingpong_rescale_and_anchor():
     ctx = torch.cat([anchor, kv], dim=1)
     _close(o.reshape(n, hw, c), _sdpa_ref(q, ctx[..., :c], ctx[..., c:], heads), rel=2.0 ** -6, abs_=4e-3,
            what="long anchor + self attention")
+
+
+def test_copy_row_blocks_pack_unpack_add():
+    """ccedit_copy_row_blocks: the pack / unpack(+skip add) halves of FrameShard's all-to-all against index_select + add_."""
+    _dev()
+    from ccedit_amd import ops
+    g = torch.Generator().manual_seed(3)
+    rows, c = 1000, 320
+    x = torch.randn(rows, c, generator=g).to(BF).cuda()
+    lens = [130, 1, 257, 64, 548]
+    srcs = [870, 0, 1, 258, 322]                       # a permutation of row runs
+    dst0, blocks = 0, []
+    for s0, n in zip(srcs, lens):
+        blocks.append((s0, dst0, n))
+        dst0 += n
+    assert dst0 == rows
+    bt = torch.tensor(blocks, dtype=torch.int64, device="cuda")
+    idx = torch.cat([torch.arange(s0, s0 + n) for s0, _, n in blocks]).cuda()
+    out = ops.copy_row_blocks(x, torch.empty_like(x), bt, max(lens))
+    assert torch.equal(out, x.index_select(0, idx))
+    inv = torch.tensor([(d0, s0, n) for s0, d0, n in blocks], dtype=torch.int64, device="cuda")
+    skip = torch.randn(rows, c, generator=g).to(BF).cuda()
+    back = ops.copy_row_blocks(out, torch.empty_like(x), inv, max(lens), add=skip)
+    assert torch.equal(back, x + skip)                 # bf16 + bf16 -> fp32 add, one rounding: exactly ATen's add_
+    f32 = torch.randn(77, 8, generator=g).cuda()       # any dtype whose rows are multiples of 16 bytes
+    b1 = torch.tensor([(70, 0, 7), (0, 7, 70)], dtype=torch.int64, device="cuda")
+    assert torch.equal(ops.copy_row_blocks(f32, torch.empty_like(f32), b1, 70), torch.cat([f32[70:], f32[:70]]))
