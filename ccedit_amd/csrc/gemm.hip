@@ -470,6 +470,14 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         return cc_lin320_launch(d, s);
     }
     if (d.tile == 0 && cc_small_conv_applicable(d)) return cc_small_conv_launch(d, s);     // few-channel 3x3 (hint stem top)
+    // 3x3 convs onto >= 1024 channels (the 16x24 level): 29-59 MB of weights do not fit an XCD's L2 and the 128 x 128 tiles of the LDS-halo
+    // kernel re-stream them per pixel tile (450 MB fetched for 63 MB of operands, round 2).  The persistent 256 x 256 tap-gather loop
+    // halves the weight bytes per FLOP: cold sweep 1280->1280 1162 / 843, 2560->1280 1220 / 895, 640->1280 1067 / 729 TF/s.  At 640
+    // channels and below the halo re-use wins (32x48 640->640: 890 / 925) and those stay.  CCEDIT_G8_CONV=0 for the A/B.
+    static const int g8c_env = getenv("CCEDIT_G8_CONV") ? atoi(getenv("CCEDIT_G8_CONV")) : 1;
+    static const int g8_env0 = getenv("CCEDIT_G8") ? atoi(getenv("CCEDIT_G8")) : 1;
+    if (d.tile == 0 && g8c_env && g8_env0 && d.mode == CCEDIT_GEMM_CONV2D && d.N >= 1024 && d.M >= 12000 && cc_g8_applicable(d, 1))
+        return cc_g8_launch(d, s, 1);
     static const int halo_env = getenv("CCEDIT_CONV_HALO") ? atoi(getenv("CCEDIT_CONV_HALO")) : 1;   // 0: A/B against the gather path
     if ((d.tile == 0 && halo_env) || d.tile == 8) {
         if (cc_conv_halo_applicable(d)) return cc_conv_halo_launch(d, s);
@@ -499,7 +507,7 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         // and 507 / 519 at 320->320, where three 128-channel tiles re-read every activation row: those stay on tap_gemm, N >= 640 above).
         // Below ~200 tiles the persistent grid is mostly idle: the 8x12 level (3264 rows) and single CFG halves of 16x24 stay too.
         static const int g8t_env = getenv("CCEDIT_G8_TEMPORAL") ? atoi(getenv("CCEDIT_G8_TEMPORAL")) : 1;      // 0: A/B
-        if (d.mode == CCEDIT_GEMM_LINEAR || (g8t_env && d.M >= 12000)) return cc_g8_launch(d, s, 0);
+        if (d.mode == CCEDIT_GEMM_LINEAR || (d.mode == CCEDIT_GEMM_TEMPORAL && g8t_env && d.M >= 12000)) return cc_g8_launch(d, s, 0);
     }
     CC_UNSUPPORTED(d.tile == 6 && d.N % 320 != 0, "ccedit_gemm: tile 6 (320-channel block shape) needs N %% 320 == 0 (N=%d)", d.N);
     int tile = d.tile;

@@ -137,10 +137,14 @@ __device__ __forceinline__ void g8_flush_stats(float (&gs)[8], float (&gq)[8], i
     }
 }
 
-// TEMPORAL: Conv1d k3 over the T keyframes of a clip (openaimodel.py:617-629, 674-687): K = [Cin / 64][3 taps][64]; K tile kt reads
-// channel chunk kt / 3 of the pixel's row in frame t + kt % 3 - 1 — the same row HW rows earlier / later — or the zero page when
-// that frame is outside the clip (Conv1d padding).  Only the activation request changes: one select per 16-byte piece.
-template <int TIH, int TJH, int EPI, bool TEMPORAL>
+// GATHER: implicit-GEMM convolutions, K = [Cin / 64][taps][64] (weight K order 1).  K tile kt reads channel chunk kt / taps of the
+// pixel's row shifted by the tap: Conv1d k3 over the T keyframes of a clip (openaimodel.py:617-629, 674-687; rows HW apart,
+// zeros outside the clip) or Conv2d 3x3 stride 1 pad 1 (openaimodel.py:445-449, 483-492; rows dy * W + dx apart, zeros outside the
+// frame).  Only the activation request changes: a uniform row offset per tap and one select (row or zero page) per 16-byte piece;
+// which taps a thread's rows have is a 9-bit mask per row, computed once per output tile.
+enum { G8_LINEAR = 0, G8_TEMPORAL = 1, G8_CONV3 = 2 };
+
+template <int TIH, int TJH, int EPI, int GATHER>
 __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     static_assert(TIH * TJH == 2, "eight MFMAs per phase");
     constexpr int BM = TIH * 128, BN = TJH * 256;
@@ -199,21 +203,32 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     const char* at;
     int rmax;
     const uint32_t ldab = (uint32_t)d.lda * 2, gcol16 = gcol * 16;
-    uint32_t prev_ok = 0, next_ok = 0;           // TEMPORAL: bit j = row j * 64 + rsub of the tile has a frame before / after it in its clip
-    const int64_t hw_bytes = (int64_t)d.HW * d.lda * 2;
+    constexpr int NTAP = GATHER == G8_CONV3 ? 9 : 3;
+    uint32_t tap_ok[(2 * BI + 2) / 3] = {};      // GATHER: 9 bits per row j * 64 + rsub of the tile (3 rows per word): bit = that tap exists
+    const int64_t row_bytes = (int64_t)d.lda * 2;
     auto set_tile = [&](int pt_, int ct_) {
         wt = Wp + (size_t)ct_ * BM * d.Kpad * 2;
         const int64_t pix0 = (int64_t)pt_ * BN;
         at = Ap + (size_t)pix0 * d.lda * 2;
         const int64_t left = d.M - 1 - pix0;
         rmax = left < BN ? (int)left : BN;
-        if constexpr (TEMPORAL) {
-            prev_ok = next_ok = 0;
+        if constexpr (GATHER != G8_LINEAR) {
+#pragma unroll
+            for (int w = 0; w < (2 * BI + 2) / 3; ++w) tap_ok[w] = 0;
 #pragma unroll
             for (int j = 0; j < 2 * BI; ++j) {
-                const int fr = (int)((pix0 + min(j * 64 + rsub, rmax)) / d.HW) % d.T;      // keyframe index inside the clip
-                prev_ok |= (uint32_t)(fr > 0) << j;
-                next_ok |= (uint32_t)(fr < d.T - 1) << j;
+                const int64_t m = pix0 + min(j * 64 + rsub, rmax);
+                uint32_t ok;
+                if constexpr (GATHER == G8_TEMPORAL) {
+                    const int fr = (int)(m / d.HW) % d.T;                                   // keyframe index inside the clip
+                    ok = (uint32_t)(fr > 0) | 2u | ((uint32_t)(fr < d.T - 1) << 2);
+                } else {
+                    const int rem = (int)(m % ((int64_t)d.Hin * d.Win));
+                    const int y = rem / d.Win, x = rem - y * d.Win;
+                    const uint32_t xm = (uint32_t)(x > 0) | 2u | ((uint32_t)(x < d.Win - 1) << 2);     // dx = -1, 0, +1
+                    ok = (y > 0 ? xm : 0u) | (xm << 3) | (y < d.Hin - 1 ? xm << 6 : 0u);                 // tap = 3 (dy + 1) + (dx + 1)
+                }
+                tap_ok[j / 3] |= ok << (9 * (j % 3));
             }
         }
     };
@@ -227,15 +242,16 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         }
     };
     auto stage_b = [&](int h, int kt, int buf) {
-        if constexpr (TEMPORAL) {
-            const int chunk = kt / 3, tap = kt - 3 * chunk;                        // uniform
-            const char* const base = at + (int64_t)(tap - 1) * hw_bytes + chunk * 128;
-            const uint32_t okm = tap == 1 ? 0xFFFFFFFFu : (tap == 0 ? prev_ok : next_ok);
+        if constexpr (GATHER != G8_LINEAR) {
+            const int chunk = kt / NTAP, tap = kt - NTAP * chunk;                  // uniform
+            const int shift = GATHER == G8_TEMPORAL ? (tap - 1) * d.HW : (tap / 3 - 1) * d.Win + (tap % 3 - 1);       // rows
+            const char* const base = at + (int64_t)shift * row_bytes + chunk * 128;
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
-                const int r = min((h * BI + i) * 64 + rsub, rmax);
+                const int j = h * BI + i;
+                const int r = min(j * 64 + rsub, rmax);
                 const char* src = base + ((uint32_t)r * ldab + gcol16);
-                src = ((okm >> (h * BI + i)) & 1) ? src : g8_zero_page;
+                src = ((tap_ok[j / 3] >> (9 * (j % 3) + tap)) & 1) ? src : g8_zero_page;
                 glds16(src, lds_wave + buf * BUF + 2 * AH + h * BH + i * 8192);
             }
         } else {
@@ -451,8 +467,10 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         const bool st = !(flags & 1);
         char* const stg = smem + BUF + wave * 8192;
         const int chw = ch0 + wr * CW;                                   // this wave's first channel (packed row)
-        const bool gn = d.gn_stats != nullptr;                           // (the launcher admits it only when a tile lies inside one frame)
-        double* const gn_slots = gn ? d.gn_stats + (size_t)(pix0 / d.gn_rows) * 64 : nullptr;
+        // GroupNorm statistics: a wave's 32-pixel tile tjf lies inside one 128-pixel block of the output tile, and frames are whole
+        // numbers of such blocks (gn_rows % 128 == 0, e.g. 384 at the 16x24 level): the frame is taken per tjf and flushed per tjf
+        const bool gn = d.gn_stats != nullptr;
+        auto gn_slots = [&](int tjf) { return d.gn_stats + (size_t)(min(pix0 + pixbase(tjf), d.M - 1) / d.gn_rows) * 64; };
         if constexpr (EPI == G8_GEGLU) {
             // packed rows 16 g + [0, 8) are values, + [8, 16) their gates: a 32-row tile yields 16 output channels
             constexpr int RB = CW, G = RB / 16;                          // staged row: CW / 2 bf16 outputs of one pixel
@@ -480,13 +498,13 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
             }
         } else if constexpr (EPI == G8_RES) {
             // fp32 staging, 64 channels x 32 pixels at a time: the residuals are added before the one rounding to bf16
-            float gs[CW / 64][8], gq[CW / 64][8];
-#pragma unroll
-            for (int cs = 0; cs < CW / 64; ++cs)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) gs[cs][e] = gq[cs][e] = 0.f;
 #pragma unroll
             for (int tjf = 0; tjf < NJ; ++tjf) {
+                float gs[CW / 64][8], gq[CW / 64][8];
+#pragma unroll
+                for (int cs = 0; cs < CW / 64; ++cs)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gs[cs][e] = gq[cs][e] = 0.f;
 #pragma unroll
                 for (int cs = 0; cs < CW / 64; ++cs) {
                     const int cb64 = chw + cs * 64;
@@ -535,19 +553,20 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                     if (tjf * (CW / 64) + cs + 2 < NSB) load_r1(tjf * (CW / 64) + cs + 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-            if (gn) {
+                if (gn) {
 #pragma unroll
-                for (int cs = 0; cs < CW / 64; ++cs) g8_flush_stats<8>(gs[cs], gq[cs], lane, chw + cs * 64 + 8 * (lane & 7), d.N, gn_slots);
+                    for (int cs = 0; cs < CW / 64; ++cs)
+                        g8_flush_stats<8>(gs[cs], gq[cs], lane, chw + cs * 64 + 8 * (lane & 7), d.N, gn_slots(tjf));
+                }
             }
         } else {
             // bf16 staging, all CW channels x 32 pixels at a time
             constexpr int RB = CW * 2, G = RB / 16;
-            float gs[8], gq[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
 #pragma unroll
             for (int tjf = 0; tjf < NJ; ++tjf) {
+                float gs[8], gq[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
 #pragma unroll
                 for (int tf = 0; tf < NI; ++tf)
 #pragma unroll
@@ -573,9 +592,9 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                         }
                     }
                 }
+                if (gn) g8_flush_stats<G>(gs, gq, lane, chw + 8 * (lane % G), d.N, gn_slots(tjf));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (gn) g8_flush_stats<G>(gs, gq, lane, chw + 8 * (lane % G), d.N, gn_slots);
         }
         G8_STAMP();
         if (!more) return;
@@ -596,12 +615,12 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     }
 }
 
-template <int TIH, int TJH, int EPI, bool TEMPORAL>
+template <int TIH, int TJH, int EPI, int GATHER>
 int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu) {
     constexpr int BM = TIH * 128, BN = TJH * 256;
     constexpr int LDS = 2 * (2 * TIH * 8192 + 2 * TJH * 16384);
     static unsigned long long attr_done = 0;
-    if (int rc = cc_max_dynamic_lds((const void*)g8_kernel<TIH, TJH, EPI, TEMPORAL>, LDS, &attr_done, "g8_kernel")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)g8_kernel<TIH, TJH, EPI, GATHER>, LDS, &attr_done, "g8_kernel")) return rc;
     const int64_t pt_n = (d.M + BN - 1) / BN, ct_n = (d.N + BM - 1) / BM;
     CcGemmDesc dd = d;
     dd.cgroup = 0;
@@ -627,8 +646,8 @@ int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu) {
     int wgs = n_cu - n_cu % 8;
     const int64_t tiles = pt_n * ct_n;
     if (tiles < wgs) wgs = (int)((tiles + 7) / 8 * 8);
-    cc_note_kernel(TEMPORAL ? "g8_kernel %dch x %dpix, temporal taps" : "g8_kernel %dch x %dpix", BM, BN);
-    hipLaunchKernelGGL((g8_kernel<TIH, TJH, EPI, TEMPORAL>), dim3((unsigned)wgs), dim3(512), LDS, s, dd);
+    cc_note_kernel(GATHER == G8_TEMPORAL ? "g8_kernel %dch x %dpix, temporal taps" : (GATHER == G8_CONV3 ? "g8_kernel %dch x %dpix, 3x3 taps" : "g8_kernel %dch x %dpix"), BM, BN);
+    hipLaunchKernelGGL((g8_kernel<TIH, TJH, EPI, GATHER>), dim3((unsigned)wgs), dim3(512), LDS, s, dd);
     return cc_launch_status("g8_kernel");
 }
 
@@ -644,17 +663,21 @@ static int g8_auto_shape(const CcGemmDesc& d) {
 // shape: 0 = by Cout, 1 = 256ch x 256pix, 2 = 128ch x 512pix
 bool cc_g8_applicable(const CcGemmDesc& d, int shape) {
     if (shape == 0) shape = g8_auto_shape(d);
-    const int bn = shape == 2 ? 512 : 256;
-    const bool geo = d.mode == CCEDIT_GEMM_LINEAR
-                         ? (d.taps == 1 && d.Kpad == d.Cin)
-                         : (d.mode == CCEDIT_GEMM_TEMPORAL && d.taps == 3 && d.korder == 1 && d.Kpad == 3 * d.Cin && d.T > 0 && d.HW > 0 &&
-                            (d.Tsrc == 0 || (d.Tsrc == d.T && d.tsrc_off == 0 && d.t0 == 0 && d.Tglob == d.T)) &&      // unsharded clips only
-                            d.act == CCEDIT_ACT_NONE && (int64_t)d.HW * d.lda * 2 < (1LL << 40));
+    bool geo;
+    if (d.mode == CCEDIT_GEMM_LINEAR)
+        geo = d.taps == 1 && d.Kpad == d.Cin;
+    else if (d.mode == CCEDIT_GEMM_TEMPORAL)
+        geo = d.taps == 3 && d.korder == 1 && d.Kpad == 3 * d.Cin && d.T > 0 && d.HW > 0 &&
+              (d.Tsrc == 0 || (d.Tsrc == d.T && d.tsrc_off == 0 && d.t0 == 0 && d.Tglob == d.T)) &&      // unsharded clips only
+              d.act == CCEDIT_ACT_NONE;
+    else          // Conv2d 3x3, stride 1, pad 1, same-size output, no fused upsample
+        geo = d.taps == 9 && d.ksize == 3 && d.korder == 1 && d.Kpad == 9 * d.Cin && d.stride == 1 && d.pad == 1 && !d.upsample &&
+              d.Hin == d.Hout && d.Win == d.Wout && d.Hin > 1 && d.Win > 1 && d.act == CCEDIT_ACT_NONE;
     return geo && d.A2 == nullptr && d.Cin % 64 == 0 && d.Kpad >= 128 && d.N % 16 == 0 &&
            (d.act == CCEDIT_ACT_NONE || d.act == CCEDIT_ACT_GEGLU) && !d.out_f32 && d.ln_eps == 0.f &&
            (!d.group_bias || (d.act == CCEDIT_ACT_NONE && d.group_rows > 0 && d.group_rows % 32 == 0 && (d.ldgb == 0 || d.ldgb % 4 == 0))) &&
 #ifndef G8_PROBE
-           (!d.gn_stats || (d.act == CCEDIT_ACT_NONE && d.gn_rows > 0 && d.gn_rows % bn == 0 && d.N % 32 == 0 && d.N >= 256)) &&
+           (!d.gn_stats || (d.act == CCEDIT_ACT_NONE && d.gn_rows > 0 && d.gn_rows % 128 == 0 && d.N % 32 == 0 && d.N >= 256)) &&
 #endif
            d.lda % 8 == 0 && d.ldc % 8 == 0 && (!d.res1 || d.ldr1 % 8 == 0) && (!d.res2 || d.ldr2 % 8 == 0) &&
            (int64_t)512 * d.lda * 2 < (1LL << 31) && d.M * ((d.N + 127) / 128) < (1LL << 37);
@@ -673,13 +696,15 @@ int cc_g8_launch(const CcGemmDesc& d, hipStream_t s, int shape) {
     }
     if (shape == 0) shape = g8_auto_shape(d);
     const int epi = d.act == CCEDIT_ACT_GEGLU ? G8_GEGLU : ((d.res1 || d.res2) ? G8_RES : G8_PLAIN);
-    const bool temporal = d.mode == CCEDIT_GEMM_TEMPORAL;
-#define G8_GO(TI, TJ, EP) (temporal ? g8_launch_shape<TI, TJ, EP, true>(d, s, n_cu) : g8_launch_shape<TI, TJ, EP, false>(d, s, n_cu))
+    const int gm = d.mode == CCEDIT_GEMM_TEMPORAL ? G8_TEMPORAL : (d.mode == CCEDIT_GEMM_CONV2D ? G8_CONV3 : G8_LINEAR);
+#define G8_GO(TI, TJ, EP)                                                                            \
+    (gm == G8_TEMPORAL ? g8_launch_shape<TI, TJ, EP, G8_TEMPORAL>(d, s, n_cu)                        \
+                       : (gm == G8_CONV3 ? g8_launch_shape<TI, TJ, EP, G8_CONV3>(d, s, n_cu) : g8_launch_shape<TI, TJ, EP, G8_LINEAR>(d, s, n_cu)))
     if (shape == 2) {
-        if (epi == G8_GEGLU) return g8_launch_shape<1, 2, G8_GEGLU, false>(d, s, n_cu);
+        if (epi == G8_GEGLU) return g8_launch_shape<1, 2, G8_GEGLU, G8_LINEAR>(d, s, n_cu);
         return epi == G8_RES ? G8_GO(1, 2, G8_RES) : G8_GO(1, 2, G8_PLAIN);
     }
-    if (epi == G8_GEGLU) return g8_launch_shape<2, 1, G8_GEGLU, false>(d, s, n_cu);
+    if (epi == G8_GEGLU) return g8_launch_shape<2, 1, G8_GEGLU, G8_LINEAR>(d, s, n_cu);
     return epi == G8_RES ? G8_GO(2, 1, G8_RES) : G8_GO(2, 1, G8_PLAIN);
 #undef G8_GO
 }

@@ -127,7 +127,7 @@ def test_temporal_conv_persistent_eight_phase(b_, t, c, cout, h, w, tile):
     r1, r2 = _rnd(n, cout, h, w, seed=6), _rnd(n, cout, h, w, seed=7)
     gb = _rnd(b_, cout, seed=8)
     pw = pack_weight(wt, bt).to("cuda")
-    with_stats = (h * w) % (512 if tile == 13 else 256) == 0 and cout % 32 == 0       # a pixel tile must lie inside one frame
+    with_stats = (h * w) % 128 == 0 and cout % 32 == 0 and cout >= 256       # frames are whole 128-pixel blocks
     kw = dict(res1=_nhwc(r1).reshape(-1, cout), res2=_nhwc(r2).reshape(-1, cout), group_bias=gb.cuda(), group_rows=t * h * w,
               gn=with_stats, tile=tile)
     y = ops.conv_temporal(_nhwc(x), t, pw, **kw)
@@ -144,6 +144,36 @@ def test_temporal_conv_persistent_eight_phase(b_, t, c, cout, h, w, tile):
     y0 = ops.conv_temporal(_nhwc(x), t, pw, tile=tile)                  # plain epilogue, no statistics
     _close(_nchw(y0), ref, what="g8 temporal conv, plain")
     _close(_nchw(ops.conv_temporal(_nhwc(x), t, pw, tile=1)), ref, what="tap_gemm temporal (same reference)")
+
+
+@pytest.mark.parametrize("tile", [12, 13])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 256, 16, 32), (3, 128, 320, 8, 16), (1, 192, 640, 24, 16), (5, 64, 384, 12, 16), (3, 64, 1280, 16, 24)])
+def test_conv3x3_persistent_eight_phase(n, cin, cout, h, w, tile):
+    """Conv2d 3x3 stride 1 pad 1 through g8_kernel's tap-gather mode (tile 12 / 13): nine shifted reads of the activation rows,
+    zeros outside the frame (also between the frames of the batch — a row shifted by +-W must not read the neighbouring frame),
+    + bias + per-frame row bias + residual + fused GroupNorm statistics, against F.conv2d; repeated launches (race screen)."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_weight
+    x = _rnd(n, cin, h, w, seed=1)
+    wt, b = _rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), _rnd(cout, seed=3)
+    res, gb = _rnd(n, cout, h, w, seed=4), _rnd(n, cout, seed=5)
+    pw = pack_weight(wt, b).to("cuda")
+    with_stats = (h * w) % 128 == 0 and cout % 32 == 0 and cout >= 256     # frames are whole 128-pixel blocks (384 at the 16x24 level)
+    kw = dict(res1=_nhwc(res).view(-1, cout), group_bias=gb.cuda(), group_rows=h * w, gn=with_stats, tile=tile)
+    y = ops.conv2d(_nhwc(x), pw, **kw)
+    ref = F.conv2d(x, wt, b, padding=1) + gb[:, :, None, None] + res
+    _close(_nchw(y), ref, what=f"g8 conv3x3 {cin}->{cout} {n}x{h}x{w} tile{tile}")
+    if with_stats:
+        st = ops.gn_stats_of(y, h * w)
+        yf = y.float().view(n, h * w, 32, cout // 32)
+        assert st is not None and torch.allclose(st[..., 0].float(), yf.sum(dim=(1, 3)), rtol=1e-4, atol=2e-2)
+        assert torch.allclose(st[..., 1].float(), (yf * yf).sum(dim=(1, 3)), rtol=1e-4, atol=2e-2)
+    for _ in range(3):
+        assert torch.equal(ops.conv2d(_nhwc(x), pw, **kw), y), "g8 conv: run-to-run difference"
+    _close(_nchw(ops.conv2d(_nhwc(x), pw, tile=tile)), F.conv2d(x, wt, b, padding=1), what="g8 conv3x3 plain")
+    with pytest.raises(Exception):
+        ops.conv2d(_nhwc(x), pw, stride=2, tile=tile)                   # strided / upsampling convs are not this kernel's
 
 
 def test_linear_persistent_groupnorm_statistics_and_row_bias():

@@ -145,6 +145,36 @@ def perf_temporal(b_, t, h, w, c, cout, res=1, tiles=(0, 1, 2, 12, 13)):
     print(f"temporal B={b_} T={t} {h}x{w} {c}->{cout} res={res}: " + "  ".join(row), flush=True)
 
 
+def perf_conv(n, h, w, cin, cout, res=True, tiles=(0, 8, 12, 13)):
+    """Conv2d 3x3 stride 1, cold operands, + row bias + residual: TF/s per block shape (0 = auto, 8 = LDS-halo kernel)."""
+    pw = pack_weight(torch.randn(cout, cin, 3, 3) * (9 * cin) ** -0.5, torch.randn(cout)).to(dev)
+    NB = 4
+    src = [torch.randn(n * h * w, cin, device=dev).to(BF) for _ in range(NB)]
+    act = [torch.empty_like(x) for x in src]
+    rs = [torch.randn(n * h * w, cout, device=dev).to(BF) for _ in range(NB)]
+    gb = torch.randn(n, cout, device=dev)
+    g1, b1 = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
+    fl = 2.0 * n * h * w * cout * cin * 9
+    row = []
+    for tl in tiles:
+        try:
+            evs = []
+            for rep in range(3):
+                for i in range(NB):
+                    hip_ln(src[i], act[i], g1, b1)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ops.conv2d(act[i].view(n, h, w, cin), pw, res1=rs[i] if res else None, group_bias=gb, group_rows=h * w, gn=(h * w) % 512 == 0, tile=tl)
+                    e1.record()
+                    if rep:
+                        evs.append((e0, e1))
+            torch.cuda.synchronize()
+            row.append(f"t{tl} {fl / (sum(x.elapsed_time(y) for x, y in evs) / len(evs)) / 1e9:5.0f}")
+        except Exception as e:
+            row.append(f"t{tl} err")
+    print(f"conv3x3 n={n} {h}x{w} {cin}->{cout}: " + "  ".join(row), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     ok = True
@@ -166,6 +196,18 @@ if __name__ == "__main__":
             ok &= check(3000, 5120, 640, geglu=True, T11=t)
             ok &= check(26112, 640, 2560, res=2, T11=t)
         print("CHECK", "PASSED" if ok else "FAILED", flush=True)
+    if what in ("all", "conv"):
+        perf_conv(34, 32, 48, 640, 640)
+        perf_conv(34, 32, 48, 1280, 640)
+        perf_conv(34, 32, 48, 320, 640)
+        perf_conv(34, 16, 24, 1280, 1280)
+        perf_conv(34, 16, 24, 2560, 1280)
+        perf_conv(34, 16, 24, 640, 1280)
+        perf_conv(34, 64, 96, 320, 320)
+        perf_conv(34, 64, 96, 640, 320)
+        perf_conv(17, 32, 48, 640, 640)
+        perf_conv(17, 16, 24, 1280, 1280)
+        perf_conv(34, 8, 12, 1280, 1280)
     if what in ("all", "temporal"):
         perf_temporal(2, 17, 64, 96, 320, 320)
         perf_temporal(1, 17, 64, 96, 320, 320)
