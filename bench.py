@@ -35,7 +35,7 @@ FLOP_PER_STEP = 77.68e12          # SURVEY.md §8d, measured from the reference 
 FLOP_PER_STEP_TVI2V = 110.31e12   # BASELINE.json config 3 (controlnet_img + anchor cross-frame attention)
 MFMA_PEAK_TFLOPS = 2500.0         # MI355X dense bf16 (MI355X_MICROARCH.md)
 T, H, W, L, CTX = 17, 64, 96, 77, 768
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"      # committed rocprofv3 PMC capture (FETCH_SIZE / WRITE_SIZE passes)
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"      # committed rocprofv3 PMC capture (FETCH_SIZE / WRITE_SIZE passes)
 
 
 def synth_inputs(device, seed=42, b=1):

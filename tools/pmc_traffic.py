@@ -8,7 +8,7 @@ def load(d, name):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != name: continue
             k = r["Kernel_Name"]
-            fam = "tap_gemm" if ("tap_gemm" in k or "conv_halo" in k or "small_conv" in k or "lin320" in k or "ff320" in k) else "attn" if ("attn_kernel" in k or "attn_short" in k) else "gn_spatial_stats" if "gn_spatial_stats" in k else \
+            fam = "tap_gemm" if ("tap_gemm" in k or "g8_kernel" in k or "conv_halo" in k or "small_conv" in k or "lin320" in k or "ff320" in k) else "attn" if ("attn_kernel" in k or "attn_short" in k) else "gn_spatial_stats" if "gn_spatial_stats" in k else \
                   "gn_spatial_apply" if "gn_spatial_apply" in k else "gn_temporal" if "gn_temporal" in k else "layernorm" if "layernorm" in k else \
                   "cat_add" if "cat_add" in k else "ours_other" if "anonymous namespace" in k or "_GLOBAL__N_" in k else "torch/setup"
             acc[fam][0] += 1; acc[fam][1] += float(r["Counter_Value"])
@@ -38,7 +38,7 @@ if len(sys.argv) > 3:
         rows = []
         for f_ in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f_)):
-                if r["Counter_Name"] == name and any(t in r["Kernel_Name"] for t in ("tap_gemm", "conv_halo", "small_conv", "lin320", "ff320")):
+                if r["Counter_Name"] == name and any(t in r["Kernel_Name"] for t in ("tap_gemm", "g8_kernel", "conv_halo", "small_conv", "lin320", "ff320")):
                     rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
         rows.sort()
         return [v for _, v in rows]
