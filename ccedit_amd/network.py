@@ -33,6 +33,8 @@ from .packing import pack_concat
 # Per-block output capture for the parity tests (tests/test_network_gpu.py reads the reference's per-block digests):
 # set to a dict and every ControlNet / UNet block stores its output under the reference's module path.  None in production.
 TRACE: Optional[dict] = None
+_DEBUG_HOLD = int(os.environ.get("CCEDIT_DEBUG_HOLD_UNTIL", "-1"))
+_DEBUG_TRACE_OVERLAP = os.environ.get("CCEDIT_DEBUG_TRACE_OVERLAP") == "1"      # debugging: per-block traces WITH the ControlNet side stream
 
 
 def _trace(name: str, t: torch.Tensor):
@@ -743,6 +745,9 @@ class ControlNet2D(UNetModel):
                 if i == 0 and not self.no_add_x:
                     _trace("controlnet.guided_hint", guided)
             outs.append(ops.conv2d(h, zc[0].pw))
+            if _DEBUG_HOLD == i:          # debugging (tools/exp/repro_fast.py): the caller's stream waits until this block is done
+                self._hold_event = torch.cuda.Event()
+                self._hold_event.record()
         h = self.middle_block.run(h, emb_silu, geo, ctx2d, ctx_len)
         _trace("controlnet.middle_block", h)
         outs.append(ops.conv2d(h, self.middle_block_out[0].pw))
@@ -891,7 +896,14 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     # The ControlNet's residuals are first needed after the UNet's middle block: with overlap_controlnet the ControlNet
     # (16 TFLOP) is launched on a side HIP stream and runs concurrently with the UNet encoder (25 TFLOP) — the two fill
     # each other's launch tails and the small 16x24 / 8x12-level kernels that cannot occupy 256 CUs alone.
-    overlap_controlnet = os.environ.get("CCEDIT_OVERLAP_CONTROLNET", "1") != "0"
+    # Round 3: -2.5 ms per step in the batched default (113.0 vs 115.5 ms, same box) — but with BOTH clips in one launch
+    # sequence the evaluation is then not run-to-run reproducible (tools/exp/repro_*.py: the first divergence is a LayerNorm of
+    # the ControlNet's first 32x48 block — 257 values — whose input checksum is identical in both runs, while the UNet's 64x96
+    # level runs beside it; no buffer changes after it was produced; serialising the side stream, or holding the main stream
+    # until the ControlNet has left its 32x48 level, restores bit-equality; cause not identified).  The two-stream CFG halves
+    # (B = 1 launches) have shown no such difference in any run.  Reproducibility is a stated property (tests/test_fullsize_gpu.py),
+    # so the side stream is the default only together with CCEDIT_SPLIT_CFG=1; CCEDIT_OVERLAP_CONTROLNET=1 / 0 overrides.
+    overlap_controlnet = os.environ.get("CCEDIT_OVERLAP_CONTROLNET", "1" if _SPLIT_CFG else "0") != "0"
     _side_stream = None
     _half_stream = None
 
@@ -972,7 +984,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
         x8 = ops.ncthw_to_nhwc(x.float().contiguous(), 8)
         control_ready = None
-        if self.overlap_controlnet and sh is None and ops.PROFILE is None and TRACE is None:
+        if self.overlap_controlnet and sh is None and ops.PROFILE is None and (TRACE is None or _DEBUG_TRACE_OVERLAP):
             main = torch.cuda.current_stream()
             if OpenAIWrapperControlLDM3DTV2V._side_stream is None:
                 OpenAIWrapperControlLDM3DTV2V._side_stream = {}
@@ -985,6 +997,10 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                 control = net.controlnet.run(x8, guided, t, ctx2d, context.shape[1], geo)
                 control_ready = torch.cuda.Event()
                 control_ready.record(side)
+            if os.environ.get("CCEDIT_DEBUG_SERIALIZE_SIDE") == "1":      # debugging: side stream, but no concurrent execution
+                main.wait_event(control_ready)
+            if _DEBUG_HOLD >= 0:
+                main.wait_event(net.controlnet._hold_event)
             for tns in (x8, ctx2d):
                 tns.record_stream(side)                 # allocated on the main stream, read on the side stream
             for tns in control:
