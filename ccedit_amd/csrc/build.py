@@ -4,16 +4,25 @@ ccedit_amd/libccedit_hip.so — git-ignored, but it travels with the repo snapsh
 from __future__ import annotations
 
 import os
+import re
+import shutil
 import subprocess
 import sys
+import tempfile
 import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.abspath(os.path.join(HERE, "..", "libccedit_hip.so"))
 SOURCES = ["gemm.hip", "gemm8p.hip", "convhalo.hip", "smallconv.hip", "lin320.hip", "ff320.hip", "norm.hip", "attention.hip", "attnshort.hip", "elementwise.hip", "core.cpp"]
 ARCH = "gfx950"
-# per-file flags: ff320's GEGLU must stay scalar fp32 (packed fp32 VALU is several times slower beside MFMAs, see the file)
-EXTRA_FLAGS = {"ff320.hip": ["-fno-slp-vectorize"]}
+# per-file flags: ff320's GEGLU must stay scalar fp32 (packed fp32 VALU is several times slower beside MFMAs, see the file).
+# norm.hip / attnshort.hip: without the SLP vectoriser nothing there becomes a packed-fp32 op whose LOW lane reads the HIGH half of
+# a register pair (`v_pk_add_f32 ... op_sel:[0,1]`).  That form returned 0 for the swizzled operand in lanes 48-63 about once per
+# 10^7 waves when another stream's tap_gemm kernel (AGPR-resident accumulators) shared the SIMD: LayerNorm beside a GEMM on a
+# second stream was not run-to-run reproducible (tools/exp/repro_e4.py; DESIGN.md section 3, streams).  check_isa() refuses it.
+EXTRA_FLAGS = {"ff320.hip": ["-fno-slp-vectorize"], "norm.hip": ["-fno-slp-vectorize"], "attnshort.hip": ["-fno-slp-vectorize"]}
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+_BAD_ISA = re.compile(r"v_pk_(add|mul|fma)_f32.*op_sel:\[[01,]*1")
 
 
 def _hipcc() -> str:
@@ -30,6 +39,21 @@ def needs_build() -> bool:
     deps = ([os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")]
             + [os.path.join(HERE, "..", "..", "include", "ccedit_hip.h")])
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def check_isa(obj: str) -> int:
+    """Disassemble the gfx950 code object inside one of our object files and count the packed-fp32 form described at EXTRA_FLAGS."""
+    if not os.path.exists(OBJDUMP):
+        return 0
+    with tempfile.TemporaryDirectory() as tmp:
+        o = shutil.copy(obj, tmp)
+        subprocess.run([OBJDUMP, "--offloading", o], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+        n = 0
+        for f in os.listdir(tmp):
+            if "amdgcn" in f:
+                dis = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], capture_output=True, text=True, check=False).stdout
+                n += sum(1 for line in dis.splitlines() if _BAD_ISA.search(line))
+    return n
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -54,6 +78,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
             sys.stderr.write(out)
     if not ok:
         raise RuntimeError("hipcc failed")
+    for s, o in zip(SOURCES, objs):
+        if s.endswith(".hip"):
+            n = check_isa(o)
+            if n:
+                raise RuntimeError(f"{s}: {n} packed-fp32 instruction(s) with a low-lane read of a high half (op_sel:[..1..]) — "
+                                   f"not safe beside another stream's GEMM, see EXTRA_FLAGS in {__file__}")
     link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", OUT]
     subprocess.check_call(link)
     if verbose:

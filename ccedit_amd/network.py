@@ -896,14 +896,15 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     # The ControlNet's residuals are first needed after the UNet's middle block: with overlap_controlnet the ControlNet
     # (16 TFLOP) is launched on a side HIP stream and runs concurrently with the UNet encoder (25 TFLOP) — the two fill
     # each other's launch tails and the small 16x24 / 8x12-level kernels that cannot occupy 256 CUs alone.
-    # Round 3: -2.5 ms per step in the batched default (113.0 vs 115.5 ms, same box) — but with BOTH clips in one launch
-    # sequence the evaluation is then not run-to-run reproducible (tools/exp/repro_*.py: the first divergence is a LayerNorm of
-    # the ControlNet's first 32x48 block — 257 values — whose input checksum is identical in both runs, while the UNet's 64x96
-    # level runs beside it; no buffer changes after it was produced; serialising the side stream, or holding the main stream
-    # until the ControlNet has left its 32x48 level, restores bit-equality; cause not identified).  The two-stream CFG halves
-    # (B = 1 launches) have shown no such difference in any run.  Reproducibility is a stated property (tests/test_fullsize_gpu.py),
-    # so the side stream is the default only together with CCEDIT_SPLIT_CFG=1; CCEDIT_OVERLAP_CONTROLNET=1 / 0 overrides.
-    overlap_controlnet = os.environ.get("CCEDIT_OVERLAP_CONTROLNET", "1" if _SPLIT_CFG else "0") != "0"
+    # Round 3: -2.5 ms per step in the batched default (113.0 vs 115.5 ms, same box).  Two streams put waves of different
+    # kernels on one SIMD, and that exposed a hazard single-stream runs never meet: a compiler-formed `v_pk_add_f32 ...
+    # op_sel:[0,1]` (packed fp32, low lane reading the high half of a register pair — LayerNorm's x - mean of the second
+    # row of a pair) read 0 for the swizzled operand in lanes 48-63 of roughly one wave in 10^7 whenever a tap_gemm kernel
+    # of the other stream was resident (tools/exp/repro_e4.py: offset == mean * rstd in 16 values of one row, only beside
+    # block shapes 1 / 2 / 3 / 6, never when idle, never with the scalar build of the same kernel).  csrc/build.py compiles
+    # the two files that had the form without the SLP vectoriser and refuses it in any object (check_isa), which restored
+    # run-to-run bit-equality with the side stream on; CCEDIT_OVERLAP_CONTROLNET=0 keeps everything on one stream.
+    overlap_controlnet = os.environ.get("CCEDIT_OVERLAP_CONTROLNET", "1") != "0"
     _side_stream = None
     _half_stream = None
 

@@ -76,6 +76,18 @@ def test_ln_eps_is_refused_where_no_kernel_normalises(libpath):
     assert lib.ccedit_gemm(ctypes.byref(d), None) == -2
 
 
+def test_no_packed_fp32_low_lane_high_half_reads(libpath):
+    """The one instruction form that was not safe beside another stream's GEMM (csrc/build.py EXTRA_FLAGS, DESIGN.md section 3
+    "Streams"): no object of the library may contain it — the build refuses it, and this checks the objects that are shipped."""
+    from ccedit_amd.csrc import build
+    if not os.path.exists(build.OBJDUMP):
+        pytest.skip("llvm-objdump not present")
+    for s in build.SOURCES:
+        o = os.path.join(build.HERE, s.rsplit(".", 1)[0] + ".o")
+        if s.endswith(".hip") and os.path.exists(o):
+            assert build.check_isa(o) == 0, s
+
+
 def test_product_never_imports_oracle():
     """The product package must not reach the CPU oracle (or any CPU fallback)."""
     import subprocess, sys
