@@ -41,6 +41,8 @@ bool cc_small_conv_applicable(const CcGemmDesc& d);       // smallconv.hip
 int cc_small_conv_launch(const CcGemmDesc& d, hipStream_t s);
 bool cc_g8_applicable(const CcGemmDesc& d, int shape);    // gemm8p.hip
 int cc_g8_launch(const CcGemmDesc& d, hipStream_t s, int shape);
+int cc_g8_split(const CcGemmDesc& d, int n_cu);
+int64_t cc_g8_workspace_bytes(const CcGemmDesc& d, int n_cu);
 
 namespace {
 
@@ -408,6 +410,13 @@ int launch_tile(const CcGemmDesc& d, int tile, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int64_t ccedit_gemm_workspace_bytes(const CcGemmDesc* desc) {
+    if (!desc || desc->M <= 0 || desc->N <= 0 || desc->Kpad <= 0) return 0;
+    if (!(desc->tile == 0 || desc->tile == 11 || desc->tile == 12)) return 0;
+    static const int g8_env = getenv("CCEDIT_G8") ? atoi(getenv("CCEDIT_G8")) : 1;
+    return g8_env ? cc_g8_workspace_bytes(*desc, 0) : 0;
+}
+
 extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     CC_CHECK_ARG(desc != nullptr, "ccedit_gemm: null descriptor");
     CcGemmDesc d = *desc;
@@ -477,6 +486,10 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     static const int g8c_env = getenv("CCEDIT_G8_CONV") ? atoi(getenv("CCEDIT_G8_CONV")) : 1;
     static const int g8_env0 = getenv("CCEDIT_G8") ? atoi(getenv("CCEDIT_G8")) : 1;
     if (d.tile == 0 && g8c_env && g8_env0 && d.mode == CCEDIT_GEMM_CONV2D && d.N >= 1024 && d.M >= 12000 && cc_g8_applicable(d, 1))
+        return cc_g8_launch(d, s, 1);
+    // Few tiles, long K (the 8x12 level: 3264 pixels x 1280 channels = 65 tiles of 256 x 256, K loops of 60-360 K tiles — a quarter of the
+    // chip busy for the whole loop on any block shape): split-K in the persistent kernel when the caller lent a workspace.
+    if (d.tile == 0 && g8_env0 && d.workspace && cc_g8_split(d, 0) > 1 && d.workspace_bytes >= cc_g8_workspace_bytes(d, 0))
         return cc_g8_launch(d, s, 1);
     static const int halo_env = getenv("CCEDIT_CONV_HALO") ? atoi(getenv("CCEDIT_CONV_HALO")) : 1;   // 0: A/B against the gather path
     if ((d.tile == 0 && halo_env) || d.tile == 8) {

@@ -52,6 +52,19 @@ template <int N>
 __device__ __forceinline__ void g8_lgkmcnt() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
+// Split-K slots cross workgroups (possibly XCDs, i.e. L2s): written and read with agent-scope accesses (sc1: write-through /
+// read past the non-coherent levels) instead of fences — a release fence is a write-back of the whole 4 MB L2 per wave, which made
+// the first version of the hand-over cost more than the K loop it shortened.  The loads are invisible to the compiler's counters:
+// the caller waits (g8_vmcnt<0>) before using the values.
+__device__ __forceinline__ void g8_store_agent(f32x4* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 g8_load_agent(const f32x4* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 __device__ __forceinline__ void g8_barrier() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -144,7 +157,12 @@ __device__ __forceinline__ void g8_flush_stats(float (&gs)[8], float (&gq)[8], i
 // which taps a thread's rows have is a 9-bit mask per row, computed once per output tile.
 enum { G8_LINEAR = 0, G8_TEMPORAL = 1, G8_CONV3 = 2 };
 
-template <int TIH, int TJH, int EPI, int GATHER>
+// SPLIT = 1: split-K for outputs with far fewer tiles than CUs (the 8x12 level: 3264 pixels x 1280 channels = 65 tiles, K loops of
+// 60-360 K tiles).  A work item is (tile, split); the d.split_k items of a tile are consecutive in the walk (same XCD), each
+// runs a contiguous share of the K tiles from zero accumulators and writes them, in register order, to its slot of d.workspace;
+// an arrival counter per tile elects the LAST arriver, which starts from the bias, adds the slots in split order 0, 1, 2, ...
+// (a fixed summation order whoever arrives last: results do not depend on timing) and runs the ordinary epilogue.
+template <int TIH, int TJH, int EPI, int GATHER, int SPLIT = 0>
 __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     static_assert(TIH * TJH == 2, "eight MFMAs per phase");
     constexpr int BM = TIH * 128, BN = TJH * 256;
@@ -161,15 +179,29 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int nk = d.Kpad >> 6;
+    const int nk_all = d.Kpad >> 6;
     const int flags = d.cgroup >> 24;           // tuning only: 1 = no output stores, 2 = next tile requested AFTER the epilogue
+    const int S = SPLIT ? d.split_k : 1;
+    int nk = nk_all, kbase = 0, sp_cur = 0;     // this work item's K tiles: [kbase, kbase + nk), its split index
 
     const G8Order ord = g8_order<BM>(d, BN);
     const int xcd = blockIdx.x & 7;
     const int nw = gridDim.x >> 3;              // workgroups per XCD
-    int g = xcd * ord.per + (blockIdx.x >> 3);
-    const int gend = min((xcd + 1) * ord.per, ord.total);
+    const int items = ord.total * S, per = SPLIT ? (items + 7) >> 3 : ord.per;
+    int g = xcd * per + (blockIdx.x >> 3);
+    const int gend = min((xcd + 1) * per, items);
     if (g >= gend) return;
+    auto decode = [&](int g_, int& pt_, int& ct_) {
+        if constexpr (SPLIT) {
+            const int tile = g_ / S, sp = g_ - tile * S;
+            g8_decode(ord, tile, pt_, ct_);
+            sp_cur = sp;
+            kbase = (int)((int64_t)sp * nk_all / S);
+            nk = (int)((int64_t)(sp + 1) * nk_all / S) - kbase;
+        } else {
+            g8_decode(ord, g_, pt_, ct_);
+        }
+    };
 
     // ---- staging: thread -> (row rsub of a 64-row issue, LDS slot p), source granule p ^ ((rsub >> 1) & 7) ----
     const int p = tid & 7, rsub = tid >> 3;
@@ -195,7 +227,7 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     }
 
     int pt, ct;
-    g8_decode(ord, g, pt, ct);
+    decode(g, pt, ct);
 
     // per-tile source bases (uniform).  Pixel rows past M are clamped to M - 1 when the B tile is requested (computed from
     // valid memory, never stored): rmax = M - 1 - pix0 is the last valid row of the tile, >= BN - 1 except in the last one.
@@ -237,11 +269,12 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         for (int i = 0; i < AI; ++i) {
             // uniform part in SGPRs (readfirstlane keeps hipcc from turning it into per-lane 64-bit induction variables),
             // per-lane part a 32-bit VGPR offset: global_load_lds_dwordx4 v, s[..]
-            const uint32_t u = __builtin_amdgcn_readfirstlane((uint32_t)((i * (64 / (TIH * 32)) * CW + h * (TIH * 32)) * d.Kpad * 2 + kt * 128));
+            const uint32_t u = __builtin_amdgcn_readfirstlane((uint32_t)((i * (64 / (TIH * 32)) * CW + h * (TIH * 32)) * d.Kpad * 2 + (kt + kbase) * 128));
             glds16(wt + u + a_lane, lds_wave + buf * BUF + h * AH + i * 8192);
         }
     };
-    auto stage_b = [&](int h, int kt, int buf) {
+    auto stage_b = [&](int h, int kt_, int buf) {
+        const int kt = kt_ + kbase;
         if constexpr (GATHER != G8_LINEAR) {
             const int chunk = kt / NTAP, tap = kt - NTAP * chunk;                  // uniform
             const int shift = GATHER == G8_TEMPORAL ? (tap - 1) * d.HW : (tap / 3 - 1) * d.Win + (tap % 3 - 1);       // rows
@@ -298,7 +331,16 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     // registers, requested before the operand requests whose counted wait also covers them.  The epilogue never touches it.
     f32x16 acc[NI][NJ];
     auto pixbase = [&](int tjf) { return (tjf / TJH) * (TJH * 128) + wc * (TJH * 32) + (tjf % TJH) * 32; };
-    auto init_acc = [&](int pt_, int ct_) {
+    auto init_acc = [&](int pt_, int ct_, bool with_bias = !SPLIT) {
+        if (!with_bias) {           // split-K partial: the bias is the reducer's starting value
+#pragma unroll
+            for (int tf = 0; tf < NI; ++tf)
+#pragma unroll
+                for (int tj = 0; tj < NJ; ++tj)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[tf][tj][e] = 0.f;
+            return;
+        }
         const float* const bias = d.bias;
         const float* const gbias = d.group_bias;       // + per-clip row bias (ResBlock: h + emb_out): a 32-pixel tile lies in ONE clip
         const int ldgb = d.ldgb ? d.ldgb : d.N;
@@ -452,10 +494,56 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         g += nw;
         const bool more = g < gend;
         int npt = 0, nct = 0;
+        const int sp = sp_cur;
         if (more) {
-            g8_decode(ord, g, npt, nct);
+            decode(g, npt, nct);
             set_tile(npt, nct);
             if (!(flags & 2)) prologue_a();
+        }
+        bool do_epi = true;
+        if constexpr (SPLIT) {
+            // ---- split-K hand-over.  Slot of (tile, split): 8 waves x NI*NJ*4 quads x 64 lanes of f32x4, register order ----
+            const int tile = ct * ord.pt_n + pt;                      // any bijection of (pt, ct) onto [0, tiles)
+            int* const cnt = (int*)d.workspace;
+            f32x4* const part = (f32x4*)((char*)d.workspace + 4096) + (size_t)tile * S * (8 * NI * NJ * 4 * 64);
+            f32x4* const mine = part + ((size_t)sp * 8 + wave) * (NI * NJ * 4 * 64) + lane;
+#pragma unroll
+            for (int tf = 0; tf < NI; ++tf)
+#pragma unroll
+                for (int tj = 0; tj < NJ; ++tj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[tf][tj][4 * q + e];
+                        g8_store_agent(mine + ((tf * NJ + tj) * 4 + q) * 64, v);
+                    }
+            g8_vmcnt<0>();                                            // this wave's slot has left the CU (agent-scope stores) ...
+            __syncthreads();                                          // ... and everybody else's, before the count
+            int* const flag = (int*)(smem + 2 * BUF);
+            if (tid == 0) *flag = atomicAdd(cnt + tile, 1);
+            __syncthreads();
+            do_epi = *flag == S - 1;
+            if (do_epi) {
+                if (tid == 0) cnt[tile] = 0;                          // ready for the next launch on this stream
+                init_acc(pt, ct, true);
+                for (int s2 = 0; s2 < S; ++s2) {
+                    const f32x4* const src = part + ((size_t)s2 * 8 + wave) * (NI * NJ * 4 * 64) + lane;
+#pragma unroll
+                    for (int tf = 0; tf < NI; ++tf)
+#pragma unroll
+                        for (int tj = 0; tj < NJ; ++tj) {
+                            f32x4 v[4];                               // agent-scope loads: the slots as the other workgroups wrote them
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = g8_load_agent(src + ((tf * NJ + tj) * 4 + q) * 64);
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");   // (ties the uses below to the wait)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[tf][tj][4 * q + e] += v[q][e];
+                        }
+                }
+            }
         }
 
         // ---- epilogue: accumulators -> wave-private LDS tile -> global, whole 128-byte lines per row.
@@ -471,7 +559,9 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         // numbers of such blocks (gn_rows % 128 == 0, e.g. 384 at the 16x24 level): the frame is taken per tjf and flushed per tjf
         const bool gn = d.gn_stats != nullptr;
         auto gn_slots = [&](int tjf) { return d.gn_stats + (size_t)(min(pix0 + pixbase(tjf), d.M - 1) / d.gn_rows) * 64; };
-        if constexpr (EPI == G8_GEGLU) {
+        if (!do_epi) {
+            // another split of this tile arrives later and writes the output
+        } else if constexpr (EPI == G8_GEGLU) {
             // packed rows 16 g + [0, 8) are values, + [8, 16) their gates: a 32-row tile yields 16 output channels
             constexpr int RB = CW, G = RB / 16;                          // staged row: CW / 2 bf16 outputs of one pixel
 #pragma unroll
@@ -612,17 +702,17 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         // those would be too, i.e. more than KEEP + 16 operations — so a count of at most KEEP + 12 (margin: the compiler may merge
         // bias loads) proves it has landed WITHOUT waiting for the epilogue's stores to be acknowledged (measured: ~1.5 us per tile).
         // Without a bias there is no such padding and the count is KEEP.
-        if (d.bias || d.group_bias) g8_vmcnt<KEEP + 12>();
+        if (!SPLIT && (d.bias || d.group_bias)) g8_vmcnt<KEEP + 12>();          // (split-K partials start from zero: no bias loads)
         else g8_vmcnt<KEEP>();
     }
 }
 
-template <int TIH, int TJH, int EPI, int GATHER>
-int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu) {
+template <int TIH, int TJH, int EPI, int GATHER, int SPLIT = 0>
+int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu, int split_k = 1) {
     constexpr int BM = TIH * 128, BN = TJH * 256;
-    constexpr int LDS = 2 * (2 * TIH * 8192 + 2 * TJH * 16384);
+    constexpr int LDS = 2 * (2 * TIH * 8192 + 2 * TJH * 16384) + (SPLIT ? 16 : 0);
     static unsigned long long attr_done = 0;
-    if (int rc = cc_max_dynamic_lds((const void*)g8_kernel<TIH, TJH, EPI, GATHER>, LDS, &attr_done, "g8_kernel")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)g8_kernel<TIH, TJH, EPI, GATHER, SPLIT>, LDS, &attr_done, "g8_kernel")) return rc;
     const int64_t pt_n = (d.M + BN - 1) / BN, ct_n = (d.N + BM - 1) / BM;
     CcGemmDesc dd = d;
     dd.cgroup = 0;
@@ -646,10 +736,14 @@ int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu) {
     static const int flag_env = getenv("CCEDIT_G8_FLAGS") ? atoi(getenv("CCEDIT_G8_FLAGS")) : 0;   // tuning (see `flags` in the kernel)
     dd.cgroup |= flag_env << 24;
     int wgs = n_cu - n_cu % 8;
-    const int64_t tiles = pt_n * ct_n;
+    dd.split_k = SPLIT ? split_k : 1;
+    const int64_t tiles = pt_n * ct_n * dd.split_k;
     if (tiles < wgs) wgs = (int)((tiles + 7) / 8 * 8);
-    cc_note_kernel(GATHER == G8_TEMPORAL ? "g8_kernel %dch x %dpix, temporal taps" : (GATHER == G8_CONV3 ? "g8_kernel %dch x %dpix, 3x3 taps" : "g8_kernel %dch x %dpix"), BM, BN);
-    hipLaunchKernelGGL((g8_kernel<TIH, TJH, EPI, GATHER>), dim3((unsigned)wgs), dim3(512), LDS, s, dd);
+    if (SPLIT)
+        cc_note_kernel(GATHER == G8_TEMPORAL ? "g8_kernel %dch x %dpix, temporal taps, split-K" : (GATHER == G8_CONV3 ? "g8_kernel %dch x %dpix, 3x3 taps, split-K" : "g8_kernel %dch x %dpix, split-K"), BM, BN);
+    else
+        cc_note_kernel(GATHER == G8_TEMPORAL ? "g8_kernel %dch x %dpix, temporal taps" : (GATHER == G8_CONV3 ? "g8_kernel %dch x %dpix, 3x3 taps" : "g8_kernel %dch x %dpix"), BM, BN);
+    hipLaunchKernelGGL((g8_kernel<TIH, TJH, EPI, GATHER, SPLIT>), dim3((unsigned)wgs), dim3(512), LDS, s, dd);
     return cc_launch_status("g8_kernel");
 }
 
@@ -685,6 +779,28 @@ bool cc_g8_applicable(const CcGemmDesc& d, int shape) {
            (int64_t)512 * d.lda * 2 < (1LL << 31) && d.M * ((d.N + 127) / 128) < (1LL << 37);
 }
 
+// Split-K factor for the 256ch x 256pix shape (1 = none): outputs whose tiles fill less than half of the chip and whose K loop is
+// long enough to share — as many splits as fit one round of the chip, at least 8 K tiles each, at most 8.  The caller's workspace
+// decides: without one (or with one too small) there is no split.  n_cu = 0: the 256 CUs of an MI355X (size queries without a GPU).
+int cc_g8_split(const CcGemmDesc& d, int n_cu) {
+    static const int env = getenv("CCEDIT_G8_SPLIT") ? atoi(getenv("CCEDIT_G8_SPLIT")) : -1;       // tuning: 0 off, n fixed
+    if (env == 0 || d.act == CCEDIT_ACT_GEGLU || !cc_g8_applicable(d, 1)) return 1;
+    const int wgs = (n_cu > 0 ? n_cu : 256) / 8 * 8;
+    const int64_t tiles = ((d.M + 255) / 256) * ((d.N + 255) / 256);
+    const int nk = d.Kpad >> 6;
+    if (tiles > 1024 || tiles * 2 > wgs || nk < 48) return 1;
+    int s = env > 0 ? env : (int)(wgs / tiles);
+    s = s > 8 ? 8 : s;
+    while (s > 1 && nk / s < 8) --s;
+    return s;
+}
+
+int64_t cc_g8_workspace_bytes(const CcGemmDesc& d, int n_cu) {
+    const int s = cc_g8_split(d, n_cu);
+    if (s <= 1) return 0;
+    return 4096 + ((d.M + 255) / 256) * ((d.N + 255) / 256) * s * (int64_t)(256 * 256 * 4);
+}
+
 int cc_g8_launch(const CcGemmDesc& d, hipStream_t s, int shape) {
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -697,6 +813,17 @@ int cc_g8_launch(const CcGemmDesc& d, hipStream_t s, int shape) {
         n_cu = prop.multiProcessorCount;
     }
     if (shape == 0) shape = g8_auto_shape(d);
+    if (shape == 1 && d.workspace) {
+        const int sk = cc_g8_split(d, n_cu);
+        if (sk > 1 && d.workspace_bytes >= cc_g8_workspace_bytes(d, n_cu)) {
+            const bool res = d.res1 || d.res2;
+            if (d.mode == CCEDIT_GEMM_TEMPORAL)
+                return res ? g8_launch_shape<2, 1, G8_RES, G8_TEMPORAL, 1>(d, s, n_cu, sk) : g8_launch_shape<2, 1, G8_PLAIN, G8_TEMPORAL, 1>(d, s, n_cu, sk);
+            if (d.mode == CCEDIT_GEMM_CONV2D)
+                return res ? g8_launch_shape<2, 1, G8_RES, G8_CONV3, 1>(d, s, n_cu, sk) : g8_launch_shape<2, 1, G8_PLAIN, G8_CONV3, 1>(d, s, n_cu, sk);
+            return res ? g8_launch_shape<2, 1, G8_RES, G8_LINEAR, 1>(d, s, n_cu, sk) : g8_launch_shape<2, 1, G8_PLAIN, G8_LINEAR, 1>(d, s, n_cu, sk);
+        }
+    }
     const int epi = d.act == CCEDIT_ACT_GEGLU ? G8_GEGLU : ((d.res1 || d.res2) ? G8_RES : G8_PLAIN);
     const int gm = d.mode == CCEDIT_GEMM_TEMPORAL ? G8_TEMPORAL : (d.mode == CCEDIT_GEMM_CONV2D ? G8_CONV3 : G8_LINEAR);
 #define G8_GO(TI, TJ, EP)                                                                            \

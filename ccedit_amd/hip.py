@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the library is loaded: to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCEDIT_HIP_LIB") or os.path.join(_HERE, "libccedit_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 GEMM_LINEAR, GEMM_CONV2D, GEMM_TEMPORAL = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
@@ -33,7 +33,8 @@ class CcGemmDesc(C.Structure):
         ("ldgb", C.c_int32), ("ln_eps", C.c_float),
         ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
         ("group_bias", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p),
-        ("gn_stats", C.c_void_p),
+        ("gn_stats", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("split_k", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -70,6 +71,7 @@ _SIGS = {
     "ccedit_last_kernel": (C.c_char_p, []),
     "ccedit_device_info": (C.c_int, [C.c_char_p, C.c_int]),
     "ccedit_gemm": (C.c_int, [C.POINTER(CcGemmDesc), C.c_void_p]),
+    "ccedit_gemm_workspace_bytes": (C.c_int64, [C.POINTER(CcGemmDesc)]),
     "ccedit_ff320": (C.c_int, [C.POINTER(CcFf320Desc), C.c_void_p]),
     "ccedit_groupnorm_spatial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),

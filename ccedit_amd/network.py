@@ -913,10 +913,11 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         return (tns.data_ptr(), tuple(tns.shape), tuple(tns.stride()), tns._version, tns.dtype)
 
     def reset_caches(self):
-        """Drop the per-clip caches (hint stem, shard slices).  Never needed for correctness — entries pin their source
-        storage, see _guided_hint — only to release the previous clip's memory early."""
+        """Drop the per-clip caches (hint stem, shard slices, captured graphs).  Never needed for correctness — entries pin
+        their source storage, see _guided_hint — only to release the previous clip's memory early."""
         self._hint_val = None
         self._hint_slices = None
+        self._graphs = None
 
     def _guided_hint(self, hint5d: torch.Tensor):
         """hint_stem(1 - (hint+1)/2), cached per source tensor.  An entry is keyed by (address, shape, strides, in-place
@@ -936,7 +937,62 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             self._hint_val[key] = (hint5d, g)
         return g
 
+    # One network evaluation is ~560 kernel launches issued from Python; where the kernels are short (the 16x24 / 8x12 levels, the
+    # norm passes) the GPU outruns the launching thread: 150 gaps of 5-10 us, 1.3 ms per step in the kernel trace
+    # (tools/exp/gaps.py).  The 59 evaluations of a clip have identical shapes and conditioning tensors, so the launch sequence is
+    # captured once into a HIP graph (torch.cuda.CUDAGraph: hipStreamBeginCapture on the stream our C-ABI launches go to — side
+    # streams join through their events) and replayed: first call with a new (shapes, conditioning tensors) key runs eagerly
+    # (fills the hint-stem cache, the per-kernel attribute guards, the allocator), the second captures, later ones copy x / t
+    # into the static inputs and replay.  Same kernels in the same order: bit-identical to the eager path
+    # (tests/test_network_gpu.py).  CCEDIT_GRAPH=0 disables; sharded / profiled / traced evaluations are always eager, and so are
+    # the two-stream CFG halves (CCEDIT_SPLIT_CFG=1: capturing four streams that fork and join inside each other crashed the
+    # runtime on ROCm 7.2 — not pursued, the batched pass is the default).
+    use_graph = os.environ.get("CCEDIT_GRAPH", "1") != "0" and not _SPLIT_CFG
+    _graphs = None
+    _graph_failed = False
+
     def forward(self, x: torch.Tensor, t: torch.Tensor, c: Dict[str, torch.Tensor], **kwargs) -> torch.Tensor:
+        if (self.use_graph and not OpenAIWrapperControlLDM3DTV2V._graph_failed and not kwargs and x.is_cuda
+                and self.frame_shard is None and ops.PROFILE is None and TRACE is None and _DEBUG_HOLD < 0
+                and not torch.cuda.is_current_stream_capturing()):
+            return self._forward_graphed(x, t, c)
+        return self._forward_eager(x, t, c, **kwargs)
+
+    def _forward_graphed(self, x, t, c):
+        key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, self.cache_hint_stem, self.overlap_controlnet,
+               tuple(sorted((k, self._tensor_key(v)) if torch.is_tensor(v) else (k, repr(v)) for k, v in c.items())))
+        if self._graphs is None:
+            self._graphs = {}
+        ent = self._graphs.get(key)
+        if ent is None:
+            while len(self._graphs) >= 2:                       # a clip uses one key; keep the previous clip's until it is replaced
+                self._graphs.pop(next(iter(self._graphs)))
+            # the conditioning tensors are pinned while the entry lives: a key match always means the same bytes (see _guided_hint)
+            self._graphs[key] = dict(pins=[v for v in c.values() if torch.is_tensor(v)])
+            return self._forward_eager(x, t, c)
+        if "graph" not in ent:
+            try:
+                ent["x"], ent["t"] = x.clone(), t.clone()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    ops.reset_stream_scratch()                  # scratch arenas of the capture stream must live in this graph's pool
+                    ent["out"] = self._forward_eager(ent["x"], ent["t"], c)
+                    ops.reset_stream_scratch()
+                ent["graph"] = g
+                ent["pins"].append(dict(self._hint_val) if isinstance(self._hint_val, dict) else None)   # the cached stem output it reads
+            except Exception as e:                              # capture is an optimisation: report once, keep evaluating eagerly
+                import warnings
+                OpenAIWrapperControlLDM3DTV2V._graph_failed = True
+                self._graphs = None
+                warnings.warn(f"HIP graph capture of the network evaluation failed ({type(e).__name__}: {e}); continuing without graphs")
+                return self._forward_eager(x, t, c)
+        else:
+            ent["x"].copy_(x)
+            ent["t"].copy_(t)
+        ent["graph"].replay()
+        return ent["out"].clone()
+
+    def _forward_eager(self, x: torch.Tensor, t: torch.Tensor, c: Dict[str, torch.Tensor], **kwargs) -> torch.Tensor:
         pair = isinstance(self.frame_shard, (tuple, list)) and not kwargs.get("_half")
         if pair and x.shape[0] != 2:
             raise ValueError("a FrameShard.cfg_pair shards the two CFG halves of a batch-2 step")
@@ -952,8 +1008,8 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             hs.wait_stream(main)
             halves = [{k: (v[i:i + 1].contiguous() if torch.is_tensor(v) else v) for k, v in c.items()} for i in range(2)]
             with torch.cuda.stream(hs):
-                e1 = self.forward(x[1:2].contiguous(), t[1:2].contiguous(), halves[1], _half=True, _shard=shards[1])
-            e0 = self.forward(x[0:1].contiguous(), t[0:1].contiguous(), halves[0], _half=True, _shard=shards[0])
+                e1 = self._forward_eager(x[1:2].contiguous(), t[1:2].contiguous(), halves[1], _half=True, _shard=shards[1])
+            e0 = self._forward_eager(x[0:1].contiguous(), t[0:1].contiguous(), halves[0], _half=True, _shard=shards[0])
             main.wait_stream(hs)
             e1.record_stream(main)
             return torch.cat([e0, e1])

@@ -136,6 +136,11 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
         out._gn_stats = (stats, gn_rows)
     elif hasattr(out, "_gn_stats"):
         del out._gn_stats              # a caller-supplied `out` is being overwritten: statistics left on it are stale
+    if m <= 8192 and pw.n * pw.kpad >= 1 << 21 and SPLIT_K:      # few output tiles, long K: lend the split-K scratch (include/ccedit_hip.h)
+        need = hip.lib().ccedit_gemm_workspace_bytes(C.byref(d))
+        if need:
+            ws = _splitk_ws(need, out.device)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -238,6 +243,21 @@ def conv_temporal_sharded(x_ext: torch.Tensor, b: int, t_local: int, t0: int, t_
 _ws_cache = {}
 
 
+SPLIT_K = os.environ.get("CCEDIT_G8_SPLIT", "1") != "0"
+_splitk_cache = {}
+
+
+def _splitk_ws(nbytes: int, device) -> torch.Tensor:
+    """Split-K scratch of the current stream (arrival counters in the first 4096 bytes: zero when handed out, left zero by every
+    call; launches of one stream are ordered, other streams get their own buffer)."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _splitk_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        _splitk_cache[key] = ws
+    return ws
+
+
 def _stats_ws(frames: int, device) -> torch.Tensor:
     key = (device, torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)
@@ -266,6 +286,16 @@ class _ZeroArena:
 
 
 _ZEROS = _ZeroArena()
+
+
+def reset_stream_scratch():
+    """Forget the scratch buffers tied to the current stream (statistics workspace, zeroed arena).  Called at both ends of a HIP-graph
+    capture: what is allocated while capturing belongs to that graph's memory pool and is zeroed by a captured fill, so a later
+    capture on the same stream must not continue in it."""
+    key = (torch.device("cuda", torch.cuda.current_device()), torch.cuda.current_stream().cuda_stream)
+    for cache in (_ws_cache, _ZEROS.slabs, _splitk_cache):
+        for k in [k for k in cache if k[1] == key[1]]:
+            del cache[k]
 
 
 def zero_stats(frames: int, device) -> torch.Tensor:

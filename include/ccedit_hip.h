@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCEDIT_ABI_VERSION 7
+#define CCEDIT_ABI_VERSION 8
 
 #define CCEDIT_OK 0
 #define CCEDIT_EINVAL (-1)       /* null pointer / bad size */
@@ -116,9 +116,20 @@ typedef struct CcGemmDesc {
      * float[M/gn_rows][32][2] (sum, sum of squares of the bf16-rounded outputs), ZEROED BY THE CALLER, added to
      * atomically.  Needs N % 32 == 0, N >= 256, bf16 output, no GEGLU.  Consumed by ccedit_groupnorm_spatial_apply. */
     double* gn_stats;
+    /* optional scratch for split-K (outputs with far fewer 256 x 256 tiles than the chip has CUs and a long K loop — the 8x12 level
+     * of the networks): ccedit_gemm_workspace_bytes(desc) bytes, 16-byte aligned, whose FIRST 4096 BYTES ARE ZERO before the
+     * first call that uses the buffer (the arrival counters; every call leaves them zero again).  One buffer may serve all calls
+     * of one stream; calls on different streams need different buffers.  null / too small: no split (same results up to the
+     * fp32 summation order of the K loop, which split-K fixes per split count). */
+    void* workspace;
+    int64_t workspace_bytes;
+    int32_t split_k;      /* internal (set by the library); pass 0 */
+    int32_t reserved0;
 } CcGemmDesc;
 
 int ccedit_gemm(const CcGemmDesc* desc, void* stream);
+/* Bytes of CcGemmDesc.workspace this call could use on an MI355X (0: the shape is never split).  No GPU needed. */
+int64_t ccedit_gemm_workspace_bytes(const CcGemmDesc* desc);
 
 /* ------------------------------------------------------------------------------------------
  * Fused transformer feed-forward, dim 320 (the 64x96 level of the UNet / ControlNet):

@@ -57,6 +57,19 @@ def main(out_path):
         c = dict(crossattn=torch.cat([ca, cb]).to(dev), control_hint=torch.cat([hint, hint]).to(dev))
         return w(torch.cat([xa, xb_]).to(dev), t, c).float().cpu().numpy()
 
+    # the same conditioning tensors three times, as a sampler does: eager, HIP-graph capture + replay, replay with another latent
+    # and timestep put into the static inputs and the first pair put back — the graph must reproduce the eager bits
+    c = dict(crossattn=torch.cat([cu, cc]).to(dev), control_hint=torch.cat([hint, hint]).to(dev))
+    xx, t2 = torch.cat([x, x]).to(dev), torch.tensor([333, 333], dtype=torch.int64, device=dev)
+    e_eager = w(xx, t, c).clone()
+    e_graph = w(xx, t, c).clone()
+    e_moved = w(torch.cat([xb, xb]).to(dev), t2, c).clone()
+    e_back = w(xx, t, c).clone()
+    graphed = bool(getattr(w, "_graphs", None)) and any("graph" in e for e in w._graphs.values())
+    assert graphed == (w.use_graph and not type(w)._graph_failed), "the HIP graph was not captured"
+    assert torch.equal(e_eager, e_graph) and torch.equal(e_eager, e_back), "HIP-graph replay differs from the eager evaluation"
+    assert not torch.equal(e_eager, e_moved), "the replay did not pick up the new latent / timestep"
+
     out = dict(eps=run(x, x, cu, cc),                 # the CFG pair of the benchmark: same latent, two prompts
                eps_same=run(x, x, cc, cc),            # identical halves -> identical predictions
                eps_other=run(x, xb, cu, cc))          # clips do not interact: half 0 must not change

@@ -28,14 +28,14 @@ def test_header_symbols_exported(libpath):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ccedit_hip.h but not exported"
     lib.ccedit_abi_version.restype = ctypes.c_int
-    assert lib.ccedit_abi_version() == 7
+    assert lib.ccedit_abi_version() == 8
 
 
 def test_binding_matches_header(libpath):
     from ccedit_amd import hip
     assert sorted(hip.EXPORTS) == _declared()
     # descriptor layouts: sizes the C side was compiled with (kept in sync by hand; a mismatch shows up here)
-    assert ctypes.sizeof(hip.CcGemmDesc) == 8 + 34 * 4 + 9 * 8
+    assert ctypes.sizeof(hip.CcGemmDesc) == 8 + 34 * 4 + 9 * 8 + (8 + 8 + 2 * 4)      # ... + workspace, workspace_bytes, split_k, reserved0 (ABI 8)
     assert ctypes.sizeof(hip.CcAttnDesc) % 8 == 0
 
 
@@ -74,6 +74,42 @@ def test_ln_eps_is_refused_where_no_kernel_normalises(libpath):
     d = desc(320, 320, 0)
     d.res1, d.ldr1 = 1, 320                     # a residual epilogue is not available together with the normalisation either
     assert lib.ccedit_gemm(ctypes.byref(d), None) == -2
+
+
+def test_split_k_workspace_size_query(libpath):
+    """ccedit_gemm_workspace_bytes: which calls would split their K loop over several workgroups, and how much scratch the
+    caller is asked to lend (4096 bytes of arrival counters + one fp32 256 x 256 slot per tile and split).  No GPU needed."""
+    from ccedit_amd import hip
+    lib = hip.lib()
+
+    def desc(m, n, cin, taps, mode):
+        d = hip.CcGemmDesc()
+        d.M, d.N, d.Cin, d.Cin1, d.taps, d.mode, d.Kpad, d.korder = m, n, cin, cin, taps, mode, cin * taps, int(taps > 1)
+        d.lda, d.ldc = cin, n
+        if mode == 1:
+            d.Hin = d.Hout = 8
+            d.Win = d.Wout = 12
+            d.stride, d.pad, d.ksize = 1, 1, 3
+        if mode == 2:
+            d.T, d.HW = 17, 96
+        d.A = d.W = d.out = 1
+        return d
+    slot = 256 * 256 * 4
+    # the 8x12 level: 3264 pixels x 1280 channels = 13 x 5 tiles -> 3 splits fill 195 of the 256 CUs
+    assert lib.ccedit_gemm_workspace_bytes(ctypes.byref(desc(3264, 1280, 1280, 9, 1))) == 4096 + 65 * 3 * slot
+    assert lib.ccedit_gemm_workspace_bytes(ctypes.byref(desc(3264, 1280, 1280, 3, 2))) == 4096 + 65 * 3 * slot
+    assert lib.ccedit_gemm_workspace_bytes(ctypes.byref(desc(3264, 1280, 5120, 1, 0))) == 4096 + 65 * 3 * slot
+    assert lib.ccedit_gemm_workspace_bytes(ctypes.byref(desc(480, 1280, 1280, 9, 1))) == 4096 + 10 * 8 * slot      # at most 8 splits
+    # short K loops, outputs that fill the chip, GEGLU and the other block shapes are never split
+    assert lib.ccedit_gemm_workspace_bytes(ctypes.byref(desc(3264, 1280, 1280, 1, 0))) == 0
+    assert lib.ccedit_gemm_workspace_bytes(ctypes.byref(desc(13056, 1280, 1280, 9, 1))) == 0
+    d = desc(3264, 1280, 5120, 1, 0)
+    d.tile = 1
+    assert lib.ccedit_gemm_workspace_bytes(ctypes.byref(d)) == 0
+    d = desc(3264, 10240, 1280, 1, 0)
+    d.act = 2
+    assert lib.ccedit_gemm_workspace_bytes(ctypes.byref(d)) == 0
+    assert lib.ccedit_gemm_workspace_bytes(None) == 0
 
 
 def test_no_packed_fp32_low_lane_high_half_reads(libpath):

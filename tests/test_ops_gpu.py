@@ -176,6 +176,66 @@ def test_conv3x3_persistent_eight_phase(n, cin, cout, h, w, tile):
         ops.conv2d(_nhwc(x), pw, stride=2, tile=tile)                   # strided / upsampling convs are not this kernel's
 
 
+def test_split_k_persistent_gemm():
+    """Few output tiles + long K (the 8x12 level): g8_kernel's split-K — partial accumulators through the caller's workspace, an
+    arrival counter per tile, the last arriver reduces in split order and runs the epilogue.  Linear / Conv1d k3 over T / Conv2d
+    3x3 with bias, row bias, residual(s) and fused GroupNorm statistics against torch; the same launch repeated gives the same
+    bits (the summation order does not depend on who arrives last); without a workspace the call takes the unsplit path."""
+    _dev()
+    from ccedit_amd import hip, ops
+    from ccedit_amd.packing import pack_weight
+    last = lambda: hip.lib().ccedit_last_kernel().decode()
+    # Linear 3264 x 1280 <- 5120 + residual (FF out-projection of the 8x12 level)
+    m, n, k = 3264, 1280, 5120
+    x, w, b, r1 = _rnd(m, k, seed=1), _rnd(n, k, seed=2, scale=k ** -0.5), _rnd(n, seed=3), _rnd(m, n, seed=4)
+    pw = pack_weight(w, b).to("cuda")
+    xc, rc = x.to(BF).cuda(), r1.to(BF).cuda()
+    y = ops.linear(xc, pw, res1=rc)
+    assert "split-K" in last(), last()
+    _close(y, F.linear(x, w, b) + r1, what="split-K linear + residual")
+    for _ in range(6):
+        assert torch.equal(ops.linear(xc, pw, res1=rc), y), "split-K linear: run-to-run difference"
+    ops.SPLIT_K = False
+    try:
+        y1 = ops.linear(xc, pw, res1=rc)
+        assert "split-K" not in last()
+    finally:
+        ops.SPLIT_K = True
+    _close(y, y1.float(), rel=2.0 ** -7, what="split-K vs unsplit")
+    # Conv2d 3x3 1280 -> 1280 on 34 frames of 8 x 12 (+ row bias + residual), then 5 frames (odd tile count, ragged last tile)
+    for nfr in (34, 5):
+        cin, cout, h, wd = 1280, 1280, 8, 12
+        xi = _rnd(nfr, cin, h, wd, seed=5)
+        wt, bc = _rnd(cout, cin, 3, 3, seed=6, scale=(9 * cin) ** -0.5), _rnd(cout, seed=7)
+        res, gb = _rnd(nfr, cout, h, wd, seed=8), _rnd(nfr, cout, seed=9)
+        pwc = pack_weight(wt, bc).to("cuda")
+        kw = dict(res1=_nhwc(res).view(-1, cout), group_bias=gb.cuda(), group_rows=h * wd)
+        yc = ops.conv2d(_nhwc(xi), pwc, **kw)
+        assert "split-K" in last() and "3x3" in last(), last()
+        _close(_nchw(yc), F.conv2d(xi, wt, bc, padding=1) + gb[:, :, None, None] + res, what=f"split-K conv3x3, {nfr} frames")
+        for _ in range(4):
+            assert torch.equal(ops.conv2d(_nhwc(xi), pwc, **kw), yc), "split-K conv: run-to-run difference"
+    # Conv1d k3 over T = 17, 2 clips of 8 x 16 (frames of 128 pixels: statistics), 1280 -> 1280, two residuals
+    b_, t, c, cout, h, wd = 2, 17, 1280, 1280, 8, 16
+    nfr = b_ * t
+    xt = _rnd(nfr, c, h, wd, seed=10)
+    wt, bt = _rnd(cout, c, 3, seed=11, scale=(3 * c) ** -0.5), _rnd(cout, seed=12)
+    xp = xt.reshape(b_, t, c, h, wd).permute(0, 3, 4, 2, 1).reshape(b_ * h * wd, c, t)
+    ref = F.conv1d(xp, wt, bt, padding=1).reshape(b_, h, wd, cout, t).permute(0, 4, 3, 1, 2).reshape(nfr, cout, h, wd)
+    r1, r2 = _rnd(nfr, cout, h, wd, seed=13), _rnd(nfr, cout, h, wd, seed=14)
+    pwt = pack_weight(wt, bt).to("cuda")
+    kw = dict(res1=_nhwc(r1).reshape(-1, cout), res2=_nhwc(r2).reshape(-1, cout), gn=True)
+    yt = ops.conv_temporal(_nhwc(xt), t, pwt, **kw)
+    assert "split-K" in last() and "temporal" in last(), last()
+    _close(_nchw(yt), ref + r1 + r2, what="split-K temporal conv")
+    st = ops.gn_stats_of(yt, h * wd)
+    yf = yt.float().view(nfr, h * wd, 32, cout // 32)
+    assert st is not None and torch.allclose(st[..., 0].float(), yf.sum(dim=(1, 3)), rtol=1e-4, atol=2e-2)
+    assert torch.allclose(st[..., 1].float(), (yf * yf).sum(dim=(1, 3)), rtol=1e-4, atol=2e-2)
+    for _ in range(4):
+        assert torch.equal(ops.conv_temporal(_nhwc(xt), t, pwt, **kw), yt), "split-K temporal: run-to-run difference"
+
+
 def test_linear_persistent_groupnorm_statistics_and_row_bias():
     """tile 11: Linear + per-group row bias + fused GroupNorm statistics (the 1x1 projections in front of a GroupNorm)."""
     _dev()

@@ -19,16 +19,19 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
 by = collections.Counter()
 dur = collections.Counter()
 for ev in prof.events():
-    if not ev.name.startswith("aten::") or ev.cpu_parent is not None and ev.cpu_parent.name.startswith("aten::"):
+    if not ev.name.startswith("aten::"):
         continue
-    dt = ev.device_time_total if hasattr(ev, "device_time_total") else ev.cuda_time_total
+    dt = getattr(ev, "self_device_time_total", 0) or 0
     if dt <= 0:
         continue
     where = "?"
-    for fr in ev.stack:
-        if "ccedit_amd" in fr or "sgm/" in fr:
-            where = fr.split("/repo/")[-1]
-            break
+    e = ev
+    while e is not None and where == "?":
+        for fr in (e.stack or []):
+            if "ccedit_amd" in fr or "sgm/" in fr or "bench.py" in fr:
+                where = fr.split("/repo/")[-1]
+                break
+        e = e.cpu_parent
     by[(ev.name, where)] += 1
     dur[(ev.name, where)] += dt
 tot = sum(dur.values())

@@ -1,0 +1,28 @@
+"""Idle time between consecutive kernels of the steady-state steps of a rocprofv3 --kernel-trace run of bench.py (single stream):
+how much of a step is launch gaps?   python tools/exp/gaps.py <trace dir>"""
+import csv, glob, os, sys
+files = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)
+rows = []
+for f in files:
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+# the timed steps: the last 5 evaluations; an evaluation starts with the ncthw_to_nhwc of x (first kernel after a long idle gap)
+tail = rows[-3000:]
+busy = sum(e - s for s, e, _ in tail)
+span = tail[-1][1] - tail[0][0]
+gaps = [(tail[i + 1][0] - tail[i][1], tail[i][2][:60], tail[i + 1][2][:60]) for i in range(len(tail) - 1)]
+pos = [g for g in gaps if g[0] > 0]
+print(f"{len(tail)} kernels: span {span / 1e6:.2f} ms, busy {busy / 1e6:.2f} ms, idle {sum(g[0] for g in pos) / 1e6:.2f} ms in {len(pos)} gaps "
+      f"(median {sorted(g[0] for g in pos)[len(pos) // 2] / 1e3:.2f} us); overlapped pairs {len(gaps) - len(pos)}")
+import collections
+hist = collections.Counter(min(int(g[0] / 1000), 20) for g in pos)
+print("gap histogram (us: count):", dict(sorted(hist.items())))
+big = sorted(pos, reverse=True)[:12]
+for g in big:
+    print(f"  {g[0] / 1e3:8.1f} us  after {g[1]}  before {g[2]}")
+by = collections.Counter()
+for g in pos:
+    by[g[1].split("(")[0][-40:]] += g[0]
+print("idle by preceding kernel (ms):", [(k, round(v / 1e6, 3)) for k, v in by.most_common(10)])
