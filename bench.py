@@ -195,6 +195,10 @@ def main():
     def step():
         return wrapper(x2, tstep, cond)
 
+    # one-time initialisation, like building the model: the wrapper runs its first evaluation eagerly and captures the second into
+    # a HIP graph (ccedit_amd/network.py) — with fewer than two warm-up steps that capture would fall into the timed region
+    for _ in range(max(0, 2 - args.warmup)):
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

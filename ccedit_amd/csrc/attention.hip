@@ -68,14 +68,28 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
     // XCD-aware 1-D block order (speed only): workgroup b runs on XCD b % 8, so all query tiles of one
     // (batch, head) group are given to ONE XCD back to back — its K/V (0.98 MB at 6144 x 40) then stays in that
     // XCD's 4 MB L2 instead of being fetched from HBM through all 8 L2s (measured: 9.6 GB fetched per launch).
+    // Few keys (text cross-attention, Lk = 77: K / V are a few KB, the launch is bound by streaming Q in and O out): the other way
+    // round — an XCD takes every eighth (batch, QUERY tile) unit and runs its heads back to back, so the heads of a query
+    // row (D-element pieces of one 128-byte line; with the head = XCD mapping above every line of Q is fetched and every line of
+    // O written through up to eight L2s) meet in one L2.
     const int qtiles = (a.Lq + NW * 32 - 1) / (NW * 32);
     const int xcd = blockIdx.x & 7;
     const int local = blockIdx.x >> 3;
-    const int grp = (local / qtiles) * 8 + xcd;            // (batch, head) group
-    if (grp >= a.batches * a.heads) return;
-    const int batch = grp / a.heads;
-    const int head = grp - batch * a.heads;
-    const int q0 = (local % qtiles) * (NW * 32) + wave * 32;
+    int batch, head, qt;
+    if (a.Lk <= 128 && a.seg1_len == 0) {
+        const int u = (local / a.heads) * 8 + xcd;         // (batch, query tile) unit: every eighth one is this XCD's, heads back to back
+        if (u >= a.batches * qtiles) return;
+        head = local % a.heads;
+        batch = u / qtiles;
+        qt = u - batch * qtiles;
+    } else {
+        const int grp = (local / qtiles) * 8 + xcd;        // (batch, head) group
+        qt = local % qtiles;
+        if (grp >= a.batches * a.heads) return;
+        batch = grp / a.heads;
+        head = grp - batch * a.heads;
+    }
+    const int q0 = qt * (NW * 32) + wave * 32;
 
     const bf16* zp = (const bf16*)g_attn_zero_page;
     const int64_t qbase = (int64_t)(batch / a.q_inner) * a.q_outer_rows + (int64_t)(batch % a.q_inner) * a.q_inner_rows;
@@ -345,7 +359,8 @@ int launch_attn(const CcAttnDesc& a, hipStream_t s) {
     if (int rc = cc_max_dynamic_lds((const void*)attn_kernel<D, NW>, lds, &attr_done, "attn")) return rc;
     const int64_t qtiles = (a.Lq + NW * 32 - 1) / (NW * 32);
     const int64_t groups = ((int64_t)a.batches * a.heads + 7) / 8 * 8;
-    dim3 grid((unsigned)(qtiles * groups));
+    const bool by_qtile = a.Lk <= 128 && a.seg1_len == 0;          // block order of the kernel: see there
+    dim3 grid((unsigned)(by_qtile ? (qtiles * a.batches + 7) / 8 * 8 * (int64_t)a.heads : qtiles * groups));
     cc_note_kernel("attn_kernel d=%d", D);
     hipLaunchKernelGGL((attn_kernel<D, NW>), grid, dim3(NW * 64), a.Lk <= 64 ? lds / 2 : lds, s, a);
     return cc_launch_status("attn_kernel");

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int 
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e >> 2][e & 3] + tb[e >> 2][e & 3] + (RES ? bf2f(rr[k][e]) : 0.f));
-                *(bf16x8*)((bf16*)d.out + (size_t)m * d.ldc + ch0 + tcol[k]) = o;
+                if (!(d.cgroup >> 24 & 1)) *(bf16x8*)((bf16*)d.out + (size_t)m * d.ldc + ch0 + tcol[k]) = o;
             }
         }
     };
@@ -305,9 +305,13 @@ int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s) {
         return CCEDIT_EUNSUPPORTED;
     }
     cc_note_kernel("lin320_kernel");
-    if (geglu) hipLaunchKernelGGL((lin320_kernel<true, false, false>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
-    else if (d.res1) hipLaunchKernelGGL((lin320_kernel<false, true, false>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
-    else if (d.ln_eps != 0.f) hipLaunchKernelGGL((lin320_kernel<false, false, true>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
-    else hipLaunchKernelGGL((lin320_kernel<false, false, false>), dim3(256), dim3(kNT), lds, s, d, d.N / kSlice, (int)pt_n);
+    static const int flag_env = getenv("CCEDIT_L320_FLAGS") ? atoi(getenv("CCEDIT_L320_FLAGS")) : 0;      // tuning: 1 = no output stores
+    CcGemmDesc dd = d;
+    dd.cgroup = flag_env << 24;
+    const CcGemmDesc& d2 = dd;
+    if (geglu) hipLaunchKernelGGL((lin320_kernel<true, false, false>), dim3(256), dim3(kNT), lds, s, d2, d.N / kSlice, (int)pt_n);
+    else if (d.res1) hipLaunchKernelGGL((lin320_kernel<false, true, false>), dim3(256), dim3(kNT), lds, s, d2, d.N / kSlice, (int)pt_n);
+    else if (d.ln_eps != 0.f) hipLaunchKernelGGL((lin320_kernel<false, false, true>), dim3(256), dim3(kNT), lds, s, d2, d.N / kSlice, (int)pt_n);
+    else hipLaunchKernelGGL((lin320_kernel<false, false, false>), dim3(256), dim3(kNT), lds, s, d2, d.N / kSlice, (int)pt_n);
     return cc_launch_status("lin320_kernel");
 }
