@@ -420,9 +420,12 @@ def time_clip(wrapper, device, num_steps=30, scale=7.5, seed=43):
     t2 = time.perf_counter()
     assert frames.shape == (1, 3, T, 8 * H, 8 * W)
     wrapper.cache_hint_stem = False
+    finite = bool(torch.isfinite(frames).all())
+    if not finite:                                 # a rate for garbage is not a measurement
+        sys.stderr.write("bench.py: the sampled clip contains non-finite values — frames_per_s withheld\n")
     return dict(sampler_s=round(t1 - t0, 3), vae_decode_s=round(t2 - t1, 3), evaluations=evals[0], hint_stem="once per clip",
                 decoder_warmup="one untimed decode",
-                frames_per_s=round(T / (t2 - t0), 3), finite=bool(torch.isfinite(frames).all()))
+                frames_per_s=round(T / (t2 - t0), 3) if finite else None, finite=finite)
 
 
 if __name__ == "__main__":

@@ -24,6 +24,8 @@
 
 bool cc_attn_short_applicable(const CcAttnDesc& a);      // attnshort.hip
 int cc_attn_short_launch(const CcAttnDesc& a, hipStream_t s);
+bool cc_attn_text_applicable(const CcAttnDesc& a);       // attntext.hip
+int cc_attn_text_launch(const CcAttnDesc& a, hipStream_t s);
 
 namespace {
 
@@ -391,6 +393,9 @@ extern "C" int ccedit_attention(const CcAttnDesc* desc, void* stream) {
     // temporal self-attention (T <= 32 keyframes per pixel): HBM-bound, own kernel organised around whole-row loads
     static const int short_env = getenv("CCEDIT_ATTN_SHORT") ? atoi(getenv("CCEDIT_ATTN_SHORT")) : 1;   // 0: A/B against attn_kernel
     if (short_env && cc_attn_short_applicable(a)) return cc_attn_short_launch(a, s);
+    // text cross-attention (<= 96 keys shared by the frames of a clip): bound by streaming the query rows, own kernel (attntext.hip)
+    static const int text_env = getenv("CCEDIT_ATTN_TEXT") ? atoi(getenv("CCEDIT_ATTN_TEXT")) : 1;      // 0: A/B against attn_kernel
+    if (text_env && cc_attn_text_applicable(a)) return cc_attn_text_launch(a, s);
     switch (a.d) {
         case 8: return dispatch_nw<8>(a, s);
         case 16: return dispatch_nw<16>(a, s);

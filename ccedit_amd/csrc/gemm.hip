@@ -478,6 +478,21 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
                        "and N %% 320 == 0, no activation / residual): not applicable to this descriptor");
         return cc_lin320_launch(d, s);
     }
+    // ln_stats: the epilogue applies the rows' LayerNorm statistics — the persistent eight-phase kernel implements it, nothing else
+    if (d.ln_stats || d.ln_sums || d.ln_colsum) {
+        const int shape = (d.tile >= 11 && d.tile <= 13) ? d.tile - 11 : 0;
+        CC_UNSUPPORTED((!d.ln_stats && !d.ln_sums) || !d.ln_colsum || !(d.tile == 0 || (d.tile >= 11 && d.tile <= 13)) || !cc_g8_applicable(d, shape),
+                       "ccedit_gemm: ln_stats needs ln_colsum and the persistent eight-phase kernel (block shape 0 / 11-13: plain Linear with "
+                       "Cin %% 64 == 0, N %% 16 == 0, no residual / row bias / gn_stats): not applicable to this descriptor");
+        return cc_g8_launch(d, s, shape);
+    }
+    if (d.row_sums) {           // the epilogue accumulates the LayerNorm statistics of what it writes: same kernel only
+        const int shape = (d.tile >= 11 && d.tile <= 13) ? d.tile - 11 : 0;
+        CC_UNSUPPORTED(!(d.tile == 0 || (d.tile >= 11 && d.tile <= 13)) || !cc_g8_applicable(d, shape),
+                       "ccedit_gemm: row_sums needs the persistent eight-phase kernel (block shape 0 / 11-13: Linear with Cin %% 64 == 0, "
+                       "N %% 16 == 0, no activation): not applicable to this descriptor");
+        return cc_g8_launch(d, s, shape);
+    }
     if (d.tile == 0 && cc_small_conv_applicable(d)) return cc_small_conv_launch(d, s);     // few-channel 3x3 (hint stem top)
     // 3x3 convs onto >= 1024 channels (the 16x24 level): 29-59 MB of weights do not fit an XCD's L2 and the 128 x 128 tiles of the LDS-halo
     // kernel re-stream them per pixel tile (450 MB fetched for 63 MB of operands, round 2).  The persistent 256 x 256 tap-gather loop

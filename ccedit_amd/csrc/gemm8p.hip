@@ -150,6 +150,31 @@ __device__ __forceinline__ void g8_flush_stats(float (&gs)[8], float (&gq)[8], i
     }
 }
 
+// LayerNorm statistics of the tensor being written (CcGemmDesc.row_sums): rs / rq = this lane's sums / sums of squares over its
+// channels of pixel rows j * step + lane / G (j = 0 .. NR - 1) of the 32-pixel tile starting at row m0.  The G lanes of a pixel
+// row are neighbours: butterfly over them, then the first of each adds the wave's share of the row to the row's double-precision
+// (sum, sum of squares) — the arrival order of double adds cannot move the fp32 (mean, rstd) taken from them.
+template <int G, int NR>
+__device__ __forceinline__ void g8_flush_rows(float (&rs)[NR], float (&rq)[NR], int lane, int64_t m0, int step, int64_t M, double* sums) {
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            rs[j] += __shfl_xor(rs[j], off);
+            rq[j] += __shfl_xor(rq[j], off);
+        }
+    if ((lane & (G - 1)) == 0) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int64_t m = m0 + j * step + lane / G;
+            if (m < M) {
+                unsafeAtomicAdd(sums + 2 * m, (double)rs[j]);
+                unsafeAtomicAdd(sums + 2 * m + 1, (double)rq[j]);
+            }
+        }
+    }
+}
+
 // GATHER: implicit-GEMM convolutions, K = [Cin / 64][taps][64] (weight K order 1).  K tile kt reads channel chunk kt / taps of the
 // pixel's row shifted by the tap: Conv1d k3 over the T keyframes of a clip (openaimodel.py:617-629, 674-687; rows HW apart,
 // zeros outside the clip) or Conv2d 3x3 stride 1 pad 1 (openaimodel.py:445-449, 483-492; rows dy * W + dx apart, zeros outside the
@@ -162,7 +187,12 @@ enum { G8_LINEAR = 0, G8_TEMPORAL = 1, G8_CONV3 = 2 };
 // runs a contiguous share of the K tiles from zero accumulators and writes them, in register order, to its slot of d.workspace;
 // an arrival counter per tile elects the LAST arriver, which starts from the bias, adds the slots in split order 0, 1, 2, ...
 // (a fixed summation order whoever arrives last: results do not depend on timing) and runs the ordinary epilogue.
-template <int TIH, int TJH, int EPI, int GATHER, int SPLIT = 0>
+// LNF = 1 (plain Linear, no residual): the rows of A are LayerNorm inputs that were NOT normalised.  With gamma folded into the
+// weights (W' = W diag(gamma), b' = b + W beta) and the row statistics (mean, rstd) in d.ln_stats,
+//     W' xhat + b' = rstd (W' x - mean W' 1) + b'
+// so the accumulators start at b' / rstd - mean * colsum(W') and the epilogue multiplies by rstd: `to_q(norm(x))`, the GEGLU
+// projection of `ff(norm(x))` (attention.py:695-716) without the normalised tensor ever being written or read.
+template <int TIH, int TJH, int EPI, int GATHER, int SPLIT = 0, int LNF = 0>
 __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     static_assert(TIH * TJH == 2, "eight MFMAs per phase");
     constexpr int BM = TIH * 128, BN = TJH * 256;
@@ -329,6 +359,18 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     // The bias is the INITIAL VALUE of the accumulators: register 4 q + e of row tile tf holds channel 32 tf + 8 q + 4 hi + e of
     // this wave row, the same for every pixel tile — 16 loads of 16 bytes per lane and output tile straight into the accumulator
     // registers, requested before the operand requests whose counted wait also covers them.  The epilogue never touches it.
+    // LNF: (mean, rstd) of row m — as ccedit_row_stats left them (ln_stats), or from the (sum, sum of squares) a producing GEMM's
+    // epilogue accumulated in double (ln_sums, see row_sums below): mean = s / K, var = q / K - mean^2 in double
+    auto ln_row = [&](int64_t m) -> f32x2 {
+        m = min(m, d.M - 1);
+        if (d.ln_sums) {
+            const double inv_k = 1.0 / (double)d.Cin;
+            const double mu = d.ln_sums[2 * m] * inv_k;
+            const double var = fmax(d.ln_sums[2 * m + 1] * inv_k - mu * mu, 0.0);
+            return f32x2{(float)mu, rsqrtf((float)var + d.ln_sums_eps)};
+        }
+        return *(const f32x2*)(d.ln_stats + 2 * m);
+    };
     f32x16 acc[NI][NJ];
     auto pixbase = [&](int tjf) { return (tjf / TJH) * (TJH * 128) + wc * (TJH * 32) + (tjf % TJH) * 32; };
     auto init_acc = [&](int pt_, int ct_, bool with_bias = !SPLIT) {
@@ -339,6 +381,29 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                 for (int tj = 0; tj < NJ; ++tj)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[tf][tj][e] = 0.f;
+            return;
+        }
+        if constexpr (LNF) {
+            float mean[NJ], invr[NJ];
+#pragma unroll
+            for (int tj = 0; tj < NJ; ++tj) {
+                const f32x2 st = ln_row((int64_t)pt_ * BN + pixbase(tj) + l31);
+                mean[tj] = st[0];
+                invr[tj] = 1.0f / st[1];
+            }
+#pragma unroll
+            for (int tf = 0; tf < NI; ++tf)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = min(ct_ * BM + wr * CW + 32 * tf + 8 * q + 4 * hi, d.N - 4);
+                    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                    if (d.bias) b = *(const f32x4*)(d.bias + c);
+                    const f32x4 cs = *(const f32x4*)(d.ln_colsum + c);
+#pragma unroll
+                    for (int tj = 0; tj < NJ; ++tj)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[tf][tj][4 * q + e] = b[e] * invr[tj] - mean[tj] * cs[e];
+                }
             return;
         }
         const float* const bias = d.bias;
@@ -559,6 +624,23 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         // numbers of such blocks (gn_rows % 128 == 0, e.g. 384 at the 16x24 level): the frame is taken per tjf and flushed per tjf
         const bool gn = d.gn_stats != nullptr;
         auto gn_slots = [&](int tjf) { return d.gn_stats + (size_t)(min(pix0 + pixbase(tjf), d.M - 1) / d.gn_rows) * 64; };
+        float ln_rstd[LNF ? NJ : 1];                 // LNF: rstd of this lane's pixel of every pixel tile (the accumulators hold W' x / 1 - ...)
+        if constexpr (LNF) {
+#pragma unroll
+            for (int tj = 0; tj < NJ; ++tj) ln_rstd[tj] = ln_row(pix0 + pixbase(tj) + l31)[1];
+        }
+        // x * rstd as an explicit scalar v_mul_f32: left to the compiler, the SLP vectoriser pairs neighbouring accumulators into
+        // v_pk_mul_f32 with rstd broadcast by op_sel — from the HIGH half of whatever register pair it landed in, which is the one
+        // packed-fp32 form csrc/build.py refuses (not safe beside another stream's GEMM)
+        auto ln_mul = [&](int tjf, float x) {
+            if constexpr (LNF) {
+                float y;
+                asm("v_mul_f32_e32 %0, %1, %2" : "=v"(y) : "v"(ln_rstd[LNF ? tjf : 0]), "v"(x));
+                return y;
+            } else {
+                return x;
+            }
+        };
         if (!do_epi) {
             // another split of this tile arrives later and writes the output
         } else if constexpr (EPI == G8_GEGLU) {
@@ -574,7 +656,7 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
 #pragma unroll
                         // (scalar fp32 GELU: the packed-fp32 form — v_pk_fma_f32 / v_pk_mul_f32, two values per issue slot — measured
                         //  the same within noise in the same-box A/B, 852 / 885 vs 836 / 900 TF/s on 52224 x 5120 <- 640)
-                        for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[tf][tjf][8 * gq + e] * gelu_erf_f(acc[tf][tjf][8 * gq + 4 + e]));
+                        for (int e = 0; e < 4; ++e) o[e] = f2bf(ln_mul(tjf, acc[tf][tjf][8 * gq + e]) * gelu_erf_f(ln_mul(tjf, acc[tf][tjf][8 * gq + 4 + e])));
                         *(bf16x4*)(stg + l31 * RB + (((2 * tf + gq) ^ (l31 & (G - 1))) << 4) + hi * 8) = o;
                     }
                 }
@@ -593,6 +675,7 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
 #pragma unroll
             for (int tjf = 0; tjf < NJ; ++tjf) {
                 float gs[CW / 64][8], gq[CW / 64][8];
+                float rs[4] = {0.f, 0.f, 0.f, 0.f}, rq[4] = {0.f, 0.f, 0.f, 0.f};      // row_sums: this lane's share of its 4 pixel rows
 #pragma unroll
                 for (int cs = 0; cs < CW / 64; ++cs)
 #pragma unroll
@@ -631,6 +714,16 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
                             if (st) *(bf16x8*)(outp + (size_t)m * d.ldc + cb) = o;
+                            if constexpr (GATHER == G8_LINEAR) {
+                                if (d.row_sums) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) {
+                                        const float f = bf2f(o[e]);      // of what the consumer will read
+                                        rs[j] += f;
+                                        rq[j] += f * f;
+                                    }
+                                }
+                            }
                             if (gn) {
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) {
@@ -650,6 +743,9 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                     for (int cs = 0; cs < CW / 64; ++cs)
                         g8_flush_stats<8>(gs[cs], gq[cs], lane, chw + cs * 64 + 8 * (lane & 7), d.N, gn_slots(tjf));
                 }
+                if constexpr (GATHER == G8_LINEAR) {
+                    if (d.row_sums) g8_flush_rows<8>(rs, rq, lane, pix0 + pixbase(tjf), 8, d.M, d.row_sums);
+                }
             }
         } else {
             // bf16 staging, all CW channels x 32 pixels at a time
@@ -657,6 +753,9 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
 #pragma unroll
             for (int tjf = 0; tjf < NJ; ++tjf) {
                 float gs[8], gq[8];
+                float rs[G / 2], rq[G / 2];                  // row_sums: this lane's share of its G / 2 pixel rows
+#pragma unroll
+                for (int j = 0; j < G / 2; ++j) rs[j] = rq[j] = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
 #pragma unroll
@@ -665,7 +764,7 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                     for (int q = 0; q < 4; ++q) {
                         bf16x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[tf][tjf][4 * q + e]);
+                        for (int e = 0; e < 4; ++e) o[e] = f2bf(ln_mul(tjf, acc[tf][tjf][4 * q + e]));
                         *(bf16x4*)(stg + l31 * RB + (((4 * tf + q) ^ (l31 & (G - 1))) << 4) + hi * 8) = o;
                     }
                 __builtin_amdgcn_sched_barrier(0);
@@ -675,6 +774,16 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                     const bf16x8 v = *(const bf16x8*)(stg + row * RB + ((c ^ (row & (G - 1))) << 4));
                     const int64_t m = pix0 + pixbase(tjf) + row;
                     if (st && m < d.M && chw + 8 * c < d.N) *(bf16x8*)(outp + (size_t)m * d.ldc + chw + 8 * c) = v;
+                    if constexpr (GATHER == G8_LINEAR && !LNF) {
+                        if (d.row_sums && chw + 8 * c < d.N) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float f = bf2f(v[e]);
+                                rs[j] += f;
+                                rq[j] += f * f;
+                            }
+                        }
+                    }
                     if (gn && m < d.M) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
@@ -685,6 +794,9 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                     }
                 }
                 if (gn) g8_flush_stats<G>(gs, gq, lane, chw + 8 * (lane % G), d.N, gn_slots(tjf));
+                if constexpr (GATHER == G8_LINEAR && !LNF) {
+                    if (d.row_sums) g8_flush_rows<G>(rs, rq, lane, pix0 + pixbase(tjf), 64 / G, d.M, d.row_sums);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -707,12 +819,12 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     }
 }
 
-template <int TIH, int TJH, int EPI, int GATHER, int SPLIT = 0>
+template <int TIH, int TJH, int EPI, int GATHER, int SPLIT = 0, int LNF = 0>
 int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu, int split_k = 1) {
     constexpr int BM = TIH * 128, BN = TJH * 256;
     constexpr int LDS = 2 * (2 * TIH * 8192 + 2 * TJH * 16384) + (SPLIT ? 16 : 0);
     static unsigned long long attr_done = 0;
-    if (int rc = cc_max_dynamic_lds((const void*)g8_kernel<TIH, TJH, EPI, GATHER, SPLIT>, LDS, &attr_done, "g8_kernel")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)g8_kernel<TIH, TJH, EPI, GATHER, SPLIT, LNF>, LDS, &attr_done, "g8_kernel")) return rc;
     const int64_t pt_n = (d.M + BN - 1) / BN, ct_n = (d.N + BM - 1) / BM;
     CcGemmDesc dd = d;
     dd.cgroup = 0;
@@ -739,11 +851,13 @@ int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu, int split_k = 
     dd.split_k = SPLIT ? split_k : 1;
     const int64_t tiles = pt_n * ct_n * dd.split_k;
     if (tiles < wgs) wgs = (int)((tiles + 7) / 8 * 8);
-    if (SPLIT)
+    if (LNF)
+        cc_note_kernel("g8_kernel %dch x %dpix, LayerNorm folded", BM, BN);
+    else if (SPLIT)
         cc_note_kernel(GATHER == G8_TEMPORAL ? "g8_kernel %dch x %dpix, temporal taps, split-K" : (GATHER == G8_CONV3 ? "g8_kernel %dch x %dpix, 3x3 taps, split-K" : "g8_kernel %dch x %dpix, split-K"), BM, BN);
     else
         cc_note_kernel(GATHER == G8_TEMPORAL ? "g8_kernel %dch x %dpix, temporal taps" : (GATHER == G8_CONV3 ? "g8_kernel %dch x %dpix, 3x3 taps" : "g8_kernel %dch x %dpix"), BM, BN);
-    hipLaunchKernelGGL((g8_kernel<TIH, TJH, EPI, GATHER, SPLIT>), dim3((unsigned)wgs), dim3(512), LDS, s, dd);
+    hipLaunchKernelGGL((g8_kernel<TIH, TJH, EPI, GATHER, SPLIT, LNF>), dim3((unsigned)wgs), dim3(512), LDS, s, dd);
     return cc_launch_status("g8_kernel");
 }
 
@@ -771,6 +885,9 @@ bool cc_g8_applicable(const CcGemmDesc& d, int shape) {
               d.Hin == d.Hout && d.Win == d.Wout && d.Hin > 1 && d.Win > 1 && d.act == CCEDIT_ACT_NONE;
     return geo && d.A2 == nullptr && d.Cin % 64 == 0 && d.Kpad >= 128 && d.N % 16 == 0 &&
            (d.act == CCEDIT_ACT_NONE || d.act == CCEDIT_ACT_GEGLU) && !d.out_f32 && d.ln_eps == 0.f &&
+           ((!d.ln_stats && !d.ln_sums) || (d.ln_colsum && !(d.ln_stats && d.ln_sums) && d.mode == CCEDIT_GEMM_LINEAR && !d.res1 && !d.res2 &&
+                                            !d.group_bias && !d.gn_stats && !d.row_sums)) &&
+           (!d.row_sums || (d.mode == CCEDIT_GEMM_LINEAR && d.act == CCEDIT_ACT_NONE)) &&
            (!d.group_bias || (d.act == CCEDIT_ACT_NONE && d.group_rows > 0 && d.group_rows % 32 == 0 && (d.ldgb == 0 || d.ldgb % 4 == 0))) &&
 #ifndef G8_PROBE
            (!d.gn_stats || (d.act == CCEDIT_ACT_NONE && d.gn_rows > 0 && d.gn_rows % 128 == 0 && d.N % 32 == 0 && d.N >= 256)) &&
@@ -813,6 +930,11 @@ int cc_g8_launch(const CcGemmDesc& d, hipStream_t s, int shape) {
         n_cu = prop.multiProcessorCount;
     }
     if (shape == 0) shape = g8_auto_shape(d);
+    if (d.ln_stats || d.ln_sums) {           // LayerNorm folded into a plain Linear / GEGLU projection (cc_g8_applicable checked the rest)
+        const bool geglu = d.act == CCEDIT_ACT_GEGLU;
+        if (shape == 2) return geglu ? g8_launch_shape<1, 2, G8_GEGLU, G8_LINEAR, 0, 1>(d, s, n_cu) : g8_launch_shape<1, 2, G8_PLAIN, G8_LINEAR, 0, 1>(d, s, n_cu);
+        return geglu ? g8_launch_shape<2, 1, G8_GEGLU, G8_LINEAR, 0, 1>(d, s, n_cu) : g8_launch_shape<2, 1, G8_PLAIN, G8_LINEAR, 0, 1>(d, s, n_cu);
+    }
     if (shape == 1 && d.workspace) {
         const int sk = cc_g8_split(d, n_cu);
         if (sk > 1 && d.workspace_bytes >= cc_g8_workspace_bytes(d, n_cu)) {

@@ -659,6 +659,73 @@ extern "C" int ccedit_groupnorm_temporal_apply(const void* x, void* y, const flo
     return cc_launch_status("groupnorm_temporal_apply");
 }
 
+// The statistics half of layernorm_kernel: (mean, rstd) per row, same summation order (a consumer that folds the LayerNorm into
+// its GEMM — CcGemmDesc.ln_stats — sees the numbers the normalising kernel would have used).
+template <int COLS>
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16* __restrict__ x, float* __restrict__ st, int64_t rows, int C, float eps, int rpw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * rpw;
+    if (row0 >= rows) return;
+    const int G8 = C >> 3;
+    const float inv_c = 1.0f / (float)C;
+    const int nr = (int)min((int64_t)rpw, rows - row0);
+    for (int r = 0; r < nr; r += 2) {
+        const bool two = r + 1 < nr;
+        const bf16* x0 = x + (size_t)(row0 + r) * C;
+        const bf16* x1 = x0 + (two ? C : 0);
+        bf16x8 t0[COLS], t1[COLS];
+#pragma unroll
+        for (int k = 0; k < COLS; ++k) {
+            const int gc = lane + 64 * k;
+            if (gc < G8) {
+                t0[k] = *(const bf16x8*)(x0 + gc * 8);
+                t1[k] = *(const bf16x8*)(x1 + gc * 8);
+            }
+        }
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < COLS; ++k)
+            if (lane + 64 * k < G8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s0 += bf2f(t0[k][e]);
+                    s1 += bf2f(t1[k][e]);
+                }
+            }
+        const float m0 = wave_sum(s0) * inv_c, m1 = wave_sum(s1) * inv_c;
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < COLS; ++k)
+            if (lane + 64 * k < G8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d0 = bf2f(t0[k][e]) - m0, d1 = bf2f(t1[k][e]) - m1;
+                    q0 += d0 * d0;
+                    q1 += d1 * d1;
+                }
+            }
+        const float r0 = rsqrtf(wave_sum(q0) * inv_c + eps), r1 = rsqrtf(wave_sum(q1) * inv_c + eps);
+        if (lane == 0) {
+            *(f32x2*)(st + 2 * (row0 + r)) = f32x2{m0, r0};
+            if (two) *(f32x2*)(st + 2 * (row0 + r + 1)) = f32x2{m1, r1};
+        }
+    }
+}
+
+extern "C" int ccedit_row_stats(const void* x, float* stats, int64_t rows, int32_t C, float eps, void* stream) {
+    CC_CHECK_ARG(x && stats, "ccedit_row_stats: null pointer");
+    CC_CHECK_ARG(rows > 0 && C > 0, "ccedit_row_stats: bad sizes");
+    CC_UNSUPPORTED(C % 8 != 0 || C > kLnCols * 512, "ccedit_row_stats: C=%d (need C%%8==0, C<=%d)", C, kLnCols * 512);
+    int rpw = kLnRowsPerWave;
+    while (rpw > 1 && (rows + 4 * rpw - 1) / (4 * rpw) < 4096) rpw >>= 1;
+    dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
+    const int cols = (C / 8 + 63) / 64;
+#define CC_RS(N) hipLaunchKernelGGL(row_stats_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, stats, rows, C, eps, rpw)
+    if (cols == 1) CC_RS(1); else if (cols == 2) CC_RS(2); else CC_RS(kLnCols);
+#undef CC_RS
+    return cc_launch_status("row_stats");
+}
+
 extern "C" int ccedit_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t C,
                                 float eps, void* stream) {
     CC_CHECK_ARG(x && y && gamma && beta, "ccedit_layernorm: null pointer");

@@ -34,7 +34,8 @@ class CcGemmDesc(C.Structure):
         ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
         ("group_bias", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p),
         ("gn_stats", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-        ("split_k", C.c_int32), ("reserved0", C.c_int32),
+        ("split_k", C.c_int32), ("reserved0", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_stats", C.c_void_p),
+        ("ln_sums", C.c_void_p), ("row_sums", C.c_void_p), ("ln_sums_eps", C.c_float), ("reserved1", C.c_int32),
     ]
 
 
@@ -83,6 +84,7 @@ _SIGS = {
     "ccedit_groupnorm_temporal_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                                   C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                                   C.c_int32, C.c_void_p]),
+    "ccedit_row_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "ccedit_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
                                    C.c_void_p]),
     "ccedit_attention": (C.c_int, [C.POINTER(CcAttnDesc), C.c_void_p]),

@@ -168,20 +168,33 @@ class CrossAttention(nn.Module):
         self.kv = pack_concat([self.to_k.weight, self.to_v.weight], device=device)
 
 
-def ln_linear(tok, norm: "Norm", pw, pw_ln):
-    """linear(LayerNorm(tok)).  With a folded weight (packing.fold_layernorm) and the K = 320 register-resident-weight
-    shape the rows are normalised inside the GEMM (CcGemmDesc.ln_eps): the normalised tensor never exists in memory."""
-    if pw_ln is not None and ops.ln320_applicable(tok.shape[0], pw_ln):
+def ln_linear(tok, norm: "Norm", pw, pw_ln, stats=None):
+    """linear(LayerNorm(tok)) without the normalised tensor ever existing in memory, given a folded weight
+    (packing.fold_layernorm): K = 320 — the rows are normalised inside the register-resident-weight GEMM (CcGemmDesc.ln_eps);
+    K = 640 / 1280 on the persistent GEMM — the GEMM runs on the raw rows and its epilogue applies their (mean, rstd)
+    (CcGemmDesc.ln_stats; `stats` = ops.row_stats(tok) when the caller has them already).  Otherwise a LayerNorm pass."""
+    if pw_ln is not None and pw_ln.cin == 320 and ops.ln320_applicable(tok.shape[0], pw_ln):
         return ops.linear(tok, pw_ln, ln_eps=norm.eps)
+    if ops.lnf_applicable(tok.shape[0], pw_ln):
+        sums = ops.ln_sums_of(tok)          # left by the GEMM that wrote tok (linear_ln_producer), else one read-only pass
+        if sums is not None:
+            return ops.linear(tok, pw_ln, ln_sums=(sums, norm.eps))
+        return ops.linear(tok, pw_ln, ln_stats=ops.row_stats(tok, norm.eps) if stats is None else stats)
     return ops.linear(ops.layernorm(tok, norm.g, norm.b, norm.eps), pw)
 
 
-def _fold_ln(weights, norm: "Norm", device):
-    """Folded projection of LayerNorm(x) for dim 320 (None elsewhere: only lin320 normalises its rows)."""
-    if weights[0].shape[1] != 320:
+def linear_ln_producer(x2d, pw, **kw):
+    """A Linear whose output is the input of a LayerNorm that ln_linear folds into the next GEMM: its epilogue also accumulates
+    the row sums (CcGemmDesc.row_sums) where that kernel runs."""
+    return ops.linear(x2d, pw, row_sums=ops.row_sums_applicable(x2d.shape[0], pw, kw.get("act", 0)), **kw)
+
+
+def _fold_ln(weights, norm: "Norm", device, biases=None, geglu=False, dims=(320, 640, 1280)):
+    """Folded projection of LayerNorm(x) (see ln_linear); None for widths no kernel folds."""
+    if weights[0].shape[1] not in dims:
         return None
     from .packing import fold_layernorm
-    return fold_layernorm(weights, None, norm.weight, norm.bias, device=device)
+    return fold_layernorm(weights, biases, norm.weight, norm.bias, device=device, geglu=geglu)
 
 
 class FeedForward(nn.Module):
@@ -204,12 +217,17 @@ class FeedForward(nn.Module):
             self.fused = pack_ff320(p.weight, p.bias, o.weight, o.bias, norm.weight, norm.bias, device=device)
             self.fused_eps = norm.eps
 
+        elif self.net[0].proj.cin in (640, 1280):          # wider levels: LayerNorm folded into the GEGLU projection (ln_linear)
+            p = self.net[0].proj
+            self.proj_ln = _fold_ln([p.weight], norm, device, biases=[p.bias], geglu=True, dims=(640, 1280))
+
+    proj_ln = None
+
     def run(self, tok, norm: "Norm"):
         """tok + FF(LayerNorm(tok)) (attention.py:695-716 `x = self.ff(self.norm3(x)) + x`)."""
         if self.fused is not None and ops.FF320 and tok.shape[0] >= 1024:
             return ops.ff320(tok, self.fused, eps=self.fused_eps)
-        n = ops.layernorm(tok, norm.g, norm.b, norm.eps)
-        g = ops.linear(n, self.net[0].proj.pw)
+        g = ln_linear(tok, norm, self.net[0].proj.pw, self.proj_ln)
         return ops.linear(g, self.net[2].pw, res1=tok)
 
 
@@ -226,21 +244,24 @@ class BasicTransformerBlock(nn.Module):
     def run(self, tok, frames: int, hw: int, ctx_kv_src, ctx_len: int, frames_per_clip: int):
         a1, a2 = self.attn1, self.attn2
         c = a1.inner
-        qkv = ops.linear(ops.layernorm(tok, self.norm1.g, self.norm1.b), a1.qkv)      # 3 slices: folding the norm does not pay
+        qkv = ln_linear(tok, self.norm1, a1.qkv, self.qkv_ln)      # (dim 320, 3 slices: folding the norm into lin320 does not pay)
         o = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], a1.heads, a1.dim_head, batches=frames, lq=hw, lk=hw)
-        tok = ops.linear(o, a1.to_out[0].pw, res1=tok)
+        tok = linear_ln_producer(o, a1.to_out[0].pw, res1=tok)
         q = ln_linear(tok, self.norm2, a2.to_q.pw, self.q2_ln)
         kv = ops.linear(ctx_kv_src, a2.kv)                     # [B*L, 2C]: once per clip, shared by its T frames
         o = ops.attention(q, kv[:, :c], kv[:, c:], a2.heads, a2.dim_head, batches=frames, lq=hw, lk=ctx_len,
                           kv_div=frames_per_clip)
-        tok = ops.linear(o, a2.to_out[0].pw, res1=tok)
+        tok = linear_ln_producer(o, a2.to_out[0].pw, res1=tok)
         return self.ff.run(tok, self.norm3)
 
     q2_ln = None
+    qkv_ln = None
 
     def post_pack(self, device):
         self.ff.pack_fused(self.norm3, device)
         self.q2_ln = _fold_ln([self.attn2.to_q.weight], self.norm2, device)
+        a1 = self.attn1
+        self.qkv_ln = _fold_ln([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], self.norm1, device, dims=(640, 1280))
 
 
 class BasicTransformerSingleLayerBlock(nn.Module):
@@ -281,7 +302,7 @@ class BasicTransformerSingleLayerBlock(nn.Module):
             o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=frames, lq=hw, lk=2 * hw,
                               kv_outer_rows=hw, seg1_len=hw, seg1_div=frames_per_clip, seg1_mul=frames_per_clip,
                               seg1_add=anchor_t)
-        tok = ops.linear(o, a.to_out[0].pw, res1=tok)
+        tok = linear_ln_producer(o, a.to_out[0].pw, res1=tok)
         return self.ff.run(tok, self.norm2)
 
     q_ln = None
@@ -302,7 +323,7 @@ class BasicTransformerSingleLayerBlock(nn.Module):
         o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=geo.b * hw, lq=t, lk=tk,
                           q_inner=hw, q_outer_rows=t * hw, q_inner_rows=1, q_seq_rows=hw,
                           kv_inner=hw, kv_outer_rows=tk * hw, kv_inner_rows=1, kv_seq_rows=hw)
-        tok = ops.linear(o, a.to_out[0].pw, res1=tok)
+        tok = linear_ln_producer(o, a.to_out[0].pw, res1=tok)
         return self.ff.run(tok, self.norm2)
 
 
@@ -326,7 +347,7 @@ class SpatialTransformer(nn.Module):
     def run_spatial(self, x, ctx2d, ctx_len, frames_per_clip, gn: bool = False):
         n, h, w, c = x.shape
         a = ops.groupnorm_spatial(x, self.norm.g, self.norm.b, self.norm.eps, False)
-        tok = ops.linear(a.view(-1, c), self.proj_in.pw)
+        tok = linear_ln_producer(a.view(-1, c), self.proj_in.pw)
         if self.disable_text_ca:
             tok = self.transformer_blocks[0].run_frames(tok, n, h * w)
         else:

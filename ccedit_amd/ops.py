@@ -85,7 +85,8 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
          group_bias: Optional[torch.Tensor] = None, group_rows: int = 0,
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, out_f32: bool = False, use_bias: bool = True, tile: int = 0,
-         gn_rows: int = 0, ln_eps: float = 0.0) -> torch.Tensor:
+         gn_rows: int = 0, ln_eps: float = 0.0, ln_stats: Optional[torch.Tensor] = None, ln_sums=None,
+         row_sums: bool = False) -> torch.Tensor:
     """out[m, :] = epilogue(sum_taps W . A[src(m, tap)]).  a2d: [rows, lda] bf16 (last dim contiguous).
 
     gn_rows > 0 (= H*W of the output frames) asks the epilogue to also accumulate the GroupNorm(32) statistics of
@@ -123,6 +124,21 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
         if not ln320_applicable(m, pw, act, res1, res2, group_bias, out_f32, gn_rows):
             raise ValueError("gemm: ln_eps needs the K = 320 register-resident-weight shape (>= 32768 rows, plain Linear)")
         d.ln_eps, d.tile = ln_eps, 9
+    if ln_stats is not None:      # rows of A are un-normalised LayerNorm inputs: (mean, rstd) applied in the epilogue (g8_kernel only)
+        if pw.colsum is None or ln_stats.dtype != torch.float32 or tuple(ln_stats.shape) != (m, 2) or not ln_stats.is_contiguous():
+            raise ValueError("gemm: ln_stats needs a packing.fold_layernorm weight and a contiguous fp32 [M, 2] statistics tensor")
+        d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), pw.colsum.data_ptr()
+    if ln_sums is not None:       # ... or their (sum, sum of squares) as the producing GEMM left them (`row_sums=True` there): (tensor, eps)
+        sums, eps = ln_sums
+        if pw.colsum is None or sums.dtype != torch.float64 or tuple(sums.shape) != (m, 2) or not sums.is_contiguous():
+            raise ValueError("gemm: ln_sums needs a packing.fold_layernorm weight and the contiguous fp64 [M, 2] sums of the producer")
+        d.ln_sums, d.ln_sums_eps, d.ln_colsum = sums.data_ptr(), eps, pw.colsum.data_ptr()
+    if row_sums:                  # LayerNorm statistics of the output, accumulated by the epilogue; they travel with the tensor (ln_sums_of)
+        sums = _ZEROS.take(2 * m, out.device).view(m, 2)
+        d.row_sums = sums.data_ptr()
+        out._ln_sums = sums
+    elif hasattr(out, "_ln_sums"):
+        del out._ln_sums
     d.korder = pw.korder
     d.A, d.A2, d.W = a2d.data_ptr(), _ptr(a2), pw.w.data_ptr()
     d.bias = _ptr(pw.bias) if use_bias else None
@@ -289,13 +305,15 @@ _ZEROS = _ZeroArena()
 
 
 def reset_stream_scratch():
-    """Forget the scratch buffers tied to the current stream (statistics workspace, zeroed arena).  Called at both ends of a HIP-graph
-    capture: what is allocated while capturing belongs to that graph's memory pool and is zeroed by a captured fill, so a later
-    capture on the same stream must not continue in it."""
-    key = (torch.device("cuda", torch.cuda.current_device()), torch.cuda.current_stream().cuda_stream)
-    for cache in (_ws_cache, _ZEROS.slabs, _splitk_cache):
-        for k in [k for k in cache if k[1] == key[1]]:
-            del cache[k]
+    """Forget every cached scratch buffer (statistics workspace, zeroed arenas, split-K workspace) of EVERY stream.  Called at both
+    ends of a HIP-graph capture: what is allocated while capturing belongs to that graph's memory pool and is zeroed by a captured
+    fill, so nothing captured later may continue in it — and a capture spans several streams (the ControlNet's side stream keeps
+    its own arenas): resetting only the capture stream's left the side stream's arena of an earlier graph in use by the next one,
+    whose replays then accumulated GroupNorm statistics onto the previous replay's (round 3: the sampler run after the step
+    benchmark produced non-finite frames)."""
+    _ws_cache.clear()
+    _ZEROS.slabs.clear()
+    _splitk_cache.clear()
 
 
 def zero_stats(frames: int, device) -> torch.Tensor:
@@ -370,6 +388,36 @@ def groupnorm_temporal_apply(x: torch.Tensor, stats: torch.Tensor, b: int, t: in
                                                         int(silu), dst_frames, dst_off, _stream()),
               "ccedit_groupnorm_temporal_apply")
     return y
+
+
+def row_stats(x2d: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """(mean, rstd) of every row: the statistics half of LayerNorm, for a GEMM that folds the normalisation (gemm(ln_stats=...))."""
+    _chk_act(x2d, "row_stats")
+    assert x2d.is_contiguous()
+    st = torch.empty((x2d.shape[0], 2), dtype=torch.float32, device=x2d.device)
+    hip.check(hip.lib().ccedit_row_stats(x2d.data_ptr(), st.data_ptr(), x2d.shape[0], x2d.shape[1], eps, _stream()), "ccedit_row_stats")
+    return st
+
+
+LNF = os.environ.get("CCEDIT_LNF", "1") != "0"       # 0: LayerNorm passes in front of the 640 / 1280-channel projections (A/B)
+
+
+def ln_sums_of(x: torch.Tensor):
+    """(sum, sum of squares) per row that the producing GEMM left on `x` (None if it did not)."""
+    return getattr(x, "_ln_sums", None)
+
+
+def row_sums_applicable(m: int, pw, act: int = ACT_NONE) -> bool:
+    """A Linear whose epilogue can accumulate the row sums of its output (the persistent eight-phase kernel's shapes)."""
+    return LNF and LN_SUMS and m >= 4096 and pw.kpad >= 640 and pw.n >= 640 and pw.taps == 1 and not pw.geglu and act == ACT_NONE
+
+
+LN_SUMS = os.environ.get("CCEDIT_LN_SUMS", "1") != "0"   # 0: statistics by ccedit_row_stats instead of the producer's epilogue (A/B)
+
+
+def lnf_applicable(m: int, pw) -> bool:
+    """ccedit_gemm's conditions for ln_stats (the persistent eight-phase kernel, csrc/gemm.hip)."""
+    return LNF and pw is not None and pw.colsum is not None and m >= 4096 and pw.kpad >= 640 and pw.n >= 640 and pw.taps == 1
 
 
 def layernorm(x2d: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor:

@@ -35,11 +35,14 @@ class PackedWeight:
     geglu: bool = False
     flops_per_row: float = 0.0      # algorithmic 2*O*I*taps (unpadded) per output row
     korder: int = 0                 # 0: K = [tap][Cin];  1: K = [Cin/64][tap][64]
+    colsum: Optional[torch.Tensor] = None   # fp32 [n]: row sums of the bf16 weights as packed (CcGemmDesc.ln_colsum), folded-LayerNorm weights only
 
     def to(self, device):
         self.w = self.w.to(device)
         if self.bias is not None:
             self.bias = self.bias.to(device)
+        if self.colsum is not None:
+            self.colsum = self.colsum.to(device)
         return self
 
 
@@ -105,16 +108,20 @@ def pack_concat(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optio
 
 
 def fold_layernorm(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optional[torch.Tensor]]], gamma: torch.Tensor,
-                   beta: torch.Tensor, device: Optional[torch.device] = None) -> PackedWeight:
+                   beta: torch.Tensor, device: Optional[torch.device] = None, geglu: bool = False) -> PackedWeight:
     """Projections of a LayerNorm output, Linear(gamma * xhat + beta) = (W diag(gamma)) xhat + (b + W beta), packed for the
-    GEMM that normalises its rows itself (CcGemmDesc.ln_eps): the affine half of the LayerNorm lives in the weights."""
+    GEMM that normalises its rows itself (CcGemmDesc.ln_eps, K = 320) or takes the row statistics and applies them in its
+    epilogue (CcGemmDesc.ln_stats: rstd (W' x - mean W' 1) + b', for which `colsum` = W' 1 of the bf16 weights as stored):
+    the affine half of the LayerNorm lives in the weights."""
     ws = [w.detach().float() for w in weights]
     g, bt = gamma.detach().float().to(ws[0].device), beta.detach().float().to(ws[0].device)
     bs = [None] * len(ws) if biases is None else list(biases)
     wf = torch.cat([w * g[None, :] for w in ws], dim=0)
     bf = torch.cat([(torch.zeros(w.shape[0], device=w.device) if b is None else b.detach().float().to(w.device)) + w @ bt
                     for w, b in zip(ws, bs)])
-    return pack_weight(wf, bf, device=device)
+    pw = pack_weight(wf, bf, geglu=geglu)
+    pw.colsum = pw.w[:pw.n].float().sum(dim=1).contiguous()
+    return pw if device is None else pw.to(device)
 
 
 # ------------------------------------------------------------------------------------------

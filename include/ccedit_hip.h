@@ -125,6 +125,22 @@ typedef struct CcGemmDesc {
     int64_t workspace_bytes;
     int32_t split_k;      /* internal (set by the library); pass 0 */
     int32_t reserved0;
+    /* optional: LayerNorm folded into a plain Linear / GEGLU projection whose K is not 320 (`to_q(norm(x))`, `ff.net[0].proj(norm(x))`
+     * of attention.py:695-716 at 640 / 1280 channels).  A holds the UN-normalised rows, W / bias the gamma / beta-folded weights
+     * (as for ln_eps), ln_colsum[N] the row sums of the bf16 weights as packed, ln_stats[M][2] = (mean, rstd) of every row of A
+     * (ccedit_row_stats).  The call computes rstd (W' x - mean colsum) + b'.  Persistent eight-phase kernel only (tile 0 / 11-13,
+     * Linear, no residual / row bias / gn_stats); refused with CCEDIT_EUNSUPPORTED elsewhere. */
+    const float* ln_colsum;
+    const float* ln_stats;
+    /* ... or ln_sums[M][2] = (sum, sum of squares) of every row of A in double, as a producing call accumulated them through
+     * row_sums; then mean = s / Cin, rstd = rsqrt(q / Cin - mean^2 + ln_sums_eps).  Exactly one of ln_stats / ln_sums. */
+    const double* ln_sums;
+    /* optional, producer side (Linear, no activation, persistent eight-phase kernel; refused elsewhere): the epilogue adds every
+     * output row's (sum, sum of squares) of the bf16-rounded values it stores to row_sums[M][2] (double, ZEROED BY THE CALLER) —
+     * the LayerNorm statistics of the tensor being written, for the call that consumes it through ln_sums. */
+    double* row_sums;
+    float ln_sums_eps;
+    int32_t reserved1;
 } CcGemmDesc;
 
 int ccedit_gemm(const CcGemmDesc* desc, void* stream);
@@ -193,6 +209,9 @@ int ccedit_groupnorm_temporal_apply(const void* x, void* y, const float* gamma, 
                                     float count, float eps, int32_t silu, int32_t dst_frames, int32_t dst_off,
                                     void* stream);
 /* LayerNorm over C (eps 1e-5) — attention.py:667-669, 755-756. x,y: [rows][C] */
+/* (mean, rstd = rsqrt(var + eps)) of every row of x[rows][C] (bf16, contiguous), fp32 pairs: the statistics half of
+ * nn.LayerNorm (attention.py:611-613), consumed by CcGemmDesc.ln_stats.  Same arithmetic as ccedit_layernorm. */
+int ccedit_row_stats(const void* x, float* stats, int64_t rows, int32_t C, float eps, void* stream);
 int ccedit_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows,
                      int32_t C, float eps, void* stream);
 

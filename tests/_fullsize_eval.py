@@ -69,6 +69,14 @@ def main(out_path):
     assert graphed == (w.use_graph and not type(w)._graph_failed), "the HIP graph was not captured"
     assert torch.equal(e_eager, e_graph) and torch.equal(e_eager, e_back), "HIP-graph replay differs from the eager evaluation"
     assert not torch.equal(e_eager, e_moved), "the replay did not pick up the new latent / timestep"
+    # a SECOND graph (other conditioning tensors, as the next clip or the sampler after the step benchmark brings): its replays must
+    # not inherit scratch (zeroed statistics arenas of the main AND the ControlNet's side stream) from the first graph's capture
+    c2 = dict(crossattn=torch.cat([cc, cu]).to(dev), control_hint=torch.cat([hint, hint]).to(dev))
+    f = [w(xx, t, c2).clone() for _ in range(4)]                   # eager, capture + replay, replay, replay
+    assert all(torch.equal(f[0], fi) for fi in f[1:]), "replays of the second HIP graph differ from its eager evaluation"
+    assert torch.equal(w(xx, t, c), e_eager) and torch.equal(w(xx, t, c2), f[0]), "the two graphs disturb each other"
+    if graphed:
+        assert sum("graph" in e for e in w._graphs.values()) == 2
 
     out = dict(eps=run(x, x, cu, cc),                 # the CFG pair of the benchmark: same latent, two prompts
                eps_same=run(x, x, cc, cc),            # identical halves -> identical predictions

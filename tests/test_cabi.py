@@ -35,7 +35,7 @@ def test_binding_matches_header(libpath):
     from ccedit_amd import hip
     assert sorted(hip.EXPORTS) == _declared()
     # descriptor layouts: sizes the C side was compiled with (kept in sync by hand; a mismatch shows up here)
-    assert ctypes.sizeof(hip.CcGemmDesc) == 8 + 34 * 4 + 9 * 8 + (8 + 8 + 2 * 4)      # ... + workspace, workspace_bytes, split_k, reserved0 (ABI 8)
+    assert ctypes.sizeof(hip.CcGemmDesc) == 8 + 34 * 4 + 9 * 8 + (8 + 8 + 2 * 4) + 4 * 8 + 2 * 4      # ... + workspace, workspace_bytes, split_k, reserved0; ln_colsum, ln_stats, ln_sums, row_sums, ln_sums_eps, reserved1 (ABI 8)
     assert ctypes.sizeof(hip.CcAttnDesc) % 8 == 0
 
 
@@ -74,6 +74,31 @@ def test_ln_eps_is_refused_where_no_kernel_normalises(libpath):
     d = desc(320, 320, 0)
     d.res1, d.ldr1 = 1, 320                     # a residual epilogue is not available together with the normalisation either
     assert lib.ccedit_gemm(ctypes.byref(d), None) == -2
+
+
+def test_ln_stats_is_refused_where_no_kernel_applies_it(libpath):
+    """CcGemmDesc.ln_stats / ln_colsum (LayerNorm applied in the epilogue of a GEMM on the raw rows): only the persistent
+    eight-phase kernel implements it; every other block shape / geometry must refuse rather than multiply folded weights with
+    un-normalised rows."""
+    from ccedit_amd import hip
+    lib = hip.lib()
+
+    def desc(cin, n, tile, **kw):
+        d = hip.CcGemmDesc()
+        d.M, d.N, d.Cin, d.Cin1, d.taps, d.Kpad = 8192, n, cin, cin, 1, cin
+        d.A = d.W = d.out = d.ln_stats = d.ln_colsum = 1
+        d.lda, d.ldc, d.tile = cin, n, tile
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    bad = [desc(640, 640, 1), desc(640, 640, 4), desc(640, 640, 6), desc(320, 320, 9), desc(640, 640, 0, res1=1, ldr1=640),
+           desc(640, 640, 0, ln_colsum=None), desc(640, 640, 0, ln_stats=None), desc(640, 640, 0, act=1), desc(640, 648, 0)]
+    for d in bad:
+        assert lib.ccedit_gemm(ctypes.byref(d), None) == -2 and b"ln_stats" in lib.ccedit_last_error(), lib.ccedit_last_error()
+    # the producer side (row_sums: the epilogue accumulates the LayerNorm statistics of what it writes) likewise
+    for d in (desc(640, 640, 1, ln_stats=None, ln_colsum=None, row_sums=1), desc(640, 640, 0, ln_stats=None, ln_colsum=None, row_sums=1, act=1),
+              desc(320, 320, 9, ln_stats=None, ln_colsum=None, row_sums=1), desc(640, 640, 0, row_sums=1)):
+        assert lib.ccedit_gemm(ctypes.byref(d), None) == -2, lib.ccedit_last_error()
 
 
 def test_split_k_workspace_size_query(libpath):

@@ -176,6 +176,66 @@ def test_conv3x3_persistent_eight_phase(n, cin, cout, h, w, tile):
         ops.conv2d(_nhwc(x), pw, stride=2, tile=tile)                   # strided / upsampling convs are not this kernel's
 
 
+@pytest.mark.parametrize("m,c,n,geglu", [(4608, 640, 1920, False), (4160, 1280, 1280, False), (4608, 640, 5120, True), (5000, 1280, 10240, True)])
+def test_layernorm_folded_into_persistent_gemm(m, c, n, geglu):
+    """CcGemmDesc.ln_stats: Linear(LayerNorm(x)) with gamma / beta folded into the weights, the GEMM run on the RAW rows and
+    (mean, rstd) applied in the epilogue — `to_q(norm(x))`, the fused q|k|v projection and the GEGLU projection of
+    `ff(norm(x))` at 640 / 1280 channels (attention.py:695-716) — against torch's LayerNorm + Linear (+ GEGLU), rows with a
+    large common offset included (mean >> std: the cancellation case of the rewritten sum); ccedit_row_stats against torch."""
+    _dev()
+    from ccedit_amd import hip, ops
+    from ccedit_amd.packing import fold_layernorm, pack_weight
+    x = _rnd(m, c, seed=1)
+    x[: m // 4] += 3.0                                  # a quarter of the rows: mean 3, std 1
+    x[m // 4: m // 2] *= 4.0
+    w, b = _rnd(n, c, seed=2, scale=c ** -0.5), _rnd(n, seed=3)
+    g, be = _rnd(c, seed=4) * 0.2 + 1.0, _rnd(c, seed=5) * 0.2
+    xc = x.to(BF).cuda()
+    xf = xc.float().cpu()
+    ref = F.linear(F.layer_norm(xf, (c,), g, be, 1e-5), w, b)
+    if geglu:
+        a, gate = ref.chunk(2, dim=-1)
+        ref = a * F.gelu(gate)
+    st = ops.row_stats(xc, 1e-5)
+    assert torch.allclose(st[:, 0].cpu(), xf.mean(dim=1), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(st[:, 1].cpu(), (xf.var(dim=1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-6)
+    pw_ln = fold_layernorm([w], [b], g, be, geglu=geglu).to("cuda")
+    assert ops.lnf_applicable(m, pw_ln)
+    y = ops.linear(xc, pw_ln, ln_stats=st)
+    assert "LayerNorm folded" in hip.lib().ccedit_last_kernel().decode()
+    _close(y, ref, what=f"LayerNorm folded into the GEMM {m}x{n}<-{c} geglu={geglu}")
+    # and against the unfused path of the product (LayerNorm pass, then the plain weights): same to bf16 rounding of the operands
+    y0 = ops.linear(ops.layernorm(xc, g.cuda(), be.cuda(), 1e-5), pack_weight(w, b, geglu=geglu).to("cuda"))
+    _close(y, y0.float(), what="folded vs LayerNorm pass + GEMM")
+    for _ in range(3):
+        assert torch.equal(ops.linear(xc, pw_ln, ln_stats=st), y), "run-to-run difference"
+    for tile in (12, 13):
+        _close(ops.linear(xc, pw_ln, ln_stats=st, tile=tile), ref, what=f"tile {tile}")
+    with pytest.raises(Exception):
+        ops.linear(xc, pw_ln, ln_stats=st, tile=1)              # no other kernel applies the statistics: refused, not ignored
+    with pytest.raises(Exception):
+        ops.linear(xc, pw_ln, ln_stats=st, res1=y)              # (nor is there a residual variant)
+    # the statistics from the PRODUCER's epilogue instead of a pass over x: x2 = Linear(z) + residual written with row_sums, then
+    # Linear(LayerNorm(x2)) through ln_sums — against torch on the x2 that was stored
+    z, w0, b0 = _rnd(m, c, seed=6), _rnd(c, c, seed=7, scale=c ** -0.5), _rnd(c, seed=8)
+    pw0 = pack_weight(w0, b0).to("cuda")
+    for res in (None, xc):
+        assert ops.row_sums_applicable(m, pw0)
+        x2 = ops.linear(z.to(BF).cuda(), pw0, res1=res, row_sums=True)
+        sums = ops.ln_sums_of(x2)
+        x2f = x2.float().cpu()
+        assert sums is not None and torch.allclose(sums[:, 0].cpu(), x2f.double().sum(dim=1), rtol=1e-6, atol=1e-3)
+        assert torch.allclose(sums[:, 1].cpu(), (x2f.double() ** 2).sum(dim=1), rtol=1e-6, atol=1e-3)
+        ref2 = F.linear(F.layer_norm(x2f, (c,), g, be, 1e-5), w, b)
+        if geglu:
+            a, gate = ref2.chunk(2, dim=-1)
+            ref2 = a * F.gelu(gate)
+        y2 = ops.linear(x2, pw_ln, ln_sums=(sums, 1e-5))
+        _close(y2, ref2, what=f"LayerNorm statistics from the producer's epilogue (residual: {res is not None})")
+        x2b = ops.linear(z.to(BF).cuda(), pw0, res1=res, row_sums=True)
+        assert torch.equal(x2b, x2) and torch.equal(ops.ln_sums_of(x2b), sums), "producer sums: run-to-run difference"
+
+
 def test_split_k_persistent_gemm():
     """Few output tiles + long K (the 8x12 level): g8_kernel's split-K — partial accumulators through the caller's workspace, an
     arrival counter per tile, the last arriver reduces in split order and runs the epilogue.  Linear / Conv1d k3 over T / Conv2d
@@ -656,6 +716,29 @@ def test_attention_fused_qkv_and_shared_text_kv():
     kk = kv[:, :c].reshape(clips, lk, c).repeat_interleave(frames_per_clip, 0)
     vv = kv[:, c:].reshape(clips, lk, c).repeat_interleave(frames_per_clip, 0)
     _close(o.reshape(n, lq, c), _sdpa_ref(q, kk, vv, heads), rel=2.0 ** -6, abs_=4e-3, what="text cross-attention")
+
+
+@pytest.mark.parametrize("d,heads,lq,lk,fpc,clips", [(40, 8, 1100, 77, 2, 2), (40, 8, 1101, 77, 2, 1), (80, 8, 700, 77, 3, 2), (160, 8, 384, 77, 6, 2),
+                                                     (40, 8, 2048, 64, 1, 3), (80, 8, 1037, 96, 2, 2), (40, 16, 600, 77, 4, 2)])
+def test_text_cross_attention_kernel(d, heads, lq, lk, fpc, clips):
+    """attn_text_kernel (attntext.hip): <= 96 keys shared by the frames of a clip; a wave owns 32 query rows and walks the heads of a
+    320-channel group.  Queries as a column slice of a wider buffer, K / V as slices of the fused [clips * Lk, 2C] projection (the
+    way BasicTransformerBlock.attn2 calls it), ragged row counts, 1 / 2 / 4 channel groups, key counts 64 / 77 / 96."""
+    _dev()
+    from ccedit_amd import hip, ops
+    c = heads * d
+    n = clips * fpc
+    qbuf = _rnd(n * lq, c + 64, seed=2)                      # q = columns [32, 32 + c) of a wider buffer (ldq != c)
+    kv = _rnd(clips * lk, 2 * c, seed=3)
+    qd, kvd = qbuf.to(BF).cuda(), kv.to(BF).cuda()
+    o = ops.attention(qd[:, 32:32 + c], kvd[:, :c], kvd[:, c:], heads, d, batches=n, lq=lq, lk=lk, kv_div=fpc)
+    assert ("attn_text_kernel" in hip.lib().ccedit_last_kernel().decode()) == (d != 160), hip.lib().ccedit_last_kernel()      # d = 160: general kernel
+    q = qd[:, 32:32 + c].float().cpu().reshape(n, lq, c)
+    kk = kvd[:, :c].float().cpu().reshape(clips, lk, c).repeat_interleave(fpc, 0)
+    vv = kvd[:, c:].float().cpu().reshape(clips, lk, c).repeat_interleave(fpc, 0)
+    _close(o.reshape(n, lq, c), _sdpa_ref(q, kk, vv, heads), rel=2.0 ** -6, abs_=4e-3, what=f"text attention d={d} heads={heads} {lq}x{lk}")
+    for _ in range(2):
+        assert torch.equal(ops.attention(qd[:, 32:32 + c], kvd[:, :c], kvd[:, c:], heads, d, batches=n, lq=lq, lk=lk, kv_div=fpc), o)
 
 
 @pytest.mark.parametrize("d,heads,t", [(40, 8, 17), (160, 8, 3), (80, 4, 4), (80, 8, 17), (160, 8, 32), (40, 16, 1), (32, 4, 9)])
