@@ -4,7 +4,8 @@ would need minutes per evaluation: size-independent properties instead.
   * the specialised kernels the full-size shapes dispatch to (LDS-halo 3x3 conv, 320-channel block shape, K rotation,
     register-resident-weight K = 320 linears, the fused dim-320 feed-forward,
     channel-tile groups, persistent temporal attention, 8-wave attention blocks, fused GroupNorm statistics, two-stream
-    CFG halves, ControlNet on a side stream, HIP-graph replay of the launch sequence) must reproduce the GENERIC kernels
+    CFG halves, ControlNet on a side stream, HIP-graph replay of the launch sequence, split-K, LayerNorm folded into the persistent
+    GEMM, the text cross-attention kernel) must reproduce the GENERIC kernels
     (tap-gather GEMM, flash kernel, two-pass GroupNorm, one stream, eager launches) — the ones the small-size tests pin against the
     oracle and the reference goldens; the graph replay must reproduce the eager evaluation bit for bit (asserted in the helper);
   * two runs give identical bits; identical CFG halves give identical predictions; the clips of a batch do not interact.
@@ -22,7 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GENERIC = dict(CCEDIT_T6="0", CCEDIT_CONV_HALO="0", CCEDIT_ATTN_SHORT="0", CCEDIT_SPLIT_CFG="0", CCEDIT_OVERLAP_CONTROLNET="0",
                CCEDIT_KROT="0", CCEDIT_CGROUP="0", CCEDIT_FUSE_GN_STATS="0", CCEDIT_TEMPORAL_ORDER="0", CCEDIT_LIN320="0",
                CCEDIT_FF320="0", CCEDIT_LN320="0", CCEDIT_T4="0", CCEDIT_BALANCED="0", CCEDIT_CONV_NARROW="0", CCEDIT_G8="0",
-               CCEDIT_GRAPH="0")
+               CCEDIT_GRAPH="0", CCEDIT_LNF="0", CCEDIT_ATTN_TEXT="0", CCEDIT_G8_SPLIT="0")
 
 
 def _rel(a, b):
