@@ -995,7 +995,9 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             try:
                 ent["x"], ent["t"] = x.clone(), t.clone()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: calls from OTHER threads (the process group's watchdog polling its events when torch.distributed is
+                # initialised — bench.py --gpus N) must not invalidate the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     ops.reset_stream_scratch()                  # scratch arenas of the capture stream must live in this graph's pool
                     ent["out"] = self._forward_eager(ent["x"], ent["t"], c)
                     ops.reset_stream_scratch()
