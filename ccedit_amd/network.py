@@ -33,8 +33,6 @@ from .packing import pack_concat
 # Per-block output capture for the parity tests (tests/test_network_gpu.py reads the reference's per-block digests):
 # set to a dict and every ControlNet / UNet block stores its output under the reference's module path.  None in production.
 TRACE: Optional[dict] = None
-_DEBUG_HOLD = int(os.environ.get("CCEDIT_DEBUG_HOLD_UNTIL", "-1"))
-_DEBUG_TRACE_OVERLAP = os.environ.get("CCEDIT_DEBUG_TRACE_OVERLAP") == "1"      # debugging: per-block traces WITH the ControlNet side stream
 
 
 def _trace(name: str, t: torch.Tensor):
@@ -766,9 +764,6 @@ class ControlNet2D(UNetModel):
                 if i == 0 and not self.no_add_x:
                     _trace("controlnet.guided_hint", guided)
             outs.append(ops.conv2d(h, zc[0].pw))
-            if _DEBUG_HOLD == i:          # debugging (tools/exp/repro_fast.py): the caller's stream waits until this block is done
-                self._hold_event = torch.cuda.Event()
-                self._hold_event.record()
         h = self.middle_block.run(h, emb_silu, geo, ctx2d, ctx_len)
         _trace("controlnet.middle_block", h)
         outs.append(ops.conv2d(h, self.middle_block_out[0].pw))
@@ -974,7 +969,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, c: Dict[str, torch.Tensor], **kwargs) -> torch.Tensor:
         if (self.use_graph and not OpenAIWrapperControlLDM3DTV2V._graph_failed and not kwargs and x.is_cuda
-                and self.frame_shard is None and ops.PROFILE is None and TRACE is None and _DEBUG_HOLD < 0
+                and self.frame_shard is None and ops.PROFILE is None and TRACE is None
                 and not torch.cuda.is_current_stream_capturing()):
             return self._forward_graphed(x, t, c)
         return self._forward_eager(x, t, c, **kwargs)
@@ -1064,7 +1059,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
         x8 = ops.ncthw_to_nhwc(x.float().contiguous(), 8)
         control_ready = None
-        if self.overlap_controlnet and sh is None and ops.PROFILE is None and (TRACE is None or _DEBUG_TRACE_OVERLAP):
+        if self.overlap_controlnet and sh is None and ops.PROFILE is None and TRACE is None:
             main = torch.cuda.current_stream()
             if OpenAIWrapperControlLDM3DTV2V._side_stream is None:
                 OpenAIWrapperControlLDM3DTV2V._side_stream = {}
@@ -1077,10 +1072,6 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                 control = net.controlnet.run(x8, guided, t, ctx2d, context.shape[1], geo)
                 control_ready = torch.cuda.Event()
                 control_ready.record(side)
-            if os.environ.get("CCEDIT_DEBUG_SERIALIZE_SIDE") == "1":      # debugging: side stream, but no concurrent execution
-                main.wait_event(control_ready)
-            if _DEBUG_HOLD >= 0:
-                main.wait_event(net.controlnet._hold_event)
             for tns in (x8, ctx2d):
                 tns.record_stream(side)                 # allocated on the main stream, read on the side stream
             for tns in control:
