@@ -149,6 +149,16 @@ def test_no_packed_fp32_low_lane_high_half_reads(libpath):
             assert build.check_isa(o) == 0, s
 
 
+def test_graft_entry_build_runs(libpath):
+    """__graft_entry__.build() is the driver's "does it build" check: it must pass on this (GPU-less) machine — compile, load, agree
+    on the ABI version with the binding, import the package and the oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_graft_entry_under_test", os.path.join(ROOT, "__graft_entry__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build()
+
+
 def test_product_never_imports_oracle():
     """The product package must not reach the CPU oracle (or any CPU fallback)."""
     import subprocess, sys
