@@ -26,6 +26,8 @@ bool cc_attn_short_applicable(const CcAttnDesc& a);      // attnshort.hip
 int cc_attn_short_launch(const CcAttnDesc& a, hipStream_t s);
 bool cc_attn_text_applicable(const CcAttnDesc& a);       // attntext.hip
 int cc_attn_text_launch(const CcAttnDesc& a, hipStream_t s);
+bool cc_attn_spatial_applicable(const CcAttnDesc& a);    // attnspatial.hip
+int cc_attn_spatial_launch(const CcAttnDesc& a, hipStream_t s);
 
 namespace {
 
@@ -396,6 +398,10 @@ extern "C" int ccedit_attention(const CcAttnDesc* desc, void* stream) {
     // text cross-attention (<= 96 keys shared by the frames of a clip): bound by streaming the query rows, own kernel (attntext.hip)
     static const int text_env = getenv("CCEDIT_ATTN_TEXT") ? atoi(getenv("CCEDIT_ATTN_TEXT")) : 1;      // 0: A/B against attn_kernel
     if (text_env && cc_attn_text_applicable(a)) return cc_attn_text_launch(a, s);
+    // long self-attention at d = 40 (the 64x96 level): the softmax arithmetic is the bound, own kernel (attnspatial.hip)
+    static const int spatial_env = getenv("CCEDIT_ATTN_SPATIAL") ? atoi(getenv("CCEDIT_ATTN_SPATIAL")) : 1;   // 0: A/B against attn_kernel
+    if (spatial_env && cc_attn_spatial_applicable(a)) return cc_attn_spatial_launch(a, s);
+    CC_UNSUPPORTED(a.flags & CCEDIT_ATTN_Q_LOG2, "ccedit_attention: CCEDIT_ATTN_Q_LOG2 is only taken by the d = 40 long self-attention kernel");
     switch (a.d) {
         case 8: return dispatch_nw<8>(a, s);
         case 16: return dispatch_nw<16>(a, s);

@@ -1,0 +1,396 @@
+// Spatial self-attention with a small head dimension (d = 40: the 6144-token attention of the 64x96 level, 8 heads x 34 frames;
+// reference: CrossAttention.forward, sgm/modules/attention.py:392-467, F.scaled_dot_product_attention at :446) — gfx950.
+//
+// The general kernel (attention.hip) is VALU-bound at d = 40: per 64-key tile and wave 14 MFMAs (448 matrix-pipe cycles) against
+// 121 VALU instructions (667 cycles) — one v_pk_fma_f32 per score pair to apply scale and running max, a rescale of the 32 output
+// accumulators on most tiles (ANY of a wave's 32 rows moving its max triggers it: ~70 % of the tiles of a 6144-key row), ~30
+// instructions of pointer / zero-page selects around the four DMA requests.  This kernel removes instructions instead of
+// re-arranging them:
+//   * softmax scale * log2(e) is folded into the query fragments once, before the loop (or arrives folded into the to_q weights:
+//     CcAttnDesc.flags bit 0), so a score leaves the MFMA in log2 units;
+//   * the running reference m~ of a query row enters THROUGH THE MFMA: d = 40 pads to three 16-deep k-steps, column 40 of the
+//     staged K tile is a constant 1 and element 40 of the lane's query fragment holds -m~ (a bf16-representable value — softmax is
+//     invariant to the reference as long as numerator and denominator use the same one).  S^T = K Q^T then IS s - m~ with the
+//     accumulators started from the inline constant 0: no per-score subtract, p = v_exp_f32(s) directly;
+//   * the reference moves only when it must: a tile takes the update path when some score exceeds the reference by more than
+//     2^16 (or on the first tile); otherwise nothing is rescaled.  bf16 P and fp32 accumulators have eight exponent bits, so a
+//     common factor <= 2^16 on a row's P changes no relative precision; the denominator comes from the same bf16 P through a ones
+//     column of V (row 40 of O^T), so numerator and denominator stay consistent whatever the reference is;
+//   * K / V tiles stream through a THREE-slot LDS ring: the requests of tile j+2 are issued at the top of tile j and waited for
+//     with a counted vmcnt two tiles later; one workgroup barrier per tile; base addresses advance in SGPRs, LDS slots are
+//     immediates of a loop unrolled by three — no address arithmetic in the loop;
+//   * the tile with masked keys (Lk % 64 != 0) is a separate instantiation: the main loop has no selects.
+// Same tile geometry, LDS image, K-row permutation and V transpose reads as attention.hip (see there).
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+__device__ __attribute__((aligned(64))) char g_as_zero_page[64];
+
+constexpr float kThr = 16.0f;          // log2 units: the reference is raised when a score exceeds it by more than this
+
+template <int N>
+__device__ __forceinline__ void as_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void as_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// V^T fragments by ds_read_b64_tr_b16 in inline asm.  Through the builtin, hipcc (ROCm 7.2) treats the transpose read as a load that
+// may alias every LDS-DMA in flight and puts `s_waitcnt vmcnt(0)` in front of the first one of each tile — the K / V requests of the
+// tiles ahead were drained in the middle of every tile (attention.hip has that wait).  In asm the reads are invisible to the
+// compiler's counters: `as_tr_wait` is the wait (LDS returns in order: "at most N outstanding" retires everything older) and ties the
+// destination registers to it, so no consumer can be scheduled above it.
+struct VFrag {
+    u32x2 lo, hi;
+};
+template <int OFF>
+__device__ __forceinline__ void as_tr_issue(VFrag& f, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                 : "=&v"(f.lo), "=&v"(f.hi)
+                 : "v"(addr), "n"(OFF), "n"(OFF + 512));
+}
+template <int N>
+__device__ __forceinline__ void as_tr_wait(VFrag& a, VFrag& b) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) : "n"(N));
+}
+__device__ __forceinline__ bf16x8 as_frag(const VFrag& f) {
+    return __builtin_bit_cast(bf16x8, u32x4{f.lo[0], f.lo[1], f.hi[0], f.hi[1]});
+}
+
+// smallest bf16-representable value >= x (x finite)
+__device__ __forceinline__ float bf16_ceil(float x) {
+    const uint32_t u = __float_as_uint(x);
+    const uint32_t r = (x >= 0.f) ? ((u + 0xFFFFu) & 0xFFFF0000u) : (u & 0xFFFF0000u);
+    return __uint_as_float(r);
+}
+
+// hipcc forms v_max3_f32 from this itself — and pads the MFMA-result -> VALU-read wait states, which it does NOT do for an operand
+// of an inline-asm v_max3_f32 (first version of this kernel: the maxima were read while the MFMA was still writing its tile)
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+constexpr int kNW = 8, kNT = kNW * 64;
+constexpr int kKB = 64 * 64 * 2, kVB = 64 * 64 * 2, kSlot = kKB + kVB;      // 16 KB per ring slot
+constexpr int kLds = 3 * kSlot;
+
+template <int D>
+__device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
+    static_assert(D % 16 == 8 && D < 64, "the reference rides in the pad column of the last k-step");
+    constexpr int KS = (D + 15) / 16;         // QK^T k-steps (last one: 8 channels + the reference column + 7 zeros)
+    constexpr int NT = (D + 1 + 31) / 32;     // O^T row tiles (D value rows + the denominator row D)
+    constexpr int PADG = D / 8;               // granule of columns [D, D+8): K: {1, 0...}, V: {1, 0...}
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    // block order: all query tiles of one (batch, head) on ONE XCD back to back (its K / V stay in that L2) — attention.hip
+    const int qtiles = (a.Lq + kNW * 32 - 1) / (kNW * 32);
+    const int xcd = blockIdx.x & 7;
+    const int local = blockIdx.x >> 3;
+    const int grp = (local / qtiles) * 8 + xcd;
+    const int qt = local % qtiles;
+    if (grp >= a.batches * a.heads) return;
+    const int batch = grp / a.heads;
+    const int head = grp - batch * a.heads;
+    const int q0 = qt * (kNW * 32) + wave * 32;
+
+    const bf16* zp = (const bf16*)g_as_zero_page;
+    const int64_t qbase = (int64_t)(batch / a.q_inner) * a.q_outer_rows + (int64_t)(batch % a.q_inner) * a.q_inner_rows;
+    const int kvb = batch / a.kv_div;
+    const int64_t kvbase = (int64_t)(kvb / a.kv_inner) * a.kv_outer_rows + (int64_t)(kvb % a.kv_inner) * a.kv_inner_rows;
+    const bf16* __restrict__ Q = (const bf16*)a.q + head * D;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + l31][16 ks + 8 hi .. +8], scaled into log2 units ----
+    bf16x8 qf[KS];
+    {
+        const int qi = q0 + l31;
+        const bf16* qrow = Q + (size_t)(qbase + (int64_t)qi * a.q_seq_rows) * a.ldq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int dofs = ks * 16 + hi * 8;
+            const bf16* src = (qi < a.Lq && dofs < D) ? qrow + dofs : zp;
+            qf[ks] = *(const bf16x8*)src;
+        }
+        if (!(a.flags & CCEDIT_ATTN_Q_LOG2)) {
+            const float sc = a.scale * 1.4426950408889634f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[ks][e] = f2bf(bf2f(qf[ks][e]) * sc);
+        }
+    }
+    // the reference column: element 0 of the last k-step's fragment on the hi lanes is column D
+    auto set_ref = [&](float ref) {
+        u32x4 w = __builtin_bit_cast(u32x4, qf[KS - 1]);
+        if (hi) w[0] = __float_as_uint(-ref) >> 16;
+        qf[KS - 1] = __builtin_bit_cast(bf16x8, w);
+    };
+
+    // ---- DMA plan: thread -> (row, granule) of the 64 x 8-granule K and V tiles; wave w fills rows 8w..8w+7 ----
+    const int drow = tid >> 3;
+    const int gk = (tid & 7) ^ ((drow >> 1) & 7);              // LDS slot -> source granule (XOR swizzle, attention.hip)
+    const int gv = (tid & 7) ^ (((drow >> 1) & 1) << 2);
+    const bool use_k = gk * 8 < D, use_v = gv * 8 < D;         // pad granules are never written by the DMA
+    const uint32_t koff = (uint32_t)((int64_t)drow * a.kv_seq_rows * a.ldk + gk * 8) * 2u;
+    const uint32_t voff = (uint32_t)((int64_t)drow * a.kv_seq_rows * a.ldv + gv * 8) * 2u;
+    const int64_t kstep = 64 * a.kv_seq_rows * (int64_t)a.ldk * 2, vstep = 64 * a.kv_seq_rows * (int64_t)a.ldv * 2;   // bytes per tile
+    const char* const kreg = (const char*)((const bf16*)a.k + head * D + kvbase * a.ldk);
+    const char* const vreg = (const char*)((const bf16*)a.v + head * D + kvbase * a.ldv);
+    // optional leading segment (anchor-frame keys, a whole number of tiles): its tiles come from another kv batch
+    const int seg_tiles = a.seg1_len >> 6;
+    const char* kseg = kreg;
+    const char* vseg = vreg;
+    if (a.seg1_len > 0) {
+        const int sb = (batch / a.seg1_div) * a.seg1_mul + a.seg1_add;
+        const int64_t sbase = (int64_t)(sb / a.kv_inner) * a.kv_outer_rows + (int64_t)(sb % a.kv_inner) * a.kv_inner_rows;
+        kseg = (const char*)((const bf16*)a.k + head * D + sbase * a.ldk);
+        vseg = (const char*)((const bf16*)a.v + head * D + sbase * a.ldv);
+    }
+    const int ntiles = (a.Lk + 63) / 64;
+    char* const lds_wave = smem + wave * 1024;
+
+    const char* kcur = seg_tiles > 0 ? kseg : kreg;            // tiles are requested in order: running (scalar) pointers
+    const char* vcur = seg_tiles > 0 ? vseg : vreg;
+    auto stage = [&](int t, int slot) {
+        if (t == seg_tiles && t > 0) {
+            kcur = kreg;
+            vcur = vreg;
+        }
+        const char* kb = kcur;
+        const char* vb = vcur;
+        kcur += kstep;
+        vcur += vstep;
+        if ((t + 1) * 64 <= a.Lk) {                             // wave-uniform
+            if (use_k) glds16(kb + koff, lds_wave + slot * kSlot);
+            if (use_v) glds16(vb + voff, lds_wave + slot * kSlot + kKB);
+        } else {                                                // the tile that reaches past Lk: those rows come from the zero page
+            const bool valid = t * 64 + drow < a.Lk;
+            if (use_k) glds16(valid ? (const void*)(kb + koff) : (const void*)zp, lds_wave + slot * kSlot);
+            if (use_v) glds16(valid ? (const void*)(vb + voff) : (const void*)zp, lds_wave + slot * kSlot + kKB);
+        }
+    };
+
+    // ---- per-lane LDS read addresses (slot and tile-row offsets are immediates) ----
+    // A-row i of an S^T tile reads K row swap23(i): a lane's 8 consecutive S^T registers are 8 consecutive keys
+    const int krow_l = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int ksw = (krow_l >> 1) & 7;
+    const char* kaddr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kaddr[ks] = smem + krow_l * 128 + (((ks * 2 + hi) ^ ksw) << 4);
+    const int i16 = lane & 15, dvhalf = (lane >> 4) & 1;
+    const int vsw = ((i16 >> 3) & 1) << 6;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
+    uint32_t vaddr[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) vaddr[n] = lds0 + kKB + (8 * hi + (i16 >> 2)) * 128 + (dvhalf * 16 + (i16 & 3) * 4) * 2 + ((n * 64) ^ vsw);
+
+    // ---- constant pad granules of all three slots: K[:, D] = 1 (the reference column), V[:, D] = 1 (the denominator row) ----
+    for (int idx = tid; idx < 3 * 64; idx += kNT) {
+        const int sl = idx >> 6, row = idx & 63;
+        *(u32x4*)(smem + sl * kSlot + row * 128 + ((PADG ^ ((row >> 1) & 7)) << 4)) = u32x4{0x00003F80u, 0u, 0u, 0u};
+        *(u32x4*)(smem + sl * kSlot + kKB + row * 128 + ((PADG ^ (((row >> 1) & 1) << 2)) << 4)) = u32x4{0x00003F80u, 0u, 0u, 0u};
+    }
+    // K columns (D, 16 KS) beyond the reference column are zero in that same granule; granules above it are never read.
+
+    f32x16 o[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+    float mref = 0.f;
+
+    stage(0, 0);
+    if (ntiles > 1) {
+        stage(1, 1);
+        as_vmcnt<2>();
+    } else {
+        as_vmcnt<0>();
+    }
+    as_barrier();
+
+    auto tile = [&](auto SLOTC, auto MASKC, int j) {
+        constexpr int SLOT = decltype(SLOTC)::value;
+        constexpr bool MASK = decltype(MASKC)::value;
+        constexpr int SB = SLOT * kSlot;
+        if (j + 2 < ntiles) stage(j + 2, (SLOT + 2) % 3);
+
+        // ---- S^T = K Q^T - m~ for the 64 keys of this tile, log2 units ----
+        f32x16 s[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t2][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kaddr[ks] + SB + t2 * 4096);
+                s[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t2], 0, 0, 0);
+            }
+        }
+        if constexpr (MASK) {          // the tile that reaches past Lk
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = j * 64 + 32 * t2 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    if (kv >= a.Lk) s[t2][r] = -INFINITY;
+                }
+        }
+        // ---- does the reference have to move?  (this lane: query q0 + l31, keys 64 j + 32 t2 + 16 (r>>3) + 8 hi + (r&7)) ----
+        float m0 = max3f(s[0][0], s[0][1], s[0][2]), m1 = max3f(s[0][3], s[0][4], s[0][5]);
+        float m2 = max3f(s[1][0], s[1][1], s[1][2]), m3 = max3f(s[1][3], s[1][4], s[1][5]);
+#pragma unroll
+        for (int r = 6; r < 16; r += 4) {
+            m0 = max3f(m0, s[0][r], s[0][r + 1]);
+            m2 = max3f(m2, s[1][r], s[1][r + 1]);
+            if (r + 2 < 16) {
+                m1 = max3f(m1, s[0][r + 2], s[0][r + 3]);
+                m3 = max3f(m3, s[1][r + 2], s[1][r + 3]);
+            }
+        }
+        float mt = fmaxf(max3f(m0, m1, m2), m3);
+        if (j == 0 || __builtin_amdgcn_ballot_w64(mt > kThr) != 0) {          // wave-uniform
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));        // row maximum (both lane halves of a query)
+            float nref = bf16_ceil(mref + mt);
+            if (j != 0) nref = fmaxf(nref, mref);          // later tiles only raise it
+            const float delta = nref - mref;
+            if (j != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+            }
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t2][r] -= delta;
+            mref = nref;
+            set_ref(mref);
+        }
+        // ---- p = 2^s;  O^T += V^T P^T (row D of O^T: the denominator, from the ones column of V) ----
+        // k-step sp covers keys 16 sp .. 16 sp + 15; its V^T fragments are requested two k-steps ahead of their MFMAs
+        static_assert(NT == 2, "fragment bookkeeping below");
+        VFrag vf[4][NT];
+        auto issue = [&](auto SPC) {
+            constexpr int SP = decltype(SPC)::value;
+            as_tr_issue<SB + SP * 2048>(vf[SP][0], vaddr[0]);
+            as_tr_issue<SB + SP * 2048>(vf[SP][1], vaddr[1]);
+        };
+        auto pexp = [&](int sp) {
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = f2bf(__builtin_amdgcn_exp2f(s[sp >> 1][8 * (sp & 1) + e]));
+            return pf;
+        };
+        auto pv = [&](int sp, bf16x8 pf) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) o[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(vf[sp][n]), pf, o[n], 0, 0, 0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        issue(I0{});
+        issue(I1{});
+        bf16x8 pf = pexp(0);
+        as_tr_wait<4>(vf[0][0], vf[0][1]);
+        pv(0, pf);
+        issue(I2{});
+        pf = pexp(1);
+        as_tr_wait<4>(vf[1][0], vf[1][1]);
+        pv(1, pf);
+        issue(I3{});
+        pf = pexp(2);
+        as_tr_wait<4>(vf[2][0], vf[2][1]);
+        pv(2, pf);
+        pf = pexp(3);
+        as_tr_wait<0>(vf[3][0], vf[3][1]);
+        pv(3, pf);
+        if (j + 2 < ntiles) as_vmcnt<2>();
+        else as_vmcnt<0>();
+        as_barrier();
+    };
+
+    const bool tail_masked = (a.Lk & 63) != 0;
+    const int nfull = tail_masked ? ntiles - 1 : ntiles;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    int j = 0;
+    for (; j + 3 <= nfull; j += 3) {
+        tile(S0{}, std::false_type{}, j);
+        tile(S1{}, std::false_type{}, j + 1);
+        tile(S2{}, std::false_type{}, j + 2);
+    }
+    if (j < nfull) {
+        tile(S0{}, std::false_type{}, j);
+        ++j;
+        if (j < nfull) {
+            tile(S1{}, std::false_type{}, j);
+            ++j;
+        }
+    }
+    if (tail_masked) {
+        const int sl = j % 3;
+        if (sl == 0) tile(S0{}, std::true_type{}, j);
+        else if (sl == 1) tile(S1{}, std::true_type{}, j);
+        else tile(S2{}, std::true_type{}, j);
+    }
+
+    // ---- normalise and store: lane holds O^T[dv = 32 n + (r&3) + 8 (r>>2) + 4 hi][q = l31]; row D is the denominator ----
+    const float l_tot = __shfl(o[D / 32][((D % 32) / 8) * 4], l31, 64);
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + l31;
+    if (qi < a.Lq) {
+        bf16* orow = (bf16*)a.o + (size_t)(qbase + (int64_t)qi * a.q_seq_rows) * a.ldo + head * D;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int dv = 32 * n + 8 * qd + 4 * hi;
+                if (dv < D) {
+                    bf16x4 w = {f2bf(o[n][qd * 4 + 0] * inv), f2bf(o[n][qd * 4 + 1] * inv), f2bf(o[n][qd * 4 + 2] * inv),
+                                f2bf(o[n][qd * 4 + 3] * inv)};
+                    *(bf16x4*)(orow + dv) = w;
+                }
+            }
+    }
+}
+
+// OCC = waves per SIMD the register allocation is held to (3: 168 VGPRs; 4: 128 — tuning: CCEDIT_AS_OCC)
+template <int D, int OCC>
+__global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void attn_spatial_kernel(const CcAttnDesc a) {
+    attn_spatial_body<D>(a);
+}
+
+template <int D, int OCC>
+int launch_spatial(const CcAttnDesc& a, hipStream_t s) {
+    static unsigned long long attr_done = 0;
+    if (int rc = cc_max_dynamic_lds((const void*)attn_spatial_kernel<D, OCC>, kLds, &attr_done, "attn_spatial")) return rc;
+    const int64_t qtiles = (a.Lq + kNW * 32 - 1) / (kNW * 32);
+    const int64_t groups = ((int64_t)a.batches * a.heads + 7) / 8 * 8;
+    cc_note_kernel("attn_spatial_kernel d=%d", D);
+    hipLaunchKernelGGL((attn_spatial_kernel<D, OCC>), dim3((unsigned)(qtiles * groups)), dim3(kNT), kLds, s, a);
+    return cc_launch_status("attn_spatial_kernel");
+}
+
+}  // namespace
+
+bool cc_attn_spatial_applicable(const CcAttnDesc& a) {
+    // per-lane byte offsets of a 64-row tile must fit 32 bits
+    const int64_t span = 64 * a.kv_seq_rows * (int64_t)(a.ldk > a.ldv ? a.ldk : a.ldv) * 2;
+    return a.d == 40 && a.Lq >= 1024 && a.Lk >= 192 && !a.causal && (a.seg1_len & 63) == 0 && span < (1ll << 31);
+}
+
+int cc_attn_spatial_launch(const CcAttnDesc& a, hipStream_t s) {
+    static const int occ = getenv("CCEDIT_AS_OCC") ? atoi(getenv("CCEDIT_AS_OCC")) : 3;
+    return occ == 4 ? launch_spatial<40, 4>(a, s) : launch_spatial<40, 3>(a, s);
+}

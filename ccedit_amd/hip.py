@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the library is loaded: to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCEDIT_HIP_LIB") or os.path.join(_HERE, "libccedit_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 GEMM_LINEAR, GEMM_CONV2D, GEMM_TEMPORAL = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
@@ -48,7 +48,7 @@ class CcAttnDesc(C.Structure):
         ("kv_div", C.c_int32), ("kv_inner", C.c_int32), ("kv_outer_rows", C.c_int64), ("kv_inner_rows", C.c_int64),
         ("kv_seq_rows", C.c_int64), ("scale", C.c_float),
         ("seg1_len", C.c_int32), ("seg1_div", C.c_int32), ("seg1_mul", C.c_int32), ("seg1_add", C.c_int32),
-        ("causal", C.c_int32), ("reserved1", C.c_int32),
+        ("causal", C.c_int32), ("flags", C.c_int32),
     ]
 
 

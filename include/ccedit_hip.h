@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCEDIT_ABI_VERSION 8
+#define CCEDIT_ABI_VERSION 9
 
 #define CCEDIT_OK 0
 #define CCEDIT_EINVAL (-1)       /* null pointer / bad size */
@@ -239,8 +239,12 @@ typedef struct CcAttnDesc {
      * (batch / seg1_div) * seg1_mul + seg1_add, keys [seg1_len, Lk) from the regular kv batch.  0 = unused. */
     int32_t seg1_len, seg1_div, seg1_mul, seg1_add;
     int32_t causal;       /* 1: key j is visible to query i only if j <= i (CLIP text encoder); Lq == Lk, no segment */
-    int32_t reserved1;
+    int32_t flags;        /* CCEDIT_ATTN_*; 0 = none (ABI 9; was reserved) */
 } CcAttnDesc;
+
+/* q already carries scale * log2(e) (folded into the to_q weights by the packer, one rounding instead of two): kernels then take
+ * p = 2^(q.k - reference) without multiplying, and `scale` is ignored */
+#define CCEDIT_ATTN_Q_LOG2 1
 
 int ccedit_attention(const CcAttnDesc* desc, void* stream);
 
