@@ -200,7 +200,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    const float sc = a.scale * 1.4426950408889634f;   // fold log2(e): softmax via exp2
+    // fold log2(e): softmax via exp2 (CCEDIT_ATTN_Q_LOG2: q already carries scale * log2 e)
+    const float sc = (a.flags & CCEDIT_ATTN_Q_LOG2) ? 1.0f : a.scale * 1.4426950408889634f;
 
     // A-row i of an S^T tile reads K row swap23(i): i = c | hi2<<2 | b<<3 | a4<<4  ->  c | b<<2 | hi2<<3 | a4<<4
     const int krow_l = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
@@ -394,14 +395,14 @@ extern "C" int ccedit_attention(const CcAttnDesc* desc, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     // temporal self-attention (T <= 32 keyframes per pixel): HBM-bound, own kernel organised around whole-row loads
     static const int short_env = getenv("CCEDIT_ATTN_SHORT") ? atoi(getenv("CCEDIT_ATTN_SHORT")) : 1;   // 0: A/B against attn_kernel
-    if (short_env && cc_attn_short_applicable(a)) return cc_attn_short_launch(a, s);
+    const bool plain_q = !(a.flags & CCEDIT_ATTN_Q_LOG2);       // the two kernels below apply `scale` themselves
+    if (short_env && plain_q && cc_attn_short_applicable(a)) return cc_attn_short_launch(a, s);
     // text cross-attention (<= 96 keys shared by the frames of a clip): bound by streaming the query rows, own kernel (attntext.hip)
     static const int text_env = getenv("CCEDIT_ATTN_TEXT") ? atoi(getenv("CCEDIT_ATTN_TEXT")) : 1;      // 0: A/B against attn_kernel
-    if (text_env && cc_attn_text_applicable(a)) return cc_attn_text_launch(a, s);
+    if (text_env && plain_q && cc_attn_text_applicable(a)) return cc_attn_text_launch(a, s);
     // long self-attention at d = 40 (the 64x96 level): the softmax arithmetic is the bound, own kernel (attnspatial.hip)
     static const int spatial_env = getenv("CCEDIT_ATTN_SPATIAL") ? atoi(getenv("CCEDIT_ATTN_SPATIAL")) : 1;   // 0: A/B against attn_kernel
     if (spatial_env && cc_attn_spatial_applicable(a)) return cc_attn_spatial_launch(a, s);
-    CC_UNSUPPORTED(a.flags & CCEDIT_ATTN_Q_LOG2, "ccedit_attention: CCEDIT_ATTN_Q_LOG2 is only taken by the d = 40 long self-attention kernel");
     switch (a.d) {
         case 8: return dispatch_nw<8>(a, s);
         case 16: return dispatch_nw<16>(a, s);

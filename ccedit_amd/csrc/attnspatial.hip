@@ -6,8 +6,8 @@
 // accumulators on most tiles (ANY of a wave's 32 rows moving its max triggers it: ~70 % of the tiles of a 6144-key row), ~30
 // instructions of pointer / zero-page selects around the four DMA requests.  This kernel removes instructions instead of
 // re-arranging them:
-//   * softmax scale * log2(e) is folded into the query fragments once, before the loop (or arrives folded into the to_q weights:
-//     CcAttnDesc.flags bit 0), so a score leaves the MFMA in log2 units;
+//   * softmax scale * log2(e) arrives folded into the to_q weights (CcAttnDesc.flags: CCEDIT_ATTN_Q_LOG2 — what the network does),
+//     so a score leaves the MFMA in log2 units; without the flag one multiply per score remains (see QLOG2 below);
 //   * the running reference m~ of a query row enters THROUGH THE MFMA: d = 40 pads to three 16-deep k-steps, column 40 of the
 //     staged K tile is a constant 1 and element 40 of the lane's query fragment holds -m~ (a bf16-representable value — softmax is
 //     invariant to the reference as long as numerator and denominator use the same one).  S^T = K Q^T then IS s - m~ with the
@@ -77,9 +77,14 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf
 
 constexpr int kNW = 8, kNT = kNW * 64;
 constexpr int kKB = 64 * 64 * 2, kVB = 64 * 64 * 2, kSlot = kKB + kVB;      // 16 KB per ring slot
-constexpr int kLds = 3 * kSlot;
+constexpr int kSlots = 3;
+constexpr int kLds = kSlots * kSlot;
 
-template <int D>
+// QLOG2: q arrives in log2 units (CCEDIT_ATTN_Q_LOG2) — scores leave the MFMA ready for v_exp_f32.  Otherwise q is used as it is
+// (scaling the bf16 fragments in here would round q a second time: at logits of +-70 that alone is several per cent of a
+// probability), reference and threshold are kept in raw q.k units and every score is multiplied by scale * log2(e) on its way into
+// the exponential: 32 more VALU instructions per tile, the price of not packing the scale into the weights.
+template <int D, bool QLOG2>
 __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     static_assert(D % 16 == 8 && D < 64, "the reference rides in the pad column of the last k-step");
     constexpr int KS = (D + 15) / 16;         // QK^T k-steps (last one: 8 channels + the reference column + 7 zeros)
@@ -119,14 +124,9 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
             const bf16* src = (qi < a.Lq && dofs < D) ? qrow + dofs : zp;
             qf[ks] = *(const bf16x8*)src;
         }
-        if (!(a.flags & CCEDIT_ATTN_Q_LOG2)) {
-            const float sc = a.scale * 1.4426950408889634f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qf[ks][e] = f2bf(bf2f(qf[ks][e]) * sc);
-        }
     }
+    const float sc = QLOG2 ? 1.0f : a.scale * 1.4426950408889634f;      // score units -> log2 units
+    const float thr = QLOG2 ? kThr : kThr / sc;                          // the threshold in score units
     // the reference column: element 0 of the last k-step's fragment on the hi lanes is column D
     auto set_ref = [&](float ref) {
         u32x4 w = __builtin_bit_cast(u32x4, qf[KS - 1]);
@@ -193,7 +193,7 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     for (int n = 0; n < NT; ++n) vaddr[n] = lds0 + kKB + (8 * hi + (i16 >> 2)) * 128 + (dvhalf * 16 + (i16 & 3) * 4) * 2 + ((n * 64) ^ vsw);
 
     // ---- constant pad granules of all three slots: K[:, D] = 1 (the reference column), V[:, D] = 1 (the denominator row) ----
-    for (int idx = tid; idx < 3 * 64; idx += kNT) {
+    for (int idx = tid; idx < kSlots * 64; idx += kNT) {
         const int sl = idx >> 6, row = idx & 63;
         *(u32x4*)(smem + sl * kSlot + row * 128 + ((PADG ^ ((row >> 1) & 7)) << 4)) = u32x4{0x00003F80u, 0u, 0u, 0u};
         *(u32x4*)(smem + sl * kSlot + kKB + row * 128 + ((PADG ^ (((row >> 1) & 1) << 2)) << 4)) = u32x4{0x00003F80u, 0u, 0u, 0u};
@@ -216,11 +216,10 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     }
     as_barrier();
 
-    auto tile = [&](auto SLOTC, auto MASKC, int j) {
+    const bool tail_masked = (a.Lk & 63) != 0;
+    auto tile = [&](auto SLOTC, int j) {
         constexpr int SLOT = decltype(SLOTC)::value;
-        constexpr bool MASK = decltype(MASKC)::value;
         constexpr int SB = SLOT * kSlot;
-        if (j + 2 < ntiles) stage(j + 2, (SLOT + 2) % 3);
 
         // ---- S^T = K Q^T - m~ for the 64 keys of this tile, log2 units ----
         f32x16 s[2];
@@ -234,7 +233,7 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
                 s[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t2], 0, 0, 0);
             }
         }
-        if constexpr (MASK) {          // the tile that reaches past Lk
+        if (tail_masked && j == ntiles - 1) {          // wave-uniform: the tile that reaches past Lk
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -256,13 +255,13 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
             }
         }
         float mt = fmaxf(max3f(m0, m1, m2), m3);
-        if (j == 0 || __builtin_amdgcn_ballot_w64(mt > kThr) != 0) {          // wave-uniform
+        if (j == 0 || __builtin_amdgcn_ballot_w64(mt > thr) != 0) {          // wave-uniform
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));        // row maximum (both lane halves of a query)
             float nref = bf16_ceil(mref + mt);
             if (j != 0) nref = fmaxf(nref, mref);          // later tiles only raise it
             const float delta = nref - mref;
             if (j != 0) {
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                const float alpha = __builtin_amdgcn_exp2f(QLOG2 ? -delta : -delta * sc);
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -287,7 +286,10 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
         auto pexp = [&](int sp) {
             bf16x8 pf;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pf[e] = f2bf(__builtin_amdgcn_exp2f(s[sp >> 1][8 * (sp & 1) + e]));
+            for (int e = 0; e < 8; ++e) {
+                const float x = s[sp >> 1][8 * (sp & 1) + e];
+                pf[e] = f2bf(__builtin_amdgcn_exp2f(QLOG2 ? x : x * sc));
+            }
             return pf;
         };
         auto pv = [&](int sp, bf16x8 pf) {
@@ -314,35 +316,21 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
         pf = pexp(3);
         as_tr_wait<0>(vf[3][0], vf[3][1]);
         pv(3, pf);
+    };
+    // tile j: request tile j+2 (its slot was read in tile j-1, before the last barrier), compute, wait for tile j+1 (counted: the
+    // requests just issued stay in flight across the barrier)
+    auto step = [&](auto SLOTC, int j) {
+        constexpr int SL = decltype(SLOTC)::value;
+        if (j + 2 < ntiles) stage(j + 2, (SL + 2) % kSlots);
+        tile(SLOTC, j);
         if (j + 2 < ntiles) as_vmcnt<2>();
         else as_vmcnt<0>();
         as_barrier();
     };
-
-    const bool tail_masked = (a.Lk & 63) != 0;
-    const int nfull = tail_masked ? ntiles - 1 : ntiles;
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    using S2 = std::integral_constant<int, 2>;
-    int j = 0;
-    for (; j + 3 <= nfull; j += 3) {
-        tile(S0{}, std::false_type{}, j);
-        tile(S1{}, std::false_type{}, j + 1);
-        tile(S2{}, std::false_type{}, j + 2);
-    }
-    if (j < nfull) {
-        tile(S0{}, std::false_type{}, j);
-        ++j;
-        if (j < nfull) {
-            tile(S1{}, std::false_type{}, j);
-            ++j;
-        }
-    }
-    if (tail_masked) {
-        const int sl = j % 3;
-        if (sl == 0) tile(S0{}, std::true_type{}, j);
-        else if (sl == 1) tile(S1{}, std::true_type{}, j);
-        else tile(S2{}, std::true_type{}, j);
+    for (int j = 0; j < ntiles; j += 3) {
+        step(std::integral_constant<int, 0>{}, j);
+        if (j + 1 < ntiles) step(std::integral_constant<int, 1>{}, j + 1);
+        if (j + 2 < ntiles) step(std::integral_constant<int, 2>{}, j + 2);
     }
 
     // ---- normalise and store: lane holds O^T[dv = 32 n + (r&3) + 8 (r>>2) + 4 hi][q = l31]; row D is the denominator ----
@@ -365,20 +353,20 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     }
 }
 
-// OCC = waves per SIMD the register allocation is held to (3: 168 VGPRs; 4: 128 — tuning: CCEDIT_AS_OCC)
-template <int D, int OCC>
-__global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void attn_spatial_kernel(const CcAttnDesc a) {
-    attn_spatial_body<D>(a);
+// four waves per SIMD (two workgroups per CU): 2.04 ms against 2.30 ms with three on the 34 x 8 x 6144^2 launch
+template <int D, bool QLOG2>
+__global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_spatial_kernel(const CcAttnDesc a) {
+    attn_spatial_body<D, QLOG2>(a);
 }
 
-template <int D, int OCC>
+template <int D, bool QLOG2>
 int launch_spatial(const CcAttnDesc& a, hipStream_t s) {
     static unsigned long long attr_done = 0;
-    if (int rc = cc_max_dynamic_lds((const void*)attn_spatial_kernel<D, OCC>, kLds, &attr_done, "attn_spatial")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)attn_spatial_kernel<D, QLOG2>, kLds, &attr_done, "attn_spatial")) return rc;
     const int64_t qtiles = (a.Lq + kNW * 32 - 1) / (kNW * 32);
     const int64_t groups = ((int64_t)a.batches * a.heads + 7) / 8 * 8;
     cc_note_kernel("attn_spatial_kernel d=%d", D);
-    hipLaunchKernelGGL((attn_spatial_kernel<D, OCC>), dim3((unsigned)(qtiles * groups)), dim3(kNT), kLds, s, a);
+    hipLaunchKernelGGL((attn_spatial_kernel<D, QLOG2>), dim3((unsigned)(qtiles * groups)), dim3(kNT), kLds, s, a);
     return cc_launch_status("attn_spatial_kernel");
 }
 
@@ -391,6 +379,5 @@ bool cc_attn_spatial_applicable(const CcAttnDesc& a) {
 }
 
 int cc_attn_spatial_launch(const CcAttnDesc& a, hipStream_t s) {
-    static const int occ = getenv("CCEDIT_AS_OCC") ? atoi(getenv("CCEDIT_AS_OCC")) : 3;
-    return occ == 4 ? launch_spatial<40, 4>(a, s) : launch_spatial<40, 3>(a, s);
+    return (a.flags & CCEDIT_ATTN_Q_LOG2) ? launch_spatial<40, true>(a, s) : launch_spatial<40, false>(a, s);
 }

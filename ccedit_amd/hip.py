@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCEDIT_HIP_LIB") or os.path.join(_HERE, "libccedit_hip.so")
 
 ABI_VERSION = 9
+ATTN_Q_LOG2 = 1          # CcAttnDesc.flags: CCEDIT_ATTN_Q_LOG2
 
 GEMM_LINEAR, GEMM_CONV2D, GEMM_TEMPORAL = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3

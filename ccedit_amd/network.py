@@ -144,6 +144,9 @@ def _seq(*mods) -> nn.Sequential:
 # ------------------------------------------------------------------------------------------
 # attention blocks
 # ------------------------------------------------------------------------------------------
+LOG2E = 1.4426950408889634
+
+
 class CrossAttention(nn.Module):
     """Parameters of sgm.modules.attention.CrossAttention (attention.py:365-390)."""
 
@@ -159,10 +162,16 @@ class CrossAttention(nn.Module):
         self.self_attn = context_dim is None
         self.qkv = None
         self.kv = None
+        self.q_log2 = False
 
     def post_pack(self, device):
         if self.self_attn:
-            self.qkv = pack_concat([self.to_q.weight, self.to_k.weight, self.to_v.weight], device=device)
+            # d = 40 (the 64x96 level, 6144 keys): softmax scale * log2(e) rides in the packed to_q rows — the attention kernel
+            # then exponentiates q.k directly (CCEDIT_ATTN_Q_LOG2), and q is rounded to bf16 once, as in the reference's
+            # `q = self.to_q(x)` (attention.py:404), instead of a second time after an in-kernel multiply
+            self.q_log2 = self.dim_head == 40 and ops.ATTN_Q_LOG2
+            qw = self.to_q.weight * (self.dim_head ** -0.5 * LOG2E) if self.q_log2 else self.to_q.weight
+            self.qkv = pack_concat([qw, self.to_k.weight, self.to_v.weight], device=device)
         self.kv = pack_concat([self.to_k.weight, self.to_v.weight], device=device)
 
 
@@ -243,7 +252,8 @@ class BasicTransformerBlock(nn.Module):
         a1, a2 = self.attn1, self.attn2
         c = a1.inner
         qkv = ln_linear(tok, self.norm1, a1.qkv, self.qkv_ln)      # (dim 320, 3 slices: folding the norm into lin320 does not pay)
-        o = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], a1.heads, a1.dim_head, batches=frames, lq=hw, lk=hw)
+        o = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], a1.heads, a1.dim_head, batches=frames, lq=hw, lk=hw,
+                          q_log2=a1.q_log2)
         tok = linear_ln_producer(o, a1.to_out[0].pw, res1=tok)
         q = ln_linear(tok, self.norm2, a2.to_q.pw, self.q2_ln)
         kv = ops.linear(ctx_kv_src, a2.kv)                     # [B*L, 2C]: once per clip, shared by its T frames
@@ -259,6 +269,7 @@ class BasicTransformerBlock(nn.Module):
         self.ff.pack_fused(self.norm3, device)
         self.q2_ln = _fold_ln([self.attn2.to_q.weight], self.norm2, device)
         a1 = self.attn1
+        assert not (a1.q_log2 and a1.to_q.weight.shape[1] in (640, 1280))      # (the folded-norm pack below carries no scale)
         self.qkv_ln = _fold_ln([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], self.norm1, device, dims=(640, 1280))
 
 

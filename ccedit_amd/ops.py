@@ -189,6 +189,7 @@ def ln320_applicable(m, pw, act=ACT_NONE, res1=None, res2=None, group_bias=None,
             and gn_rows == 0)
 
 
+ATTN_Q_LOG2 = os.environ.get("CCEDIT_ATTN_Q_LOG2", "1") != "0"      # 0: softmax scale applied inside the attention kernels (A/B)
 FF320 = os.environ.get("CCEDIT_FF320", "1") != "0"      # 0: LayerNorm + two GEMMs instead of the fused dim-320 feed-forward
 
 
@@ -432,8 +433,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, d: 
               q_inner: int = 1, q_outer_rows: Optional[int] = None, q_inner_rows: int = 0, q_seq_rows: int = 1,
               kv_div: int = 1, kv_inner: int = 1, kv_outer_rows: Optional[int] = None, kv_inner_rows: int = 0,
               kv_seq_rows: int = 1, out: Optional[torch.Tensor] = None,
-              seg1_len: int = 0, seg1_div: int = 1, seg1_mul: int = 0, seg1_add: int = 0, causal: bool = False) -> torch.Tensor:
-    """q/k/v: 2-D row-major views [rows, >= heads*d] (may be column slices of a fused buffer)."""
+              seg1_len: int = 0, seg1_div: int = 1, seg1_mul: int = 0, seg1_add: int = 0, causal: bool = False,
+              q_log2: bool = False) -> torch.Tensor:
+    """q/k/v: 2-D row-major views [rows, >= heads*d] (may be column slices of a fused buffer).  q_log2: q already carries
+    d^-0.5 * log2(e) (folded into the to_q weights by the packer)."""
     for tns in (q, k, v):
         assert tns.dtype == BF16 and tns.is_cuda and tns.stride(-1) == 1
     if out is None:
@@ -448,6 +451,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, d: 
     a.scale = float(d) ** -0.5
     a.seg1_len, a.seg1_div, a.seg1_mul, a.seg1_add = seg1_len, seg1_div, seg1_mul, seg1_add
     a.causal = int(causal)
+    a.flags = hip.ATTN_Q_LOG2 if q_log2 else 0
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -990,6 +990,52 @@ def test_attention_long_pingpong_rescale_and_anchor():
            what="long anchor + self attention")
 
 
+def test_attention_spatial_kernel_reference_column_and_prescaled_q():
+    """attn_spatial_kernel (attnspatial.hip; d = 40, >= 1024 queries, >= 192 keys): the softmax reference rides in the pad column of
+    the last QK^T k-step and moves only when a score exceeds it by 2^16.  Checked here: the kernel is the one dispatched; spikes far
+    beyond the threshold in a late tile (one that would overflow exp2 if it were exponentiated against the old reference); a first
+    tile whose scores are all very negative; q arriving pre-multiplied by d^-0.5 log2(e) (CCEDIT_ATTN_Q_LOG2), on this kernel and on
+    the general one; the two-segment keys of TVI2V with a segment of whole tiles; bit-identical repeats."""
+    _dev()
+    from ccedit_amd import hip, ops
+    heads, d, lq, lk = 2, 40, 1024, 640
+    c = heads * d
+    last = lambda: hip.lib().ccedit_last_kernel().decode()
+    for spike, row, key in ((4.0, 700, 450), (16.0, 33, 639), (12.0, 1023, 64)):
+        q, k, v = _rnd(1, lq, c, seed=1), _rnd(1, lk, c, seed=2), _rnd(1, lk, c, seed=3)
+        k[0, key] = q[0, row] * spike                     # 4: 2^36 over the row's other scores; 16: 2^146 — beyond fp32's exp2 range
+        k[0, :64] -= q[0, row] * 2.0                      # the row's first tile far BELOW its later maximum
+        q, k = q.to(BF).float(), k.to(BF).float()         # (logits of this size magnify the bf16 rounding of the INPUTS: not under test)
+        args = (q.reshape(-1, c).to(BF).cuda(), k.reshape(-1, c).to(BF).cuda(), v.reshape(-1, c).to(BF).cuda(), heads, d)
+        o = ops.attention(*args, batches=1, lq=lq, lk=lk)
+        assert "attn_spatial_kernel" in last(), last()
+        _close(o.reshape(1, lq, c), _sdpa_ref(q, k, v, heads), rel=2.0 ** -6, abs_=4e-3, what=f"spatial attention, spike x{spike}")
+        assert torch.equal(o, ops.attention(*args, batches=1, lq=lq, lk=lk))
+    # pre-scaled q: same result as the in-kernel scale up to the second bf16 rounding of q that the flag avoids
+    for lq2, lk2, kern in ((1280, 1280, "attn_spatial_kernel"), (200, 200, "attn_kernel")):
+        q, k, v = _rnd(2, lq2, c, seed=4), _rnd(2, lk2, c, seed=5), _rnd(2, lk2, c, seed=6)
+        qs = (q * (d ** -0.5 * 1.4426950408889634)).to(BF)
+        o = ops.attention(qs.reshape(-1, c).cuda(), k.reshape(-1, c).to(BF).cuda(), v.reshape(-1, c).to(BF).cuda(), heads, d,
+                          batches=2, lq=lq2, lk=lk2, q_log2=True)
+        assert kern in last(), last()
+        ref = _sdpa_ref(qs.float() / (d ** -0.5 * 1.4426950408889634), k, v, heads)
+        _close(o.reshape(2, lq2, c), ref, rel=2.0 ** -6, abs_=4e-3, what=f"attention with q in log2 units ({kern})")
+    # anchor + self keys, the anchor segment a whole number of key tiles (17 x 64), ragged query tiles
+    heads, t, clips, hw = 4, 3, 2, 1088
+    c = heads * d
+    n = clips * t
+    q = _rnd(n, hw, c, seed=7)
+    kv = _rnd(n, hw, 2 * c, seed=8)
+    kvd = kv.reshape(-1, 2 * c).to(BF).cuda()
+    o = ops.attention(q.reshape(-1, c).to(BF).cuda(), kvd[:, :c], kvd[:, c:], heads, d, batches=n, lq=hw, lk=2 * hw,
+                      kv_outer_rows=hw, seg1_len=hw, seg1_div=t, seg1_mul=t, seg1_add=t // 2)
+    assert "attn_spatial_kernel" in last(), last()
+    anchor = kv.reshape(clips, t, hw, 2 * c)[:, t // 2].repeat_interleave(t, 0)
+    ctx = torch.cat([anchor, kv], dim=1)
+    _close(o.reshape(n, hw, c), _sdpa_ref(q, ctx[..., :c], ctx[..., c:], heads), rel=2.0 ** -6, abs_=4e-3,
+           what="spatial kernel, anchor + self keys")
+
+
 def test_copy_row_blocks_pack_unpack_add():
     """ccedit_copy_row_blocks: the pack / unpack(+skip add) halves of FrameShard's all-to-all against index_select + add_."""
     _dev()

@@ -6,8 +6,8 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")
 
 VARIANTS = {
     "general (attn_kernel)": {"CCEDIT_ATTN_SPATIAL": "0"},
-    "spatial occ3": {"CCEDIT_AS_OCC": "3"},
-    "spatial occ4": {"CCEDIT_AS_OCC": "4"},
+    "spatial": {},
+    "spatial, q in log2 units": {"PROBE_Q_LOG2": "1"},
 }
 
 
@@ -19,12 +19,15 @@ def one():
     c = heads * d
     qkv = torch.randn(n * l, 3 * c, device="cuda").to(torch.bfloat16)
     q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
-    f = lambda: ops.attention(q, k, v, heads, d, batches=n, lq=l, lk=l)
+    pre = os.environ.get("PROBE_Q_LOG2", "0") == "1"
+    if pre:
+        q = (q.float() * (d ** -0.5 * 1.4426950408889634)).to(torch.bfloat16)
+    f = lambda: ops.attention(q, k, v, heads, d, batches=n, lq=l, lk=l, q_log2=pre)
     o = f()
     kern = hip.lib().ccedit_last_kernel().decode()
     # reference on one (frame, head) pair in fp32
     qq, kk, vv = (t[:l, :d].float() for t in (q, k, v))
-    ref = torch.softmax(qq @ kk.T * d ** -0.5, -1) @ vv
+    ref = torch.softmax(qq @ kk.T * (0.6931471805599453 if pre else d ** -0.5), -1) @ vv
     err = (o[:l, :d].float() - ref).abs().max().item()
     ts = []
     for _ in range(3):
