@@ -34,8 +34,9 @@ if ROOT not in sys.path:
 FLOP_PER_STEP = 77.68e12          # SURVEY.md §8d, measured from the reference modules on the meta device
 FLOP_PER_STEP_TVI2V = 110.31e12   # BASELINE.json config 3 (controlnet_img + anchor cross-frame attention)
 MFMA_PEAK_TFLOPS = 2500.0         # MI355X dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0             # HBM3E spec (ibid.; a float4 copy measures 6290)
 T, H, W, L, CTX = 17, 64, 96, 77, 768
-PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"      # committed rocprofv3 PMC capture (FETCH_SIZE / WRITE_SIZE passes)
+PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"      # committed rocprofv3 PMC capture (FETCH_SIZE / WRITE_SIZE passes)
 
 
 def synth_inputs(device, seed=42, b=1):
@@ -59,10 +60,11 @@ def build_model(device, tvi2v=False):
     return w
 
 
-def cpu_baseline(wrapper):
+def cpu_baseline(wrapper, tvi2v=False):
     """Oracle (CPU fp32 restatement, `kind: port`) on a bounded sample of the same workload: the same
     full-width network and weights on a crop — B=2 (CFG), T=6 keyframes, latent 32x48 — timed on the host
-    cores; converted to steps/s through the FLOPs ATen actually executed (FlopCounterMode)."""
+    cores; converted to steps/s through the FLOPs ATen actually executed (FlopCounterMode).  The full-size step is NOT run on
+    the CPU (about 100 s per evaluation): `value` is the crop's FLOP rate divided by the full-size step's FLOPs."""
     from oracle import ccedit_oracle as O
     from torch.utils.flop_counter import FlopCounterMode
     threads = min(os.cpu_count() or 1, 32)        # ATen's CPU kernels stop scaling (and collapse) far below 256 threads
@@ -72,18 +74,24 @@ def cpu_baseline(wrapper):
     tt, hh, ww = 6, 32, 48
     x = torch.randn(2, 4, tt, hh, ww, generator=g)
     c = dict(crossattn=torch.randn(2, L, CTX, generator=g), control_hint=torch.rand(2, 3, tt, 8 * hh, 8 * ww, generator=g) * 2 - 1)
+    if tvi2v:
+        cf = torch.randn(1, 4, hh, ww, generator=g) * 0.18215
+        c["cond_feat"] = torch.cat([cf, cf])
     t = torch.tensor([601, 601], dtype=torch.int64)
     with torch.no_grad():
         with FlopCounterMode(display=False) as fc:
             t0 = time.time()
-            O.network_forward(sd, O.NetConfig(), x, t, c)
+            O.network_forward(sd, O.NetConfig(crossframe=tvi2v), x, t, c)
             dt = time.time() - t0
     flops = float(fc.get_total_flops())
-    out = dict(value=(flops / dt) / FLOP_PER_STEP, unit="UNet steps/s (FLOP-equivalent)", cores=threads,
+    per_step = FLOP_PER_STEP_TVI2V if tvi2v else FLOP_PER_STEP
+    out = dict(value=(flops / dt) / per_step, unit="UNet steps/s (FLOP-equivalent)", cores=threads,
                kind="port", seconds=round(dt, 2), cpu_tflops=round(flops / dt / 1e12, 3),
-               sample=f"oracle network_forward, full-width weights, B=2 T={tt} latent {hh}x{ww}: {flops/1e12:.2f} TFLOP in {dt:.1f}s; "
-                      f"steps/s = CPU FLOP/s / 77.68 TFLOP")
-    out.update(cpu_config1_end_to_end(sd, threads))
+               sample=f"oracle network_forward ({'TVI2V' if tvi2v else 'TV2V'}), full-width weights, B=2 T={tt} latent {hh}x{ww}: "
+                      f"{flops/1e12:.2f} TFLOP in {dt:.1f}s; steps/s = CPU FLOP/s / {per_step / 1e12:.2f} TFLOP (a conversion of the "
+                      f"crop's rate — the full-size step itself is not run on the CPU)")
+    if not tvi2v:
+        out.update(cpu_config1_end_to_end(sd, threads))
     return out
 
 
@@ -274,29 +282,41 @@ def main():
             for fam in ("tap_gemm", "attention"):
                 for shape, n, ms, tf in ops.PROFILE.by_shape(fam)[:int(os.environ.get('CCEDIT_BREAKDOWN_ROWS', '40'))]:
                     print(f"{fam:9s} {str(shape):60s} x{n:3d} {ms:8.3f} ms {tf:7.1f} TF/s", file=sys.stderr)
-        by_kernel = [dict(kernel=r["kernel"], launches=r["launches"], ms=round(r["ms"], 3), tflops=round(r["tflops"], 1),
-                          frac=round(r["tflops"] / MFMA_PEAK_TFLOPS, 4)) for r in ops.PROFILE.by_kernel()]
+        by_kernel = []
+        for r in ops.PROFILE.by_kernel():
+            row = dict(kernel=r["kernel"], launches=r["launches"], ms=round(r["ms"], 3), alg_bytes_per_launch=round(r["bytes"] / r["launches"]))
+            if r["family"] == "memory":         # bandwidth-bound passes: algorithmic bytes / time against HBM
+                row.update(bound="hbm", gbytes_per_s=round(r["gbytes_per_s"], 1), frac=round(r["gbytes_per_s"] / HBM_PEAK_GBS, 4),
+                           gbytes=round(r["bytes"] / 1e9, 3))
+            else:
+                row.update(bound="mfma", tflops=round(r["tflops"], 1), frac=round(r["tflops"] / MFMA_PEAK_TFLOPS, 4))
+            by_kernel.append(row)
         ops.PROFILE = None
         g = prof["tap_gemm"]
         ach = g["flops"] / (g["total_ms"] * 1e-3) / 1e12
-        # `achieved` / `frac` price the whole GEMM family (every ccedit_gemm + ccedit_ff320 launch of the step) as before;
-        # `kernel` names the single template with the most time in it and `by_kernel` prices every template on its own
-        # (GEMM and attention templates, HIP events of this profiled step) — the family number hides the slow launches.
-        dom = max((r for r in by_kernel if not r["kernel"].startswith("attn")), key=lambda r: r["ms"], default=None)
-        roof = dict(bound="mfma", kernel=dom["kernel"] if dom else None, kernel_tflops=dom["tflops"] if dom else None,
-                    kernel_frac=dom["frac"] if dom else None,
+        # The DOMINANT kernel = the single template with the most time in it over ALL rows (GEMM, attention and memory passes):
+        # `kernel*`, `achieved`, `frac` are ITS algorithmic FLOPs / its HIP-event time in this profiled step (reproducible from
+        # the rocprofv3 summary under profiles/: calls x average duration of that kernel's row).  The whole GEMM family
+        # (every ccedit_gemm + ccedit_ff320 launch of the step), which earlier rounds reported as `achieved`, stays as `family_*`.
+        dom = max(by_kernel, key=lambda r: r["ms"])
+        dom_mfma = dom["bound"] == "mfma"
+        roof = dict(bound=dom["bound"], kernel=dom["kernel"], kernel_launches=dom["launches"], kernel_ms_per_step=dom["ms"],
+                    avg_launch_us=round(1e3 * dom["ms"] / dom["launches"], 2),
+                    achieved=dom["tflops"] if dom_mfma else dom["gbytes_per_s"],
+                    peak=MFMA_PEAK_TFLOPS if dom_mfma else HBM_PEAK_GBS, unit="TFLOP/s" if dom_mfma else "GB/s",
+                    frac=dom["frac"], traffic=None, algorithmic_bytes_per_launch=dom["alg_bytes_per_launch"],
                     family="ccedit_gemm + ccedit_ff320 (g8_kernel, conv_halo_kernel, tap_gemm_kernel, lin320_kernel, ff320_kernel, small_conv3x3_kernel)",
-                    achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None, launches=g["launches"],
-                    avg_launch_us=round(g["avg_us"], 2), algorithmic_flops_per_step=g["flops"], by_kernel=by_kernel)
+                    family_achieved=round(ach, 1), family_frac=round(ach / MFMA_PEAK_TFLOPS, 4), family_launches=g["launches"],
+                    family_avg_launch_us=round(g["avg_us"], 2), algorithmic_flops_per_step=g["flops"], by_kernel=by_kernel)
         # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 PMC passes of this
         # same workload (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH x2 per
         # MI355X_MICROARCH.md), averaged per tap_gemm launch like `achieved`.
         # The capture records the hash of the kernel sources it was taken from (tools/pmc_traffic.sh); a capture of OTHER
         # kernels is not reported: traffic stays null and the line says why.
         pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
-        roof["algorithmic_bytes_per_launch"] = round(g["bytes"] / g["launches"])
-        if not tvi2v and os.path.exists(pmc):
+        roof["family_algorithmic_bytes_per_launch"] = round(g["bytes"] / g["launches"])
+        pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE.replace(".json", "_tvi2v.json")) if tvi2v else pmc
+        if os.path.exists(pmc):
             with open(pmc) as f:
                 cap = json.load(f)
             tg = cap.get("tap_gemm")
@@ -304,10 +324,16 @@ def main():
             if src != kernel_source_hash():
                 roof["traffic_note"] = (f"profiles/{PMC_TRAFFIC_FILE} was captured from kernel sources {src}, this build is "
                                         f"{kernel_source_hash()}: stale, not reported (re-run tools/pmc_traffic.sh)")
-            elif tg and tg["launches"]:
-                roof["traffic"] = round((tg["fetch_bytes_x2"] + tg["write_bytes"]) / tg["launches"])
-                roof["traffic_unit"] = f"HBM bytes per ccedit_gemm launch (rocprofv3 PMC, profiles/{PMC_TRAFFIC_FILE})"
-                roof["traffic_launches"] = tg["launches"]
+            else:
+                sym = (cap.get("by_symbol") or {}).get(dom["kernel"].split(" ")[0])          # e.g. "attn_spatial_kernel"
+                if sym and sym["launches"]:
+                    roof["traffic"] = round((sym["fetch_bytes_x2"] + sym["write_bytes"]) / sym["launches"])
+                    roof["traffic_unit"] = (f"bytes past the L2 per {dom['kernel'].split(' ')[0]} launch (rocprofv3 PMC: FETCH_SIZE x2 + "
+                                            f"WRITE_SIZE, all instantiations of the template, profiles/{PMC_TRAFFIC_FILE})")
+                    roof["traffic_launches"] = sym["launches"]
+                if tg and tg["launches"]:
+                    roof["family_traffic"] = round((tg["fetch_bytes_x2"] + tg["write_bytes"]) / tg["launches"])
+                    roof["family_traffic_unit"] = "bytes past the L2 per ccedit_gemm / ccedit_ff320 launch"
                 roof["traffic_kernel_source_hash"] = src
         a = prof.get("attention")
         if a:
@@ -321,16 +347,17 @@ def main():
     # outside the timed region above.  N > 1 replicas: every rank runs its own clip at the same time (rank 0's is reported);
     # frame-sharded: the one clip runs through the sharded wrapper on all ranks.
     clip = None
-    if not args.no_clip and not tvi2v:
+    if not args.no_clip:
         if dist is not None:
             dist.barrier()
-        clip = time_clip(wrapper, device, seed=43 if shard else 43 + rank)
+        # config 3 (reference README.md:63-77): 50 steps = 99 evaluations at cfg 7 with the reference-frame latent as cond_feat
+        clip = time_clip(wrapper, device, seed=43 if shard else 43 + rank, **(dict(num_steps=50, scale=7.0, tvi2v=True) if tvi2v else {}))
         if rank != 0:
             clip = None
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not tvi2v:
-        cpu = cpu_baseline(wrapper)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(wrapper, tvi2v)
 
     if rank == 0:
         line = {
@@ -379,8 +406,8 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def time_clip(wrapper, device, num_steps=30, scale=7.5, seed=43):
-    """One full clip: DPMPP2SAncestral (30 steps = 59 evaluations) + AutoencoderKL decode -> frames/s."""
+def time_clip(wrapper, device, num_steps=30, scale=7.5, seed=43, tvi2v=False):
+    """One full clip: DPMPP2SAncestral (30 steps = 59 evaluations; TVI2V: 50 steps = 99) + AutoencoderKL decode -> frames/s."""
     from ccedit_amd.config import instantiate_from_config
     from ccedit_amd.sgm_compat import build_vae
     from ccedit_amd.utils.synth import fill_module_
@@ -399,6 +426,9 @@ def time_clip(wrapper, device, num_steps=30, scale=7.5, seed=43):
     x, cross_c, cross_uc, hint = synth_inputs(device, seed=seed)
     c = dict(crossattn=cross_c, control_hint=hint)
     uc = dict(crossattn=cross_uc, control_hint=hint.clone())
+    if tvi2v:          # the VAE-encoded reference frame, identical in c and uc (sampling_tv2v_ref.py:405-445)
+        cf = (torch.randn(1, 4, H, W, generator=torch.Generator().manual_seed(seed + 100)) * 0.18215).to(device)
+        c["cond_feat"], uc["cond_feat"] = cf, cf.clone()
     evals = [0]
 
     def network(xx, tt, cond):
@@ -423,8 +453,9 @@ def time_clip(wrapper, device, num_steps=30, scale=7.5, seed=43):
     finite = bool(torch.isfinite(frames).all())
     if not finite:                                 # a rate for garbage is not a measurement
         sys.stderr.write("bench.py: the sampled clip contains non-finite values — frames_per_s withheld\n")
-    return dict(sampler_s=round(t1 - t0, 3), vae_decode_s=round(t2 - t1, 3), evaluations=evals[0], hint_stem="once per clip",
-                decoder_warmup="one untimed decode",
+    return dict(sampler_s=round(t1 - t0, 3), vae_decode_s=round(t2 - t1, 3), evaluations=evals[0], sampler_steps=num_steps, cfg_scale=scale,
+                hint_stem="once per clip", decoder_warmup="one untimed decode",
+                vae="bf16 storage / fp32 accumulation (the reference decodes in fp32, diffusion.py:151-156)",
                 frames_per_s=round(T / (t2 - t0), 3) if finite else None, finite=finite)
 
 

@@ -337,7 +337,11 @@ extern "C" int ccedit_ff320(const CcFf320Desc* desc, void* stream) {
     CC_UNSUPPORTED(d.ldx % 8 != 0 || d.ldo % 8 != 0 || d.ldx < kC || d.ldo < kC, "ccedit_ff320: ldx=%d / ldo=%d", d.ldx, d.ldo);
     const int64_t rounds = (d.M + 4 * kWavePix - 1) / (4 * kWavePix);
     CC_UNSUPPORTED(rounds > 2147483647LL, "ccedit_ff320: M too large");
+#ifdef CCEDIT_TUNING      // probe builds only (-DCCEDIT_TUNING): the product library never reads a switch that changes results
     static const int abl = getenv("CCEDIT_FF320_ABL") ? atoi(getenv("CCEDIT_FF320_ABL")) : 0;
+#else
+    constexpr int abl = 0;
+#endif
     void (*kern)(const CcFf320Desc, int) = ff320_kernel<0>;
     switch (abl) {        // tuning only (bit mask, see the kernel); results are wrong for abl != 0
         case 1: kern = ff320_kernel<1>; break;

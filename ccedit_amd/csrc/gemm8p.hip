@@ -17,11 +17,13 @@
 //     phases after it was read and is re-filled four to six phases before it is read again;
 //   * the wave halves are offset by one barrier (ping-pong): LDS fragment reads and DMA issue of one half run under the
 //     MFMAs of the other, `s_setprio` keeps the matrix pipe with the half that is in its MFMA block;
-//   * persistent workgroups (one per CU): the first seven half tiles of the NEXT output tile are requested before the
-//     epilogue of the current one, so the cold-operand latency (~1.5 us in the network) hides under the stores;
-//   * the epilogue goes from the accumulators straight to global memory: v_permlane32_swap turns the 32x32 MFMA layout
-//     (a lane owns 4 channels of a pixel) into 8 consecutive channels per lane = 16-byte stores, bias / SiLU / GEGLU /
-//     residuals applied in registers — no LDS staging, no barriers, so the prefetch above may use the whole ring.
+//   * persistent workgroups (one per CU): the first K tile of the NEXT output tile is requested (buffer 0) before the epilogue of
+//     the current one, so the cold-operand latency (~1.5 us in the network) hides under the stores; the second after it;
+//   * bias (+ the per-clip embedding row) is the accumulators' initial value; the epilogue turns each wave's 128-channel x 32-pixel
+//     blocks around in 8 KB of its OWN inside buffer 1 (a wave's LDS accesses execute in order: no workgroup barrier) and stores
+//     16 bytes per lane along a pixel's channels — whole 128-byte lines; GEGLU before the staging, residuals after it, GroupNorm /
+//     LayerNorm statistics from the bf16 values written.  (The first version went registers -> global through v_permlane32_swap:
+//     8.2 us per tile against 2.9)
 //
 // LDS: [buffer 0 | buffer 1] x [A half 0 | A half 1 | B half 0 | B half 1], a half = 128 rows x 128 B (64 k).  Rows are
 // written lane-linearly by the DMA; 16-byte granule g of row r sits at slot g ^ ((r >> 1) & 7) (source-side swizzle,
@@ -71,14 +73,6 @@ __device__ __forceinline__ void g8_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Exchange between the two lane halves: afterwards lanes 0-31 hold (x, y) = (own x, partner's x), lanes 32-63
-// (partner's y, own y) — with x / y the 4-channel groups q / q + 1 of a 32x32 accumulator tile that makes 8 consecutive
-// channels per lane: 8 q + (0..7) in the low half, 8 (q + 1) + (0..7) in the high half.
-__device__ __forceinline__ void g8_swap(float& x, float& y) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    x = __uint_as_float(r[0]);
-    y = __uint_as_float(r[1]);
-}
 
 struct G8Order {          // 32-bit on purpose: the tile walk runs once per output tile in every wave (M < 2^31 rows)
     int pt_n, ct_n, Q, total, per;
@@ -153,7 +147,11 @@ __device__ __forceinline__ void g8_flush_stats(float (&gs)[8], float (&gq)[8], i
 // LayerNorm statistics of the tensor being written (CcGemmDesc.row_sums): rs / rq = this lane's sums / sums of squares over its
 // channels of pixel rows j * step + lane / G (j = 0 .. NR - 1) of the 32-pixel tile starting at row m0.  The G lanes of a pixel
 // row are neighbours: butterfly over them, then the first of each adds the wave's share of the row to the row's double-precision
-// (sum, sum of squares) — the arrival order of double adds cannot move the fp32 (mean, rstd) taken from them.
+// (sum, sum of squares).  The channel tiles of a row meet in DOUBLE atomics: arrival order moves a total by ~1e-16 relative, which
+// reaches the fp32 (mean, rstd) derived from it only where that double value sits within 1e-16 of an fp32 rounding boundary —
+// not excluded, never observed (tests/test_fullsize_gpu.py compares whole evaluations bit for bit across processes), and unlike
+// split-K (fixed summation order) not guaranteed.  The variance is q / K - mean^2 in double from fp32 lane partials of bf16 values:
+// for |mean| >> std it is as accurate as the partials (test_layernorm_folded_into_persistent_gemm runs rows with mean = 30 std).
 template <int G, int NR>
 __device__ __forceinline__ void g8_flush_rows(float (&rs)[NR], float (&rq)[NR], int lane, int64_t m0, int step, int64_t M, double* sums) {
 #pragma unroll
@@ -845,7 +843,11 @@ int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu, int split_k = 
             dd.cgroup = (int)((ct_n + ng - 1) / ng);
         }
     }
-    static const int flag_env = getenv("CCEDIT_G8_FLAGS") ? atoi(getenv("CCEDIT_G8_FLAGS")) : 0;   // tuning (see `flags` in the kernel)
+#ifdef CCEDIT_TUNING      // probe builds only (-DCCEDIT_TUNING): the product library never reads a switch that changes results
+    static const int flag_env = getenv("CCEDIT_G8_FLAGS") ? atoi(getenv("CCEDIT_G8_FLAGS")) : 0;   // see `flags` in the kernel
+#else
+    constexpr int flag_env = 0;
+#endif
     dd.cgroup |= flag_env << 24;
     int wgs = n_cu - n_cu % 8;
     dd.split_k = SPLIT ? split_k : 1;

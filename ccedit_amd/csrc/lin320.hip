@@ -305,7 +305,11 @@ int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s) {
         return CCEDIT_EUNSUPPORTED;
     }
     cc_note_kernel("lin320_kernel");
-    static const int flag_env = getenv("CCEDIT_L320_FLAGS") ? atoi(getenv("CCEDIT_L320_FLAGS")) : 0;      // tuning: 1 = no output stores
+#ifdef CCEDIT_TUNING      // probe builds only (-DCCEDIT_TUNING): the product library never reads a switch that changes results
+    static const int flag_env = getenv("CCEDIT_L320_FLAGS") ? atoi(getenv("CCEDIT_L320_FLAGS")) : 0;      // 1 = no output stores
+#else
+    constexpr int flag_env = 0;
+#endif
     CcGemmDesc dd = d;
     dd.cgroup = flag_env << 24;
     const CcGemmDesc& d2 = dd;

@@ -72,8 +72,15 @@ class Norm(nn.Module):
         self.b = self.bias.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+# Bumped by every pack_tree(): anything that bakes the ADDRESSES of packed weights (captured HIP graphs, cached hint-stem outputs:
+# network.OpenAIWrapperControlLDM3DTV2V) keys on it, so a re-pack — a second checkpoint, a LoRA merge, new control scales — can never
+# be followed by a replay that reads the freed weight tensors of the previous pack.
+PACK_GENERATION = [0]
+
+
 def pack_tree(module: nn.Module, device) -> None:
     """Pack every leaf container under `module` (composite modules may add fused weights on top)."""
+    PACK_GENERATION[0] += 1
     for m in module.modules():
         if isinstance(m, (Conv, Linear, Norm)) and not getattr(m, "_packed_by_parent", False):
             m.pack(device)

@@ -27,7 +27,7 @@ import torch.nn as nn
 
 from . import ops
 from .hip import ACT_SILU
-from .layers import Conv, Linear, Norm, Slot, pack_tree
+from .layers import PACK_GENERATION, Conv, Linear, Norm, Slot, pack_tree
 from .packing import pack_concat
 
 # Per-block output capture for the parity tests (tests/test_network_gpu.py reads the reference's per-block digests):
@@ -939,6 +939,8 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     def _tensor_key(tns: torch.Tensor):
         return (tns.data_ptr(), tuple(tns.shape), tuple(tns.stride()), tns._version, tns.dtype)
 
+    _fail_capture_for_test = False      # tests/test_network_gpu.py: make the next capture raise after its launches were recorded
+
     def reset_caches(self):
         """Drop the per-clip caches (hint stem, shard slices, captured graphs).  Never needed for correctness — entries pin
         their source storage, see _guided_hint — only to release the previous clip's memory early."""
@@ -952,7 +954,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         later tensor (the next clip's hint) can be handed that address by the caching allocator — a key match always
         means the same bytes."""
         net = self.diffusion_model.controlnet
-        key = self._tensor_key(hint5d)
+        key = self._tensor_key(hint5d) + (PACK_GENERATION[0],)        # (a re-pack replaces the stem's weights)
         if self.cache_hint_stem and isinstance(self._hint_val, dict) and key in self._hint_val:
             return self._hint_val[key][1]
         # control_hint in [-1,1] -> 1 - (h+1)/2 (wrappers.py:160-162), fused into the layout change
@@ -986,7 +988,8 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         return self._forward_eager(x, t, c, **kwargs)
 
     def _forward_graphed(self, x, t, c):
-        key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, self.cache_hint_stem, self.overlap_controlnet,
+        # PACK_GENERATION: a captured graph holds the addresses of the packed weights it was recorded with
+        key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, self.cache_hint_stem, self.overlap_controlnet, PACK_GENERATION[0],
                tuple(sorted((k, self._tensor_key(v)) if torch.is_tensor(v) else (k, repr(v)) for k, v in c.items())))
         if self._graphs is None:
             self._graphs = {}
@@ -1004,15 +1007,23 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                 # thread_local: calls from OTHER threads (the process group's watchdog polling its events when torch.distributed is
                 # initialised — bench.py --gpus N) must not invalidate the capture
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    ops.reset_stream_scratch()                  # scratch arenas of the capture stream must live in this graph's pool
-                    ent["out"] = self._forward_eager(ent["x"], ent["t"], c)
+                    # scratch arenas used while capturing must live in this graph's pool, and nothing outside the capture may go on
+                    # using them: their zero fills are only RECORDED, and after a failed capture never run at all — the eager
+                    # fallback would accumulate statistics onto uninitialised memory and wait on garbage split-K counters
                     ops.reset_stream_scratch()
+                    try:
+                        ent["out"] = self._forward_eager(ent["x"], ent["t"], c)
+                        if self._fail_capture_for_test:
+                            raise RuntimeError("capture failure injected by a test")
+                    finally:
+                        ops.reset_stream_scratch()
                 ent["graph"] = g
                 ent["pins"].append(dict(self._hint_val) if isinstance(self._hint_val, dict) else None)   # the cached stem output it reads
             except Exception as e:                              # capture is an optimisation: report once, keep evaluating eagerly
                 import warnings
                 OpenAIWrapperControlLDM3DTV2V._graph_failed = True
                 self._graphs = None
+                ops.reset_stream_scratch()                      # (again: whatever the aborted capture left behind)
                 warnings.warn(f"HIP graph capture of the network evaluation failed ({type(e).__name__}: {e}); continuing without graphs")
                 return self._forward_eager(x, t, c)
         else:

@@ -28,19 +28,23 @@ class LaunchProfile:
     def __init__(self):
         self.records = {}          # family -> list of (start_event, end_event, algorithmic_flops, algorithmic_bytes)
 
-    def add(self, family, e0, e1, flops, nbytes, shape=None):
-        k = hip.lib().ccedit_last_kernel()           # the kernel template the entry point just dispatched to
-        self.records.setdefault(family, []).append((e0, e1, flops, nbytes, shape, k.decode() if k else "?"))
+    def add(self, family, e0, e1, flops, nbytes, shape=None, kernel=None):
+        if kernel is None:
+            k = hip.lib().ccedit_last_kernel()           # the kernel template the entry point just dispatched to
+            kernel = k.decode() if k else "?"
+        self.records.setdefault(family, []).append((e0, e1, flops, nbytes, shape, kernel))
 
-    def by_kernel(self, families=("tap_gemm", "attention")):
-        """[{kernel, launches, ms, tflops}] over the given families, sorted by time."""
+    def by_kernel(self, families=("tap_gemm", "attention", "memory")):
+        """[{kernel, launches, ms, tflops, gbytes_per_s}] over the given families, sorted by time (gbytes_per_s: algorithmic bytes
+        over the launch time — the number to hold against HBM for the `memory` family: norms, concatenation, layout passes)."""
         torch.cuda.synchronize()
         acc = {}
         for fam in families:
-            for a, b, fl, _, _, k in self.records.get(fam, []):
-                n, ms, f = acc.get(k, (0, 0.0, 0.0))
-                acc[k] = (n + 1, ms + a.elapsed_time(b), f + fl)
-        return sorted(({"kernel": k, "launches": n, "ms": ms, "tflops": f / (ms * 1e-3) / 1e12} for k, (n, ms, f) in acc.items()),
+            for a, b, fl, nb, _, k in self.records.get(fam, []):
+                n, ms, f, by, _ = acc.get(k, (0, 0.0, 0.0, 0.0, fam))
+                acc[k] = (n + 1, ms + a.elapsed_time(b), f + fl, by + nb, fam)
+        return sorted(({"kernel": k, "family": fam, "launches": n, "ms": ms, "tflops": f / (ms * 1e-3) / 1e12,
+                        "gbytes_per_s": by / (ms * 1e-3) / 1e9, "bytes": by} for k, (n, ms, f, by, fam) in acc.items()),
                       key=lambda r: -r["ms"])
 
     def by_shape(self, family):
@@ -67,6 +71,18 @@ PROFILE: Optional[LaunchProfile] = None
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def _launch_mem(kernel: str, nbytes: float, fn):
+    """Run one bandwidth-bound launch; under bench.py's profiled step also time it (HIP events on the launch stream) with its
+    algorithmic bytes (every operand read once, the result written once)."""
+    if PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    PROFILE.add("memory", e0, e1, 0.0, float(nbytes), None, kernel)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -345,13 +361,16 @@ def groupnorm_spatial(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, 
     st = gn_stats_of(x, h * w)
     if st is not None:
         assert st.shape[0] == n
-        hip.check(hip.lib().ccedit_groupnorm_spatial_apply(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                                           st.data_ptr(), n, h * w, c, eps, int(silu), _stream()),
-                  "ccedit_groupnorm_spatial_apply")
+        _launch_mem("gn_spatial_apply (statistics from the producer)", 4.0 * x.numel(), lambda: hip.check(
+            hip.lib().ccedit_groupnorm_spatial_apply(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                     st.data_ptr(), n, h * w, c, eps, int(silu), _stream()),
+            "ccedit_groupnorm_spatial_apply"))
         return y
-    hip.check(hip.lib().ccedit_groupnorm_spatial(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                                 _stats_ws(n, x.device).data_ptr(), n, h * w, c, eps, int(silu), _stream()),
-              "ccedit_groupnorm_spatial")
+    ws = _stats_ws(n, x.device)
+    _launch_mem("gn_spatial stats + apply (two reads)", 6.0 * x.numel(), lambda: hip.check(
+        hip.lib().ccedit_groupnorm_spatial(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                           ws.data_ptr(), n, h * w, c, eps, int(silu), _stream()),
+        "ccedit_groupnorm_spatial"))
     return y
 
 
@@ -360,8 +379,9 @@ def groupnorm_temporal(x: torch.Tensor, b: int, t: int, gamma, beta, eps: float,
     n, h, w, c = x.shape
     assert n == b * t
     y = torch.empty_like(x)
-    hip.check(hip.lib().ccedit_groupnorm_temporal(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                                  b, t, h * w, c, eps, int(silu), _stream()), "ccedit_groupnorm_temporal")
+    _launch_mem("gn_temporal", 4.0 * x.numel(), lambda: hip.check(
+        hip.lib().ccedit_groupnorm_temporal(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                            b, t, h * w, c, eps, int(silu), _stream()), "ccedit_groupnorm_temporal"))
     return y
 
 
@@ -396,7 +416,8 @@ def row_stats(x2d: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     _chk_act(x2d, "row_stats")
     assert x2d.is_contiguous()
     st = torch.empty((x2d.shape[0], 2), dtype=torch.float32, device=x2d.device)
-    hip.check(hip.lib().ccedit_row_stats(x2d.data_ptr(), st.data_ptr(), x2d.shape[0], x2d.shape[1], eps, _stream()), "ccedit_row_stats")
+    _launch_mem("row_stats", 2.0 * x2d.numel(), lambda: hip.check(
+        hip.lib().ccedit_row_stats(x2d.data_ptr(), st.data_ptr(), x2d.shape[0], x2d.shape[1], eps, _stream()), "ccedit_row_stats"))
     return st
 
 
@@ -424,8 +445,9 @@ def lnf_applicable(m: int, pw) -> bool:
 def layernorm(x2d: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor:
     _chk_act(x2d, "layernorm")
     y = torch.empty_like(x2d)
-    hip.check(hip.lib().ccedit_layernorm(x2d.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                         x2d.shape[0], x2d.shape[1], eps, _stream()), "ccedit_layernorm")
+    _launch_mem("layernorm", 4.0 * x2d.numel(), lambda: hip.check(
+        hip.lib().ccedit_layernorm(x2d.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                   x2d.shape[0], x2d.shape[1], eps, _stream()), "ccedit_layernorm"))
     return y
 
 
@@ -457,7 +479,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, d: 
         e0.record()
         hip.check(hip.lib().ccedit_attention(C.byref(a), _stream()), "ccedit_attention")
         e1.record()
-        PROFILE.add("attention", e0, e1, 4.0 * batches * heads * lq * lk * d, 0.0, (batches, heads, d, lq, lk))
+        nb = 2.0 * heads * d * (2.0 * batches * lq + 2.0 * (batches // kv_div) * lk)          # q, o, k, v once
+        PROFILE.add("attention", e0, e1, 4.0 * batches * heads * lq * lk * d, nb, (batches, heads, d, lq, lk))
         return out
     hip.check(hip.lib().ccedit_attention(C.byref(a), _stream()), "ccedit_attention")
     return out
@@ -498,12 +521,16 @@ def cat_add(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor], gn: boo
     if gn and FUSE_GN_STATS and a.dim() == 4 and (c1 + c2) % 32 == 0 and c1 + c2 <= 2560:
         n, hw = a.shape[0], a.shape[1] * a.shape[2]
         stats = zero_stats(n, a.device)
-        hip.check(hip.lib().ccedit_cat_add_gn(a.data_ptr(), b.data_ptr(), _ptr(c), out.data_ptr(), stats.data_ptr(), n, hw,
-                                              c1, c2, _stream()), "ccedit_cat_add_gn")
+        nb = 2.0 * (a.numel() + b.numel() * (2 if c is not None else 1) + out.numel())
+        _launch_mem("cat_add_gn", nb, lambda: hip.check(
+            hip.lib().ccedit_cat_add_gn(a.data_ptr(), b.data_ptr(), _ptr(c), out.data_ptr(), stats.data_ptr(), n, hw,
+                                        c1, c2, _stream()), "ccedit_cat_add_gn"))
         out._gn_stats = (stats, hw)
         return out
-    hip.check(hip.lib().ccedit_cat_add(a.data_ptr(), b.data_ptr(), _ptr(c), out.data_ptr(), a.numel() // c1, c1, c2,
-                                       _stream()), "ccedit_cat_add")
+    nb = 2.0 * (a.numel() + b.numel() * (2 if c is not None else 1) + out.numel())
+    _launch_mem("cat_add", nb, lambda: hip.check(
+        hip.lib().ccedit_cat_add(a.data_ptr(), b.data_ptr(), _ptr(c), out.data_ptr(), a.numel() // c1, c1, c2,
+                                 _stream()), "ccedit_cat_add"))
     return out
 
 

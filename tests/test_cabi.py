@@ -28,7 +28,8 @@ def test_header_symbols_exported(libpath):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ccedit_hip.h but not exported"
     lib.ccedit_abi_version.restype = ctypes.c_int
-    assert lib.ccedit_abi_version() == 8
+    from ccedit_amd import hip
+    assert lib.ccedit_abi_version() == 9 == hip.ABI_VERSION
 
 
 def test_binding_matches_header(libpath):

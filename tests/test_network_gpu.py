@@ -312,6 +312,75 @@ def test_hip_graph_replay_reproduces_eager_evaluation(g160_wrapper):
         w.reset_caches()
 
 
+def test_failed_graph_capture_falls_back_to_bit_equal_eager_evaluation(g160_wrapper):
+    """A capture that fails AFTER its launches were recorded: the statistics arenas / split-K workspaces handed out during
+    the capture belong to the aborted graph's pool and their zero fills never ran — the eager fallback (that call and every later
+    one) must not continue in them.  The failure is injected; the results must be the eager bits."""
+    import warnings
+    w = g160_wrapper
+    cls = type(w)
+    g = torch.Generator().manual_seed(78)
+    c = dict(crossattn=torch.randn(2, 77, 128, generator=g).cuda(), control_hint=(torch.rand(2, 3, 4, 64, 64, generator=g) * 2 - 1).cuda())
+    xs = [torch.randn(2, 4, 4, 8, 8, generator=g).cuda() for _ in range(3)]
+    t = torch.tensor([500, 500], dtype=torch.int64).cuda()
+    saved = w.use_graph
+    try:
+        w.use_graph = False
+        w.reset_caches()
+        eager = [w(x, t, c).clone() for x in xs]
+        w.use_graph = True
+        w.reset_caches()
+        cls._fail_capture_for_test = True
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            got = [w(x, t, c).clone() for x in xs]              # eager (new key), failing capture -> eager, eager
+        assert cls._graph_failed and any("capture" in str(r.message) for r in rec)
+        for i, (a, b) in enumerate(zip(got, eager)):
+            assert torch.isfinite(a).all() and torch.equal(a, b), f"call {i} after the failed capture differs from the eager evaluation"
+    finally:
+        cls._fail_capture_for_test = False
+        cls._graph_failed = False
+        w.use_graph = saved
+        w.reset_caches()
+
+
+def test_repack_invalidates_captured_graphs_and_hint_stem_cache(g160_wrapper):
+    """A captured graph holds the addresses of the packed weights: after a re-pack with different weights the same
+    conditioning tensors must NOT replay it."""
+    w = g160_wrapper
+    g = torch.Generator().manual_seed(79)
+    c = dict(crossattn=torch.randn(2, 77, 128, generator=g).cuda(), control_hint=(torch.rand(2, 3, 4, 64, 64, generator=g) * 2 - 1).cuda())
+    x = torch.randn(2, 4, 4, 8, 8, generator=g).cuda()
+    t = torch.tensor([321, 321], dtype=torch.int64).cuda()
+    saved = w.use_graph
+    net = w.diffusion_model
+    p = net.out[2].weight                      # the UNet's last conv: scaling it scales eps
+    stem = net.controlnet.input_hint_block[0].weight
+    keep, keep_stem = p.detach().clone(), stem.detach().clone()
+    try:
+        w.use_graph = True
+        w.reset_caches()
+        outs = [w(x, t, c).clone() for _ in range(3)]            # eager, capture, replay
+        assert torch.equal(outs[0], outs[2]) and any("graph" in e for e in w._graphs.values())
+        with torch.no_grad():
+            p.mul_(2.0)
+            stem.mul_(0.5)
+        net.pack(x.device)
+        again = w(x, t, c).clone()
+        w.use_graph = False
+        w.reset_caches()
+        ref = w(x, t, c)
+        assert torch.equal(again, ref), "the evaluation after a re-pack did not use the new weights"
+        assert not torch.equal(again, outs[0])
+    finally:
+        with torch.no_grad():
+            p.copy_(keep)
+            stem.copy_(keep_stem)
+        net.pack(x.device)
+        w.use_graph = saved
+        w.reset_caches()
+
+
 def test_sampler_trajectory_vs_reference_golden(golden_dir, g160_wrapper):
     """DPMPP2SAncestral + VanillaCFGTV2V(7.5) + DiscreteDenoiser, 5 steps, injected noise."""
     from ccedit_amd.config import instantiate_from_config

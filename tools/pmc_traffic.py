@@ -8,10 +8,21 @@ def load(d, name):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != name: continue
             k = r["Kernel_Name"]
-            fam = "tap_gemm" if ("tap_gemm" in k or "g8_kernel" in k or "conv_halo" in k or "small_conv" in k or "lin320" in k or "ff320" in k) else "attn" if ("attn_kernel" in k or "attn_short" in k) else "gn_spatial_stats" if "gn_spatial_stats" in k else \
+            fam = "tap_gemm" if ("tap_gemm" in k or "g8_kernel" in k or "conv_halo" in k or "small_conv" in k or "lin320" in k or "ff320" in k) else "attn" if ("attn_kernel" in k or "attn_short" in k or "attn_spatial" in k or "attn_text" in k) else "gn_spatial_stats" if "gn_spatial_stats" in k else \
                   "gn_spatial_apply" if "gn_spatial_apply" in k else "gn_temporal" if "gn_temporal" in k else "layernorm" if "layernorm" in k else \
                   "cat_add" if "cat_add" in k else "ours_other" if "anonymous namespace" in k or "_GLOBAL__N_" in k else "torch/setup"
             acc[fam][0] += 1; acc[fam][1] += float(r["Counter_Value"])
+    return acc
+def load_symbols(d, name):
+    """the same per kernel SYMBOL (template name without its arguments): what bench.py attaches to its dominant kernel"""
+    import re
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != name: continue
+            m = re.search(r"(\w+_kernel)\b", r["Kernel_Name"])
+            if not m or ("anonymous namespace" not in r["Kernel_Name"] and "_GLOBAL__N_" not in r["Kernel_Name"]): continue
+            acc[m.group(1)][0] += 1; acc[m.group(1)][1] += float(r["Counter_Value"])
     return acc
 f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 print(f"{'family':20s} {'launches':>8s} {'FETCH GB':>10s} {'FETCHx2 GB':>11s} {'WRITE GB':>10s}")
@@ -27,6 +38,9 @@ if os.environ.get("PMC_JSON"):
     from bench import kernel_source_hash
     out = {k: {"launches": f[k][0], "fetch_bytes_x2": 2 * f[k][1] * 1024, "write_bytes": w[k][1] * 1024}
            for k in sorted(set(f) | set(w))}
+    fs_, ws_ = load_symbols(sys.argv[1], "FETCH_SIZE"), load_symbols(sys.argv[2], "WRITE_SIZE")
+    out["by_symbol"] = {k: {"launches": fs_[k][0], "fetch_bytes_x2": 2 * fs_[k][1] * 1024, "write_bytes": ws_[k][1] * 1024}
+                        for k in sorted(set(fs_) | set(ws_))}
     out["kernel_source_hash"] = kernel_source_hash()
     _json.dump(out, open(os.environ["PMC_JSON"], "w"), indent=1)
 
