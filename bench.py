@@ -282,6 +282,12 @@ def main():
             for fam in ("tap_gemm", "attention"):
                 for shape, n, ms, tf in ops.PROFILE.by_shape(fam)[:int(os.environ.get('CCEDIT_BREAKDOWN_ROWS', '40'))]:
                     print(f"{fam:9s} {str(shape):60s} x{n:3d} {ms:8.3f} ms {tf:7.1f} TF/s", file=sys.stderr)
+            mem = {}
+            for a_, b_, _, nb, shape, _k in ops.PROFILE.records.get("memory", []):
+                e = mem.setdefault(shape, [0, 0.0, 0.0])
+                e[0] += 1; e[1] += a_.elapsed_time(b_); e[2] += nb
+            for shape, (n, ms, nb) in sorted(mem.items(), key=lambda kv: -kv[1][1]):
+                print(f"memory    {str(shape):60s} x{n:3d} {ms:8.3f} ms {nb / (ms * 1e-3) / 1e9:7.0f} GB/s", file=sys.stderr)
         by_kernel = []
         for r in ops.PROFILE.by_kernel():
             row = dict(kernel=r["kernel"], launches=r["launches"], ms=round(r["ms"], 3), alg_bytes_per_launch=round(r["bytes"] / r["launches"]))

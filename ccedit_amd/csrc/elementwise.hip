@@ -69,69 +69,82 @@ __global__ void cat_add_kernel(const bf16* __restrict__ a, const bf16* __restric
     }
 }
 
-// The same concatenation, one wave per pixel row, also accumulating the GroupNorm(32, C1+C2) statistics of the
-// tensor it writes (the decoder's in_layers.0 reads them instead of re-reading the tensor): lane l owns granules
-// l, l+64, ... of the row; block-level reduction in LDS, then 64 global atomics per block.
-constexpr int kCatCols = 5;       // C1 + C2 <= 2560
-__global__ __launch_bounds__(256) void cat_add_gn_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b,
+// The same concatenation, also accumulating the GroupNorm(32, C1+C2) statistics of the tensor it writes (the decoder's in_layers.0
+// reads them instead of re-reading the tensor).  A thread owns ONE 16-byte granule column of the output row (its source — a, or
+// b + c — is fixed, so there is no divergence inside a wave except at the seam) and walks rows RS apart, four rows in flight:
+// 16 statistics registers per thread instead of 80, eight waves per SIMD, every lane busy at every width (round 3's kernel gave a
+// wave one row and left 40 of 64 lanes idle at 640 channels: 0.6 - 3.4 TB/s).  Per-channel sums meet in LDS slots that each have ONE
+// writer, are added per group in a fixed order, and only the cross-workgroup sum uses (double) atomics: same bits every run.
+constexpr int kCatMaxC = 2560;
+__global__ __launch_bounds__(320) void cat_add_gn_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b,
                                                          const bf16* __restrict__ c, bf16* __restrict__ out,
                                                          double* __restrict__ stats, int hw, int C1, int C2,
-                                                         int pix_per_block) {
-    __shared__ float sS[4][64];           // one slot set per wave, summed in a fixed order (reproducible, see norm.hip)
+                                                         int rows_per_block, int RS) {
+    extern __shared__ __attribute__((aligned(16))) char cat_smem[];
+    float* const csum = (float*)cat_smem;                 // [RS][C] sums, then [RS][C] sums of squares
+    const int C = C1 + C2, gt = C >> 3, g1 = C1 >> 3, cpg = C >> 5;
+    float* const csq = csum + RS * C;
     const int frame = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g1 = C1 >> 3, gt = (C1 + C2) >> 3, cpg = (C1 + C2) >> 5;
-    (&sS[0][0])[threadIdx.x] = 0.f;
-    __syncthreads();
-    float sum[kCatCols][8], sq[kCatCols][8];
+    const int rs = threadIdx.x / gt, g = threadIdx.x - rs * gt;          // row lane, granule column
+    const int p0 = blockIdx.x * rows_per_block, p1 = min(p0 + rows_per_block, hw);
+    const bool from_a = g < g1;
+    const bf16* src0 = from_a ? a + g * 8 : b + (g - g1) * 8;
+    const bf16* src1 = (!from_a && c) ? c + (g - g1) * 8 : nullptr;
+    const int ld = from_a ? C1 : C2;
+    float sum[8], sq[8];
 #pragma unroll
-    for (int k = 0; k < kCatCols; ++k)
+    for (int e = 0; e < 8; ++e) sum[e] = sq[e] = 0.f;
+    auto emit = [&](int64_t row, bf16x8 u, bf16x8 w) {
+        bf16x8 v = u;
+        if (src1) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sum[k][e] = sq[k][e] = 0.f;
-    const int p1 = min((int)(blockIdx.x + 1) * pix_per_block, hw);
-    for (int pix = blockIdx.x * pix_per_block + wave; pix < p1; pix += 4) {
-        const int64_t row = (int64_t)frame * hw + pix;
+            for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(u[e]) + bf2f(w[e]));
+        }
+        *(bf16x8*)(out + row * C + g * 8) = v;
 #pragma unroll
-        for (int k = 0; k < kCatCols; ++k) {
-            const int g = lane + 64 * k;
-            if (g < gt) {
-                bf16x8 v;
-                if (g < g1) {
-                    v = *(const bf16x8*)(a + row * C1 + g * 8);
-                } else {
-                    v = *(const bf16x8*)(b + row * C2 + (g - g1) * 8);
-                    if (c) {
-                        const bf16x8 w = *(const bf16x8*)(c + row * C2 + (g - g1) * 8);
+        for (int e = 0; e < 8; ++e) {
+            const float f = bf2f(v[e]);
+            sum[e] += f;
+            sq[e] += f * f;
+        }
+    };
+    if (rs < RS) {
+        int pix = p0 + rs;
+        for (; pix + 3 * RS < p1; pix += 4 * RS) {              // four rows of this column in flight
+            bf16x8 u[4], w[4];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(w[e]));
-                    }
-                }
-                *(bf16x8*)(out + row * (C1 + C2) + g * 8) = v;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = bf2f(v[e]);
-                    sum[k][e] += f;
-                    sq[k][e] += f * f;
-                }
+            for (int k = 0; k < 4; ++k) {
+                const int64_t row = (int64_t)frame * hw + pix + k * RS;
+                u[k] = *(const bf16x8*)(src0 + row * ld);
+                if (src1) w[k] = *(const bf16x8*)(src1 + row * ld);
+                else w[k] = u[k];
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) emit((int64_t)frame * hw + pix + k * RS, u[k], w[k]);
+        }
+        for (; pix < p1; pix += RS) {
+            const int64_t row = (int64_t)frame * hw + pix;
+            const bf16x8 u = *(const bf16x8*)(src0 + row * ld);
+            emit(row, u, src1 ? *(const bf16x8*)(src1 + row * ld) : u);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            csum[rs * C + g * 8 + e] = sum[e];
+            csq[rs * C + g * 8 + e] = sq[e];
         }
     }
-#pragma unroll
-    for (int k = 0; k < kCatCols; ++k) {
-        const int g = lane + 64 * k;
-        if (g < gt) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int grp = (g * 8 + e) / cpg;
-                atomicAdd(&sS[wave][grp * 2], sum[k][e]);
-                atomicAdd(&sS[wave][grp * 2 + 1], sq[k][e]);
-            }
-        }
-    }
     __syncthreads();
-    if (threadIdx.x < 64)
-        unsafeAtomicAdd(&stats[frame * 64 + threadIdx.x], (double)sS[0][threadIdx.x] + (double)sS[1][threadIdx.x] +
-                                                              (double)sS[2][threadIdx.x] + (double)sS[3][threadIdx.x]);
+    if (threadIdx.x < 64) {                                      // thread (group, sum | sum of squares): fixed summation order
+        const int grp = threadIdx.x >> 1;
+        const float* src = (threadIdx.x & 1) ? csq : csum;
+        double t = 0.0;
+        for (int r = 0; r < RS; ++r) {
+            float part = 0.f;
+            for (int ch = grp * cpg; ch < (grp + 1) * cpg; ++ch) part += src[r * C + ch];
+            t += (double)part;
+        }
+        unsafeAtomicAdd(&stats[frame * 64 + threadIdx.x], t);
+    }
 }
 
 __global__ void add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ y, int64_t n8) {
@@ -339,12 +352,15 @@ extern "C" int ccedit_cat_add(const void* a, const void* b, const void* c, void*
 extern "C" int ccedit_cat_add_gn(const void* a, const void* b, const void* c, void* out, double* stats, int32_t frames,
                                  int32_t hw, int32_t C1, int32_t C2, void* stream) {
     CC_CHECK_ARG(a && b && out && stats && frames > 0 && hw > 0, "ccedit_cat_add_gn: bad args");
-    CC_UNSUPPORTED(C1 % 8 || C2 % 8 || (C1 + C2) % 32 || C1 + C2 > kCatCols * 512,
-                   "ccedit_cat_add_gn: C1=%d C2=%d (multiples of 8, sum a multiple of 32 and <= %d)", C1, C2, kCatCols * 512);
-    int ppb = 256;
-    while (ppb > 32 && (int64_t)((hw + ppb - 1) / ppb) * frames < 1024) ppb >>= 1;
-    hipLaunchKernelGGL(cat_add_gn_kernel, dim3((hw + ppb - 1) / ppb, frames), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)a, (const bf16*)b, (const bf16*)c, (bf16*)out, stats, hw, C1, C2, ppb);
+    CC_UNSUPPORTED(C1 % 8 || C2 % 8 || (C1 + C2) % 32 || C1 + C2 > kCatMaxC || C1 + C2 < 64,
+                   "ccedit_cat_add_gn: C1=%d C2=%d (multiples of 8, sum a multiple of 32, 64 <= sum <= %d)", C1, C2, kCatMaxC);
+    const int C = C1 + C2, gt = C / 8;
+    int RS = 320 / gt;                       // rows a workgroup works on side by side
+    RS = RS < 1 ? 1 : (RS > 4 ? 4 : RS);
+    int ppb = 256;                           // rows per workgroup: as many as still leave ~2000 workgroups
+    while (ppb > 8 * RS && (int64_t)((hw + ppb - 1) / ppb) * frames < 2048) ppb >>= 1;
+    hipLaunchKernelGGL(cat_add_gn_kernel, dim3((hw + ppb - 1) / ppb, frames), dim3(gt * RS), 2 * RS * C * sizeof(float),
+                       (hipStream_t)stream, (const bf16*)a, (const bf16*)b, (const bf16*)c, (bf16*)out, stats, hw, C1, C2, ppb, RS);
     return cc_launch_status("cat_add_gn");
 }
 

@@ -5,6 +5,7 @@
 // 16-byte granules (8 channels) l, l+64, l+128, ... of the row, so a wave's load of one pixel is a
 // single contiguous, fully coalesced C*2-byte burst and per-channel affine parameters live in registers.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -159,6 +160,72 @@ __global__ __launch_bounds__(256) void gn_spatial_apply_kernel(const bf16* __res
             }
         }
     }
+}
+
+// One-pass form for small frames (the 8x12 level: 96 pixels x 40 channels per group = 7.7 KB): a workgroup owns one (frame, group),
+// keeps its hw x (C/32) values in registers between the statistics and the normalisation — one read, one write, one launch, where
+// the general path is a zero-fill, a statistics kernel and an apply kernel over a tensor the caches hold anyway (38 us per site
+// against 8; 21 sites per step have no producer statistics at that level).  C % 256 == 0 (a group is whole 16-byte granules),
+// at most 8 granules per thread.  Fixed summation order: lanes -> wave (butterfly), waves in index order.
+constexpr int kGnOneUnits = 8;
+__global__ __launch_bounds__(256) void gn_spatial_onepass_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 int hw, int C, float eps, int silu) {
+    __shared__ float s_part[4][2];
+    const int frame = blockIdx.y, grp = blockIdx.x;
+    const int cpg = C >> 5, gpg = cpg >> 3;                 // channels / granules per group
+    const int units = hw * gpg;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bf16* xf = x + (size_t)frame * hw * C + grp * cpg;
+    bf16* yf = y + (size_t)frame * hw * C + grp * cpg;
+    bf16x8 v[kGnOneUnits];
+    int off[kGnOneUnits];
+#pragma unroll
+    for (int k = 0; k < kGnOneUnits; ++k) {
+        const int u = k * 256 + threadIdx.x;
+        const int pix = u / gpg, gr = u - pix * gpg;
+        off[k] = u < units ? pix * C + gr * 8 : -1;
+        if (off[k] >= 0) v[k] = *(const bf16x8*)(xf + off[k]);
+    }
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < kGnOneUnits; ++k)
+        if (off[k] >= 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = bf2f(v[k][e]);
+                s += f;
+                q += f * f;
+            }
+        }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) {
+        s_part[wave][0] = s;
+        s_part[wave][1] = q;
+    }
+    __syncthreads();
+    const float ts = (s_part[0][0] + s_part[1][0]) + (s_part[2][0] + s_part[3][0]);
+    const float tq = (s_part[0][1] + s_part[1][1]) + (s_part[2][1] + s_part[3][1]);
+    const float inv_n = 1.0f / ((float)cpg * (float)hw);
+    const float mean = ts * inv_n;
+    const float rstd = rsqrtf(fmaxf(tq * inv_n - mean * mean, 0.f) + eps);
+#pragma unroll
+    for (int k = 0; k < kGnOneUnits; ++k)
+        if (off[k] >= 0) {
+            const int c0 = grp * cpg + (off[k] % C);                       // (off % C = granule offset inside the group slice)
+            const f32x4 ga0 = *(const f32x4*)(gamma + c0), ga1 = *(const f32x4*)(gamma + c0 + 4);
+            const f32x4 be0 = *(const f32x4*)(beta + c0), be1 = *(const f32x4*)(beta + c0 + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = rstd * (e < 4 ? ga0[e & 3] : ga1[e & 3]);
+                float f = (bf2f(v[k][e]) - mean) * a + (e < 4 ? be0[e & 3] : be1[e & 3]);
+                if (silu) f = silu_f(f);
+                o[e] = f2bf(f);
+            }
+            *(bf16x8*)(yf + off[k]) = o;
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -353,6 +420,102 @@ __global__ __launch_bounds__(256) void gn_temporal_cached_kernel(const bf16* __r
     }
 #pragma unroll
     for (int t = 0; t < kGtCacheT; ++t)
+        if (t < T) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = bf2f(cache[t][e]) * a[e] + bb[e];
+                if (silu) f = silu_f(f);
+                o[e] = f2bf(f);
+            }
+            *(bf16x8*)(yb + t * fstride) = o;
+        }
+}
+
+// The same single sweep with every lane busy: a THREAD owns one 16-byte granule of one pixel (all T rows of it in registers),
+// consecutive threads walk the granules of a pixel and then the next pixel — [pixels][C] is contiguous, so a wave's load is one
+// 1 KB burst whatever C is (the wave-per-(pixel, slice) mapping above runs 40 of 64 lanes at C = 320 / 640 / 1280: 2.7 - 3.9 TB/s).
+// 320 threads = 8 / 4 / 2 pixels of 320 / 640 / 1280 channels.  Statistics: every thread writes the sums of the (at most two) groups
+// its granule touches into its OWN LDS slot; one thread per (pixel, group) adds the two or three granules of that group in
+// ascending order — no atomics, same bits every run.  C % 320 == 0, C / 32 >= 8.
+constexpr int kGtFlatThreads = 320;
+template <int CT>            // rows cached per thread (>= T): 17 for the 17-keyframe clips — 12 registers fewer than the general 20
+__global__ __launch_bounds__(kGtFlatThreads) void gn_temporal_flat_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                          int64_t npix, int T, int hw, int C, float eps, int silu) {
+    __shared__ f32x4 s_part[kGtFlatThreads];                 // per granule: (sum, sq) of its first group part, (sum, sq) of its second
+    __shared__ f32x2 s_stat[8 * 32];                         // per (pixel of the block, group): mean, rstd
+    const int gpp = C >> 3, cpg = C >> 5;
+    const int ppb = kGtFlatThreads / gpp;                    // pixels per block
+    const int pl = threadIdx.x / gpp, gc = threadIdx.x - pl * gpp;
+    const int64_t gp = (int64_t)blockIdx.x * ppb + pl;       // (clip, pixel) index
+    const bool on = gp < npix;
+    const int64_t b = on ? gp / hw : 0;
+    const int64_t pix = on ? gp - b * hw : 0;
+    const size_t fstride = (size_t)hw * C;
+    const bf16* xb = x + ((size_t)b * T * hw + pix) * C + gc * 8;
+    bf16* yb = y + ((size_t)b * T * hw + pix) * C + gc * 8;
+    bf16x8 cache[CT];
+    const int g0 = (gc * 8) / cpg, split = (g0 + 1) * cpg - gc * 8;       // channels [0, split) of the granule belong to group g0
+    if (on) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+            if (t < T) cache[t] = *(const bf16x8*)(xb + t * fstride);
+        float sum[8], sq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] = sq[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+            if (t < T) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = bf2f(cache[t][e]);
+                    sum[e] += f;
+                    sq[e] += f * f;
+                }
+            }
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool first = e < split;
+            s0 += first ? sum[e] : 0.f;
+            q0 += first ? sq[e] : 0.f;
+            s1 += first ? 0.f : sum[e];
+            q1 += first ? 0.f : sq[e];
+        }
+        s_part[threadIdx.x] = f32x4{s0, q0, s1, q1};
+    }
+    __syncthreads();
+    if (threadIdx.x < ppb * 32) {
+        const int p = threadIdx.x >> 5, g = threadIdx.x & 31;
+        const int gr0 = (g * cpg) >> 3, gr1 = ((g + 1) * cpg - 1) >> 3;    // granules that hold channels of group g
+        float ts = 0.f, tq = 0.f;
+        for (int gr = gr0; gr <= gr1; ++gr) {
+            const f32x4 pt = s_part[p * gpp + gr];
+            const bool first = (gr * 8) / cpg == g;                         // is g the granule's first group?
+            ts += first ? pt[0] : pt[2];
+            tq += first ? pt[1] : pt[3];
+        }
+        const float inv_n = 1.0f / ((float)cpg * (float)T);
+        const float mean = ts * inv_n;
+        s_stat[p * 32 + g] = f32x2{mean, rsqrtf(fmaxf(tq * inv_n - mean * mean, 0.f) + eps)};
+    }
+    __syncthreads();
+    if (!on) return;
+    float a[8], bb[8];
+    {
+        const f32x4 ga0 = *(const f32x4*)(gamma + gc * 8), ga1 = *(const f32x4*)(gamma + gc * 8 + 4);
+        const f32x4 be0 = *(const f32x4*)(beta + gc * 8), be1 = *(const f32x4*)(beta + gc * 8 + 4);
+        const f32x2 st0 = s_stat[pl * 32 + g0], st1 = s_stat[pl * 32 + min(g0 + 1, 31)];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool first = e < split;
+            a[e] = (first ? st0[1] : st1[1]) * (e < 4 ? ga0[e & 3] : ga1[e & 3]);
+            bb[e] = (e < 4 ? be0[e & 3] : be1[e & 3]) - (first ? st0[0] : st1[0]) * a[e];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
         if (t < T) {
             bf16x8 o;
 #pragma unroll
@@ -588,6 +751,10 @@ extern "C" int ccedit_groupnorm_spatial(const void* x, void* y, const float* gam
     CC_UNSUPPORTED(C % 32 != 0 || C > kMaxCols * 512, "ccedit_groupnorm_spatial: C=%d (need C%%32==0, C<=%d)", C,
                    kMaxCols * 512);
     hipStream_t s = (hipStream_t)stream;
+    if (C % 256 == 0 && (int64_t)hw * (C / 256) <= 256 * kGnOneUnits) {       // small frames: one pass, one launch
+        hipLaunchKernelGGL(gn_spatial_onepass_kernel, dim3(32, frames), dim3(256), 0, s, (const bf16*)x, (bf16*)y, gamma, beta, hw, C, eps, silu);
+        return cc_launch_status("groupnorm_spatial (one pass)");
+    }
     // (a kernel, not hipMemsetAsync: the runtime's fill of these 17 KB takes ~23 us of device time per call, 0.5 ms per step)
     hipLaunchKernelGGL(zero_f64_kernel, dim3((unsigned)((64 * frames + 255) / 256)), dim3(256), 0, s, stats_ws, 64 * frames);
     const int apb = gn_pix_per_block(hw, frames, 4, 2048);
@@ -625,7 +792,18 @@ extern "C" int ccedit_groupnorm_temporal(const void* x, void* y, const float* ga
     dim3 grid((unsigned)((waves + 3) / 4));
     int nsl = 1;                                   // channel slices: whole groups, at most 512 channels each
     while (nsl < 32 && C / nsl > 512) nsl <<= 1;
-    if (T <= kGtCacheT && (C >> 3) % nsl == 0) {
+    static const int flat_env = getenv("CCEDIT_GN_FLAT") ? atoi(getenv("CCEDIT_GN_FLAT")) : 1;      // 0: A/B against the wave-per-slice mapping
+    // (measured, 2 x 17 frames: 70 / 38 us against 73 / 40 at 64x96 / 32x48; the small levels — a few hundred workgroups — are
+    //  1 - 2 us better with the wave-per-slice mapping's larger grid)
+    if (flat_env && T <= kGtCacheT && C % 320 == 0 && C <= 1280 && waves * (C >> 3) >= 700 * kGtFlatThreads) {
+        const int ppb = kGtFlatThreads / (C >> 3);
+        if (T <= 17)
+            hipLaunchKernelGGL(gn_temporal_flat_kernel<17>, dim3((unsigned)((waves + ppb - 1) / ppb)), dim3(kGtFlatThreads), 0, (hipStream_t)stream,
+                               (const bf16*)x, (bf16*)y, gamma, beta, waves, T, hw, C, eps, silu);
+        else
+            hipLaunchKernelGGL(gn_temporal_flat_kernel<kGtCacheT>, dim3((unsigned)((waves + ppb - 1) / ppb)), dim3(kGtFlatThreads), 0, (hipStream_t)stream,
+                               (const bf16*)x, (bf16*)y, gamma, beta, waves, T, hw, C, eps, silu);
+    } else if (T <= kGtCacheT && (C >> 3) % nsl == 0) {
         const int64_t nw = waves * nsl;
         hipLaunchKernelGGL(gn_temporal_cached_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16*)x, (bf16*)y, gamma, beta, B, T, hw, C, nsl, eps, silu);

@@ -73,7 +73,7 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def _launch_mem(kernel: str, nbytes: float, fn):
+def _launch_mem(kernel: str, nbytes: float, fn, shape=None):
     """Run one bandwidth-bound launch; under bench.py's profiled step also time it (HIP events on the launch stream) with its
     algorithmic bytes (every operand read once, the result written once)."""
     if PROFILE is None:
@@ -82,7 +82,7 @@ def _launch_mem(kernel: str, nbytes: float, fn):
     e0.record()
     fn()
     e1.record()
-    PROFILE.add("memory", e0, e1, 0.0, float(nbytes), None, kernel)
+    PROFILE.add("memory", e0, e1, 0.0, float(nbytes), (kernel,) + tuple(shape or ()), kernel)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -364,13 +364,13 @@ def groupnorm_spatial(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, 
         _launch_mem("gn_spatial_apply (statistics from the producer)", 4.0 * x.numel(), lambda: hip.check(
             hip.lib().ccedit_groupnorm_spatial_apply(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                      st.data_ptr(), n, h * w, c, eps, int(silu), _stream()),
-            "ccedit_groupnorm_spatial_apply"))
+            "ccedit_groupnorm_spatial_apply"), (n, h, w, c))
         return y
     ws = _stats_ws(n, x.device)
     _launch_mem("gn_spatial stats + apply (two reads)", 6.0 * x.numel(), lambda: hip.check(
         hip.lib().ccedit_groupnorm_spatial(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                            ws.data_ptr(), n, h * w, c, eps, int(silu), _stream()),
-        "ccedit_groupnorm_spatial"))
+        "ccedit_groupnorm_spatial"), (n, h, w, c))
     return y
 
 
@@ -381,7 +381,7 @@ def groupnorm_temporal(x: torch.Tensor, b: int, t: int, gamma, beta, eps: float,
     y = torch.empty_like(x)
     _launch_mem("gn_temporal", 4.0 * x.numel(), lambda: hip.check(
         hip.lib().ccedit_groupnorm_temporal(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                            b, t, h * w, c, eps, int(silu), _stream()), "ccedit_groupnorm_temporal"))
+                                            b, t, h * w, c, eps, int(silu), _stream()), "ccedit_groupnorm_temporal"), (n, h, w, c))
     return y
 
 
@@ -447,7 +447,7 @@ def layernorm(x2d: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor
     y = torch.empty_like(x2d)
     _launch_mem("layernorm", 4.0 * x2d.numel(), lambda: hip.check(
         hip.lib().ccedit_layernorm(x2d.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                   x2d.shape[0], x2d.shape[1], eps, _stream()), "ccedit_layernorm"))
+                                   x2d.shape[0], x2d.shape[1], eps, _stream()), "ccedit_layernorm"), tuple(x2d.shape))
     return y
 
 
@@ -524,7 +524,7 @@ def cat_add(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor], gn: boo
         nb = 2.0 * (a.numel() + b.numel() * (2 if c is not None else 1) + out.numel())
         _launch_mem("cat_add_gn", nb, lambda: hip.check(
             hip.lib().ccedit_cat_add_gn(a.data_ptr(), b.data_ptr(), _ptr(c), out.data_ptr(), stats.data_ptr(), n, hw,
-                                        c1, c2, _stream()), "ccedit_cat_add_gn"))
+                                        c1, c2, _stream()), "ccedit_cat_add_gn"), (n, hw, c1, c2))
         out._gn_stats = (stats, hw)
         return out
     nb = 2.0 * (a.numel() + b.numel() * (2 if c is not None else 1) + out.numel())

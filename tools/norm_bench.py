@@ -28,3 +28,16 @@ for (h, w, c) in [(64, 96, 320), (32, 48, 640), (16, 24, 1280), (8, 12, 1280)]:
     tl = timeit(lambda: ops.layernorm(nxt().view(-1, c), g, b))
     print(f"{h}x{w} C={c} ({mb:.0f} MB): spatial GN {ts:.1f} us ({3*mb/ts/1e3:.2f} TB/s of 3 passes)  "
           f"temporal GN {tt:.1f} us ({2*mb/tt/1e3:.2f} TB/s of 2 passes)  LN {tl:.1f} us ({2*mb/tl/1e3:.2f} TB/s)")
+
+# concatenation + statistics (decoder skip joins) at the shapes of the step
+for (hw_, c1, c2) in [((64, 96), 320, 320), ((64, 96), 640, 320), ((32, 48), 1280, 640), ((32, 48), 640, 640), ((16, 24), 1280, 1280), ((8, 12), 1280, 1280)]:
+    h, w = hw_
+    n = B * T
+    sets = [(torch.randn(n, h, w, c1, device="cuda").to(torch.bfloat16), torch.randn(n, h, w, c2, device="cuda").to(torch.bfloat16),
+             torch.randn(n, h, w, c2, device="cuda").to(torch.bfloat16)) for _ in range(4 if h >= 32 else 10)]
+    i = [0]
+    def nxt3():
+        i[0] = (i[0] + 1) % len(sets); return sets[i[0]]
+    t = timeit(lambda: ops.cat_add(*nxt3(), gn=True))
+    mb = n * h * w * (2 * c1 + 3 * c2) * 2 / 1e6
+    print(f"cat_add_gn {h}x{w} {c1}+{c2} ({mb:.0f} MB): {t:.1f} us ({mb/t/1e3:.2f} TB/s)")
