@@ -620,7 +620,11 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         const int chw = ch0 + wr * CW;                                   // this wave's first channel (packed row)
         // GroupNorm statistics: a wave's 32-pixel tile tjf lies inside one 128-pixel block of the output tile, and frames are whole
         // numbers of such blocks (gn_rows % 128 == 0, e.g. 384 at the 16x24 level): the frame is taken per tjf and flushed per tjf
+#ifdef G8_PROBE
+        const bool gn = false;                       // (probe builds borrow the gn_stats pointer for their stamps)
+#else
         const bool gn = d.gn_stats != nullptr;
+#endif
         auto gn_slots = [&](int tjf) { return d.gn_stats + (size_t)(min(pix0 + pixbase(tjf), d.M - 1) / d.gn_rows) * 64; };
         float ln_rstd[LNF ? NJ : 1];                 // LNF: rstd of this lane's pixel of every pixel tile (the accumulators hold W' x / 1 - ...)
         if constexpr (LNF) {

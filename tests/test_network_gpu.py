@@ -541,12 +541,13 @@ def test_full_width_network_vs_oracle():
     assert r < NET_TOL
 
 
-def test_tvi2v_network_eval_vs_reference_golden(golden_dir):
-    """BASELINE.json config 3 path: controlnet_img (cond_feat) + anchor cross-frame attention (two-segment KV)."""
+@pytest.mark.parametrize("fname", ["net_tvi2v_g160.npz", "net_tvi2v_g160_t17.npz"])
+def test_tvi2v_network_eval_vs_reference_golden(golden_dir, fname):
+    """BASELINE.json config 3 path: controlnet_img (cond_feat) + anchor cross-frame attention (two-segment KV); T = 3 and T = 17."""
     _need_gpu()
     from ccedit_amd.sgm_compat import build_network
     from ccedit_amd.utils.synth import fill_module_
-    z = np.load(os.path.join(golden_dir, "net_tvi2v_g160.npz"))
+    z = np.load(os.path.join(golden_dir, fname))
     w = build_network("cpu", crossframe=True, **G160)
     fill_module_(w, prefix="model.")
     w.diffusion_model.pack("cuda")

@@ -239,11 +239,12 @@ def test_clip_text_encoder_matches_transformers(golden_dir):
     assert rel < 1e-5, f"clip text rel rms err {rel}"
 
 
-def test_tvi2v_network_eval_matches_reference(golden_dir):
+@pytest.mark.parametrize("fname", ["net_tvi2v_g160.npz", "net_tvi2v_g160_t17.npz"])
+def test_tvi2v_network_eval_matches_reference(golden_dir, fname):
     """TVI2V branch (BASELINE.json config 3): controlnet_img on `cond_feat` + SpatialTransformer3DCA
-    anchor cross-frame attention, against the reference's own output."""
+    anchor cross-frame attention, against the reference's own output (T = 3 at 16x24 and T = 17 at 8x16)."""
     from ccedit_amd.sgm_compat import build_network_spec
-    z = np.load(os.path.join(golden_dir, "net_tvi2v_g160.npz"))
+    z = np.load(os.path.join(golden_dir, fname))
     cfg = O.NetConfig(model_channels=160, num_heads=4, context_dim=128, crossframe=True)
     spec = build_network_spec(dict(model_channels=160, num_heads=4, context_dim=128, crossframe=True))
     with open(os.path.join(golden_dir, "keys_tvi2v_g160.json")) as f:

@@ -5,5 +5,5 @@ cd "$(dirname "$0")/../../ccedit_amd/csrc"
 out=$1; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DG8_PROBE "$@" -x hip -c gemm8p.hip -o /tmp/gemm8p_probe.o
 objs=""
-for f in gemm convhalo smallconv lin320 ff320 norm attention attnshort elementwise core; do objs="$objs $f.o"; done
+for f in gemm convhalo smallconv lin320 ff320 norm attention attnspatial attnshort attntext elementwise core; do objs="$objs $f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/gemm8p_probe.o -o "$out"

@@ -58,6 +58,13 @@ def run(m, n, k, geglu=False, res=False, tile=11):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:            # M,N,K[,res][,geglu][,tile=T] ...
+        for spec in sys.argv[1:]:
+            f = spec.split(",")
+            kw = dict(res="res" in f, geglu="geglu" in f)
+            kw.update({"tile": int(x[5:]) for x in f if x.startswith("tile=")})
+            run(int(f[0]), int(f[1]), int(f[2]), **kw)
+        sys.exit(0)
     run(52224, 5120, 640)
     run(52224, 5120, 640, geglu=True)
     run(13056, 10240, 1280, geglu=True)
