@@ -157,8 +157,10 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
             const int n = (int)(m / hwout);
             const int rem = (int)(m - (int64_t)n * hwout);
             const int oy = rem / d.Wout, ox = rem - oy * d.Wout;
-            ra[i] = ok ? oy * d.stride - d.pad : -100000;
-            rb[i] = ox * d.stride - d.pad;
+            // subpix: parity (py, px) of an upsample + 3x3 conv on the low-resolution source — a 2 x 2 window starting at (oy - 1 + py, ox - 1 + px)
+            const int pad_y = d.subpix ? 1 - ((d.subpix - 1) >> 1) : d.pad, pad_x = d.subpix ? 1 - ((d.subpix - 1) & 1) : d.pad;
+            ra[i] = ok ? oy * d.stride - pad_y : -100000;
+            rb[i] = ox * d.stride - pad_x;
             rrow[i] = (MODE == M_CONV) ? n * d.Hin * d.Win + ra[i] * d.Win + rb[i] : n * d.Hin * d.Win;
         } else if constexpr (MODE == M_TEMPORAL) {
             const int frame = (int)(m / d.HW);
@@ -440,6 +442,12 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         CC_CHECK_ARG(d.ksize * d.ksize == d.taps && d.Hin > 0 && d.Win > 0 && d.Hout > 0 && d.Wout > 0 && d.stride > 0,
                      "ccedit_gemm: bad conv2d geometry");
         CC_CHECK_ARG(d.M % ((int64_t)d.Hout * d.Wout) == 0, "ccedit_gemm: M not a whole number of frames");
+        CC_CHECK_ARG(d.subpix >= 0 && d.subpix <= 4, "ccedit_gemm: subpix must be 0..4");
+        CC_UNSUPPORTED(d.subpix && (d.ksize != 2 || d.stride != 1 || d.upsample || d.Hin != d.Hout || d.Win != d.Wout || d.gn_stats || d.A2 ||
+                                    4 * d.M >= (1LL << 31)),
+                       "ccedit_gemm: subpix needs ksize 2, stride 1, a same-size low-resolution frame, no gn_stats / second source");
+    } else if (d.subpix) {
+        CC_CHECK_ARG(false, "ccedit_gemm: subpix is a CONV2D mode");
     } else if (d.mode == CCEDIT_GEMM_TEMPORAL) {
         CC_CHECK_ARG(d.T > 0 && d.HW > 0 && d.M % ((int64_t)d.T * d.HW) == 0, "ccedit_gemm: bad temporal geometry");
         CC_CHECK_ARG(d.taps % 2 == 1, "ccedit_gemm: temporal taps must be odd");
@@ -504,7 +512,7 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         return cc_g8_launch(d, s, 1);
     // Few tiles, long K (the 8x12 level: 3264 pixels x 1280 channels = 65 tiles of 256 x 256, K loops of 60-360 K tiles — a quarter of the
     // chip busy for the whole loop on any block shape): split-K in the persistent kernel when the caller lent a workspace.
-    if (d.tile == 0 && g8_env0 && d.workspace && cc_g8_split(d, 0) > 1 && d.workspace_bytes >= cc_g8_workspace_bytes(d, 0))
+    if (d.tile == 0 && g8_env0 && !d.subpix && d.workspace && cc_g8_split(d, 0) > 1 && d.workspace_bytes >= cc_g8_workspace_bytes(d, 0))
         return cc_g8_launch(d, s, 1);
     static const int halo_env = getenv("CCEDIT_CONV_HALO") ? atoi(getenv("CCEDIT_CONV_HALO")) : 1;   // 0: A/B against the gather path
     if ((d.tile == 0 && halo_env) || d.tile == 8) {
@@ -529,7 +537,7 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     // and the single CFG halves (two-stream execution): 26112 x 5120 <- 640 GEGLU 945 / 588, 6528 x 10240 <- 1280 GEGLU 964 / 677.
     // Not below 4096 rows (fewer than ~100 tiles: most CUs idle) and not for K = 320 (lin320 / ff320 own those).
     static const int g8_env = getenv("CCEDIT_G8") ? atoi(getenv("CCEDIT_G8")) : 1;      // 0: A/B against the older block shapes
-    if (d.tile == 0 && g8_env && d.M >= 4096 && d.Kpad >= 640 && d.N >= 640 && cc_g8_applicable(d, 0)) {
+    if (d.tile == 0 && g8_env && !d.subpix && d.M >= 4096 && d.Kpad >= 640 && d.N >= 640 && cc_g8_applicable(d, 0)) {
         // Conv1d k3 over T: the same K loop with the activation rows gathered HW rows away (cold sweep, + residual, against the
         // best older shape: 32x48 640->640 746 / 703, 1280->1280 1034 / 883; 16x24 1280->1280 981 / 917; 64x96 640->640 801 / 692 —
         // and 507 / 519 at 320->320, where three 128-channel tiles re-read every activation row: those stay on tap_gemm, N >= 640 above).

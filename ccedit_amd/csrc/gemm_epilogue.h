@@ -3,6 +3,15 @@
 // bias, SiLU / quick-GELU / GEGLU, two residuals and the optional GroupNorm(32) statistics of the tensor written.
 #pragma once
 #include "common.h"
+// Output row of GEMM row m: m itself, or — CcGemmDesc.subpix — the pixel (2 oy + py, 2 ox + px) of the 2x-upsampled frame
+__device__ __forceinline__ size_t cc_out_row(const CcGemmDesc& d, int64_t m) {
+    if (!d.subpix) return (size_t)m;
+    const int hw = d.Hout * d.Wout;
+    const int n = (int)(m / hw), rem = (int)(m - (int64_t)n * hw);
+    const int oy = rem / d.Wout, ox = rem - oy * d.Wout;
+    return ((size_t)n * 2 * d.Hout + 2 * oy + ((d.subpix - 1) >> 1)) * (2 * d.Wout) + 2 * ox + ((d.subpix - 1) & 1);
+}
+#include "common.h"
 
 // Dynamic LDS a kernel needs so that the epilogue can stage at least one wave column (host and device agree on it).
 constexpr int epi_lds_total(int bmc, int bnp, int tj, int lds_main) {
@@ -97,7 +106,7 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
                     o[e] = f2bf((x0[e] + bx[e]) * gelu_erf_f(g0[e] + bg[e]));
                     o[4 + e] = f2bf((x1[e] + bx[4 + e]) * gelu_erf_f(g1[e] + bg[4 + e]));
                 }
-                *(bf16x8*)((bf16*)d.out + (size_t)m * d.ldc + (rx >> 1)) = o;
+                *(bf16x8*)((bf16*)d.out + cc_out_row(d, m) * d.ldc + (rx >> 1)) = o;
             }
         }
     } else {
@@ -197,14 +206,14 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
                         for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
                     }
                     if (d.out_f32) {
-                        float* op = (float*)d.out + (size_t)m * d.ldc + cb;
+                        float* op = (float*)d.out + cc_out_row(d, m) * d.ldc + cb;
                         *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
                         *(f32x4*)(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
                     } else {
                         bf16x8 o;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-                        *(bf16x8*)((bf16*)d.out + (size_t)m * d.ldc + cb) = o;
+                        *(bf16x8*)((bf16*)d.out + cc_out_row(d, m) * d.ldc + cb) = o;
                         if (d.gn_stats) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
@@ -226,10 +235,10 @@ __device__ __forceinline__ void gemm_epilogue(const CcGemmDesc& d, f32x16 (&acc)
                         for (int e = 0; e < 4; ++e) v[e] += bf2f(rv[e]);
                     }
                     if (d.out_f32) {
-                        *(f32x4*)((float*)d.out + (size_t)m * d.ldc + cb) = f32x4{v[0], v[1], v[2], v[3]};
+                        *(f32x4*)((float*)d.out + cc_out_row(d, m) * d.ldc + cb) = f32x4{v[0], v[1], v[2], v[3]};
                     } else {
                         bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                        *(bf16x4*)((bf16*)d.out + (size_t)m * d.ldc + cb) = o;
+                        *(bf16x4*)((bf16*)d.out + cc_out_row(d, m) * d.ldc + cb) = o;
                     }
                 }
             }

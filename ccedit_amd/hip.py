@@ -35,7 +35,7 @@ class CcGemmDesc(C.Structure):
         ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
         ("group_bias", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p),
         ("gn_stats", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-        ("split_k", C.c_int32), ("reserved0", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_stats", C.c_void_p),
+        ("split_k", C.c_int32), ("subpix", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_stats", C.c_void_p),
         ("ln_sums", C.c_void_p), ("row_sums", C.c_void_p), ("ln_sums_eps", C.c_float), ("reserved1", C.c_int32),
     ]
 

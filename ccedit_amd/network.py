@@ -531,8 +531,18 @@ class Upsample3D(nn.Module):
         self.conv = Conv(channels, channels, 3)
         self.conv_temporal = Conv(channels, channels, 3, dims=1)
 
+    conv_parity = None
+
+    def post_pack(self, device):
+        from .packing import pack_upsample_parities
+        if ops.SUBPIX and self.conv.cin % 64 == 0:
+            self.conv_parity = pack_upsample_parities(self.conv.weight, self.conv.bias, device=device)
+
     def run(self, x, geo):
-        s = ops.conv2d(x, self.conv.pw, upsample=True)
+        if self.conv_parity is not None:        # four 2 x 2 convolutions on the low-resolution tensor: 4/9 of the multiply-adds
+            s = ops.conv2d_upsampled(x, self.conv_parity)
+        else:
+            s = ops.conv2d(x, self.conv.pw, upsample=True)
         return temporal_conv3(s, self.conv_temporal.pw, geo, res_self=True)
 
 

@@ -102,7 +102,7 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, out_f32: bool = False, use_bias: bool = True, tile: int = 0,
          gn_rows: int = 0, ln_eps: float = 0.0, ln_stats: Optional[torch.Tensor] = None, ln_sums=None,
-         row_sums: bool = False) -> torch.Tensor:
+         row_sums: bool = False, subpix: int = 0) -> torch.Tensor:
     """out[m, :] = epilogue(sum_taps W . A[src(m, tap)]).  a2d: [rows, lda] bf16 (last dim contiguous).
 
     gn_rows > 0 (= H*W of the output frames) asks the epilogue to also accumulate the GroupNorm(32) statistics of
@@ -119,8 +119,9 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
     n_store = pw.n_out if pw.geglu else pw.n
     if out is None:
         out = torch.empty((m, n_store), dtype=torch.float32 if out_f32 else BF16, device=a2d.device)
-    assert out.stride(-1) == 1 and out.shape[0] == m
+    assert out.stride(-1) == 1 and out.shape[0] == (4 * m if subpix else m)
     d = CcGemmDesc()
+    d.subpix = subpix
     d.M, d.N, d.Cin, d.Cin1, d.taps, d.mode = m, pw.n, pw.cin, cin1, pw.taps, mode
     d.Hin, d.Win, d.Hout, d.Wout = hin, win, hout, wout
     d.stride, d.pad, d.ksize, d.upsample = stride, pad, pw.ksize, int(upsample)
@@ -182,7 +183,7 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
         alg_bytes = (a2d.shape[0] * cin1 * 2 + (a2.shape[0] * a2.shape[1] * 2 if a2 is not None else 0)      # sources, once
                      + m * out.shape[1] * out.element_size() + nres * m * pw.n * 2 + pw.n * pw.kpad * 2)   # out, residuals, W
         PROFILE.add("tap_gemm", e0, e1, pw.flops_per_row * m, float(alg_bytes),
-                    (("lin", "conv", "temp")[mode] + ("+up" if upsample else ""), m, pw.n, pw.taps * pw.cin, stride,
+                    (("lin", "conv", "temp")[mode] + ("+up" if upsample else "") + ("+up(parity)" if subpix else ""), m, pw.n, pw.taps * pw.cin, stride,
                      int(res1 is not None) + int(res2 is not None), d.act))
         return out
     hip.check(hip.lib().ccedit_gemm(C.byref(d), _stream()), "ccedit_gemm")
@@ -248,6 +249,20 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, ups
     out = gemm(x.reshape(-1, c), pw, mode=GEMM_CONV2D, m=n * hout * wout, hin=h, win=w, hout=hout, wout=wout,
                stride=stride, pad=pad, upsample=upsample, a2=a2, gn_rows=hout * wout if gn else 0, **kw)
     return carry_gn_stats(out, out.view(n, hout, wout, out.shape[-1]))
+
+
+SUBPIX = os.environ.get("CCEDIT_SUBPIX", "1") != "0"      # 0: upsample + 3x3 conv through the nine-tap gather (A/B)
+
+
+def conv2d_upsampled(x: torch.Tensor, pws) -> torch.Tensor:
+    """conv3x3(nearest_upsample_2x(x)) as four 2 x 2 convolutions on x, one per output parity (packing.pack_upsample_parities):
+    x (N, H, W, C) -> (N, 2H, 2W, Cout); every launch writes its quarter of the output pixels in place."""
+    _chk_act(x, "conv2d_upsampled")
+    n, h, w, c = x.shape
+    out = torch.empty((n * 4 * h * w, pws[0].n), dtype=BF16, device=x.device)
+    for p, pw in enumerate(pws):
+        gemm(x.reshape(-1, c), pw, mode=GEMM_CONV2D, m=n * h * w, hin=h, win=w, hout=h, wout=w, stride=1, pad=0, out=out, subpix=p + 1)
+    return out.view(n, 2 * h, 2 * w, pws[0].n)
 
 
 def conv_temporal(x: torch.Tensor, t: int, pw: PackedWeight, gn: bool = False, **kw) -> torch.Tensor:

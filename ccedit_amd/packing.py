@@ -97,6 +97,31 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
     return PackedWeight(buf, bb, n, (o // 2) if geglu else o, cin, taps, kpad, ksize, geglu, 2.0 * o * i * taps, korder)
 
 
+def pack_upsample_parities(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, device: Optional[torch.device] = None):
+    """conv3x3(nearest_upsample_2x(x)) (Upsample.forward, openaimodel.py:204-217 / 254-263) as four 2 x 2 convolutions on x itself, one
+    per output parity (py, px): an output pixel (2y + py, 2x + px) reads up-sampled rows 2y + py - 1 + ky, i.e. source rows
+    y - 1, y, y for py = 0 and y, y, y + 1 for py = 1 — taps that land on the same source pixel are added up in fp32 BEFORE the bf16
+    rounding (one rounding per merged tap; the nine-tap path rounds each of the merged taps separately).  4/9 of the multiply-adds.
+    Returns [PackedWeight] in CcGemmDesc.subpix order p = 2 py + px; `flops_per_row` stays the ALGORITHMIC 2 * 9 * O * I per output
+    pixel of the reference convolution (what bench.py prices), not the 2 * 4 * O * I executed."""
+    w = weight.detach().to(torch.float32)
+    assert w.ndim == 4 and w.shape[2] == 3 and w.shape[3] == 3
+    merge = (((0,), (1, 2)), ((0, 1), (2,)))               # parity -> for each of the two window positions, the 3x3 taps it collects
+    out = []
+    for py in range(2):
+        for px in range(2):
+            w2 = torch.zeros(w.shape[0], w.shape[1], 2, 2, dtype=torch.float32, device=w.device)
+            for dy in range(2):
+                for dx in range(2):
+                    for ky in merge[py][dy]:
+                        for kx in merge[px][dx]:
+                            w2[:, :, dy, dx] += w[:, :, ky, kx]
+            pw = pack_weight(w2, bias, device=device)
+            pw.flops_per_row = 2.0 * w.shape[0] * w.shape[1] * 9
+            out.append(pw)
+    return out
+
+
 def pack_concat(weights: Sequence[torch.Tensor], biases: Optional[Sequence[Optional[torch.Tensor]]] = None,
                 device: Optional[torch.device] = None) -> PackedWeight:
     """Stack several (O_i, I) projections along O (fused q|k|v GEMM)."""

@@ -124,7 +124,14 @@ typedef struct CcGemmDesc {
     void* workspace;
     int64_t workspace_bytes;
     int32_t split_k;      /* internal (set by the library); pass 0 */
-    int32_t reserved0;
+    /* 0 = off.  p + 1 (p = 0..3; ABI 9, was reserved): one output PARITY of `conv3x3(nearest_upsample_2x(x))` (Upsample.forward,
+     * openaimodel.py:204-217 / 254-263) evaluated on the LOW-resolution source.  An output pixel (2 oy + py, 2 ox + px), py = p >> 1,
+     * px = p & 1, sees only a 2 x 2 neighbourhood of the source: its nine taps collapse onto four with summed weights
+     * (ccedit_amd/packing.py:pack_upsample_parities), 4/9 of the multiply-adds.  CONV2D with ksize 2, stride 1, Hout x Wout = Hin x Win =
+     * the source frame, M = source pixels; tap (dy, dx) reads source pixel (oy - 1 + py + dy, ox - 1 + px + dx), zeros outside the
+     * frame; the result row of source pixel (n, oy, ox) is stored at row (n 2H + 2 oy + py) 2W + 2 ox + px of `out`, which holds
+     * 4 M rows.  `pad` / `upsample` are ignored; no gn_stats. */
+    int32_t subpix;
     /* optional: LayerNorm folded into a plain Linear / GEGLU projection whose K is not 320 (`to_q(norm(x))`, `ff.net[0].proj(norm(x))`
      * of attention.py:695-716 at 640 / 1280 channels).  A holds the UN-normalised rows, W / bias the gamma / beta-folded weights
      * (as for ln_eps), ln_colsum[N] the row sums of the bf16 weights as packed, ln_stats[M][2] = (mean, rstd) of every row of A

@@ -990,6 +990,25 @@ def test_attention_long_pingpong_rescale_and_anchor():
            what="long anchor + self attention")
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(3, 8, 12, 128, 192), (2, 16, 24, 64, 320), (1, 5, 7, 64, 64)])
+def test_upsample_conv_as_four_parity_convs(n, h, w, cin, cout):
+    """conv3x3(nearest 2x(x)) (openaimodel.py:254-263) evaluated as four 2 x 2 convolutions on x (CcGemmDesc.subpix): against fp32 torch
+    and against the nine-tap gather on the virtual up-sampled tensor; odd frame sizes; repeated launches bit-identical."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_upsample_parities, pack_weight
+    x = _rnd(n, cin, h, w, seed=1)
+    wt, b = _rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), _rnd(cout, seed=3)
+    xd = _nhwc(x)
+    y = ops.conv2d_upsampled(xd, pack_upsample_parities(wt, b, device="cuda"))
+    assert y.shape == (n, 2 * h, 2 * w, cout)
+    ref = F.conv2d(F.interpolate(x.to(BF).float(), scale_factor=2, mode="nearest"), wt, b, padding=1)
+    _close(_nchw(y), ref, what="upsample + conv3x3 as parity convs")
+    nine = ops.conv2d(xd, pack_weight(wt, b).to("cuda"), upsample=True)
+    _close(y, nine, rel=2.0 ** -7, abs_=2e-3, what="parity convs vs nine-tap gather")
+    assert torch.equal(y, ops.conv2d_upsampled(xd, pack_upsample_parities(wt, b, device="cuda")))
+
+
 def test_attention_spatial_kernel_reference_column_and_prescaled_q():
     """attn_spatial_kernel (attnspatial.hip; d = 40, >= 1024 queries, >= 192 keys): the softmax reference rides in the pad column of
     the last QK^T k-step and moves only when a score exceeds it by 2^16.  Checked here: the kernel is the one dispatched; spikes far

@@ -16,6 +16,29 @@ elif which == "qkv":
     x = torch.randn(N * 6144, 320, device="cuda").to(BF)
     pw = pack_weight(torch.randn(960, 320) * 0.05).to("cuda")
     f = lambda: ops.linear(x, pw, tile=int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+elif which == "g8geglu":         # GEGLU projection of the 32x48 level with the LayerNorm folded (g8_kernel 256x256, LNF)
+    from ccedit_amd.packing import fold_layernorm
+    x = torch.randn(N * 1536, 640, device="cuda").to(BF)
+    pw = fold_layernorm([torch.randn(5120, 640) * 0.04], [torch.randn(5120)], torch.ones(640), torch.zeros(640), device="cuda", geglu=True)
+    st = ops.row_stats(x, 1e-5)
+    f = lambda: ops.linear(x, pw, ln_stats=st)
+elif which == "g8res":           # 52224 x 640 <- 640 + residual (g8_kernel 128ch x 512pix)
+    x = torch.randn(N * 1536, 640, device="cuda").to(BF)
+    r = torch.randn(N * 1536, 640, device="cuda").to(BF)
+    pw = pack_weight(torch.randn(640, 640) * 0.04, torch.randn(640)).to("cuda")
+    f = lambda: ops.linear(x, pw, res1=r)
+elif which == "g8conv":          # 3x3 conv 1280 -> 1280 at 16x24 (g8_kernel 256x256, 3x3 tap gather)
+    x = torch.randn(N, 16, 24, 1280, device="cuda").to(BF)
+    pw = pack_weight(torch.randn(1280, 1280, 3, 3) * 0.01, torch.randn(1280)).to("cuda")
+    f = lambda: ops.conv2d(x, pw)
+elif which == "lin320":          # 208896 x 320 <- 320 + residual (lin320_kernel)
+    x = torch.randn(N * 6144, 320, device="cuda").to(BF)
+    r = torch.randn(N * 6144, 320, device="cuda").to(BF)
+    pw = pack_weight(torch.randn(320, 320) * 0.05, torch.randn(320)).to("cuda")
+    f = lambda: ops.linear(x, pw, res1=r)
+elif which == "attnq":           # the network's call: q pre-scaled into log2 units
+    q = torch.randn(N * 6144, 960, device="cuda").to(BF)
+    f = lambda: ops.attention(q[:, :320], q[:, 320:640], q[:, 640:], 8, 40, batches=N, lq=6144, lk=6144, q_log2=True)
 elif which == "attn":
     q = torch.randn(N * 6144, 960, device="cuda").to(BF)
     f = lambda: ops.attention(q[:, :320], q[:, 320:640], q[:, 640:], 8, 40, batches=N, lq=6144, lk=6144)

@@ -12,7 +12,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py 2>/dev/null | tail -1 > $O/${tag}_bench_line_default.json
-python $R/bench.py --workload tvi2v --no-cpu-baseline 2>/dev/null | tail -1 > $O/${tag}_bench_line_tvi2v.json
+python $R/bench.py --workload tvi2v 2>/dev/null | tail -1 > $O/${tag}_bench_line_tvi2v.json
 for mode in single streams; do
   rm -rf /tmp/pf_$mode
   if [ $mode = single ]; then export CCEDIT_SPLIT_CFG=0 CCEDIT_OVERLAP_CONTROLNET=0; sfx=""; else unset CCEDIT_SPLIT_CFG CCEDIT_OVERLAP_CONTROLNET; sfx="_streams"; fi
@@ -21,4 +21,11 @@ for mode in single streams; do
 done
 unset CCEDIT_SPLIT_CFG CCEDIT_OVERLAP_CONTROLNET
 PMC_JSON=$O/${tag}_pmc_traffic.json bash $R/tools/pmc_traffic.sh > $O/${tag}_pmc_traffic.txt 2>&1
+PMC_BENCH_ARGS="--workload tvi2v" PMC_JSON=$O/${tag}_pmc_traffic_tvi2v.json bash $R/tools/pmc_traffic.sh > $O/${tag}_pmc_traffic_tvi2v.txt 2>&1
+# matrix-pipe / VALU counters of the dominant kernels (tools/pmc_r04.sh: two --pmc passes each, --kernel-trace only)
+for spec in "attn_spatial attnq" "g8_kernel g8geglu" "g8_kernel g8res" "g8_kernel g8conv" "conv_halo conv" "lin320 lin320"; do
+  set -- $spec
+  echo "=== $2 ($1) ===" >> $O/${tag}_pmc_counters.txt
+  bash $R/tools/pmc_r04.sh $1 $2 >> $O/${tag}_pmc_counters.txt 2>&1
+done
 ls -la $O/${tag}_*
