@@ -158,7 +158,8 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
             const int rem = (int)(m - (int64_t)n * hwout);
             const int oy = rem / d.Wout, ox = rem - oy * d.Wout;
             // subpix: parity (py, px) of an upsample + 3x3 conv on the low-resolution source — a 2 x 2 window starting at (oy - 1 + py, ox - 1 + px)
-            const int pad_y = d.subpix ? 1 - ((d.subpix - 1) >> 1) : d.pad, pad_x = d.subpix ? 1 - ((d.subpix - 1) & 1) : d.pad;
+            // vpad: the source frames carry their own halo rows (RowShard) — one row less of vertical padding
+            const int pad_y = (d.subpix ? 1 - ((d.subpix - 1) >> 1) : d.pad) - (d.vpad ? 1 : 0), pad_x = d.subpix ? 1 - ((d.subpix - 1) & 1) : d.pad;
             ra[i] = ok ? oy * d.stride - pad_y : -100000;
             rb[i] = ox * d.stride - pad_x;
             rrow[i] = (MODE == M_CONV) ? n * d.Hin * d.Win + ra[i] * d.Win + rb[i] : n * d.Hin * d.Win;
@@ -443,11 +444,13 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
                      "ccedit_gemm: bad conv2d geometry");
         CC_CHECK_ARG(d.M % ((int64_t)d.Hout * d.Wout) == 0, "ccedit_gemm: M not a whole number of frames");
         CC_CHECK_ARG(d.subpix >= 0 && d.subpix <= 4, "ccedit_gemm: subpix must be 0..4");
-        CC_UNSUPPORTED(d.subpix && (d.ksize != 2 || d.stride != 1 || d.upsample || d.Hin != d.Hout || d.Win != d.Wout || d.gn_stats || d.A2 ||
+        CC_CHECK_ARG(d.vpad == 0 || d.vpad == 1, "ccedit_gemm: vpad must be 0 or 1");
+        CC_UNSUPPORTED(d.vpad && (d.upsample || d.tile > 3), "ccedit_gemm: vpad runs on the generic tap-gather block shapes only, without the fused upsample");
+        CC_UNSUPPORTED(d.subpix && (d.ksize != 2 || d.stride != 1 || d.upsample || d.Hin != d.Hout + (d.vpad ? 2 : 0) || d.Win != d.Wout || d.gn_stats || d.A2 ||
                                     4 * d.M >= (1LL << 31)),
                        "ccedit_gemm: subpix needs ksize 2, stride 1, a same-size low-resolution frame, no gn_stats / second source");
-    } else if (d.subpix) {
-        CC_CHECK_ARG(false, "ccedit_gemm: subpix is a CONV2D mode");
+    } else if (d.subpix || d.vpad) {
+        CC_CHECK_ARG(false, "ccedit_gemm: subpix / vpad are CONV2D modes");
     } else if (d.mode == CCEDIT_GEMM_TEMPORAL) {
         CC_CHECK_ARG(d.T > 0 && d.HW > 0 && d.M % ((int64_t)d.T * d.HW) == 0, "ccedit_gemm: bad temporal geometry");
         CC_CHECK_ARG(d.taps % 2 == 1, "ccedit_gemm: temporal taps must be odd");
@@ -501,22 +504,22 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
                        "N %% 16 == 0, no activation): not applicable to this descriptor");
         return cc_g8_launch(d, s, shape);
     }
-    if (d.tile == 0 && cc_small_conv_applicable(d)) return cc_small_conv_launch(d, s);     // few-channel 3x3 (hint stem top)
+    if (d.tile == 0 && !d.vpad && cc_small_conv_applicable(d)) return cc_small_conv_launch(d, s);     // few-channel 3x3 (hint stem top)
     // 3x3 convs onto >= 1024 channels (the 16x24 level): 29-59 MB of weights do not fit an XCD's L2 and the 128 x 128 tiles of the LDS-halo
     // kernel re-stream them per pixel tile (450 MB fetched for 63 MB of operands, round 2).  The persistent 256 x 256 tap-gather loop
     // halves the weight bytes per FLOP: cold sweep 1280->1280 1162 / 843, 2560->1280 1220 / 895, 640->1280 1067 / 729 TF/s.  At 640
     // channels and below the halo re-use wins (32x48 640->640: 890 / 925) and those stay.  CCEDIT_G8_CONV=0 for the A/B.
     static const int g8c_env = getenv("CCEDIT_G8_CONV") ? atoi(getenv("CCEDIT_G8_CONV")) : 1;
     static const int g8_env0 = getenv("CCEDIT_G8") ? atoi(getenv("CCEDIT_G8")) : 1;
-    if (d.tile == 0 && g8c_env && g8_env0 && d.mode == CCEDIT_GEMM_CONV2D && d.N >= 1024 && d.M >= 12000 && cc_g8_applicable(d, 1))
+    if (d.tile == 0 && g8c_env && g8_env0 && !d.vpad && d.mode == CCEDIT_GEMM_CONV2D && d.N >= 1024 && d.M >= 12000 && cc_g8_applicable(d, 1))
         return cc_g8_launch(d, s, 1);
     // Few tiles, long K (the 8x12 level: 3264 pixels x 1280 channels = 65 tiles of 256 x 256, K loops of 60-360 K tiles — a quarter of the
     // chip busy for the whole loop on any block shape): split-K in the persistent kernel when the caller lent a workspace.
-    if (d.tile == 0 && g8_env0 && !d.subpix && d.workspace && cc_g8_split(d, 0) > 1 && d.workspace_bytes >= cc_g8_workspace_bytes(d, 0))
+    if (d.tile == 0 && g8_env0 && !d.subpix && !d.vpad && d.workspace && cc_g8_split(d, 0) > 1 && d.workspace_bytes >= cc_g8_workspace_bytes(d, 0))
         return cc_g8_launch(d, s, 1);
     static const int halo_env = getenv("CCEDIT_CONV_HALO") ? atoi(getenv("CCEDIT_CONV_HALO")) : 1;   // 0: A/B against the gather path
-    if ((d.tile == 0 && halo_env) || d.tile == 8) {
-        if (cc_conv_halo_applicable(d)) return cc_conv_halo_launch(d, s);
+    if ((d.tile == 0 && halo_env && !d.vpad) || d.tile == 8) {
+        if (!d.vpad && cc_conv_halo_applicable(d)) return cc_conv_halo_launch(d, s);
         CC_UNSUPPORTED(d.tile == 8, "ccedit_gemm: tile 8 (LDS-halo 3x3 conv) does not apply to this descriptor");
     }
     // K = 320 Linear over many pixels: weights resident in registers, activations streamed once (lin320.hip)

@@ -769,6 +769,15 @@ extern "C" int ccedit_groupnorm_spatial(const void* x, void* y, const float* gam
     return cc_launch_status("groupnorm_spatial");
 }
 
+extern "C" int ccedit_groupnorm_spatial_stats(const void* x, double* stats, int32_t frames, int32_t hw, int32_t C, void* stream) {
+    CC_CHECK_ARG(x && stats && frames > 0 && hw > 0 && C > 0, "ccedit_groupnorm_spatial_stats: bad args");
+    CC_UNSUPPORTED(C % 32 != 0 || C > kMaxCols * 512, "ccedit_groupnorm_spatial_stats: C=%d (need C%%32==0, C<=%d)", C, kMaxCols * 512);
+    int spb = 256;
+    while (spb > 16 && (int64_t)((hw + spb - 1) / spb) * frames < 512) spb >>= 1;
+    hipLaunchKernelGGL(gn_spatial_stats_kernel, dim3((hw + spb - 1) / spb, frames), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, stats, hw, C, spb);
+    return cc_launch_status("groupnorm_spatial_stats");
+}
+
 extern "C" int ccedit_groupnorm_spatial_apply(const void* x, void* y, const float* gamma, const float* beta,
                                               const double* stats, int32_t frames, int32_t hw, int32_t C, float eps,
                                               int32_t silu, void* stream) {

@@ -36,7 +36,7 @@ class CcGemmDesc(C.Structure):
         ("group_bias", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p),
         ("gn_stats", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("split_k", C.c_int32), ("subpix", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_stats", C.c_void_p),
-        ("ln_sums", C.c_void_p), ("row_sums", C.c_void_p), ("ln_sums_eps", C.c_float), ("reserved1", C.c_int32),
+        ("ln_sums", C.c_void_p), ("row_sums", C.c_void_p), ("ln_sums_eps", C.c_float), ("vpad", C.c_int32),
     ]
 
 
@@ -79,6 +79,7 @@ _SIGS = {
                                            C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ccedit_groupnorm_spatial_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                                  C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "ccedit_groupnorm_spatial_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ccedit_groupnorm_temporal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ccedit_groupnorm_temporal_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -49,8 +49,42 @@ class Geometry:
     activations hold only this rank's t = shard.t_local keyframes of every clip; temporal ops then exchange halos /
     statistics / K-V rows with the other ranks (see temporal_gn / temporal_conv3 / run_temporal)."""
 
-    def __init__(self, b: int, t: int, shard=None):
+    def __init__(self, b: int, t: int, shard=None, rows=None):
         self.b, self.t, self.shard = b, t, shard
+        self.rows = rows            # parallel.RowShard: every rank holds 1 / N of the ROWS of all frames (sconv3 / sgn / gathered K / V)
+
+
+def sconv3(x, pw, geo: Geometry, stride: int = 1, **kw):
+    """Conv2d 3x3, pad 1 (stride 1 or 2).  Rows sharded (geo.rows): the neighbour ranks' boundary rows are received first and the
+    kernel runs on the extended frames without vertical padding (CcGemmDesc.vpad)."""
+    rs = geo.rows
+    if rs is None:
+        return ops.conv2d(x, pw, stride=stride, **kw)
+    return ops.conv2d(rs.halo_rows(x, below=stride == 1), pw, stride=stride, vpad=True, **kw)
+
+
+def sgn(x, norm: "Norm", geo: Geometry, silu: bool):
+    """Spatial GroupNorm(32) (+SiLU).  Rows sharded: the (frame, group) sums a producer left on `x` (or a statistics pass) are this
+    rank's share — all-reduced over the ranks once per tensor, then applied locally."""
+    rs = geo.rows
+    if rs is not None:
+        n, h, w, c = x.shape
+        st = ops.gn_stats_of(x, h * w)
+        if st is None:
+            st = ops.groupnorm_spatial_stats(x)
+        if getattr(x, "_gn_global", None) is not st:        # (the tensor these statistics were reduced into, if they were already)
+            ops.set_gn_stats(x, rs.gn_stats(st))
+            x._gn_global = st
+    return ops.groupnorm_spatial(x, norm.g, norm.b, norm.eps, silu)
+
+
+def gathered_kv(kv2d, frames: int, geo: Geometry):
+    """K | V rows of `frames` frames, (frames * pixels, 2C): with sharded rows the other ranks' rows of every frame are all-gathered
+    (the spatial self-attention's keys are the whole frame; queries stay local)."""
+    if geo is None or geo.rows is None:
+        return kv2d
+    c2 = kv2d.shape[-1]
+    return geo.rows.gather_rows(kv2d.reshape(frames, -1, c2)).reshape(-1, c2)
 
 
 def temporal_gn(x, norm: "Norm", geo: Geometry, silu: bool, ext: bool = False):
@@ -248,12 +282,17 @@ class BasicTransformerBlock(nn.Module):
         self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head)
         self.norm1, self.norm2, self.norm3 = Norm(dim, 1e-5), Norm(dim, 1e-5), Norm(dim, 1e-5)
 
-    def run(self, tok, frames: int, hw: int, ctx_kv_src, ctx_len: int, frames_per_clip: int):
+    def run(self, tok, frames: int, hw: int, ctx_kv_src, ctx_len: int, frames_per_clip: int, geo: Optional[Geometry] = None):
         a1, a2 = self.attn1, self.attn2
         c = a1.inner
         qkv = ln_linear(tok, self.norm1, a1.qkv, self.qkv_ln)      # (dim 320, 3 slices: folding the norm into lin320 does not pay)
-        o = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], a1.heads, a1.dim_head, batches=frames, lq=hw, lk=hw,
-                          q_log2=a1.q_log2)
+        if geo is not None and geo.rows is not None:               # rows sharded: local queries against the whole frame's keys
+            kv = gathered_kv(qkv[:, c:], frames, geo)
+            o = ops.attention(qkv[:, :c], kv[:, :c], kv[:, c:], a1.heads, a1.dim_head, batches=frames, lq=hw, lk=hw * geo.rows.world,
+                              q_log2=a1.q_log2)
+        else:
+            o = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], a1.heads, a1.dim_head, batches=frames, lq=hw, lk=hw,
+                              q_log2=a1.q_log2)
         tok = linear_ln_producer(o, a1.to_out[0].pw, res1=tok)
         q = ln_linear(tok, self.norm2, a2.to_q.pw, self.q2_ln)
         kv = ops.linear(ctx_kv_src, a2.kv)                     # [B*L, 2C]: once per clip, shared by its T frames
@@ -282,7 +321,7 @@ class BasicTransformerSingleLayerBlock(nn.Module):
         self.ff = FeedForward(dim)
         self.norm1, self.norm2 = Norm(dim, 1e-5), Norm(dim, 1e-5)
 
-    def run_frames(self, tok, frames: int, hw: int, anchor_t: Optional[int] = None, frames_per_clip: int = 1, shard=None):
+    def run_frames(self, tok, frames: int, hw: int, anchor_t: Optional[int] = None, frames_per_clip: int = 1, shard=None, geo=None):
         """Per-frame attention with K/V from the un-normalised tokens.  anchor_t is None: plain self-attention
         (controlnet_img's SpatialTransformer, disable_text_ca).  Otherwise the keys are
         [tokens of frame anchor_t of the same clip ; own tokens] — SpatialTransformer3DCA 'center_self'."""
@@ -290,7 +329,16 @@ class BasicTransformerSingleLayerBlock(nn.Module):
         c = a.inner
         q = ln_linear(tok, self.norm1, a.to_q.pw, self.q_ln)
         kv = ops.linear(tok, a.kv)
-        if anchor_t is None:
+        if geo is not None and geo.rows is not None:               # rows sharded: the keys are the whole frame(s), gathered
+            kv = gathered_kv(kv, frames, geo)
+            hwk = hw * geo.rows.world
+            if anchor_t is None:
+                o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=frames, lq=hw, lk=hwk)
+            else:                                                  # the anchor keyframe's rows are rows of the same gathered tensor
+                o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=frames, lq=hw, lk=2 * hwk,
+                                  kv_outer_rows=hwk, seg1_len=hwk, seg1_div=frames_per_clip, seg1_mul=frames_per_clip,
+                                  seg1_add=anchor_t)
+        elif anchor_t is None:
             o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=frames, lq=hw, lk=hw)
         elif shard is not None:
             # keyframes sharded over ranks: `anchor_t` is a GLOBAL frame index; its K/V rows are broadcast by the owning
@@ -353,19 +401,19 @@ class SpatialTransformer(nn.Module):
             self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, n_heads, d_head, context_dim)])
         self.proj_out = Conv(inner, in_channels, 1)
 
-    def run_spatial(self, x, ctx2d, ctx_len, frames_per_clip, gn: bool = False):
+    def run_spatial(self, x, ctx2d, ctx_len, frames_per_clip, gn: bool = False, geo: Optional[Geometry] = None):
         n, h, w, c = x.shape
-        a = ops.groupnorm_spatial(x, self.norm.g, self.norm.b, self.norm.eps, False)
+        a = sgn(x, self.norm, geo, False) if geo is not None else ops.groupnorm_spatial(x, self.norm.g, self.norm.b, self.norm.eps, False)
         tok = linear_ln_producer(a.view(-1, c), self.proj_in.pw)
         if self.disable_text_ca:
-            tok = self.transformer_blocks[0].run_frames(tok, n, h * w)
+            tok = self.transformer_blocks[0].run_frames(tok, n, h * w, geo=geo)
         else:
-            tok = self.transformer_blocks[0].run(tok, n, h * w, ctx2d, ctx_len, frames_per_clip)
+            tok = self.transformer_blocks[0].run(tok, n, h * w, ctx2d, ctx_len, frames_per_clip, geo=geo)
         y = ops.linear(tok, self.proj_out.pw, res1=x.view(-1, c), gn_rows=h * w if gn else 0)
         return ops.carry_gn_stats(y, y.view(n, h, w, c))
 
     def run(self, x, geo, ctx2d, ctx_len):
-        return self.run_spatial(x, ctx2d, ctx_len, geo.t, gn=True)      # the next block opens with a GroupNorm
+        return self.run_spatial(x, ctx2d, ctx_len, geo.t, gn=True, geo=geo)      # the next block opens with a GroupNorm
 
 
 class SpatialTransformer3D(SpatialTransformer):
@@ -383,7 +431,7 @@ class SpatialTransformer3D(SpatialTransformer):
         self.proj_out_temporal = Conv(inner, in_channels, 1, dims=1)
 
     def run(self, x, geo, ctx2d, ctx_len):
-        y = self.run_spatial(x, ctx2d, ctx_len, geo.t)
+        y = self.run_spatial(x, ctx2d, ctx_len, geo.t, geo=geo)
         n, h, w, c = y.shape
         if _a2a(geo):       # the whole temporal branch (GroupNorm_T, projections, attention over T, FF) is per pixel:
             sh = geo.shard  # it runs on all T frames of this rank's pixel block, between two all-to-alls
@@ -423,11 +471,11 @@ class SpatialTransformer3DCA(SpatialTransformer3D):
         y = super().run(x, geo, ctx2d, ctx_len)
         n, h, w, c = y.shape
         nc = self.norm_temporal_ca
-        a = ops.groupnorm_spatial(y, nc.g, nc.b, nc.eps, False)
+        a = sgn(y, nc, geo, False)
         tok = ops.linear(a.view(-1, c), self.proj_in_temporal_ca.pw)
         t_glob = geo.t if geo.shard is None else geo.shard.t_glob
         tok = self.transformer_blocks_temporal_ca[0].run_frames(tok, n, h * w, anchor_t=t_glob // 2, frames_per_clip=geo.t,
-                                                                shard=geo.shard)
+                                                                shard=geo.shard, geo=geo)
         z = ops.linear(tok, self.proj_out_temporal_ca.pw, res1=y.view(-1, c), gn_rows=h * w)
         return ops.carry_gn_stats(z, z.view(n, h, w, c))
 
@@ -447,14 +495,12 @@ class ResBlock(nn.Module):
 
     def run(self, x, emb_silu, geo: Geometry):
         n, h, w, _ = x.shape
-        gn = self.in_layers[0]
-        a = ops.groupnorm_spatial(x, gn.g, gn.b, gn.eps, True)
+        a = sgn(x, self.in_layers[0], geo, True)
         e = emb_silu.of(self)                                                      # (B, Cout) fp32 = emb_layers(emb)
-        hid = ops.conv2d(a, self.in_layers[2].pw, group_bias=e, group_rows=geo.t * h * w, gn=True)
-        gn = self.out_layers[0]
-        a = ops.groupnorm_spatial(hid, gn.g, gn.b, gn.eps, True)
+        hid = sconv3(a, self.in_layers[2].pw, geo, group_bias=e, group_rows=geo.t * h * w, gn=True)
+        a = sgn(hid, self.out_layers[0], geo, True)
         skip = x if isinstance(self.skip_connection, Slot) else ops.conv2d(x, self.skip_connection.pw)
-        return ops.conv2d(a, self.out_layers[3].pw, res1=skip.view(-1, skip.shape[-1]), gn=True)
+        return sconv3(a, self.out_layers[3].pw, geo, res1=skip.view(-1, skip.shape[-1]), gn=True)
 
 
 class ResBlock3D(nn.Module):
@@ -478,17 +524,15 @@ class ResBlock3D(nn.Module):
 
     def run(self, x, emb_silu, geo: Geometry):
         n, h, w, _ = x.shape
-        gn = self.in_layers[0]
-        a = ops.groupnorm_spatial(x, gn.g, gn.b, gn.eps, True)
-        s = ops.conv2d(a, self.in_layers[2].pw)
+        a = sgn(x, self.in_layers[0], geo, True)
+        s = sconv3(a, self.in_layers[2].pw, geo)
         co = s.shape[-1]
         e = emb_silu.of(self)
         # stf output (s + conv_t) and the `+ emb_out` of openaimodel.py:762 in one epilogue
         hid = temporal_gn_conv3(s, self.in_layers_temporal[0], self.in_layers_temporal[2].pw, geo, group_bias=e,
                                 group_rows=geo.t * h * w, gn=True)
-        gn = self.out_layers[0]
-        a = ops.groupnorm_spatial(hid, gn.g, gn.b, gn.eps, True)
-        s2 = ops.conv2d(a, self.out_layers[3].pw)
+        a = sgn(hid, self.out_layers[0], geo, True)
+        s2 = sconv3(a, self.out_layers[3].pw, geo)
         if isinstance(self.skip_connection, Slot):
             skip = x
         else:
@@ -506,7 +550,7 @@ class Downsample(nn.Module):
         self.op = Conv(channels, channels, 3, stride=2)
 
     def run(self, x, geo):
-        return ops.conv2d(x, self.op.pw, stride=2, gn=True)
+        return sconv3(x, self.op.pw, geo, stride=2, gn=True)
 
 
 class Downsample3D(nn.Module):
@@ -518,7 +562,7 @@ class Downsample3D(nn.Module):
         self.conv_temporal = Conv(channels, channels, 3, dims=1)
 
     def run(self, x, geo):
-        s = ops.conv2d(x, self.op.pw, stride=2)
+        s = sconv3(x, self.op.pw, geo, stride=2)
         return temporal_conv3(s, self.conv_temporal.pw, geo, res_self=True, gn=True)
 
 
@@ -539,7 +583,11 @@ class Upsample3D(nn.Module):
             self.conv_parity = pack_upsample_parities(self.conv.weight, self.conv.bias, device=device)
 
     def run(self, x, geo):
-        if self.conv_parity is not None:        # four 2 x 2 convolutions on the low-resolution tensor: 4/9 of the multiply-adds
+        if geo.rows is not None:                # rows sharded: one low-resolution halo row from each neighbour
+            if self.conv_parity is None:
+                raise NotImplementedError("row-sharded Upsample3D needs the parity form (channels % 64 == 0, CCEDIT_SUBPIX on)")
+            s = ops.conv2d_upsampled(geo.rows.halo_rows(x), self.conv_parity, vpad=True)
+        elif self.conv_parity is not None:      # four 2 x 2 convolutions on the low-resolution tensor: 4/9 of the multiply-adds
             s = ops.conv2d_upsampled(x, self.conv_parity)
         else:
             s = ops.conv2d(x, self.conv.pw, upsample=True)
@@ -758,12 +806,13 @@ class ControlNet2D(UNetModel):
             for zc in list(self.zero_convs) + [self.middle_block_out]:
                 zc[0].pack(device, scale=self.control_scales)
 
-    def hint_stem(self, hint_nhwc):
+    def hint_stem(self, hint_nhwc, rows=None):
         h = hint_nhwc
+        geo = Geometry(1, 1, rows=rows)
         convs = [m for m in self.input_hint_block if isinstance(m, Conv)]
         for i, cv in enumerate(convs):
             last = i == len(convs) - 1
-            h = ops.conv2d(h, cv.pw, stride=cv.stride, act=0 if last else ACT_SILU)
+            h = sconv3(h, cv.pw, geo, stride=cv.stride, act=0 if last else ACT_SILU)
         return h
 
     def run(self, x_nhwc, guided, timesteps, ctx2d, ctx_len, geo: Geometry) -> List[torch.Tensor]:
@@ -775,9 +824,9 @@ class ControlNet2D(UNetModel):
         h = x_nhwc
         for i, (block, zc) in enumerate(zip(self.input_blocks, self.zero_convs)):
             if i == 0 and self.no_add_x:
-                h = ops.conv2d(guided, block[0].pw)
+                h = sconv3(guided, block[0].pw, geo)
             elif i == 0:
-                h = ops.conv2d(h, block[0].pw, res1=guided.view(-1, guided.shape[-1]))     # h = conv(x); h += guided_hint
+                h = sconv3(h, block[0].pw, geo, res1=guided.view(-1, guided.shape[-1]))     # h = conv(x); h += guided_hint
             else:
                 h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
             if TRACE is not None:
@@ -840,13 +889,15 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
                     ops.add(fr, ic[b], out=fr)
                 if hasattr(hh, "_gn_stats"):
                     del hh._gn_stats                             # modified in place: the producer's statistics are stale
+                if hasattr(hh, "_gn_global"):
+                    del hh._gn_global
             return hh
 
         hs = []
         h = x_nhwc
         for i, block in enumerate(self.input_blocks):
             if i == 0:
-                s = ops.conv2d(h, block[0].pw)
+                s = sconv3(h, block[0].pw, geo)
                 h = temporal_conv3(s, self.input_blocks_temporal[0].pw, geo, res_self=True)
             else:
                 h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
@@ -860,13 +911,12 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
             h = ops.cat_add(h, hs.pop(), control.pop(), gn=True)          # cat([h, hs.pop() + control.pop()], dim=1)
             h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
             _trace(f"output_blocks.{len(self.output_blocks) - len(hs) - 1}", h)
-        gn = self.out[0]
-        a = ops.groupnorm_spatial(h, gn.g, gn.b, gn.eps, True)
+        a = sgn(h, self.out[0], geo, True)
         n, hh, ww, _ = a.shape
         oc = self.out_channels
         ocp = (oc + 7) // 8 * 8
         s = torch.zeros((n * hh * ww, ocp), dtype=torch.bfloat16, device=a.device)
-        ops.conv2d(a, self.out[2].pw, out=s[:, : self.out[2].pw.n])
+        sconv3(a, self.out[2].pw, geo, out=s[:, : self.out[2].pw.n])
         if _a2a(geo):       # SiLU + Conv1d_T on this rank's pixel block; the caller all-gathers the pixel blocks
             sh = geo.shard
             sp = sh.to_pixels(s, geo.b, hh * ww)
@@ -930,6 +980,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     _hint_val = None
     _hint_slices = None
     frame_shard = None          # parallel.FrameShard: split the T keyframes of each clip over the ranks (config 4)
+    row_shard = None            # parallel.RowShard: split the latent ROWS of every frame over the ranks (config 4, balanced)
     # The ControlNet's residuals are first needed after the UNet's middle block: with overlap_controlnet the ControlNet
     # (16 TFLOP) is launched on a side HIP stream and runs concurrently with the UNet encoder (25 TFLOP) — the two fill
     # each other's launch tails and the small 16x24 / 8x12-level kernels that cannot occupy 256 CUs alone.
@@ -958,7 +1009,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         self._hint_slices = None
         self._graphs = None
 
-    def _guided_hint(self, hint5d: torch.Tensor):
+    def _guided_hint(self, hint5d: torch.Tensor, rows=None):
         """hint_stem(1 - (hint+1)/2), cached per source tensor.  An entry is keyed by (address, shape, strides, in-place
         version) AND keeps a reference to the source tensor: while the entry lives its storage cannot be freed, so no
         later tensor (the next clip's hint) can be handed that address by the caching allocator — a key match always
@@ -969,7 +1020,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             return self._hint_val[key][1]
         # control_hint in [-1,1] -> 1 - (h+1)/2 (wrappers.py:160-162), fused into the layout change
         hint8 = ops.ncthw_to_nhwc(hint5d.float().contiguous(), 8, scale=-0.5, shift=0.5)
-        g = net.hint_stem(hint8)
+        g = net.hint_stem(hint8, rows=rows)
         if self.cache_hint_stem:
             if not isinstance(self._hint_val, dict) or len(self._hint_val) >= 4:     # one entry per CFG half (+ shards)
                 self._hint_val = {}
@@ -992,7 +1043,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, c: Dict[str, torch.Tensor], **kwargs) -> torch.Tensor:
         if (self.use_graph and not OpenAIWrapperControlLDM3DTV2V._graph_failed and not kwargs and x.is_cuda
-                and self.frame_shard is None and ops.PROFILE is None and TRACE is None
+                and self.frame_shard is None and self.row_shard is None and ops.PROFILE is None and TRACE is None
                 and not torch.cuda.is_current_stream_capturing()):
             return self._forward_graphed(x, t, c)
         return self._forward_eager(x, t, c, **kwargs)
@@ -1086,12 +1137,27 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                 # a stable tensor object so the hint-stem cache can hit; the entry pins the source (see _guided_hint)
                 self._hint_slices[hk] = (c["control_hint"], hint5.contiguous())
             hint5 = self._hint_slices[hk][1]
-        geo = Geometry(b, x.shape[2], sh)
+        rs = self.row_shard
+        cond_feat = c.get("cond_feat", None)
+        if rs is not None:             # keep this rank's latent rows of every frame (and the 8x finer hint rows that feed them)
+            if sh is not None:
+                raise ValueError("frame_shard and row_shard are alternative decompositions of one clip")
+            r0, r1 = rs.rows(lh)
+            x = x[:, :, :, r0:r1]
+            hk = self._tensor_key(c["control_hint"]) + ("rows", r0, r1)
+            if not isinstance(self._hint_slices, dict) or len(self._hint_slices) >= 4:
+                self._hint_slices = {}
+            if hk not in self._hint_slices:
+                self._hint_slices[hk] = (c["control_hint"], hint5[:, :, :, 8 * r0:8 * r1].contiguous())
+            hint5 = self._hint_slices[hk][1]
+            if cond_feat is not None:
+                cond_feat = cond_feat[:, :, r0:r1]
+        geo = Geometry(b, x.shape[2], sh, rows=rs)
         context = c["crossattn"]
         ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
         x8 = ops.ncthw_to_nhwc(x.float().contiguous(), 8)
         control_ready = None
-        if self.overlap_controlnet and sh is None and ops.PROFILE is None and TRACE is None:
+        if self.overlap_controlnet and sh is None and rs is None and ops.PROFILE is None and TRACE is None:
             main = torch.cuda.current_stream()
             if OpenAIWrapperControlLDM3DTV2V._side_stream is None:
                 OpenAIWrapperControlLDM3DTV2V._side_stream = {}
@@ -1109,17 +1175,18 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             for tns in control:
                 tns.record_stream(main)                 # and vice versa
         else:
-            guided = self._guided_hint(hint5)
+            guided = self._guided_hint(hint5, rows=rs)
             control = net.controlnet.run(x8, guided, t, ctx2d, context.shape[1], geo)
         img_control = None
-        cond_feat = c.get("cond_feat", None)
         if cond_feat is not None and (sh is None or sh.owner_of(nt // 2) == sh.rank):
             # TVI2V (wrappers.py:176-190): controlnet_img on the reference latent; its residuals only touch keyframe T//2,
             # so under frame sharding only the rank holding that keyframe evaluates it
             cf8 = ops.ncthw_to_nhwc(cond_feat.float()[:, :, None].contiguous(), 8)
-            img_control = net.controlnet_img.run(None, cf8, t, None, 0, Geometry(b, 1))
+            img_control = net.controlnet_img.run(None, cf8, t, None, 0, Geometry(b, 1, rows=rs))
         eps = net.run(x8, t, ctx2d, context.shape[1], control, geo, img_control, control_ready=control_ready)
         if sh is not None:             # all ranks get the full (B, C, T, h, w) prediction (1.6 MB at 17x64x96)
             eps = sh.gather_pixels(eps.view(-1, eps.shape[-1]), b, lh * lw) if sh.mode == "a2a" else sh.gather_frames(eps, b)
             eps = eps.view(b * nt, lh, lw, -1)
+        if rs is not None:             # all ranks get the full prediction: the row blocks of every frame, in rank order
+            eps = rs.gather_rows(eps.view(b * nt, -1, eps.shape[-1])).view(b * nt, lh, lw, -1)
         return ops.nhwc_to_ncthw(eps, b, nt, net.out_channels)

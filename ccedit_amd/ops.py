@@ -102,7 +102,7 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, out_f32: bool = False, use_bias: bool = True, tile: int = 0,
          gn_rows: int = 0, ln_eps: float = 0.0, ln_stats: Optional[torch.Tensor] = None, ln_sums=None,
-         row_sums: bool = False, subpix: int = 0) -> torch.Tensor:
+         row_sums: bool = False, subpix: int = 0, vpad: bool = False) -> torch.Tensor:
     """out[m, :] = epilogue(sum_taps W . A[src(m, tap)]).  a2d: [rows, lda] bf16 (last dim contiguous).
 
     gn_rows > 0 (= H*W of the output frames) asks the epilogue to also accumulate the GroupNorm(32) statistics of
@@ -121,7 +121,7 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
         out = torch.empty((m, n_store), dtype=torch.float32 if out_f32 else BF16, device=a2d.device)
     assert out.stride(-1) == 1 and out.shape[0] == (4 * m if subpix else m)
     d = CcGemmDesc()
-    d.subpix = subpix
+    d.subpix, d.vpad = subpix, int(vpad)
     d.M, d.N, d.Cin, d.Cin1, d.taps, d.mode = m, pw.n, pw.cin, cin1, pw.taps, mode
     d.Hin, d.Win, d.Hout, d.Wout = hin, win, hout, wout
     d.stride, d.pad, d.ksize, d.upsample = stride, pad, pw.ksize, int(upsample)
@@ -234,7 +234,7 @@ def ff320(x2d: torch.Tensor, pk: PackedFF320, eps: float = 1e-5, ln: bool = True
 
 
 def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, upsample: bool = False,
-           x2: Optional[torch.Tensor] = None, gn: bool = False, out_hw: Optional[tuple] = None, **kw) -> torch.Tensor:
+           x2: Optional[torch.Tensor] = None, gn: bool = False, out_hw: Optional[tuple] = None, vpad: bool = False, **kw) -> torch.Tensor:
     """x: (N, H, W, C) -> (N, Hout, Wout, Cout); 3x3 (pad 1) or 1x1 (pad 0) by the packed kernel size.
     gn=True: the output feeds a spatial GroupNorm — accumulate its statistics in the epilogue."""
     n, h, w, c = x.shape
@@ -243,6 +243,10 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, ups
     hv, wv = (2 * h, 2 * w) if upsample else (h, w)
     hout = (hv + 2 * pad - pw.ksize) // stride + 1
     wout = (wv + 2 * pad - pw.ksize) // stride + 1
+    if vpad:                        # the frames carry their own halo rows (RowShard): no vertical padding
+        assert pw.ksize == 3 and pad == 1 and not upsample and x2 is None
+        hout = (hv - pw.ksize) // stride + 1
+        kw["vpad"] = True
     if out_hw is not None:          # asymmetric padding (VAE Downsample, model.py:74-93: pad right/bottom only, conv pad 0):
         hout, wout = out_hw         # taps that fall outside the source read zeros, so only the output size changes
     a2 = None if x2 is None else x2.reshape(-1, x2.shape[-1])
@@ -254,14 +258,17 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, ups
 SUBPIX = os.environ.get("CCEDIT_SUBPIX", "1") != "0"      # 0: upsample + 3x3 conv through the nine-tap gather (A/B)
 
 
-def conv2d_upsampled(x: torch.Tensor, pws) -> torch.Tensor:
+def conv2d_upsampled(x: torch.Tensor, pws, vpad: bool = False) -> torch.Tensor:
     """conv3x3(nearest_upsample_2x(x)) as four 2 x 2 convolutions on x, one per output parity (packing.pack_upsample_parities):
-    x (N, H, W, C) -> (N, 2H, 2W, Cout); every launch writes its quarter of the output pixels in place."""
+    x (N, H, W, C) -> (N, 2H, 2W, Cout); every launch writes its quarter of the output pixels in place.  vpad: x carries one halo
+    row above and below its H rows (RowShard)."""
     _chk_act(x, "conv2d_upsampled")
-    n, h, w, c = x.shape
+    n, hx, w, c = x.shape
+    h = hx - 2 if vpad else hx
     out = torch.empty((n * 4 * h * w, pws[0].n), dtype=BF16, device=x.device)
     for p, pw in enumerate(pws):
-        gemm(x.reshape(-1, c), pw, mode=GEMM_CONV2D, m=n * h * w, hin=h, win=w, hout=h, wout=w, stride=1, pad=0, out=out, subpix=p + 1)
+        gemm(x.reshape(-1, c), pw, mode=GEMM_CONV2D, m=n * h * w, hin=hx, win=w, hout=h, wout=w, stride=1, pad=0, out=out, subpix=p + 1,
+             vpad=vpad)
     return out.view(n, 2 * h, 2 * w, pws[0].n)
 
 
@@ -387,6 +394,21 @@ def groupnorm_spatial(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, 
                                            ws.data_ptr(), n, h * w, c, eps, int(silu), _stream()),
         "ccedit_groupnorm_spatial"), (n, h, w, c))
     return y
+
+
+def groupnorm_spatial_stats(x: torch.Tensor) -> torch.Tensor:
+    """(sum, sum of squares) per (frame, group) of x (N, H, W, C): double (N, 32, 2).  The statistics half of `groupnorm_spatial` for
+    frames whose rows are sharded over ranks: all-reduce, divide by the number of ranks, attach with `set_gn_stats`."""
+    _chk_act(x, "groupnorm_spatial_stats")
+    n, h, w, c = x.shape
+    st = zero_stats(n, x.device)
+    hip.check(hip.lib().ccedit_groupnorm_spatial_stats(x.data_ptr(), st.data_ptr(), n, h * w, c, _stream()), "ccedit_groupnorm_spatial_stats")
+    return st
+
+
+def set_gn_stats(x: torch.Tensor, stats: torch.Tensor):
+    x._gn_stats = (stats, x.shape[1] * x.shape[2])
+    return x
 
 
 def groupnorm_temporal(x: torch.Tensor, b: int, t: int, gamma, beta, eps: float, silu: bool) -> torch.Tensor:

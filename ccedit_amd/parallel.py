@@ -50,6 +50,14 @@ def cfg_pair_efficiency(t_glob: int, world: int) -> float:
     return (sum(both) / len(both)) / max(both)
 
 
+def row_sharding_efficiency(latent_rows: int, world: int) -> float:
+    """Load-balance ceiling of RowShard: every rank holds latent_rows / world rows of every frame at the top level and 1/2, 1/4, 1/8
+    of that below — 1.0 whenever the deepest level (latent_rows / 8) still divides, which is the only case RowShard accepts."""
+    if latent_rows % (8 * world):
+        raise ValueError(f"{latent_rows} latent rows: the deepest level has {latent_rows // 8}, not divisible by {world} ranks")
+    return 1.0
+
+
 def max_over_ranks(seconds: float, device=None) -> float:
     """MAX all-reduce of a wall-clock interval (identity when torch.distributed is not initialised)."""
     import torch.distributed as dist
@@ -60,63 +68,34 @@ def max_over_ranks(seconds: float, device=None) -> float:
     return float(t.item())
 
 
-class FrameShard:
-    """One clip's T keyframes split contiguously over the ranks of a process group (BASELINE.json config 4).
+class _ShardComm:
+    """Communicator plumbing shared by the two single-clip decompositions (FrameShard: keyframes, RowShard: latent rows): rank / world
+    of a process group, host staging for non-RCCL backends, byte / collective counters, device events around every exchange and the
+    host-issue-order log the tests compare across ranks."""
 
-    Every rank holds frames [t0, t1) of EVERY clip of the batch, i.e. a (B, t_local, H, W, C) slab of each
-    frames-outermost activation.  Spatial work is frame-local.  Temporal work (Conv1d k3 over T, GroupNorm over
-    C/32 x T, temporal attention — every pixel independent) depends on `mode`:
-      * "a2a" (default): `to_pixels` transposes the slab with one all-to-all into (all T frames x this rank's 1/world of
-        the pixels), the UNSHARDED temporal kernels run on it, `to_frames` transposes back; `gather_pixels` collects the
-        final prediction.  Nothing else is exchanged.
-      * "halo" (round 1): `halo` (one boundary frame to / from each neighbour, point-to-point) for the convolutions,
-        `allreduce` (per-(clip, pixel, group) sum / sum of squares, fp32) for the normalisations, `gather_frames`
-        (all-gather of the K/V rows) for the attention.
-    `broadcast` serves the TVI2V anchor frame in both modes.  Collectives go through torch.distributed: backend "nccl"
-    (= RCCL on ROCm) moves device tensors directly; with "gloo" (CPU tests, or several ranks sharing one GPU) tensors are
-    staged through host memory.  `bytes_sent`, `n_collectives` and (with `timing = []`) device events around every
-    exchange are what `bench.py --shard-frames` reports.
-    """
-
-    def __init__(self, t_glob: int, rank: Optional[int] = None, world: Optional[int] = None, group=None,
-                 mode: str = "a2a", heavy_last: bool = False):
-        import torch.distributed as dist
-        if mode not in ("a2a", "halo"):
-            raise ValueError(f"FrameShard mode {mode!r}: 'a2a' or 'halo'")
-        self.mode = mode
-        self.dist = dist
-        self.group = group
-        self.rank = dist.get_rank(group) if rank is None else rank
-        self.world = dist.get_world_size(group) if world is None else world
-        if self.world > t_glob:
-            raise ValueError(f"cannot shard {t_glob} keyframes over {self.world} ranks")
-        self.t_glob = t_glob
-        self.bounds = frame_shards(t_glob, self.world)
-        if heavy_last:                         # the ranks with one extra keyframe are the LAST ones (see cfg_pair)
-            sizes = [b - a for a, b in self.bounds][::-1]
-            self.bounds, s0 = [], 0
-            for n in sizes:
-                self.bounds.append((s0, s0 + n))
-                s0 += n
-        self.t0, self.t1 = self.bounds[self.rank]
-        self.t_local = self.t1 - self.t0
-        self.t_max = max(b - a for a, b in self.bounds)
-        self.staged = dist.get_backend(group) != "nccl"
-        self.bytes_sent = 0
-        self.n_collectives = 0
-        self.timing = None                     # a list: (start, stop) device events around every exchange (bench.py)
-        self._plans = {}
-        self._slabs = {}
-
-    # -- instrumentation ------------------------------------------------------------------------
     issue_log = None       # class-wide: a list collects (partition, kind, elements) of every collective in HOST ISSUE ORDER — all
     #                        shards of the process append to the same list, so the interleaving of two communicators is visible.
     #                        Ranks whose logs differ would deadlock on real links; tests compare them across ranks.
 
+    def _init_comm(self, rank, world, group):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.staged = dist.get_backend(group) != "nccl"
+        self.bytes_sent = 0
+        self.n_collectives = 0
+        self.timing = None                     # a list: (start, stop) device events around every exchange (bench.py)
+
+    def _log_partition(self) -> int:
+        return 0
+
     def _tick(self, t: torch.Tensor, kind: str = "a2a"):
         self.n_collectives += 1
-        if FrameShard.issue_log is not None:
-            FrameShard.issue_log.append((int(self.bounds[0][1] - self.bounds[0][0] != self.t_max), kind, int(t.numel())))
+        log = self.issue_log                   # (class attribute of the shard's class, or of the base)
+        if log is not None:
+            log.append((self._log_partition(), kind, int(t.numel())))
         if self.timing is None or not t.is_cuda:
             return None
         ev = torch.cuda.Event(enable_timing=True)
@@ -137,6 +116,156 @@ class FrameShard:
         self.bytes_sent, self.n_collectives = 0, 0
         if self.timing is not None:
             self.timing = []
+
+    def _out(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().cpu().contiguous() if (self.staged and t.is_cuda) else t.contiguous()
+
+    def _global_rank(self, r: int) -> int:
+        return r if self.group is None else self.dist.get_global_rank(self.group, r)
+
+    def allreduce(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place SUM over the ranks."""
+        ev = self._tick(t, "allreduce")
+        if self.staged and t.is_cuda:
+            h = t.detach().cpu()
+            self.dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, group=self.group)
+        self._tock(ev)
+        self.bytes_sent += t.numel() * t.element_size()
+        return t
+
+    def _neighbours(self, to_prev: torch.Tensor, to_next: torch.Tensor, kind: str):
+        """Send `to_prev` to rank - 1 and `to_next` to rank + 1; return (received from rank - 1, received from rank + 1), None at
+        the ends of the rank list.  Contiguous tensors of identical shape; point-to-point, both directions in one batch."""
+        dist = self.dist
+        dev = to_prev.device
+        ops_, prev_buf, next_buf = [], None, None
+        ev = self._tick(to_prev, kind)
+        f_out, l_out = self._out(to_prev), self._out(to_next)
+        if self.rank > 0:
+            prev_buf = torch.empty_like(f_out)
+            peer = self._global_rank(self.rank - 1)      # P2POp peers are GLOBAL ranks, also inside a sub-group
+            ops_.append(dist.P2POp(dist.isend, f_out, peer, self.group))
+            ops_.append(dist.P2POp(dist.irecv, prev_buf, peer, self.group))
+        if self.rank < self.world - 1:
+            next_buf = torch.empty_like(l_out)
+            peer = self._global_rank(self.rank + 1)
+            ops_.append(dist.P2POp(dist.isend, l_out, peer, self.group))
+            ops_.append(dist.P2POp(dist.irecv, next_buf, peer, self.group))
+        if ops_:
+            for r in dist.batch_isend_irecv(ops_):
+                r.wait()
+        self._tock(ev)
+        self.bytes_sent += (int(self.rank > 0) + int(self.rank < self.world - 1)) * to_prev.numel() * to_prev.element_size()
+        prev = None if prev_buf is None else prev_buf.to(dev)
+        nxt = None if next_buf is None else next_buf.to(dev)
+        return prev, nxt
+
+
+class RowShard(_ShardComm):
+    """ONE clip, the latent ROWS of every frame split contiguously over the ranks (BASELINE.json config 4 — the balanced decomposition:
+    the reference has no multi-GPU path, scripts/sampling/sampling_tv2v.py:106 is a single .to("cuda")).
+
+    Every rank holds all B * T frames of rows [r h / N, (r + 1) h / N) at every level of the networks (h = 64, 32, 16, 8 latent rows
+    at 512 x 768: any N in {2, 4, 8} divides them all), i.e. a (B * T, h / N, w, C) slab of each frames-outermost activation — 1 / N of
+    the work of EVERY kernel, whatever T is (whole keyframes of T = 17 over 8 ranks cap at 0.71 / 0.85, `sharding_efficiency`).
+      * temporal operators (Conv1d over T, GroupNorm over C/32 x T, temporal attention) see all T frames of their pixels: LOCAL, no
+        exchange — the 272 transpositions per step of FrameShard's pair mode do not exist here;
+      * 3x3 convolutions need the neighbour ranks' boundary rows: `halo_rows` (one row up, one down, point-to-point) builds the
+        (h / N + 2)-row source the conv kernels take with CcGemmDesc.vpad (zero rows where the frame ends);
+      * spatial GroupNorm: local (sum, sum of squares) per (frame, group), `gn_stats` all-reduces the 32 doubles per frame;
+      * spatial self-attention: queries are local, `gather_rows` all-gathers the K / V rows of the frame (the RCCL all-gather
+        BASELINE.json names, at the spatial attention where this decomposition needs it); text cross-attention is local;
+      * the TVI2V anchor frame is a frame like any other: its K / V rows are part of the gathered tensor — no broadcast.
+    Collectives go through torch.distributed as in FrameShard (nccl = RCCL, gloo staged through the host)."""
+
+    mode = "rows"
+
+    def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, group=None):
+        self._init_comm(rank, world, group)
+
+    def rows(self, h: int) -> Tuple[int, int]:
+        """[r0, r1) of this rank at a level with h rows."""
+        if h % self.world:
+            raise ValueError(f"{h} rows cannot be split evenly over {self.world} ranks (the frame height must be a multiple of "
+                             f"{8 * 8 * self.world} pixels: three stride-2 levels below the latent)")
+        n = h // self.world
+        return self.rank * n, (self.rank + 1) * n
+
+    def halo_rows(self, x: torch.Tensor, below: bool = True) -> torch.Tensor:
+        """x (n, h_local, w, C) -> (n, 1 + h_local + below, w, C): the last row of rank - 1 on top, the first row of rank + 1 at the
+        bottom (`below`; a stride-2 convolution reads only upwards), zero rows at the ends of the frame."""
+        n, h, w, c = x.shape
+        up, down = self._neighbours(x[:, 0].contiguous(), x[:, h - 1].contiguous(), "halo_rows")
+        top = up if up is not None else x.new_zeros((n, w, c))
+        pieces = [top.view(n, 1, w, c), x]
+        if below:
+            bot = down if down is not None else x.new_zeros((n, w, c))
+            pieces.append(bot.view(n, 1, w, c))
+        return torch.cat(pieces, dim=1)
+
+    def gn_stats(self, stats: torch.Tensor) -> torch.Tensor:
+        """Local (sum, sum of squares) per (frame, group) -> the frame's, scaled by 1 / world: ccedit_groupnorm_spatial_apply divides
+        by the LOCAL element count, and (sum / N) / (count / N) is the mean over the whole frame (exact for N a power of two)."""
+        self.allreduce(stats)
+        stats.mul_(1.0 / self.world)
+        return stats
+
+    def gather_rows(self, x: torch.Tensor) -> torch.Tensor:
+        """x (frames, p_local, C): this rank's pixel rows of every frame -> (frames, world * p_local, C), every rank's in order."""
+        ev = self._tick(x, "gather_rows")
+        send = self._out(x)
+        bufs = [torch.empty_like(send) for _ in range(self.world)]
+        self.dist.all_gather(bufs, send, group=self.group)
+        self._tock(ev)
+        self.bytes_sent += send.numel() * send.element_size()
+        return torch.cat(bufs, dim=1).to(x.device)
+
+
+class FrameShard(_ShardComm):
+    """One clip's T keyframes split contiguously over the ranks of a process group (BASELINE.json config 4).
+
+    Every rank holds frames [t0, t1) of EVERY clip of the batch, i.e. a (B, t_local, H, W, C) slab of each
+    frames-outermost activation.  Spatial work is frame-local.  Temporal work (Conv1d k3 over T, GroupNorm over
+    C/32 x T, temporal attention — every pixel independent) depends on `mode`:
+      * "a2a" (default): `to_pixels` transposes the slab with one all-to-all into (all T frames x this rank's 1/world of
+        the pixels), the UNSHARDED temporal kernels run on it, `to_frames` transposes back; `gather_pixels` collects the
+        final prediction.  Nothing else is exchanged.
+      * "halo" (round 1): `halo` (one boundary frame to / from each neighbour, point-to-point) for the convolutions,
+        `allreduce` (per-(clip, pixel, group) sum / sum of squares, fp32) for the normalisations, `gather_frames`
+        (all-gather of the K/V rows) for the attention.
+    `broadcast` serves the TVI2V anchor frame in both modes.  Collectives go through torch.distributed: backend "nccl"
+    (= RCCL on ROCm) moves device tensors directly; with "gloo" (CPU tests, or several ranks sharing one GPU) tensors are
+    staged through host memory.  `bytes_sent`, `n_collectives` and (with `timing = []`) device events around every
+    exchange are what `bench.py --shard-frames` reports.
+    """
+
+    def __init__(self, t_glob: int, rank: Optional[int] = None, world: Optional[int] = None, group=None,
+                 mode: str = "a2a", heavy_last: bool = False):
+        if mode not in ("a2a", "halo"):
+            raise ValueError(f"FrameShard mode {mode!r}: 'a2a' or 'halo' (the row decomposition is parallel.RowShard)")
+        self.mode = mode
+        self._init_comm(rank, world, group)
+        if self.world > t_glob:
+            raise ValueError(f"cannot shard {t_glob} keyframes over {self.world} ranks")
+        self.t_glob = t_glob
+        self.bounds = frame_shards(t_glob, self.world)
+        if heavy_last:                         # the ranks with one extra keyframe are the LAST ones (see cfg_pair)
+            sizes = [b - a for a, b in self.bounds][::-1]
+            self.bounds, s0 = [], 0
+            for n in sizes:
+                self.bounds.append((s0, s0 + n))
+                s0 += n
+        self.t0, self.t1 = self.bounds[self.rank]
+        self.t_local = self.t1 - self.t0
+        self.t_max = max(b - a for a, b in self.bounds)
+        self._plans = {}
+        self._slabs = {}
+
+    def _log_partition(self) -> int:
+        return int(self.bounds[0][1] - self.bounds[0][0] != self.t_max)
 
     # -- layout transposition (mode "a2a") ----------------------------------------------------------
     def _plan(self, b: int, hw: int, device):
@@ -264,48 +393,10 @@ class FrameShard:
                                    add=None if add is None else add.contiguous())
 
     # -- helpers --------------------------------------------------------------------------------
-    def _out(self, t: torch.Tensor) -> torch.Tensor:
-        return t.detach().cpu().contiguous() if (self.staged and t.is_cuda) else t.contiguous()
-
-    def allreduce(self, t: torch.Tensor) -> torch.Tensor:
-        """In-place SUM over the ranks."""
-        ev = self._tick(t, "allreduce")
-        if self.staged and t.is_cuda:
-            h = t.detach().cpu()
-            self.dist.all_reduce(h, group=self.group)
-            t.copy_(h)
-        else:
-            self.dist.all_reduce(t, group=self.group)
-        self._tock(ev)
-        self.bytes_sent += t.numel() * t.element_size()
-        return t
-
     def halo(self, first: torch.Tensor, last: torch.Tensor):
         """Send my first local frame to rank-1 and my last to rank+1; return (frame before my first, frame after my
         last) — None at the clip ends.  first/last: contiguous tensors of identical shape."""
-        dist = self.dist
-        dev = first.device
-        ops_, prev_buf, next_buf = [], None, None
-        ev = self._tick(first, "halo")
-        f_out, l_out = self._out(first), self._out(last)
-        if self.rank > 0:
-            prev_buf = torch.empty_like(f_out)
-            peer = self._global_rank(self.rank - 1)      # P2POp peers are GLOBAL ranks, also inside a sub-group
-            ops_.append(dist.P2POp(dist.isend, f_out, peer, self.group))
-            ops_.append(dist.P2POp(dist.irecv, prev_buf, peer, self.group))
-        if self.rank < self.world - 1:
-            next_buf = torch.empty_like(l_out)
-            peer = self._global_rank(self.rank + 1)
-            ops_.append(dist.P2POp(dist.isend, l_out, peer, self.group))
-            ops_.append(dist.P2POp(dist.irecv, next_buf, peer, self.group))
-        if ops_:
-            for r in dist.batch_isend_irecv(ops_):
-                r.wait()
-        self._tock(ev)
-        self.bytes_sent += (int(self.rank > 0) + int(self.rank < self.world - 1)) * first.numel() * first.element_size()
-        prev = None if prev_buf is None else prev_buf.to(dev)
-        nxt = None if next_buf is None else next_buf.to(dev)
-        return prev, nxt
+        return self._neighbours(first, last, "halo")
 
     def owner_of(self, t_global: int) -> int:
         """Rank holding global keyframe t_global."""
@@ -342,9 +433,6 @@ class FrameShard:
                 ranks = list(range(dist.get_world_size())) if g0 is None else dist.get_process_group_ranks(g0)
                 g1 = dist.new_group(ranks)
         return (FrameShard(t_glob, group=g0, mode=mode), FrameShard(t_glob, group=g1, mode=mode, heavy_last=True))
-
-    def _global_rank(self, r: int) -> int:
-        return r if self.group is None else self.dist.get_global_rank(self.group, r)
 
     def gather_pixels(self, y2d: torch.Tensor, b: int, hw: int) -> torch.Tensor:
         """(b * t_glob * hw_local, C) pixel-layout rows -> (b * t_glob * hw, C): every rank's pixel block, in order."""

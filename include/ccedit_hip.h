@@ -147,7 +147,12 @@ typedef struct CcGemmDesc {
      * the LayerNorm statistics of the tensor being written, for the call that consumes it through ln_sums. */
     double* row_sums;
     float ln_sums_eps;
-    int32_t reserved1;
+    /* CONV2D, 0 = off (ABI 9, was reserved).  1: the source frames carry their own vertical halo — Hin = the rows the taps may touch
+     * (one row above and, for stride 1, one below the rows that produce output; zeros where the frame ends), Hout = output rows — so
+     * the vertical padding is one less than `pad` (resp. than the parity's, with subpix; then Hin == Hout + 2).  How a frame whose ROWS
+     * are sharded over ranks is convolved after the neighbours' boundary rows were received (ccedit_amd/parallel.py: RowShard;
+     * BASELINE.json config 4).  Generic tap-gather kernel only. */
+    int32_t vpad;
 } CcGemmDesc;
 
 int ccedit_gemm(const CcGemmDesc* desc, void* stream);
@@ -199,6 +204,10 @@ int ccedit_groupnorm_spatial(const void* x, void* y, const float* gamma, const f
 int ccedit_groupnorm_spatial_apply(const void* x, void* y, const float* gamma, const float* beta,
                                    const double* stats, int32_t frames, int32_t hw, int32_t C, float eps,
                                    int32_t silu, void* stream);
+/* The statistics half alone: adds (sum, sum of squares) of every (frame, group) to stats = double[frames][32][2], ZEROED BY THE CALLER —
+ * for frames whose rows are sharded over ranks (RowShard): local sums, all-reduced by the caller, then ccedit_groupnorm_spatial_apply
+ * with the sums divided by the number of ranks (its element count is the LOCAL hw). */
+int ccedit_groupnorm_spatial_stats(const void* x, double* stats, int32_t frames, int32_t hw, int32_t C, void* stream);
 /* GroupNorm(32, C) over (C/32 x T) per pixel — the normalization() / norm_temporal applied to the
  * '(b h w) c t' view (openaimodel.py:617-619, 674-676; attention.py:1085, 1176).
  * x: [B*T][hw][C]; one statistics group = T frames x C/32 channels at one pixel. */

@@ -48,7 +48,7 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_grad_enabled(False)
-    from ccedit_amd.parallel import FrameShard
+    from ccedit_amd.parallel import FrameShard, RowShard
     from ccedit_amd.sgm_compat import build_network
     from ccedit_amd.utils.synth import fill_module_
     cfg = dict(G, crossframe=True) if crossframe else G
@@ -59,17 +59,22 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     cc = {k: v.cuda() for k, v in c.items()}
     ref = w(x2.cuda(), t.cuda(), cc).cpu() if rank == 0 else None      # unsharded evaluation
     groups = (None, dist.new_group(list(range(world)))) if rccl else (None, None)      # bench.py's two-communicator arrangement
-    shards = FrameShard.cfg_pair(T, groups=groups) if mode == "pair" else (FrameShard(T, mode=mode),)
+    cls = RowShard if mode == "rows" else FrameShard
+    if mode == "rows":        # the balanced decomposition: 1 / world of the latent ROWS of every frame per rank
+        shards = (RowShard(),)
+        w.row_shard = shards[0]
+    else:
+        shards = FrameShard.cfg_pair(T, groups=groups) if mode == "pair" else (FrameShard(T, mode=mode),)
+        w.frame_shard = shards if mode == "pair" else shards[0]
     assert all(s.staged != rccl for s in shards)
-    w.frame_shard = shards if mode == "pair" else shards[0]
-    FrameShard.issue_log = []
+    cls.issue_log = []
     out = w(x2.cuda(), t.cuda(), cc).cpu()
     torch.cuda.synchronize()
     # Every rank must have issued the SAME sequence of collectives (kind, size class, communicator) from its host thread — with
     # two communicators on two streams ("pair") a rank-dependent order is the classic RCCL deadlock.  Element counts differ
     # between ranks only through the shard sizes, so the comparable part is (partition, kind).
-    mine = [(p_, k_) for p_, k_, _ in FrameShard.issue_log]
-    FrameShard.issue_log = None
+    mine = [(p_, k_) for p_, k_, _ in cls.issue_log]
+    cls.issue_log = None
     logs = [None] * world
     dist.all_gather_object(logs, mine)
     assert all(l == logs[0] for l in logs), "ranks issued their collectives in different orders"
@@ -90,11 +95,14 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("world,crossframe,mode", [(1, False, "a2a"), (1, True, "pair-rccl"), (1, False, "halo-rccl"), (2, False, "a2a"), (2, True, "a2a"), (2, False, "pair"),
-                                                   (2, True, "pair"), (2, False, "halo"), (2, True, "halo")])
+                                                   (2, True, "pair"), (2, False, "halo"), (2, True, "halo"),
+                                                   (1, True, "rows-rccl"), (2, False, "rows"), (2, True, "rows")])
 # uneven 3- and 4-way splits: primitives in test_parallel_gloo.py (several processes time-slicing one GPU through
 # host-staged gloo take minutes).  crossframe=True: TVI2V — the centre keyframe (rank 1 of 2 at T=5) adds img_control and
 # broadcasts its K/V.  "-rccl": one rank on the nccl (= RCCL) backend — every exchange degenerates to a self-exchange, but the
-# calls, tensor placement and communicator set-up are the ones the multi-GPU run makes.  mode: "a2a" = all-to-all layout transposition around the temporal ops; "pair" = the same with the two
+# calls, tensor placement and communicator set-up are the ones the multi-GPU run makes.  "rows" = parallel.RowShard: every rank holds
+# all keyframes of 1 / world of the latent rows (8 of 16 here; 4 / 2 / 1 at the deeper levels) — halo rows for the 3x3 convs, all-reduced
+# GroupNorm sums, all-gathered K / V for the spatial attention, temporal operators local.  mode: "a2a" = all-to-all layout transposition around the temporal ops; "pair" = the same with the two
 # CFG halves on mirrored partitions and two streams; "halo" = round-1 halo / all-reduce / all-gather exchanges
 def test_sharded_network_matches_unsharded(world, crossframe, mode):
     if not torch.cuda.is_available():

@@ -1009,6 +1009,49 @@ def test_upsample_conv_as_four_parity_convs(n, h, w, cin, cout):
     assert torch.equal(y, ops.conv2d_upsampled(xd, pack_upsample_parities(wt, b, device="cuda")))
 
 
+def test_convs_on_row_slabs_with_halo_rows_equal_the_whole_frame():
+    """CcGemmDesc.vpad (parallel.RowShard): a frame cut into row slabs, each extended by its neighbours' boundary rows (zeros at the
+    frame ends), convolved slab by slab — 3x3 stride 1, 3x3 stride 2, upsample + 3x3 in parity form — must reproduce the convolution
+    of the whole frame bit for bit (same kernels, same summation order per output pixel is not guaranteed across block shapes, so
+    the comparison is at rounding level) and the fp32 reference."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_upsample_parities, pack_weight
+    n, h, w, cin, cout, parts = 3, 16, 12, 64, 128, 4
+    x = _rnd(n, cin, h, w, seed=1)
+    wt, b = _rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), _rnd(cout, seed=3)
+    xd = _nhwc(x)
+    pw = pack_weight(wt, b).to("cuda")
+    par = pack_upsample_parities(wt, b, device="cuda")
+    hl = h // parts
+    zero = torch.zeros_like(xd[:, :1])
+
+    def ext(r, below=True):
+        top = xd[:, r * hl - 1:r * hl] if r > 0 else zero
+        rows = [top, xd[:, r * hl:(r + 1) * hl]]
+        if below:
+            rows.append(xd[:, (r + 1) * hl:(r + 1) * hl + 1] if r < parts - 1 else zero)
+        return torch.cat(rows, dim=1).contiguous()
+
+    full = ops.conv2d(xd, pw)
+    slabs = torch.cat([ops.conv2d(ext(r), pw, vpad=True) for r in range(parts)], dim=1)
+    _close(_nchw(slabs), F.conv2d(x.to(BF).float(), wt, b, padding=1), what="row slabs, conv3x3")
+    _close(slabs, full, rel=2.0 ** -8, abs_=1e-3, what="row slabs vs whole frame, conv3x3")
+    full2 = ops.conv2d(xd, pw, stride=2)
+    slabs2 = torch.cat([ops.conv2d(ext(r, below=False), pw, stride=2, vpad=True) for r in range(parts)], dim=1)
+    assert slabs2.shape == full2.shape
+    _close(_nchw(slabs2), F.conv2d(x.to(BF).float(), wt, b, stride=2, padding=1), what="row slabs, conv3x3 stride 2")
+    fullu = ops.conv2d_upsampled(xd, par)
+    slabsu = torch.cat([ops.conv2d_upsampled(ext(r), par, vpad=True) for r in range(parts)], dim=1)
+    assert slabsu.shape == fullu.shape
+    assert torch.equal(slabsu, fullu), "parity convs on row slabs differ from the whole frame"
+    # the statistics half of the spatial GroupNorm: slab sums add up to the frame's
+    st = sum(ops.groupnorm_spatial_stats(xd[:, r * hl:(r + 1) * hl].contiguous()).clone() for r in range(parts))
+    xf = xd.float().view(n, h * w, 32, cin // 32)
+    assert torch.allclose(st[..., 0].float().cpu(), xf.sum(dim=(1, 3)).cpu(), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[..., 1].float().cpu(), (xf * xf).sum(dim=(1, 3)).cpu(), rtol=1e-4, atol=1e-2)
+
+
 def test_attention_spatial_kernel_reference_column_and_prescaled_q():
     """attn_spatial_kernel (attnspatial.hip; d = 40, >= 1024 queries, >= 192 keys): the softmax reference rides in the pad column of
     the last QK^T k-step and moves only when a score exceeds it by 2^16.  Checked here: the kernel is the one dispatched; spikes far

@@ -195,3 +195,62 @@ def test_frame_shard_inside_a_subgroup_gloo():
         p.join(30)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+# ------------------------------------------------------------------------------------------
+# parallel.RowShard (BASELINE.json config 4, the balanced decomposition): every rank holds 1 / world of the ROWS of all frames
+# ------------------------------------------------------------------------------------------
+def _row_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ccedit_amd.parallel import RowShard
+    rs = RowShard()
+    RowShard.issue_log = []
+    n, h, w, c = 34, 8 * world, 6, 4                       # T = 17 keyframes x 2 clips
+    g = torch.Generator().manual_seed(5)
+    full = torch.randn(n, h, w, c, generator=g)
+    r0, r1 = rs.rows(h)
+    mine = full[:, r0:r1].contiguous()
+    ok = True
+    # halo rows: the extended slab is the zero-padded frame's rows [r0 - 1, r1 + 1)
+    pad = torch.nn.functional.pad(full, (0, 0, 0, 0, 1, 1))
+    ok &= torch.equal(rs.halo_rows(mine), pad[:, r0:r1 + 2])
+    ok &= torch.equal(rs.halo_rows(mine, below=False), pad[:, r0:r1 + 1])
+    # GroupNorm sums: local (sum, sum of squares) -> the frame's, divided by the number of ranks
+    st = torch.stack([mine.double().sum(dim=(1, 2, 3)), (mine.double() ** 2).sum(dim=(1, 2, 3))], dim=1)
+    want = torch.stack([full.double().sum(dim=(1, 2, 3)), (full.double() ** 2).sum(dim=(1, 2, 3))], dim=1) / world
+    ok &= torch.allclose(rs.gn_stats(st), want, rtol=1e-12)
+    # K / V rows: every rank ends with all pixel rows of every frame, in row order
+    ok &= torch.equal(rs.gather_rows(mine.view(n, -1, c)), full.view(n, -1, c))
+    q.put((rank, bool(ok), rs.n_collectives, rs.bytes_sent, [k for _, k, _ in RowShard.issue_log]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_row_shard_primitives_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_row_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), [r[:2] for r in res]
+    assert all(r[2] == 4 and r[4] == res[0][4] for r in res)              # same collectives, same order, on every rank
+    assert res[0][4] == ["halo_rows", "halo_rows", "allreduce", "gather_rows"]
+    # an interior rank sends two boundary rows per halo exchange, the end ranks one
+    assert res[0][3] < res[world // 2][3] or world == 2
+
+
+def test_row_shard_is_balanced_where_frame_sharding_is_not():
+    from ccedit_amd.parallel import cfg_pair_efficiency, row_sharding_efficiency, sharding_efficiency
+    for world in (2, 4, 8):
+        assert row_sharding_efficiency(64, world) == 1.0                     # 64 / 32 / 16 / 8 latent rows divide by 2, 4, 8
+    assert sharding_efficiency(17, 8) < cfg_pair_efficiency(17, 8) < 0.9 < row_sharding_efficiency(64, 8)
+    with pytest.raises(ValueError):
+        row_sharding_efficiency(60, 8)
