@@ -143,10 +143,11 @@ def main():
     ap.add_argument("--shard-frames", action="store_true",
                     help="N>1: BASELINE.json config 4 — ONE clip, its T=17 keyframes sharded over the ranks; default N>1 mode "
                          "is config 5 (one clip per GPU, no collective)")
-    ap.add_argument("--shard-mode", choices=["pair", "a2a", "halo"], default="pair",
+    ap.add_argument("--shard-mode", choices=["pair", "a2a", "halo", "rows"], default="pair",
                     help="pair: all-to-all layout transposition around the temporal ops, the two CFG halves on mirrored "
                          "partitions, two communicators and two streams; a2a: the same transposition, one partition; halo: "
-                         "round-1 halo p2p + statistics all-reduce + K/V all-gather")
+                         "round-1 halo p2p + statistics all-reduce + K/V all-gather; rows: every rank holds all keyframes of 1/N of the "
+                         "latent rows (halo rows for the 3x3 convs, all-reduced GroupNorm sums, all-gathered K/V, temporal ops local)")
     ap.add_argument("--workload", choices=["tv2v", "tvi2v"], default="tv2v",
                     help="tv2v = BASELINE.json config 2 (the headline metric); tvi2v = config 3 (ref-frame cfca network)")
     ap.add_argument("--no-profile-step", action="store_true", help="skip the extra HIP-event profiled step (PMC runs)")
@@ -186,8 +187,11 @@ def main():
     x, cross_c, cross_uc, hint = synth_inputs(device, seed=42 + (0 if shard else rank))
     shards = ()
     if shard:
-        from ccedit_amd.parallel import FrameShard
-        if args.shard_mode == "pair":               # a communicator per CFG half: their exchanges run independently
+        from ccedit_amd.parallel import FrameShard, RowShard
+        if args.shard_mode == "rows":               # the balanced decomposition (ceiling 1.0): rows of every frame, not keyframes
+            shards = (RowShard(),)
+            wrapper.row_shard = shards[0]
+        elif args.shard_mode == "pair":             # a communicator per CFG half: their exchanges run independently
             shards = FrameShard.cfg_pair(T)
             wrapper.frame_shard = shards
         else:
@@ -234,19 +238,20 @@ def main():
     roof = None
     extra = {}
     if shard:
-        from ccedit_amd.parallel import cfg_pair_efficiency, sharding_efficiency
+        from ccedit_amd.parallel import cfg_pair_efficiency, row_sharding_efficiency, sharding_efficiency
         for s_ in shards:
             s_.timing = []
             s_.reset_counters()
         step()
         torch.cuda.synchronize()
         mine = torch.tensor([sum(s_.bytes_sent for s_ in shards), sum(s_.n_collectives for s_ in shards),
-                             sum(s_.comm_ms() for s_ in shards), sum(s_.t_local for s_ in shards)], dtype=torch.float64)
+                             sum(s_.comm_ms() for s_ in shards), sum(getattr(s_, "t_local", T) for s_ in shards)], dtype=torch.float64)
         for s_ in shards:
             s_.timing = None
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather_object(allr, mine)
         keep, wrapper.frame_shard = wrapper.frame_shard, None
+        keep_rows, wrapper.row_shard = wrapper.row_shard, None
         step()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -254,11 +259,13 @@ def main():
             step()
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        wrapper.frame_shard = keep
+        wrapper.frame_shard, wrapper.row_shard = keep, keep_rows
         single_ms = max_over_ranks_ms(single_ms, dist, device, backend)
-        ceiling = cfg_pair_efficiency(T, world) if args.shard_mode == "pair" else sharding_efficiency(T, world)
+        ceiling = (row_sharding_efficiency(H, world) if args.shard_mode == "rows" else
+                   cfg_pair_efficiency(T, world) if args.shard_mode == "pair" else sharding_efficiency(T, world))
         extra["shard"] = dict(
             mode=args.shard_mode, frame_instances_per_rank=[int(a[3]) * (1 if args.shard_mode == "pair" else 2) for a in allr],
+            latent_rows_per_rank=(H // world if args.shard_mode == "rows" else H), measured_on="NOT measured over xGMI unless n_gpus real devices ran it",
             ceiling=round(ceiling, 4), single_gpu_ms_per_step=round(single_ms, 3),
             efficiency_per_gpu=round(single_ms / (world * ms_per_step), 4),
             exchanges_per_step=int(allr[0][1]), bytes_sent_per_step_max_rank=int(max(a[0] for a in allr)),
@@ -378,7 +385,9 @@ def main():
                                     "TV2V depth-midas, 17x512x768, one network evaluation = ControlNet2D + pseudo-3D UNet on "
                                     "B=2 (cfg 7.5 uncond+cond) x T=17 frames, latent 64x96, 77x768 text context; "
                                     "77.68 TFLOP/step; a 30-step DPMPP2SAncestral clip = 59 such steps + VAE decode"),
-                       "parallelism": (f"one clip, T=17 keyframes sharded over the ranks (mode {args.shard_mode}: " +
+                       "parallelism": ("one clip, the latent ROWS of every keyframe sharded over the ranks (halo rows for the 3x3 convs, all-reduced "
+                                       "GroupNorm sums, RCCL all-gather of K/V at the spatial attention, temporal ops local)" if shard and args.shard_mode == "rows" else
+                                       f"one clip, T=17 keyframes sharded over the ranks (mode {args.shard_mode}: " +
                                        ("halo p2p + stats all-reduce + K/V all-gather)" if args.shard_mode == "halo" else
                                         "all-to-all frame<->pixel transposition around every temporal op)") if shard else
                                        "1 clip per GPU (replicas, no collective)" if world > 1 else "single GPU"),
