@@ -979,6 +979,8 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     cache_hint_stem = True
     _hint_val = None
     _hint_slices = None
+    _hint_dup = None
+    dedup_hint = os.environ.get("CCEDIT_HINT_DEDUP", "1") != "0"      # 0: evaluate the hint stem on both CFG halves (A/B)
     frame_shard = None          # parallel.FrameShard: split the T keyframes of each clip over the ranks (config 4)
     row_shard = None            # parallel.RowShard: split the latent ROWS of every frame over the ranks (config 4, balanced)
     # The ControlNet's residuals are first needed after the UNet's middle block: with overlap_controlnet the ControlNet
@@ -1007,6 +1009,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         their source storage, see _guided_hint — only to release the previous clip's memory early."""
         self._hint_val = None
         self._hint_slices = None
+        self._hint_dup = None
         self._graphs = None
 
     def _guided_hint(self, hint5d: torch.Tensor, rows=None):
@@ -1018,9 +1021,25 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         key = self._tensor_key(hint5d) + (PACK_GENERATION[0],)        # (a re-pack replaces the stem's weights)
         if self.cache_hint_stem and isinstance(self._hint_val, dict) and key in self._hint_val:
             return self._hint_val[key][1]
+        # The two CFG halves carry the SAME hint (the sampling scripts give `uc` a clone of c's control_hint, sampling_tv2v.py:339-344,
+        # and the guider concatenates them): the stem — eight per-frame convolutions at up to 512 x 768 — is evaluated on one half and its
+        # output repeated.  Whether the halves are equal is decided by comparing them once per hint tensor (a device compare and one
+        # host sync, remembered with the tensor's identity + version like the caches above; never decided while capturing a graph).
+        dup = False
+        if self.dedup_hint and hint5d.shape[0] % 2 == 0:
+            if not isinstance(self._hint_dup, dict) or len(self._hint_dup) >= 8:
+                self._hint_dup = {}
+            ent = self._hint_dup.get(key)
+            if ent is None and not torch.cuda.is_current_stream_capturing():
+                k = hint5d.shape[0] // 2
+                ent = self._hint_dup[key] = (hint5d, bool(torch.equal(hint5d[:k], hint5d[k:])))
+            dup = ent is not None and ent[1]
+        src = hint5d[: hint5d.shape[0] // 2] if dup else hint5d
         # control_hint in [-1,1] -> 1 - (h+1)/2 (wrappers.py:160-162), fused into the layout change
-        hint8 = ops.ncthw_to_nhwc(hint5d.float().contiguous(), 8, scale=-0.5, shift=0.5)
+        hint8 = ops.ncthw_to_nhwc(src.float().contiguous(), 8, scale=-0.5, shift=0.5)
         g = net.hint_stem(hint8, rows=rows)
+        if dup:
+            g = torch.cat([g, g])
         if self.cache_hint_stem:
             if not isinstance(self._hint_val, dict) or len(self._hint_val) >= 4:     # one entry per CFG half (+ shards)
                 self._hint_val = {}

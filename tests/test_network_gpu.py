@@ -381,6 +381,35 @@ def test_repack_invalidates_captured_graphs_and_hint_stem_cache(g160_wrapper):
         w.reset_caches()
 
 
+def test_hint_stem_is_shared_between_identical_cfg_halves(g160_wrapper):
+    """The guider's doubled batch carries the same control_hint twice: the stem runs on one half and its output is repeated — the same
+    bits as evaluating both halves; different halves are detected (once per tensor) and evaluated separately."""
+    w = g160_wrapper
+    g = torch.Generator().manual_seed(80)
+    h1 = torch.rand(1, 3, 4, 64, 64, generator=g) * 2 - 1
+    h2 = torch.rand(1, 3, 4, 64, 64, generator=g) * 2 - 1
+    ca = torch.randn(2, 77, 128, generator=g).cuda()
+    x = torch.randn(2, 4, 4, 8, 8, generator=g).cuda()
+    t = torch.tensor([250, 250], dtype=torch.int64).cuda()
+    saved, saved_graph = w.dedup_hint, w.use_graph
+    try:
+        w.use_graph = False
+        for hint in (torch.cat([h1, h1]).cuda(), torch.cat([h1, h2]).cuda()):
+            c = dict(crossattn=ca, control_hint=hint)
+            w.dedup_hint = False
+            w.reset_caches()
+            ref = w(x, t, c).clone()
+            w.dedup_hint = True
+            w.reset_caches()
+            got = w(x, t, c).clone()
+            assert torch.equal(got, ref)
+            same = bool(torch.equal(hint[:1], hint[1:]))
+            assert [v[1] for v in w._hint_dup.values()] == [same]
+    finally:
+        w.dedup_hint, w.use_graph = saved, saved_graph
+        w.reset_caches()
+
+
 def test_sampler_trajectory_vs_reference_golden(golden_dir, g160_wrapper):
     """DPMPP2SAncestral + VanillaCFGTV2V(7.5) + DiscreteDenoiser, 5 steps, injected noise."""
     from ccedit_amd.config import instantiate_from_config
