@@ -13,6 +13,7 @@
 // same time, so the activation rows come out of that XCD's L2 for all but the first.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -281,6 +282,279 @@ __global__ __launch_bounds__(kNT, 1) void lin320_kernel(const CcGemmDesc d, int 
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// lin320s_kernel: the same weights-in-registers idea with NO K split and a deep activation ring.
+//
+// lin320_kernel above moves 2.8-3.5 TB/s: its tile period (~4 us for 40-60 KB per CU) is the latency of ONE tile fetch —
+// three 21 KB buffers keep 40 KB per CU in flight, and by Little's law 40 KB x 256 CUs / (3-4 us loaded HBM latency) is
+// just that rate.  The two fp32 staging tiles where the K halves meet (83 KB) are what keeps the ring short.  Here:
+//  * 16x16x32 MFMAs, A = weights: the 20 sixteen-channel tiles of a slice go 3 + 2 to the two waves of each SIMD (waves
+//    w and w + 4), every wave spans all of K (30 / 20 fragments = 120 / 80 VGPRs), no channel padding (320 rows, not 384)
+//    and no meeting of partial sums.
+//  * the accumulators START from the bias (+ the residual tile, which arrives by DMA like the activations) and leave as
+//    bf16 through an LDS tile in row layout — for the residual variant the very tile the residual came in: lane (pixel,
+//    4 channels) reads and later writes the same 8 bytes, so that needs no synchronisation at all.  The output pass of
+//    tile i - 1 (whole 640-byte rows, 16 bytes per lane) runs after the loop-top barrier of tile i: ONE barrier per tile.
+//  * seven 21 KB buffers: plain 5 activation tiles + 2 output tiles (80 KB in flight per CU), residual 3 activation + 4
+//    residual/output tiles (2 x 40 KB in flight).  No register-returning global load is left in the loop, so nothing the
+//    compiler waits for drains the DMA queue; the only wait is the counted one below (loads return in order: with at most
+//    `the DMA instructions of the later tiles` outstanding, tile i + 1 has landed).
+// Requires M % 32 == 0 (every tile whole: the number of memory instructions per iteration is what the counted wait
+// relies on); other shapes keep lin320_kernel.
+constexpr int kBufsS = 7;
+
+template <int N>
+__device__ __forceinline__ void l3_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void l3_vmcnt_n(int n) {      // n is wave-uniform
+    switch (n) {
+        case 0: l3_vmcnt<0>(); break;
+        case 2: l3_vmcnt<2>(); break;
+        case 3: l3_vmcnt<3>(); break;
+        case 4: l3_vmcnt<4>(); break;
+        case 6: l3_vmcnt<6>(); break;
+        case 8: l3_vmcnt<8>(); break;
+        case 9: l3_vmcnt<9>(); break;
+        case 12: l3_vmcnt<12>(); break;
+        default: l3_vmcnt<0>(); break;
+    }
+}
+
+template <bool RES, bool LN>
+__global__ __launch_bounds__(kNT, 1) void lin320s_kernel(const CcGemmDesc d, int nslice, int pt_n) {
+    static_assert(!(RES && LN), "the normalised projections have no residual");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RX = RES ? 3 : 5;             // activation ring
+    constexpr int RO = kBufsS - RX;             // output (RES: residual, then output in place) ring: 4 / 2
+    char* const sXr = smem;
+    char* const sOr = smem + RX * kXBuf;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g4 = lane >> 4;
+
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int lanes = 32 / nslice;
+    const int slice = j % nslice, plane = j / nslice;
+    if (plane >= lanes) return;
+    const int per_xcd = (pt_n + 7) >> 3;
+    const int pt_lo = xcd * per_xcd, pt_hi = min(pt_lo + per_xcd, pt_n);
+    const int pt0 = pt_lo + plane;
+    if (pt0 >= pt_hi) return;
+    const int ntile = (pt_hi - pt0 + lanes - 1) / lanes;        // tiles of this workgroup: pt0 + i * lanes
+    const int ch0 = slice * kSlice;
+
+    // ---- DMA plan (as lin320_kernel): slot n of a tile = row n / 41, granule n % 41 (granule 40 = row padding) ----
+    const bf16* __restrict__ Ap = (const bf16*)d.A;
+    const bf16* __restrict__ Rp = (const bf16*)d.res1;
+    constexpr int kIssues = (kWaveIssues + 7) / 8;             // 3 per thread
+    int soffx[kIssues], soffr[kIssues];
+#pragma unroll
+    for (int i = 0; i < kIssues; ++i) {
+        const int n = (i * 8 + wave) * 64 + lane;
+        const int r = n / kGPR, g = n - r * kGPR;
+        const bool ok = r < kP && g < kK / 8;
+        soffx[i] = ok ? r * d.lda + g * 8 : -1;
+        soffr[i] = ok && RES ? r * d.ldr1 + ch0 + g * 8 : -1;
+    }
+    const int my_issues = (2 * 8 + wave < kWaveIssues) ? 3 : 2;      // DMA instructions of this wave per tile and tensor
+    const int per_tile = my_issues * (RES ? 2 : 1);
+    auto stage = [&](int i, int xb, int ob) {
+        const int64_t pix0 = (int64_t)(pt0 + i * lanes) * kP;
+        const bf16* xbase = Ap + pix0 * d.lda;
+#pragma unroll
+        for (int q = 0; q < kIssues; ++q)
+            if (q * 8 + wave < kWaveIssues)      // wave-uniform
+                glds16(soffx[q] >= 0 ? (const void*)(xbase + soffx[q]) : (const void*)g_zero_page_w, sXr + xb * kXBuf + (q * 8 + wave) * 1024);
+        if constexpr (RES) {
+            const bf16* rbase = Rp + pix0 * d.ldr1;
+#pragma unroll
+            for (int q = 0; q < kIssues; ++q)
+                if (q * 8 + wave < kWaveIssues)
+                    glds16(soffr[q] >= 0 ? (const void*)(rbase + soffr[q]) : (const void*)g_zero_page_w, sOr + ob * kXBuf + (q * 8 + wave) * 1024);
+        }
+    };
+
+    // ---- output pass plan: task t = tid + 512 k = one 16-byte granule of one of the 32 rows ----
+    constexpr int kTPR = kSlice / 8, kTasks = kP * kTPR;        // 40 per row, 1280 per tile
+    constexpr int kTI = (kTasks + kNT - 1) / kNT;               // 3 (waves 0..3) / 2
+    const int nt_mine = wave < 4 ? 3 : 2;                       // 1280 = 2 * 512 + 256
+    int tlds[kTI];
+    int64_t tout[kTI];
+#pragma unroll
+    for (int k = 0; k < kTI; ++k) {
+        const int t = tid + kNT * k;
+        const int r = t / kTPR, gq = t - r * kTPR;
+        tlds[k] = r * kRS + gq * 16;
+        tout[k] = (int64_t)r * d.ldc + ch0 + gq * 8;
+    }
+
+    auto body = [&](auto ntw_) {
+        constexpr int NTW = decltype(ntw_)::value;              // channel tiles of this wave: 3 (waves 0..3) / 2
+        const int tile0 = (wave & 3) * 5 + (NTW == 3 ? 0 : 3);
+        // ---- the weight rows of this wave: A-operand fragments, resident for the whole kernel ----
+        bf16x8 wf[NTW][kK / 32];
+        f32x4 bq[NTW];
+        {
+            const bf16* __restrict__ Wp = (const bf16*)d.W;
+#pragma unroll
+            for (int ti = 0; ti < NTW; ++ti) {
+                const bf16* row = Wp + (size_t)(ch0 + 16 * (tile0 + ti) + c16) * d.Kpad + g4 * 8;
+#pragma unroll
+                for (int ks = 0; ks < kK / 32; ++ks) wf[ti][ks] = *(const bf16x8*)(row + ks * 32);
+                const int cb = ch0 + 16 * (tile0 + ti) + 4 * g4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bq[ti][e] = d.bias ? d.bias[cb + e] : 0.f;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the weights are in: from here on the queue holds DMA and stores only
+
+        const int xlane = c16 * kRS + g4 * 16;                  // B fragment of pixel tile p, k-step ks: + p * 16 rows + ks * 64
+        const int olane = c16 * kRS + (16 * tile0 + 4 * g4) * 2;      // C cell (pixel, 4 channels): + p * 16 rows + ti * 32
+
+        // tiles 0 .. RX-2 are requested up front; tile i + RX - 1 at the top of iteration i
+        int xs = 0, os = 0;                                      // ring slots the NEXT staged tile goes to
+        int staged = 0;
+        for (; staged < RX - 1 && staged < ntile; ++staged) {
+            stage(staged, xs, os);
+            xs = xs == RX - 1 ? 0 : xs + 1;
+            os = os == RO - 1 ? 0 : os + 1;
+        }
+        l3_vmcnt_n((staged - 1) * per_tile);                    // tile 0 has landed (this wave's part)
+        int xb = 0, ob = 0, obp = 0;                             // slots of tile i / of tile i - 1's output
+        for (int i = 0; i < ntile; ++i) {
+            lds_barrier();      // tile i is in LDS for every wave; output tile i-1 is complete; X slot of tile i-1 and O slot of tile i-2 are free
+            if (staged < ntile) {
+                stage(staged, xs, os);
+                ++staged;
+                xs = xs == RX - 1 ? 0 : xs + 1;
+                os = os == RO - 1 ? 0 : os + 1;
+            }
+            char* const xt = sXr + xb * kXBuf;
+            char* const ot = sOr + ob * kXBuf;
+            if constexpr (LN) {
+                // 16 threads per pixel row, two-pass fp32 statistics, the normalised row written back in place (lin320_kernel)
+                char* const rowp = xt + (tid >> 4) * kRS;
+                const int sub = tid & 15;
+                bf16x8 t[3];
+                float sm = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int g = sub + 16 * k;
+                    if (g < kK / 8) {
+                        t[k] = *(const bf16x8*)(rowp + g * 16);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sm += bf2f(t[k][e]);
+                    }
+                }
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) sm += __shfl_xor(sm, m, 16);
+                const float mean = sm * (1.0f / kK);
+                float q = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (sub + 16 * k < kK / 8) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float dv = bf2f(t[k][e]) - mean;
+                            q += dv * dv;
+                        }
+                    }
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) q += __shfl_xor(q, m, 16);
+                const float rstd = rsqrtf(q * (1.0f / kK) + d.ln_eps);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int g = sub + 16 * k;
+                    if (g < kK / 8) {
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = f2bf((bf2f(t[k][e]) - mean) * rstd);
+                        *(bf16x8*)(rowp + g * 16) = o;
+                    }
+                }
+                lds_barrier();
+            }
+
+            // output pass of tile i - 1, first half: its rows out of LDS
+            bf16x8 ov[kTI];
+            if (i > 0) {
+                const char* const pt = sOr + obp * kXBuf;
+#pragma unroll
+                for (int k = 0; k < kTI; ++k)
+                    if (k < nt_mine) ov[k] = *(const bf16x8*)(pt + tlds[k]);
+            }
+            // accumulators start from the bias (+ the residual cell)
+            f32x4 acc[NTW][2];
+#pragma unroll
+            for (int ti = 0; ti < NTW; ++ti)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    acc[ti][p] = bq[ti];
+                    if constexpr (RES) {
+                        const bf16x4 r = *(const bf16x4*)(ot + olane + p * 16 * kRS + ti * 32);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[ti][p][e] += bf2f(r[e]);
+                    }
+                }
+            const char* const xq0 = xt + xlane;
+            bf16x8 xq[3][2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                xq[0][p] = *(const bf16x8*)(xq0 + p * 16 * kRS);
+                xq[1][p] = *(const bf16x8*)(xq0 + p * 16 * kRS + 64);
+            }
+#pragma unroll
+            for (int ks = 0; ks < kK / 32; ++ks) {
+                if (ks + 2 < kK / 32) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) xq[(ks + 2) % 3][p] = *(const bf16x8*)(xq0 + p * 16 * kRS + (ks + 2) * 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ti = 0; ti < NTW; ++ti)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        acc[ti][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ti][ks], xq[ks % 3][p], acc[ti][p], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 1 && i > 0) {
+                    // output pass of tile i - 1, second half: whole rows to memory while the matrix pipe is busy
+                    bf16* const op = (bf16*)d.out + (int64_t)(pt0 + (i - 1) * lanes) * kP * d.ldc;
+#pragma unroll
+                    for (int k = 0; k < kTI; ++k)
+                        if (k < nt_mine) *(bf16x8*)(op + tout[k]) = ov[k];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // bf16 cells of this wave's channels into the output tile
+#pragma unroll
+            for (int ti = 0; ti < NTW; ++ti)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[ti][p][e]);
+                    *(bf16x4*)(ot + olane + p * 16 * kRS + ti * 32) = o;
+                }
+            // tile i + 1 must have landed (this wave's part) before the next barrier: at most the DMA of the tiles after it
+            // may still be outstanding
+            if (i + 1 < ntile) l3_vmcnt_n((staged - (i + 2)) * per_tile);
+            obp = ob;
+            xb = xb == RX - 1 ? 0 : xb + 1;
+            ob = ob == RO - 1 ? 0 : ob + 1;
+        }
+        lds_barrier();
+        {
+            const char* const pt = sOr + obp * kXBuf;
+            bf16* const op = (bf16*)d.out + (int64_t)(pt0 + (ntile - 1) * lanes) * kP * d.ldc;
+#pragma unroll
+            for (int k = 0; k < kTI; ++k)
+                if (k < nt_mine) *(bf16x8*)(op + tout[k]) = *(const bf16x8*)(pt + tlds[k]);
+        }
+    };
+    if (wave < 4) body(std::integral_constant<int, 3>{});
+    else body(std::integral_constant<int, 2>{});
+}
+
 }  // namespace
 
 // bias, GEGLU or no activation, bf16 out, no residual / group bias / statistics (the other K = 320 layers keep tap_gemm)
@@ -303,6 +577,20 @@ int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s) {
     if (pt_n > 2147483647LL) {
         cc_set_error("ccedit_gemm: grid too large");
         return CCEDIT_EUNSUPPORTED;
+    }
+    // whole tiles and no GEGLU: the deep-ring variant.  CCEDIT_LIN320S=0 for the A/B against the K-split kernel.
+    static const int s_env = getenv("CCEDIT_LIN320S") ? atoi(getenv("CCEDIT_LIN320S")) : 1;
+    if (s_env && !geglu && d.M % kP == 0) {
+        const int lds_s = kBufsS * kXBuf;
+        static unsigned long long attr_s[3] = {0, 0, 0};
+        if (int rc = cc_max_dynamic_lds((const void*)lin320s_kernel<false, false>, lds_s, &attr_s[0], "lin320s")) return rc;
+        if (int rc = cc_max_dynamic_lds((const void*)lin320s_kernel<true, false>, lds_s, &attr_s[1], "lin320s")) return rc;
+        if (int rc = cc_max_dynamic_lds((const void*)lin320s_kernel<false, true>, lds_s, &attr_s[2], "lin320s")) return rc;
+        cc_note_kernel("lin320s_kernel");
+        if (d.res1) hipLaunchKernelGGL((lin320s_kernel<true, false>), dim3(256), dim3(kNT), lds_s, s, d, d.N / kSlice, (int)pt_n);
+        else if (d.ln_eps != 0.f) hipLaunchKernelGGL((lin320s_kernel<false, true>), dim3(256), dim3(kNT), lds_s, s, d, d.N / kSlice, (int)pt_n);
+        else hipLaunchKernelGGL((lin320s_kernel<false, false>), dim3(256), dim3(kNT), lds_s, s, d, d.N / kSlice, (int)pt_n);
+        return cc_launch_status("lin320s_kernel");
     }
     cc_note_kernel("lin320_kernel");
 #ifdef CCEDIT_TUNING      // probe builds only (-DCCEDIT_TUNING): the product library never reads a switch that changes results

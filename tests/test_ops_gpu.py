@@ -474,11 +474,14 @@ def test_conv3x3_upsample_and_concat():
     _close(_nchw(y), F.conv2d(torch.cat([x, x2], 1), wt2, b, padding=1), what="dual-source conv3x3")
 
 
-@pytest.mark.parametrize("m,n", [(1000, 320), (130, 960), (64, 640), (33000, 320), (40000, 2560), (70000, 960)])
+@pytest.mark.parametrize("m,n", [(1000, 320), (130, 960), (64, 640), (33000, 320), (40000, 2560), (70000, 960),
+                                 (32, 320), (2080, 960), (8416, 640), (65536, 320), (104448, 640)])
 def test_linear_k320_register_resident_weights(m, n):
     """tile 9 = lin320_kernel (lin320.hip): K = 320, a 320-channel weight slice lives in registers as MFMA fragments (two
     K halves in two wave sets), 32-pixel activation tiles stream past it and the output pass of a tile runs under the MFMAs
-    of the next.  Bias, GEGLU, strided operands, tail in M, slices in N."""
+    of the next.  Bias, GEGLU, strided operands, tail in M, slices in N.  M % 32 == 0 without GEGLU = lin320s_kernel (no K
+    split, 16x16x32 tiles 3 + 2 per SIMD, seven-buffer ring, residual tile by DMA): one tile, fewer tiles than the ring is
+    deep, ragged XCD ranges, the full-size shapes."""
     _dev()
     from ccedit_amd import ops
     from ccedit_amd.packing import pack_weight
