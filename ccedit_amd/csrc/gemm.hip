@@ -37,6 +37,8 @@ bool cc_conv_halo_applicable(const CcGemmDesc& d);        // convhalo.hip
 int cc_conv_halo_launch(const CcGemmDesc& d, hipStream_t s);
 bool cc_lin320_applicable(const CcGemmDesc& d);           // lin320.hip
 int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s);
+bool cc_lin640_applicable(const CcGemmDesc& d);           // lin640.hip
+int cc_lin640_launch(const CcGemmDesc& d, hipStream_t s);
 bool cc_small_conv_applicable(const CcGemmDesc& d);       // smallconv.hip
 int cc_small_conv_launch(const CcGemmDesc& d, hipStream_t s);
 bool cc_g8_applicable(const CcGemmDesc& d, int shape);    // gemm8p.hip
@@ -489,7 +491,16 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
                        "and N %% 320 == 0, no activation / residual): not applicable to this descriptor");
         return cc_lin320_launch(d, s);
     }
-    // ln_stats: the epilogue applies the rows' LayerNorm statistics — the persistent eight-phase kernel implements it, nothing else
+    // K = 640 Linear over many whole 16-pixel tiles (the 32x48 level): weights resident in registers, activations streamed once
+    // (lin640.hip) — bias, one residual, row_sums, or the folded LayerNorm (ln_stats / ln_sums).  CCEDIT_LIN640=0: A/B against gemm8p.
+    static const int l640_env = getenv("CCEDIT_LIN640") ? atoi(getenv("CCEDIT_LIN640")) : 1;
+    // (automatic from 1024 channels: at N = 640 the three slices re-fetch the activations three times and every CU's fetch rate is
+    //  what bounds the kernel — 65 / 77 us plain / residual at 52224 rows against 67 / 72 for gemm8p; 112 / 135 at 1280, 167 / 215 at 1920)
+    if ((d.tile == 0 && l640_env && d.M >= 16384 && d.N >= 1024) || d.tile == 10) {
+        if (cc_lin640_applicable(d)) return cc_lin640_launch(d, s);
+        CC_UNSUPPORTED(d.tile == 10, "ccedit_gemm: tile 10 (register-resident weights, K = 640) does not apply to this descriptor");
+    }
+    // ln_stats: the epilogue applies the rows' LayerNorm statistics — the persistent eight-phase kernel and lin640s implement it, nothing else
     if (d.ln_stats || d.ln_sums || d.ln_colsum) {
         const int shape = (d.tile >= 11 && d.tile <= 13) ? d.tile - 11 : 0;
         CC_UNSUPPORTED((!d.ln_stats && !d.ln_sums) || !d.ln_colsum || !(d.tile == 0 || (d.tile >= 11 && d.tile <= 13)) || !cc_g8_applicable(d, shape),

@@ -1,0 +1,356 @@
+// Linear layers with K = 640 over many pixels (the 32x48 level: proj_in / proj_out, to_q, to_out, the fused q,k,v projection) with
+// the WEIGHTS HELD IN REGISTERS — lin320s_kernel's scheme (lin320.hip) at twice the K — gfx950.
+//
+// The persistent LDS-tiled GEMM (gemm8p.hip) runs these at 480-650 TF/s: 640 channels are 2.5 of its 256-channel tiles, a tile's
+// prologue and epilogue are not covered by anything (one workgroup per CU), and both operands go through LDS again for every
+// tile.  Here a workgroup keeps a 256-channel slice of W (320 KB) as MFMA A-operand fragments for its whole life — wave w holds
+// channels [32 w, 32 w + 32) x all 640 k (2 x 20 fragments, 160 VGPRs) — and streams 16-pixel activation tiles past it: global ->
+// LDS by DMA into a ring of five 21 KB buffers (82 KB in flight per CU), 40 v_mfma_f32_16x16x32_bf16 per wave and tile, every
+// activation fragment read from LDS feeding two of them.  (One 16-channel tile per wave — 128-channel slices — needs a fragment
+// read per MFMA: 256 B/clk, the whole LDS bandwidth of the CU; measured 2 us per 32-pixel tile whatever the memory system did,
+// slower than gemm8p.)  The slices of a layer (3 for 640 channels — the third half empty —, 8 for the 1920 of q,k,v) are different
+// workgroups of one XCD walking the SAME pixel tiles, so the activation rows come out of that XCD's L2 for all but the first.
+//
+// Waves 0..3 issue the DMA, waves 4..7 the stores and atomics: a requesting wave's vector-memory queue then holds loads only and
+// the counted wait is exact (a store in the same queue has to complete as well before the count can fall to the number of younger
+// loads).  No register-returning load inside the loop (the compiler's wait for it would drain the DMA queue).
+//
+// Epilogue in registers: the C layout gives lane (pixel, 4 channels) — the accumulators start from the bias (+ the residual
+// cell: the residual slice arrives by DMA like the activations), leave as bf16 into an LDS tile in row layout (for the residual
+// variant the tile the residual came in, every lane reading and later writing its own 8 bytes) and go to memory one iteration
+// later as whole 512-byte row pieces, 16 bytes per lane.  One barrier per tile.
+//   LNF  (CcGemmDesc.ln_stats / ln_sums + ln_colsum): the rows are LayerNorm inputs; the tile's 16 (sum, sum of squares) or
+//        (mean, rstd) pairs ride in spare lanes of the tile's last DMA instruction; accumulators start at
+//        b' / rstd - mean colsum(W') and are multiplied by rstd at the end (the formula of gemm8p.hip).
+//   row_sums: every lane sums its eight bf16-rounded outputs (and their squares), two cross-lane steps make that 32 channels, the
+//        eight waves meet in DOUBLE in LDS (ds_add_f64: exact for these fp32 partials, so order-independent) and 32 threads add
+//        the slice's totals to row_sums[M][2] with double atomics one iteration later — as gemm8p.hip does across channel tiles.
+// Requires M % 16 == 0 (whole tiles: the counted wait relies on the number of loads per iteration), K = Kpad = 640, N % 128 == 0.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+__device__ __attribute__((aligned(64))) char g_zero_page_6[64];
+
+constexpr int kK = 640, kKS = kK / 32;          // 20 MFMA k-steps
+constexpr int kP = 16;                          // pixels per tile
+constexpr int kRS = kK * 2 + 16;                // LDS row stride of the activation tile: 324 dwords (rows 4 banks apart)
+constexpr int kGPR = kRS / 16;                  // 81 sixteen-byte slots per padded row
+constexpr int kXI = (kP * kGPR + 63) / 64;      // 21 wave-wide DMA instructions per tile (the last: 16 lanes of rows, then the statistics)
+constexpr int kXBuf = kXI * 1024;               // 21,504 B
+constexpr int kStatOff = kP * kRS;              // 20,736: 16 x 16 B — (sum, sumsq) doubles or (mean, rstd) floats of the tile's rows
+constexpr int kSlice = 256;                     // channels per workgroup
+constexpr int kORS = kSlice * 2 + 16;           // output / residual tile row: 528 B (132 dwords)
+constexpr int kOGPR = kORS / 16;                // 33
+constexpr int kOI = (kP * kOGPR + 63) / 64;     // 9 DMA instructions (the last: 16 lanes)
+constexpr int kOBuf = kP * kORS;                // 8,448 B
+constexpr int kRX = 5;                          // activation ring
+constexpr int kROres = 6, kROplain = 2;         // residual / output ring (residual tiles travel as far ahead as the activations)
+constexpr int kNT = 512;
+constexpr int kLds = kRX * kXBuf + kROres * kOBuf + 2 * kP * 16;      // + two [16][2] double accumulators of the row sums: 158,720 B
+constexpr int kXD = 6;                          // activation fragments in flight per wave (LDS read -> MFMA distance, in k-steps)
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void l6_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void l6_vmcnt_n(int n) {      // n is wave-uniform: (tiles still in flight) x (loads per tile of this wave)
+    switch (n) {
+        case 5: l6_vmcnt<5>(); break;
+        case 6: l6_vmcnt<6>(); break;
+        case 7: l6_vmcnt<7>(); break;
+        case 8: l6_vmcnt<8>(); break;
+        case 10: l6_vmcnt<10>(); break;
+        case 12: l6_vmcnt<12>(); break;
+        case 14: l6_vmcnt<14>(); break;
+        case 15: l6_vmcnt<15>(); break;
+        case 16: l6_vmcnt<16>(); break;
+        case 18: l6_vmcnt<18>(); break;
+        case 21: l6_vmcnt<21>(); break;
+        case 24: l6_vmcnt<24>(); break;
+        default: l6_vmcnt<0>(); break;
+    }
+}
+
+template <bool RES, bool LNF>
+__global__ __launch_bounds__(kNT, 1) void lin640s_kernel(const CcGemmDesc d, int nslice, int pt_n) {
+    static_assert(!(RES && LNF), "the normalised projections have no residual");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RO = RES ? kROres : kROplain;
+    char* const sXr = smem;
+    char* const sOr = smem + kRX * kXBuf;
+    double* const sSum = (double*)(smem + kRX * kXBuf + kROres * kOBuf);      // [2][16][2]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g4 = lane >> 4;
+
+    // workgroup b runs on XCD b % 8: its 32 workgroups take (32 / nslice) pixel lanes x nslice channel slices
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int lanes = 32 / nslice;
+    const int slice = j % nslice, plane = j / nslice;
+    if (plane >= lanes) return;
+    const int per_xcd = (pt_n + 7) >> 3;
+    const int pt_lo = xcd * per_xcd, pt_hi = min(pt_lo + per_xcd, pt_n);
+    const int pt0 = pt_lo + plane;
+    if (pt0 >= pt_hi) return;
+    const int ntile = (pt_hi - pt0 + lanes - 1) / lanes;        // tiles of this workgroup: pt0 + i * lanes
+    const int ch0 = slice * kSlice;
+    const bool rsum = d.row_sums != nullptr;                     // (uniform)
+    const bool live = ch0 + 32 * wave < d.N;                     // N % 256 == 128: waves 4..7 of the last slice have no channels
+
+    // ---- DMA plan (waves 0..3).  The DMA writes LDS lane-linearly; slot n of the activation tile = row n / 81, granule n % 81
+    //      (granule 80 = padding); instruction q belongs to wave q % 4.  Last instruction: lanes 0..15 end row 15, lanes 16..31
+    //      fetch the statistics of row lane - 16 (LNF), the rest idle. ----
+    const bool dma_wave = wave < 4;
+    const bf16* __restrict__ Ap = (const bf16*)d.A;
+    constexpr int kXQ = (kXI + 3) / 4;                           // 6 (the sixth: wave 0 only)
+    int soffx[kXQ];
+#pragma unroll
+    for (int i = 0; i < kXQ; ++i) {
+        const int n = (i * 4 + (wave & 3)) * 64 + lane;
+        const int r = n / kGPR, g = n - r * kGPR;
+        soffx[i] = (r < kP && g < kK / 8) ? r * d.lda + g * 8 : (r < kP ? -1 : -2);      // -1: padding (zeros), -2: beyond the tile
+    }
+    const int x_issues = wave == 0 ? 6 : 5;
+    // residual slice: slot n = row n / 33, granule n % 33 (32 = padding); instruction q belongs to wave (q + 1) % 4
+    const bf16* __restrict__ Rp = (const bf16*)d.res1;
+    constexpr int kRQ = 3;
+    int soffr[kRQ] = {-2, -2, -2};
+    int rq_[kRQ] = {-1, -1, -1};
+    if constexpr (RES) {
+#pragma unroll
+        for (int k = 0; k < kRQ; ++k) {
+            const int q = ((wave + 3) & 3) + 4 * k;              // q with (q + 1) % 4 == wave
+            if (q < kOI) {
+                rq_[k] = q;
+                const int n = q * 64 + lane;
+                const int r = n / kOGPR, g = n - r * kOGPR;
+                soffr[k] = (r < kP && g < kSlice / 8 && ch0 + g * 8 < d.N) ? r * d.ldr1 + ch0 + g * 8 : (r < kP ? -1 : -2);
+            }
+        }
+    }
+    const int r_issues = RES ? (wave == 1 ? 3 : 2) : 0;
+    const int per_tile = x_issues + r_issues;                    // loads of one tile in this wave's queue (waves 0..3)
+    const bool sums_in = LNF && d.ln_sums != nullptr;            // else d.ln_stats (floats)
+    auto stage = [&](int i, int xb, int ob) {
+        if (!dma_wave) return;
+        const int64_t pix0 = (int64_t)(pt0 + i * lanes) * kP;
+        const bf16* xbase = Ap + pix0 * d.lda;
+        char* const xd = sXr + xb * kXBuf;
+#pragma unroll
+        for (int q = 0; q < kXQ - 1; ++q)
+            glds16(soffx[q] >= 0 ? (const void*)(xbase + soffx[q]) : (const void*)g_zero_page_6, xd + (q * 4 + wave) * 1024);
+        if (wave == 0) {                                         // instruction 20: the tail of row 15, then the statistics
+            const void* src = soffx[kXQ - 1] >= 0 ? (const void*)(xbase + soffx[kXQ - 1]) : (const void*)g_zero_page_6;
+            bool on = soffx[kXQ - 1] != -2;
+            if constexpr (LNF) {
+                if (lane >= 16 && lane < 32) {
+                    on = sums_in || lane < 24;
+                    if (sums_in) src = (const void*)(d.ln_sums + 2 * (pix0 + (lane - 16)));
+                    else src = (const void*)(d.ln_stats + 2 * (pix0 + 2 * (lane - 16)));
+                }
+            }
+            if (on) glds16(src, xd + (kXI - 1) * 1024);
+        }
+        if constexpr (RES) {
+            const bf16* rbase = Rp + pix0 * d.ldr1;
+            char* const rd = sOr + ob * kOBuf;
+#pragma unroll
+            for (int k = 0; k < kRQ; ++k)
+                if (rq_[k] >= 0) {                               // wave-uniform
+                    if (soffr[k] != -2) glds16(soffr[k] >= 0 ? (const void*)(rbase + soffr[k]) : (const void*)g_zero_page_6, rd + rq_[k] * 1024);
+                }
+        }
+    };
+
+    // ---- the weight rows of this wave: A-operand fragments, resident for the whole kernel; bias (and colsum) of the lane's 2 x 4 channels ----
+    bf16x8 wf[2][kKS];
+    f32x4 bq[2], cq[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int cr = min(ch0 + 32 * wave + 16 * ti + c16, d.N - 1);      // (dead waves: any valid row)
+        const bf16* __restrict__ row = (const bf16*)d.W + (size_t)cr * d.Kpad + g4 * 8;
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) wf[ti][ks] = *(const bf16x8*)(row + ks * 32);
+        const int cb = min(ch0 + 32 * wave + 16 * ti + 4 * g4, d.N - 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bq[ti][e] = d.bias ? d.bias[cb + e] : 0.f;
+            cq[ti][e] = LNF ? d.ln_colsum[cb + e] : 0.f;
+        }
+    }
+    if (tid < 2 * kP * 2) sSum[tid] = 0.0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the weights are in: from here on a requesting wave's queue holds DMA only
+
+    const int xlane = c16 * kRS + g4 * 16;                      // B fragment of k-step ks: + ks * 64
+    const int olane = c16 * kORS + (32 * wave + 4 * g4) * 2;    // C cell (pixel, 4 channels) of channel tile ti: + ti * 32
+    // output pass (waves 4..7): thread t - 256 takes 16-byte granule t % 32 of rows t / 32 and t / 32 + 8 of the tile (16 rows x 32 granules)
+    const int ot0 = tid & 255;
+    const int olds = (ot0 >> 5) * kORS + (ot0 & 31) * 16;
+    const int64_t oout = (int64_t)(ot0 >> 5) * d.ldc + ch0 + (ot0 & 31) * 8;
+    const bool ost = !dma_wave && ch0 + (ot0 & 31) * 8 < d.N;
+
+    int xs = 0, os = 0, staged = 0;                              // ring slots the NEXT staged tile goes to
+    for (; staged < kRX - 1 && staged < ntile; ++staged) {
+        stage(staged, xs, os);
+        xs = xs == kRX - 1 ? 0 : xs + 1;
+        os = os == RO - 1 ? 0 : os + 1;
+    }
+    if (dma_wave) l6_vmcnt_n((staged - 1) * per_tile);          // tile 0 has landed (this wave's part)
+    int xb = 0, ob = 0, obp = 0;                                 // slots of tile i / of tile i - 1's output
+    const double inv_k = 1.0 / kK;
+    for (int i = 0; i < ntile; ++i) {
+        lds_barrier();      // tile i is in LDS for every wave; output tile i-1 and its row sums are complete; the X slot of tile i-1 and the O slot of tile i-2 are free
+        if (staged < ntile) {
+            stage(staged, xs, os);
+            ++staged;
+            xs = xs == kRX - 1 ? 0 : xs + 1;
+            os = os == RO - 1 ? 0 : os + 1;
+        }
+        const char* const xt = sXr + xb * kXBuf;
+        char* const ot = sOr + ob * kOBuf;
+        // output pass of tile i - 1, first half: its row pieces out of LDS; its row sums to memory
+        bf16x8 ov[2];
+        if (i > 0 && !dma_wave) {
+            ov[0] = *(const bf16x8*)(sOr + obp * kOBuf + olds);
+            ov[1] = *(const bf16x8*)(sOr + obp * kOBuf + olds + 8 * kORS);
+            if (rsum && wave == 5 && lane < 2 * kP) {
+                double* const acc2 = sSum + ((i - 1) & 1) * 2 * kP + lane;
+                const double v = *acc2;
+                *acc2 = 0.0;
+                unsafeAtomicAdd(d.row_sums + 2 * ((int64_t)(pt0 + (i - 1) * lanes) * kP) + lane, v);
+            }
+        }
+        // accumulators start from the bias (+ the residual cell) — or b' / rstd - mean colsum for the folded LayerNorm
+        f32x4 acc[2];
+        float rstd = 1.f;
+        if constexpr (LNF) {
+            float mu;
+            const char* sp = xt + kStatOff;
+            if (sums_in) {
+                const double s = *(const double*)(sp + c16 * 16), q = *(const double*)(sp + c16 * 16 + 8);
+                const double m = s * inv_k;
+                const double var = fmax(q * inv_k - m * m, 0.0);
+                mu = (float)m;
+                rstd = rsqrtf((float)var + d.ln_sums_eps);
+            } else {
+                const f32x2 st = *(const f32x2*)(sp + c16 * 8);
+                mu = st[0];
+                rstd = st[1];
+            }
+            const float ir = 1.0f / rstd;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[ti][e] = bq[ti][e] * ir - mu * cq[ti][e];
+        } else {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                acc[ti] = bq[ti];
+                if constexpr (RES) {
+                    const bf16x4 r = *(const bf16x4*)(ot + olane + ti * 32);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[ti][e] += bf2f(r[e]);
+                }
+            }
+        }
+        if (live) {
+            const char* const xq0 = xt + xlane;
+            bf16x8 xq[kXD];
+#pragma unroll
+            for (int ks = 0; ks < kXD - 1; ++ks) xq[ks] = *(const bf16x8*)(xq0 + ks * 64);
+#pragma unroll
+            for (int ks = 0; ks < kKS; ++ks) {
+                if (ks + kXD - 1 < kKS) xq[(ks + kXD - 1) % kXD] = *(const bf16x8*)(xq0 + (ks + kXD - 1) * 64);
+                __builtin_amdgcn_sched_barrier(0);
+                // the compiler counts the reads still in flight behind this fragment (all issued above, in order)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti) acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ti][ks], xq[ks % kXD], acc[ti], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 3 && i > 0 && ost) {
+                    // output pass of tile i - 1, second half: to memory while the matrix pipe is busy
+                    bf16* const op = (bf16*)d.out + (int64_t)(pt0 + (i - 1) * lanes) * kP * d.ldc + oout;
+                    *(bf16x8*)op = ov[0];
+                    *(bf16x8*)(op + 8 * (int64_t)d.ldc) = ov[1];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else if (i > 0 && ost) {
+            bf16* const op = (bf16*)d.out + (int64_t)(pt0 + (i - 1) * lanes) * kP * d.ldc + oout;
+            *(bf16x8*)op = ov[0];
+            *(bf16x8*)(op + 8 * (int64_t)d.ldc) = ov[1];
+        }
+        // bf16 cells of this wave's 32 channels into the output tile; row sums of the rounded values
+        if (live) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = f2bf(LNF ? acc[ti][e] * rstd : acc[ti][e]);
+                    const float v = bf2f(o[e]);
+                    s += v;
+                    q += v * v;
+                }
+                *(bf16x4*)(ot + olane + ti * 32) = o;
+            }
+            if (rsum) {
+                s += __shfl_xor(s, 16);
+                q += __shfl_xor(q, 16);
+                s += __shfl_xor(s, 32);
+                q += __shfl_xor(q, 32);
+                if (g4 == 0) {
+                    // (asm: for an LDS atomic the compiler first drains the vector-memory queue — the DMA writes LDS too)
+                    const uint32_t a2 = (uint32_t)(uintptr_t)(LDS_AS char*)(sSum + (i & 1) * 2 * kP + 2 * c16);
+                    asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %2 offset:8" ::"v"(a2), "v"((double)s), "v"((double)q) : "memory");
+                }
+            }
+        }
+        // tile i + 1 must have landed (this wave's part) before the next barrier: at most the loads of the tiles after it may be outstanding
+        if (i + 1 < ntile && dma_wave) l6_vmcnt_n((staged - (i + 2)) * per_tile);
+        obp = ob;
+        xb = xb == kRX - 1 ? 0 : xb + 1;
+        ob = ob == RO - 1 ? 0 : ob + 1;
+    }
+    lds_barrier();
+    {
+        const int64_t pix0 = (int64_t)(pt0 + (ntile - 1) * lanes) * kP;
+        if (ost) {
+            bf16* const op = (bf16*)d.out + pix0 * d.ldc + oout;
+            *(bf16x8*)op = *(const bf16x8*)(sOr + obp * kOBuf + olds);
+            *(bf16x8*)(op + 8 * (int64_t)d.ldc) = *(const bf16x8*)(sOr + obp * kOBuf + olds + 8 * kORS);
+        }
+        if (rsum && wave == 5 && lane < 2 * kP) unsafeAtomicAdd(d.row_sums + 2 * pix0 + lane, sSum[((ntile - 1) & 1) * 2 * kP + lane]);
+    }
+}
+
+}  // namespace
+
+// plain Linear with K = 640 over whole 16-pixel tiles: bias, one residual, row_sums, or the folded LayerNorm (no residual)
+bool cc_lin640_applicable(const CcGemmDesc& d) {
+    const bool lnf = d.ln_stats || d.ln_sums;
+    return d.mode == CCEDIT_GEMM_LINEAR && d.taps == 1 && d.A2 == nullptr && d.Cin == kK && d.Kpad == kK && d.N % 128 == 0 &&
+           (d.N + kSlice - 1) / kSlice <= 32 && d.M % kP == 0 && d.gn_stats == nullptr && d.res2 == nullptr && d.group_bias == nullptr && !d.out_f32 &&
+           d.act == CCEDIT_ACT_NONE && d.ldc % 8 == 0 && (d.res1 == nullptr || d.ldr1 % 8 == 0) && d.ln_eps == 0.f &&
+           (!lnf || (d.ln_colsum && !(d.ln_stats && d.ln_sums) && !d.res1 && !d.row_sums)) && (lnf || !d.ln_colsum);
+}
+
+int cc_lin640_launch(const CcGemmDesc& d, hipStream_t s) {
+    static unsigned long long attr_done[3] = {0, 0, 0};
+    if (int rc = cc_max_dynamic_lds((const void*)lin640s_kernel<false, false>, kLds, &attr_done[0], "lin640s")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)lin640s_kernel<true, false>, kLds, &attr_done[1], "lin640s")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)lin640s_kernel<false, true>, kLds, &attr_done[2], "lin640s")) return rc;
+    const int64_t pt_n = d.M / kP;
+    if (pt_n > 2147483647LL) {
+        cc_set_error("ccedit_gemm: grid too large");
+        return CCEDIT_EUNSUPPORTED;
+    }
+    cc_note_kernel("lin640s_kernel");
+    const int nslice = (d.N + kSlice - 1) / kSlice;
+    if (d.res1) hipLaunchKernelGGL((lin640s_kernel<true, false>), dim3(256), dim3(kNT), kLds, s, d, nslice, (int)pt_n);
+    else if (d.ln_stats || d.ln_sums) hipLaunchKernelGGL((lin640s_kernel<false, true>), dim3(256), dim3(kNT), kLds, s, d, nslice, (int)pt_n);
+    else hipLaunchKernelGGL((lin640s_kernel<false, false>), dim3(256), dim3(kNT), kLds, s, d, nslice, (int)pt_n);
+    return cc_launch_status("lin640s_kernel");
+}

@@ -509,6 +509,72 @@ def test_linear_k320_register_resident_weights(m, n):
             ops.linear(xc, pw, act=1, tile=9)
 
 
+@pytest.mark.parametrize("m,n", [(16, 640), (2064, 1920), (8416, 128), (8208, 384), (52224, 640), (17408, 1280), (26112, 1920)])
+def test_linear_k640_register_resident_weights(m, n):
+    """tile 10 = lin640s_kernel (lin640.hip): K = 640, a 256-channel weight slice lives in registers (wave w: 32 channels x
+    all of K), 16-pixel activation tiles stream past it through a five-buffer DMA ring, the slices of a layer walk the same
+    tiles on one XCD (N % 256 == 128: the last slice half empty).  Bias / no bias, strided operands, residual (the residual tile by DMA, output in place), the LayerNorm
+    statistics of the output (row_sums) and the folded LayerNorm from (mean, rstd) or from a producer's sums — one tile, fewer
+    tiles than the ring is deep, ragged XCD ranges, the full-size shapes (automatic dispatch from 16384 rows)."""
+    _dev()
+    from ccedit_amd import hip, ops
+    from ccedit_amd.packing import fold_layernorm, pack_weight
+    k = 640
+    last = lambda: hip.lib().ccedit_last_kernel().decode()
+    x, w, b = _rnd(m, k, seed=1), _rnd(n, k, seed=2, scale=k ** -0.5), _rnd(n, seed=3)
+    x[: m // 4] += 3.0
+    pw = pack_weight(w, b).to("cuda")
+    xc = x.to(BF).cuda()
+    xf = xc.float().cpu()
+    tile = 0 if m >= 16384 and n >= 1024 else 10       # the automatic dispatch takes it from 16384 rows x 1024 channels
+    ref = F.linear(xf, w, b)
+    y = ops.linear(xc, pw, tile=tile)
+    assert "lin640s" in last(), last()
+    _close(y, ref, what=f"lin640s {m}x{n}")
+    _close(ops.linear(xc, pack_weight(w).to("cuda"), tile=tile), F.linear(xf, w), what="lin640s no bias")
+    wide = torch.zeros(m, 2 * n, dtype=BF, device="cuda")
+    xs = torch.cat([_rnd(m, 64, seed=9), xf], dim=1).to(BF).cuda()
+    ops.linear(xs[:, 64:], pw, out=wide[:, n:], tile=tile)
+    assert torch.equal(wide[:, n:], y) and wide[:, :n].abs().max().item() == 0, "strided source / out"
+    r1 = _rnd(m, n, seed=4).to(BF)
+    rw = torch.cat([r1, r1], dim=1).cuda()                  # residual rows of a wider matrix
+    yr = ops.linear(xc, pw, res1=rw[:, n:], tile=tile)
+    assert "lin640s" in last(), last()
+    _close(yr, ref + r1.float(), what="lin640s residual")
+    # producer side: (sum, sum of squares) of the stored rows, with and without the residual; run-to-run identical
+    for res in (None, rw[:, :n]):
+        y2 = ops.linear(xc, pw, res1=res, row_sums=True, tile=tile)
+        assert "lin640s" in last(), last()
+        assert torch.equal(y2, yr if res is not None else y)
+        sums = ops.ln_sums_of(y2)
+        y2f = y2.float().cpu().double()
+        assert torch.allclose(sums[:, 0].cpu(), y2f.sum(dim=1), rtol=1e-6, atol=1e-3)
+        assert torch.allclose(sums[:, 1].cpu(), (y2f ** 2).sum(dim=1), rtol=1e-6, atol=1e-3)
+        y3 = ops.linear(xc, pw, res1=res, row_sums=True, tile=tile)
+        assert torch.equal(y3, y2) and torch.equal(ops.ln_sums_of(y3), sums), "producer sums: run-to-run difference"
+    # consumer side: Linear(LayerNorm(x)) on the raw rows from (mean, rstd) and from the producer's sums
+    g, be = _rnd(k, seed=14) * 0.2 + 1.0, _rnd(k, seed=15) * 0.2
+    pw_ln = fold_layernorm([w], [b], g, be).to("cuda")
+    ref_ln = F.linear(F.layer_norm(xf, (k,), g, be, 1e-5), w, b)
+    st = ops.row_stats(xc, 1e-5)
+    yl = ops.linear(xc, pw_ln, ln_stats=st, tile=tile)
+    assert "lin640s" in last(), last()
+    _close(yl, ref_ln, what="lin640s LayerNorm folded (mean, rstd)")
+    sx = torch.stack([xf.double().sum(dim=1), (xf.double() ** 2).sum(dim=1)], dim=1).cuda()
+    yl2 = ops.linear(xc, pw_ln, ln_sums=(sx, 1e-5), tile=tile)
+    assert "lin640s" in last(), last()
+    _close(yl2, ref_ln, what="lin640s LayerNorm folded (sums)")
+    if m >= 4096:
+        _close(yl2, ops.linear(xc, pw_ln, ln_stats=st, tile=12).float(), what="lin640s vs the persistent GEMM")
+    for _ in range(2):
+        assert torch.equal(ops.linear(xc, pw_ln, ln_sums=(sx, 1e-5), tile=tile), yl2), "run-to-run difference"
+    if tile == 10:                                     # epilogues it does not implement are refused, not mis-computed
+        with pytest.raises(Exception):
+            ops.linear(xc, pw, act=1, tile=10)
+        with pytest.raises(Exception):
+            ops.linear(xc[:-1], pw, tile=10)
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("cout", [320, 640, 256])
 def test_gemm_fused_groupnorm_statistics(tile, cout):

@@ -11,15 +11,23 @@ M = 34 * 6144
 
 
 def timeit(f, n=20):
-    for _ in range(3):
-        f()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        f()
-    e1.record()
-    torch.cuda.synchronize()
+    """n launches replayed from a HIP graph (host overhead out of the picture)"""
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(n):
+                f()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
 
