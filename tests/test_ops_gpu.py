@@ -526,7 +526,7 @@ def test_linear_k640_register_resident_weights(m, n):
     pw = pack_weight(w, b).to("cuda")
     xc = x.to(BF).cuda()
     xf = xc.float().cpu()
-    tile = 0 if m >= 16384 and n >= 1024 else 10       # the automatic dispatch takes it from 16384 rows x 1024 channels
+    tile = 0 if m >= 16384 and n >= 1024 else 10       # the automatic dispatch takes every epilogue from 16384 rows x 1024 channels
     ref = F.linear(xf, w, b)
     y = ops.linear(xc, pw, tile=tile)
     assert "lin640s" in last(), last()

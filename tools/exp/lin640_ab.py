@@ -8,6 +8,7 @@ from ccedit_amd import ops, hip
 from ccedit_amd.packing import pack_weight, fold_layernorm
 BF = torch.bfloat16
 M = 34 * 1536
+TILE = int(os.environ.get("TILE", "0"))       # 10 forces lin640s_kernel (automatic only from 1024 output channels), 12 / 13 gemm8p
 
 
 def timeit(f, n=20):
@@ -38,13 +39,13 @@ for n in (640, 1280, 1920):
     pw = pack_weight(torch.randn(n, 640) * 0.04, torch.randn(n)).to("cuda")
     out = torch.empty(M, n, dtype=BF, device="cuda")
     fl = 2 * M * 640 * n
-    t = timeit(lambda: ops.linear(x, pw, out=out))
+    t = timeit(lambda: ops.linear(x, pw, out=out, tile=TILE))
     print(f"plain     N={n:4d}: {t:7.1f} us  {fl / t / 1e6:6.0f} TF/s   [{hip.lib().ccedit_last_kernel().decode()}]")
-    t = timeit(lambda: ops.linear(x, pw, res1=r, out=out))
+    t = timeit(lambda: ops.linear(x, pw, res1=r, out=out, tile=TILE))
     print(f"res       N={n:4d}: {t:7.1f} us  {fl / t / 1e6:6.0f} TF/s")
-    t = timeit(lambda: ops.linear(x, pw, res1=r, out=out, row_sums=True))
+    t = timeit(lambda: ops.linear(x, pw, res1=r, out=out, row_sums=True, tile=TILE))
     print(f"res+sums  N={n:4d}: {t:7.1f} us  {fl / t / 1e6:6.0f} TF/s")
     pl = fold_layernorm([torch.randn(n, 640) * 0.04], [torch.randn(n)], torch.ones(640), torch.zeros(640)).to("cuda")
-    t = timeit(lambda: ops.linear(x, pl, ln_stats=st, out=out))
+    t = timeit(lambda: ops.linear(x, pl, ln_stats=st, out=out, tile=TILE))
     print(f"ln        N={n:4d}: {t:7.1f} us  {fl / t / 1e6:6.0f} TF/s   [{hip.lib().ccedit_last_kernel().decode()}]")
 print("CCEDIT_LIN640 =", os.environ.get("CCEDIT_LIN640", "1"))

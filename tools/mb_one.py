@@ -36,6 +36,12 @@ elif which == "lin320":          # 208896 x 320 <- 320 + residual (lin320_kernel
     r = torch.randn(N * 6144, 320, device="cuda").to(BF)
     pw = pack_weight(torch.randn(320, 320) * 0.05, torch.randn(320)).to("cuda")
     f = lambda: ops.linear(x, pw, res1=r)
+elif which == "lin640":          # fused q,k,v projection of the 32x48 level, LayerNorm folded: 52224 x 1920 <- 640 (lin640s_kernel)
+    from ccedit_amd.packing import fold_layernorm
+    x = torch.randn(N * 1536, 640, device="cuda").to(BF)
+    pw = fold_layernorm([torch.randn(1920, 640) * 0.04], [torch.randn(1920)], torch.ones(640), torch.zeros(640)).to("cuda")
+    st = ops.row_stats(x, 1e-5)
+    f = lambda: ops.linear(x, pw, ln_stats=st)
 elif which == "attnq":           # the network's call: q pre-scaled into log2 units
     q = torch.randn(N * 6144, 960, device="cuda").to(BF)
     f = lambda: ops.attention(q[:, :320], q[:, 320:640], q[:, 640:], 8, 40, batches=N, lq=6144, lk=6144, q_log2=True)

@@ -23,9 +23,12 @@ unset CCEDIT_SPLIT_CFG CCEDIT_OVERLAP_CONTROLNET
 PMC_JSON=$O/${tag}_pmc_traffic.json bash $R/tools/pmc_traffic.sh > $O/${tag}_pmc_traffic.txt 2>&1
 PMC_BENCH_ARGS="--workload tvi2v" PMC_JSON=$O/${tag}_pmc_traffic_tvi2v.json bash $R/tools/pmc_traffic.sh > $O/${tag}_pmc_traffic_tvi2v.txt 2>&1
 # matrix-pipe / VALU counters of the dominant kernels (tools/pmc_r04.sh: two --pmc passes each, --kernel-trace only)
-for spec in "attn_spatial attnq" "g8_kernel g8geglu" "g8_kernel g8res" "g8_kernel g8conv" "conv_halo conv" "lin320 lin320"; do
+for spec in "attn_spatial attnq" "g8_kernel g8geglu" "g8_kernel g8res" "g8_kernel g8conv" "conv_halo conv" "lin320 lin320" "lin640 lin640"; do
   set -- $spec
   echo "=== $2 ($1) ===" >> $O/${tag}_pmc_counters.txt
   bash $R/tools/pmc_r04.sh $1 $2 >> $O/${tag}_pmc_counters.txt 2>&1
 done
+# the same attention launch on the general kernel it replaced (round 3's), same box
+echo "=== attnq, CCEDIT_ATTN_SPATIAL=0 (attn_kernel<40,8>) ===" >> $O/${tag}_pmc_counters.txt
+CCEDIT_ATTN_SPATIAL=0 bash $R/tools/pmc_r04.sh "attn_kernel" attnq >> $O/${tag}_pmc_counters.txt 2>&1
 ls -la $O/${tag}_*
