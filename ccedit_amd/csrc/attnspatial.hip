@@ -60,6 +60,10 @@ template <int N>
 __device__ __forceinline__ void as_tr_wait(VFrag& a, VFrag& b) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) : "n"(N));
 }
+template <int N>
+__device__ __forceinline__ void as_tr_wait3(VFrag& a, VFrag& b, VFrag& c) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi) : "n"(N));
+}
 __device__ __forceinline__ bf16x8 as_frag(const VFrag& f) {
     return __builtin_bit_cast(bf16x8, u32x4{f.lo[0], f.lo[1], f.hi[0], f.hi[1]});
 }
@@ -84,7 +88,7 @@ constexpr int kLds = kSlots * kSlot;
 // (scaling the bf16 fragments in here would round q a second time: at logits of +-70 that alone is several per cent of a
 // probability), reference and threshold are kept in raw q.k units and every score is multiplied by scale * log2(e) on its way into
 // the exponential: 32 more VALU instructions per tile, the price of not packing the scale into the weights.
-template <int D, bool QLOG2>
+template <int D, bool QLOG2, bool PV16>
 __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     static_assert(D % 16 == 8 && D < 64, "the reference rides in the pad column of the last k-step");
     constexpr int KS = (D + 15) / 16;         // QK^T k-steps (last one: 8 channels + the reference column + 7 zeros)
@@ -137,7 +141,9 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     // ---- DMA plan: thread -> (row, granule) of the 64 x 8-granule K and V tiles; wave w fills rows 8w..8w+7 ----
     const int drow = tid >> 3;
     const int gk = (tid & 7) ^ ((drow >> 1) & 7);              // LDS slot -> source granule (XOR swizzle, attention.hip)
-    const int gv = (tid & 7) ^ (((drow >> 1) & 1) << 2);
+    // PV16: V rows are swizzled in 32-byte chunks (one 16-channel MFMA row tile each): chunk c of row r at c ^ vsw16(r)
+    auto vsw16 = [](int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); };
+    const int gv = PV16 ? (((((tid & 7) >> 1) ^ vsw16(drow)) << 1) | (tid & 1)) : ((tid & 7) ^ (((drow >> 1) & 1) << 2));
     const bool use_k = gk * 8 < D, use_v = gv * 8 < D;         // pad granules are never written by the DMA
     const uint32_t koff = (uint32_t)((int64_t)drow * a.kv_seq_rows * a.ldk + gk * 8) * 2u;
     const uint32_t voff = (uint32_t)((int64_t)drow * a.kv_seq_rows * a.ldv + gv * 8) * 2u;
@@ -180,7 +186,9 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
 
     // ---- per-lane LDS read addresses (slot and tile-row offsets are immediates) ----
     // A-row i of an S^T tile reads K row swap23(i): a lane's 8 consecutive S^T registers are 8 consecutive keys
-    const int krow_l = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    // (PV16: A-row i reads K row 16 (i>>2 & 1) + (i & 3) + 4 (i >> 3): register r of lane (q, hi) is key 32 t2 + 16 hi + r — sixteen
+    //  consecutive keys per lane, which two v_permlane16_swap per register pair turn into the 16x16x32 B operand)
+    const int krow_l = PV16 ? (((l31 >> 2) & 1) << 4) + (l31 & 3) + ((l31 >> 3) << 2) : ((l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1));
     const int ksw = (krow_l >> 1) & 7;
     const char* kaddr[KS];
 #pragma unroll
@@ -191,20 +199,34 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     uint32_t vaddr[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) vaddr[n] = lds0 + kKB + (8 * hi + (i16 >> 2)) * 128 + (dvhalf * 16 + (i16 & 3) * 4) * 2 + ((n * 64) ^ vsw);
+    // PV16: A operand of the 16x16x32 product = V^T[dv = 16 m + (lane & 15)][kv = 32 ks + 8 g + e]: lane group g transposes the 4-key x
+    // 16-channel blocks at rows 8 g + (0..3) and 8 g + 4 + (0..3) of channel chunk m
+    constexpr int NM = (D + 1 + 15) / 16;     // 16-channel row tiles of O^T (D value rows + the denominator row D)
+    const int g4 = lane >> 4;
+    uint32_t vaddr16[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+        vaddr16[m] = lds0 + kKB + (8 * g4 + (i16 >> 2)) * 128 + (((m ^ (((i16 >> 3) & 1) | ((g4 & 1) << 1))) << 5) + (i16 & 3) * 8);
 
     // ---- constant pad granules of all three slots: K[:, D] = 1 (the reference column), V[:, D] = 1 (the denominator row) ----
     for (int idx = tid; idx < kSlots * 64; idx += kNT) {
         const int sl = idx >> 6, row = idx & 63;
         *(u32x4*)(smem + sl * kSlot + row * 128 + ((PADG ^ ((row >> 1) & 7)) << 4)) = u32x4{0x00003F80u, 0u, 0u, 0u};
-        *(u32x4*)(smem + sl * kSlot + kKB + row * 128 + ((PADG ^ (((row >> 1) & 1) << 2)) << 4)) = u32x4{0x00003F80u, 0u, 0u, 0u};
+        const int vslot = PV16 ? ((((PADG >> 1) ^ vsw16(row)) << 1) | (PADG & 1)) : (PADG ^ (((row >> 1) & 1) << 2));
+        *(u32x4*)(smem + sl * kSlot + kKB + row * 128 + (vslot << 4)) = u32x4{0x00003F80u, 0u, 0u, 0u};
     }
     // K columns (D, 16 KS) beyond the reference column are zero in that same granule; granules above it are never read.
 
-    f32x16 o[NT];
+    f32x16 o[PV16 ? 1 : NT];
+    f32x4 o16[PV16 ? NM : 1][2];              // PV16: O^T[dv = 16 m + 4 g + reg][q = 16 t + (lane & 15)]
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int n = 0; n < (PV16 ? 1 : NT); ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+#pragma unroll
+    for (int m = 0; m < (PV16 ? NM : 1); ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) o16[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float mref = 0.f;
 
     stage(0, 0);
@@ -238,7 +260,7 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int kv = j * 64 + 32 * t2 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    const int kv = PV16 ? j * 64 + 32 * t2 + 16 * hi + r : j * 64 + 32 * t2 + 16 * (r >> 3) + 8 * hi + (r & 7);
                     if (kv >= a.Lk) s[t2][r] = -INFINITY;
                 }
         }
@@ -262,10 +284,19 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
             const float delta = nref - mref;
             if (j != 0) {
                 const float alpha = __builtin_amdgcn_exp2f(QLOG2 ? -delta : -delta * sc);
+                if constexpr (PV16) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
+                    for (int t = 0; t < 2; ++t) {
+                        const float at = __shfl(alpha, 16 * t + i16, 64);      // the factor of query 16 t + (lane & 15)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+                        for (int m = 0; m < NM; ++m) o16[m][t] *= at;
+                    }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+                }
             }
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
@@ -276,6 +307,52 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
         }
         // ---- p = 2^s;  O^T += V^T P^T (row D of O^T: the denominator, from the ones column of V) ----
         // k-step sp covers keys 16 sp .. 16 sp + 15; its V^T fragments are requested two k-steps ahead of their MFMAs
+        if constexpr (PV16) {
+            // 16x16x32 tiles: k-step t2 covers keys 32 t2 .. + 31; 3 channel tiles x 2 query tiles = 6 MFMAs of 16 cycles per k-step
+            // (192 cycles per tile against the 256 of four 32x32x16 k-steps over a half-empty second channel tile)
+            static_assert(NM == 3, "fragment bookkeeping below");
+            VFrag vf[2][NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) as_tr_issue<SB>(vf[0][m], vaddr16[m]);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) as_tr_issue<SB + 4096>(vf[1][m], vaddr16[m]);
+            auto pexp16 = [&](int t2, bf16x8& b0, bf16x8& b1) {
+                uint32_t pk[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float x0 = s[t2][2 * jj], x1 = s[t2][2 * jj + 1];
+                    const bf16x2 pr = {f2bf(__builtin_amdgcn_exp2f(QLOG2 ? x0 : x0 * sc)), f2bf(__builtin_amdgcn_exp2f(QLOG2 ? x1 : x1 * sc))};
+                    pk[jj] = __builtin_bit_cast(uint32_t, pr);
+                }
+                u32x4 w0, w1;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    // rows (16 lanes) of the wave: [q 0-15 hi 0 | q 16-31 hi 0 | q 0-15 hi 1 | q 16-31 hi 1]; the swap exchanges the
+                    // odd rows of keys 2jj.. with the even rows of keys 8 + 2jj..: first result = query tile 0, second = query tile 1,
+                    // each with keys 8 g + 2 jj, + 1 in lane group g — the B operand's k order
+                    const auto r = __builtin_amdgcn_permlane16_swap(pk[jj], pk[4 + jj], false, false);
+                    w0[jj] = r[0];
+                    w1[jj] = r[1];
+                }
+                b0 = __builtin_bit_cast(bf16x8, w0);
+                b1 = __builtin_bit_cast(bf16x8, w1);
+            };
+            auto pv16 = [&](int ks, const bf16x8& b0, const bf16x8& b1) {
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    o16[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf[ks][m]), b0, o16[m][0], 0, 0, 0);
+                    o16[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf[ks][m]), b1, o16[m][1], 0, 0, 0);
+                }
+            };
+            bf16x8 b0, b1;
+            pexp16(0, b0, b1);
+            as_tr_wait3<6>(vf[0][0], vf[0][1], vf[0][2]);
+            pv16(0, b0, b1);
+            pexp16(1, b0, b1);
+            as_tr_wait3<0>(vf[1][0], vf[1][1], vf[1][2]);
+            pv16(1, b0, b1);
+            return;
+        }
         static_assert(NT == 2, "fragment bookkeeping below");
         VFrag vf[4][NT];
         auto issue = [&](auto SPC) {
@@ -333,6 +410,27 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
         if (j + 2 < ntiles) step(std::integral_constant<int, 2>{}, j + 2);
     }
 
+    if constexpr (PV16) {
+        // ---- lane holds O^T[dv = 16 m + 4 g + reg][q = 16 t + (lane & 15)]; row D = 40 (m 2, g 2, reg 0) is the denominator ----
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float l_t = __shfl(o16[D / 16][t][0], 16 * ((D % 16) / 4) + i16, 64);
+            const float inv_t = 1.0f / l_t;
+            const int qi = q0 + 16 * t + i16;
+            if (qi < a.Lq) {
+                bf16* orow = (bf16*)a.o + (size_t)(qbase + (int64_t)qi * a.q_seq_rows) * a.ldo + head * D;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const int dv = 16 * m + 4 * g4;
+                    if (dv < D) {
+                        bf16x4 w = {f2bf(o16[m][t][0] * inv_t), f2bf(o16[m][t][1] * inv_t), f2bf(o16[m][t][2] * inv_t), f2bf(o16[m][t][3] * inv_t)};
+                        *(bf16x4*)(orow + dv) = w;
+                    }
+                }
+            }
+        }
+        return;
+    }
     // ---- normalise and store: lane holds O^T[dv = 32 n + (r&3) + 8 (r>>2) + 4 hi][q = l31]; row D is the denominator ----
     const float l_tot = __shfl(o[D / 32][((D % 32) / 8) * 4], l31, 64);
     const float inv = 1.0f / l_tot;
@@ -354,19 +452,19 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
 }
 
 // four waves per SIMD (two workgroups per CU): 2.04 ms against 2.30 ms with three on the 34 x 8 x 6144^2 launch
-template <int D, bool QLOG2>
+template <int D, bool QLOG2, bool PV16>
 __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_spatial_kernel(const CcAttnDesc a) {
-    attn_spatial_body<D, QLOG2>(a);
+    attn_spatial_body<D, QLOG2, PV16>(a);
 }
 
-template <int D, bool QLOG2>
+template <int D, bool QLOG2, bool PV16>
 int launch_spatial(const CcAttnDesc& a, hipStream_t s) {
     static unsigned long long attr_done = 0;
-    if (int rc = cc_max_dynamic_lds((const void*)attn_spatial_kernel<D, QLOG2>, kLds, &attr_done, "attn_spatial")) return rc;
+    if (int rc = cc_max_dynamic_lds((const void*)attn_spatial_kernel<D, QLOG2, PV16>, kLds, &attr_done, "attn_spatial")) return rc;
     const int64_t qtiles = (a.Lq + kNW * 32 - 1) / (kNW * 32);
     const int64_t groups = ((int64_t)a.batches * a.heads + 7) / 8 * 8;
     cc_note_kernel("attn_spatial_kernel d=%d", D);
-    hipLaunchKernelGGL((attn_spatial_kernel<D, QLOG2>), dim3((unsigned)(qtiles * groups)), dim3(kNT), kLds, s, a);
+    hipLaunchKernelGGL((attn_spatial_kernel<D, QLOG2, PV16>), dim3((unsigned)(qtiles * groups)), dim3(kNT), kLds, s, a);
     return cc_launch_status("attn_spatial_kernel");
 }
 
@@ -379,5 +477,8 @@ bool cc_attn_spatial_applicable(const CcAttnDesc& a) {
 }
 
 int cc_attn_spatial_launch(const CcAttnDesc& a, hipStream_t s) {
-    return (a.flags & CCEDIT_ATTN_Q_LOG2) ? launch_spatial<40, true>(a, s) : launch_spatial<40, false>(a, s);
+    // CCEDIT_ATTN_PV16=0: the PV product in 32x32x16 tiles (A/B; same sums in a different order: results differ in the last bit)
+    static const int pv16 = getenv("CCEDIT_ATTN_PV16") ? atoi(getenv("CCEDIT_ATTN_PV16")) : 1;
+    if (pv16) return (a.flags & CCEDIT_ATTN_Q_LOG2) ? launch_spatial<40, true, true>(a, s) : launch_spatial<40, false, true>(a, s);
+    return (a.flags & CCEDIT_ATTN_Q_LOG2) ? launch_spatial<40, true, false>(a, s) : launch_spatial<40, false, false>(a, s);
 }

@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")
 
 VARIANTS = {
     "general (attn_kernel)": {"CCEDIT_ATTN_SPATIAL": "0"},
+    "spatial, PV in 32x32x16 tiles": {"CCEDIT_ATTN_PV16": "0"},
+    "spatial, PV 32x32x16, q in log2 units": {"CCEDIT_ATTN_PV16": "0", "PROBE_Q_LOG2": "1"},
     "spatial": {},
     "spatial, q in log2 units": {"PROBE_Q_LOG2": "1"},
 }
