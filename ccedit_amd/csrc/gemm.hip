@@ -38,6 +38,8 @@ int cc_conv_halo_launch(const CcGemmDesc& d, hipStream_t s);
 bool cc_lin320_applicable(const CcGemmDesc& d);           // lin320.hip
 int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s);
 bool cc_lin640_applicable(const CcGemmDesc& d);           // lin640.hip
+bool cc_temp320_applicable(const CcGemmDesc& d);          // temp320.hip
+int cc_temp320_launch(const CcGemmDesc& d, hipStream_t s);
 int cc_lin640_launch(const CcGemmDesc& d, hipStream_t s);
 bool cc_small_conv_applicable(const CcGemmDesc& d);       // smallconv.hip
 int cc_small_conv_launch(const CcGemmDesc& d, hipStream_t s);
@@ -476,7 +478,7 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     if (d.gn_stats && !(d.tile >= 11 && d.tile <= 13)) {      // (the persistent Linear shapes refuse gn_stats themselves)
         CC_CHECK_ARG(d.gn_rows > 0 && d.gn_rows % 128 == 0 && d.M % d.gn_rows == 0,
                      "ccedit_gemm: gn_stats needs gn_rows %% 128 == 0 dividing M (gn_rows=%d)", d.gn_rows);
-        CC_CHECK_ARG(d.gn_rows % 256 == 0 || d.tile <= 1 || d.tile == 8,
+        CC_CHECK_ARG(d.gn_rows % 256 == 0 || d.tile <= 1 || d.tile == 8 || d.tile == 14,
                      "ccedit_gemm: gn_rows=%d is not a multiple of 256: only the 128-pixel block shape (tile 1) applies", d.gn_rows);
         CC_UNSUPPORTED(d.tile == 6, "ccedit_gemm: gn_stats is not available with the 320-channel block shape (tile 6)");
         CC_UNSUPPORTED(d.N % 32 != 0 || d.N < 256 || d.out_f32 || d.act == CCEDIT_ACT_GEGLU,
@@ -490,6 +492,13 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
                        "ccedit_gemm: ln_eps needs the register-resident K = 320 kernel (block shape 0 / 9, plain Linear with K = 320 "
                        "and N %% 320 == 0, no activation / residual): not applicable to this descriptor");
         return cc_lin320_launch(d, s);
+    }
+    // Conv1d k3 over T at 320 input channels over many pixels (the 64x96 level): all three taps' weights in registers, pixel columns
+    // streamed frame by frame (temp320.hip).  CCEDIT_TEMP320=0: A/B against the tiled kernels.
+    static const int t320_env = getenv("CCEDIT_TEMP320") ? atoi(getenv("CCEDIT_TEMP320")) : 1;
+    if ((d.tile == 0 && t320_env && d.M >= 100000) || d.tile == 14) {
+        if (cc_temp320_applicable(d)) return cc_temp320_launch(d, s);
+        CC_UNSUPPORTED(d.tile == 14, "ccedit_gemm: tile 14 (streaming Conv1d k3, 320 input channels) does not apply to this descriptor");
     }
     // K = 640 Linear over many whole 16-pixel tiles (the 32x48 level): weights resident in registers, activations streamed once
     // (lin640.hip) — bias, one residual, row_sums, or the folded LayerNorm (ln_stats / ln_sums).  CCEDIT_LIN640=0: A/B against gemm8p.

@@ -89,7 +89,9 @@ typedef struct CcGemmDesc {
                            * 3-5 = wider 8-wave shapes, 6 = 320ch x 128pix (N % 320 == 0, no gn_stats), 8 = LDS-halo 3x3 conv,
                            * 9 = register-resident weights (Linear, K = 320, N % 320 == 0, bias + one residual or GEGLU epilogue),
                            * 10 = the same at K = 640 (Linear, N % 128 == 0, M % 16 == 0; bias, one residual, row_sums, ln_stats / ln_sums),
-                           * 11-13 = persistent eight-phase GEMM (block shape by Cout / 256ch x 256pix / 128ch x 512pix) */
+                           * 11-13 = persistent eight-phase GEMM (block shape by Cout / 256ch x 256pix / 128ch x 512pix),
+                           * 14 = streaming Conv1d k3 over T with 320 input channels (TEMPORAL, N % 64 == 0, HW % 16 == 0, unsharded frames;
+                           *      bias, per-clip row bias, up to two residuals, gn_stats) */
     int32_t korder;       /* weight K order: 0 = [tap][Cin]; 1 = [Cin/64][tap][64] (needs Cin % 64 == 0) */
     int32_t gn_rows;      /* with gn_stats: output rows per frame (H*W), a multiple of 128 dividing M (not a
                            * multiple of 256: block shape 1 is used); else 0 */

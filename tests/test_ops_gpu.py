@@ -146,6 +146,53 @@ def test_temporal_conv_persistent_eight_phase(b_, t, c, cout, h, w, tile):
     _close(_nchw(ops.conv_temporal(_nhwc(x), t, pw, tile=1)), ref, what="tap_gemm temporal (same reference)")
 
 
+@pytest.mark.parametrize("b_,t,cout,h,w", [(2, 5, 320, 8, 16), (1, 17, 320, 16, 24), (2, 2, 640, 4, 8), (3, 3, 64, 4, 4), (2, 17, 320, 32, 48)])
+def test_temporal_conv_streaming_320(b_, t, cout, h, w):
+    """tile 14 = temp320s_kernel (temp320.hip): Conv1d k3 over T at 320 input channels with all three taps' weights in registers,
+    pixel columns walked frame by frame with three rolling accumulators (zero padding at the clip ends and BETWEEN the clips of a
+    batch is the missing MFMA), 128-channel slices (320 = 128 + 128 + 64), bias + per-clip row bias + zero / one / two residuals
+    (tiles by DMA, output in place) + GroupNorm statistics with 10-channel groups straddling the lanes' channel quads — against
+    F.conv1d; repeated launches bit-identical; the automatic dispatch takes it from 100000 rows."""
+    _dev()
+    from ccedit_amd import hip, ops
+    from ccedit_amd.packing import pack_weight
+    c, n = 320, b_ * t
+    x = _rnd(n, c, h, w, seed=1)
+    wt, bt = _rnd(cout, c, 3, seed=4, scale=(3 * c) ** -0.5), _rnd(cout, seed=5)
+    xp = x.reshape(b_, t, c, h, w).permute(0, 3, 4, 2, 1).reshape(b_ * h * w, c, t)
+    ref = F.conv1d(xp, wt, bt, padding=1).reshape(b_, h, w, cout, t).permute(0, 4, 3, 1, 2).reshape(n, cout, h, w)
+    r1, r2 = _rnd(n, cout, h, w, seed=6), _rnd(n, cout, h, w, seed=7)
+    gb = _rnd(b_, cout, seed=8)
+    pw = pack_weight(wt, bt).to("cuda")
+    tile = 0 if n * h * w >= 100000 else 14
+    last = lambda: hip.lib().ccedit_last_kernel().decode()
+    with_stats = cout % 32 == 0 and cout >= 320 and (h * w) % 128 == 0
+    xc = _nhwc(x)
+    y0 = ops.conv_temporal(xc, t, pw, tile=tile)
+    assert "temp320s" in last(), last()
+    _close(_nchw(y0), ref, what=f"temp320s plain T={t} {h}x{w} -> {cout}")
+    y1 = ops.conv_temporal(xc, t, pw, res1=_nhwc(r1).reshape(-1, cout), group_bias=gb.cuda(), group_rows=t * h * w, tile=tile)
+    assert "temp320s" in last(), last()
+    _close(_nchw(y1), ref + r1 + gb.repeat_interleave(t, 0)[:, :, None, None], what="temp320s + row bias + residual")
+    kw = dict(res1=_nhwc(r1).reshape(-1, cout), res2=_nhwc(r2).reshape(-1, cout), group_bias=gb.cuda(), group_rows=t * h * w,
+              gn=with_stats, tile=tile)
+    y = ops.conv_temporal(xc, t, pw, **kw)
+    assert "temp320s" in last(), last()
+    _close(_nchw(y), ref + r1 + r2 + gb.repeat_interleave(t, 0)[:, :, None, None], what="temp320s + row bias + two residuals")
+    if with_stats:
+        st = ops.gn_stats_of(y, h * w)
+        assert st is not None
+        yf = y.float().view(n, h * w, 32, cout // 32)
+        assert torch.allclose(st[..., 0].float(), yf.sum(dim=(1, 3)), rtol=1e-4, atol=2e-2)
+        assert torch.allclose(st[..., 1].float(), (yf * yf).sum(dim=(1, 3)), rtol=1e-4, atol=2e-2)
+    for _ in range(3):
+        y_ = ops.conv_temporal(xc, t, pw, **kw)
+        assert torch.equal(y_, y), "temp320s: run-to-run difference"
+        if with_stats:
+            assert torch.equal(ops.gn_stats_of(y_, h * w), st), "temp320s statistics: run-to-run difference"
+    _close(y.float(), ops.conv_temporal(xc, t, pw, **{**kw, "tile": 1}).float(), what="temp320s vs tap_gemm")
+
+
 @pytest.mark.parametrize("tile", [12, 13])
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 256, 16, 32), (3, 128, 320, 8, 16), (1, 192, 640, 24, 16), (5, 64, 384, 12, 16), (3, 64, 1280, 16, 24)])
 def test_conv3x3_persistent_eight_phase(n, cin, cout, h, w, tile):
