@@ -503,10 +503,10 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     // K = 640 Linear over many whole 16-pixel tiles (the 32x48 level): weights resident in registers, activations streamed once
     // (lin640.hip) — bias, one residual, row_sums, or the folded LayerNorm (ln_stats / ln_sums).  CCEDIT_LIN640=0: A/B against gemm8p.
     static const int l640_env = getenv("CCEDIT_LIN640") ? atoi(getenv("CCEDIT_LIN640")) : 1;
-    // (at 52224 rows, lin640s / gemm8p: 1920 channels 162 / 220 us, 1280: 111 / 140; at 640 the three slices — the third half empty —
-    //  fetch the activations three times and a CU's fetch rate bounds the kernel: plain 64 / 68, residual 70 / 75, but with row_sums
-    //  81 / 82 and with the folded LayerNorm 67 / 65 — those two stay on gemm8p below 1024 channels)
-    if ((d.tile == 0 && l640_env && d.M >= 16384 && (d.N >= 1024 || (!d.row_sums && !d.ln_stats && !d.ln_sums))) || d.tile == 10) {
+    // (at 52224 rows, lin640s / gemm8p: 1920 channels 147 / 220 us, 1280: 105 / 140; at 640 the three slices — the third half empty —
+    //  fetch the activations three times: plain 63 / 68, residual 66 / 75, with row_sums 74 / 82, but with the folded LayerNorm
+    //  67 / 65 — that one stays on gemm8p below 1024 channels)
+    if ((d.tile == 0 && l640_env && d.M >= 16384 && (d.N >= 1024 || (!d.ln_stats && !d.ln_sums))) || d.tile == 10) {
         if (cc_lin640_applicable(d)) return cc_lin640_launch(d, s);
         CC_UNSUPPORTED(d.tile == 10, "ccedit_gemm: tile 10 (register-resident weights, K = 640) does not apply to this descriptor");
     }

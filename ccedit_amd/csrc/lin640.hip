@@ -31,8 +31,6 @@
 
 namespace {
 
-__device__ __attribute__((aligned(64))) char g_zero_page_6[64];
-
 constexpr int kK = 640, kKS = kK / 32;          // 20 MFMA k-steps
 constexpr int kP = 16;                          // pixels per tile
 // Activation tile in LDS: 16 rows of 80 sixteen-byte granules, NO padding; granule j of row r sits at position j ^ (r & 15) of its
@@ -47,36 +45,20 @@ constexpr int kXI = kP * kGPR / 64;             // 20 wave-wide DMA instructions
 constexpr int kStatOff = kP * kRS;              // 20,480: 16 x 16 B — (sum, sumsq) doubles or (mean, rstd) floats of the tile's rows
 constexpr int kXBuf = kStatOff + 1024;          // 21,504 B
 constexpr int kSlice = 256;                     // channels per workgroup
-constexpr int kORS = kSlice * 2 + 16;           // output / residual tile row: 528 B (132 dwords)
-constexpr int kOGPR = kORS / 16;                // 33
-constexpr int kOI = (kP * kOGPR + 63) / 64;     // 9 DMA instructions (the last: 16 lanes)
-constexpr int kOBuf = kP * kORS;                // 8,448 B
+constexpr int kORS = kSlice * 2;                // output / residual tile row: 512 B = 32 granules, granule g at (g & 16) | ((g & 15) ^ row)
+constexpr int kOBuf = kP * kORS;                // 8,192 B = 8 DMA instructions, two per requesting wave
 constexpr int kRX = 5;                          // activation ring
 constexpr int kROres = 6, kROplain = 2;         // residual / output ring (residual tiles travel as far ahead as the activations)
 constexpr int kNT = 512;
-constexpr int kLds = kRX * kXBuf + kROres * kOBuf + 2 * kP * 16;      // + two [16][2] double accumulators of the row sums: 158,720 B
+constexpr int kLds = kRX * kXBuf + kROres * kOBuf + 2 * kP * 16;      // + two [16][2] double accumulators of the row sums: 157,184 B
 constexpr int kXDmax = 6;                       // activation fragments in flight per wave (LDS read -> MFMA distance, in k-steps; 5 with the LayerNorm's extra registers)
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int N>
 __device__ __forceinline__ void l6_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void l6_vmcnt_n(int n) {      // n is wave-uniform: (tiles still in flight) x (loads per tile of this wave)
-    switch (n) {
-        case 5: l6_vmcnt<5>(); break;
-        case 6: l6_vmcnt<6>(); break;
-        case 7: l6_vmcnt<7>(); break;
-        case 8: l6_vmcnt<8>(); break;
-        case 10: l6_vmcnt<10>(); break;
-        case 12: l6_vmcnt<12>(); break;
-        case 14: l6_vmcnt<14>(); break;
-        case 15: l6_vmcnt<15>(); break;
-        case 16: l6_vmcnt<16>(); break;
-        case 18: l6_vmcnt<18>(); break;
-        case 21: l6_vmcnt<21>(); break;
-        case 24: l6_vmcnt<24>(); break;
-        default: l6_vmcnt<0>(); break;
-    }
-}
+// (these loops are bound by instruction issue — temp320.hip has the measurement: ring slots are wrap-around counters, tile addresses
+//  running byte offsets, every lane of every DMA instruction has a valid source (no selects, no exec masks), and every requesting wave
+//  issues the same number of loads per tile, so the counted waits are compile-time constants)
 
 template <bool RES, bool LNF>
 __global__ __launch_bounds__(kNT, 1) void lin640s_kernel(const CcGemmDesc d, int nslice, int pt_n) {
@@ -105,63 +87,65 @@ __global__ __launch_bounds__(kNT, 1) void lin640s_kernel(const CcGemmDesc d, int
     const bool rsum = d.row_sums != nullptr;                     // (uniform)
     const bool live = ch0 + 32 * wave < d.N;                     // N % 256 == 128: waves 4..7 of the last slice have no channels
 
-    // ---- DMA plan (waves 0..3).  The DMA writes LDS lane-linearly; slot n of the activation tile = row n / 81, granule n % 81
-    //      (granule 80 = padding); instruction q belongs to wave q % 4.  Last instruction: lanes 0..15 end row 15, lanes 16..31
-    //      fetch the statistics of row lane - 16 (LNF), the rest idle. ----
+    // ---- DMA plan (waves 0..3; every lane of every instruction has a valid source).  Activations: instruction q -> wave q % 4, slot n of
+    //      the tile = row n / 80, position n % 80 <- source granule position ^ (row & 15).  Residual slice: two instructions per wave,
+    //      slot (r, p) <- granule (p & 16) | ((p & 15) ^ r) (channels beyond N clamped).  LNF: four lanes per wave fetch the statistics. ----
     const bool dma_wave = wave < 4;
-    const bf16* __restrict__ Ap = (const bf16*)d.A;
     constexpr int kXQ = kXI / 4;                                 // 5 per requesting wave
-    int soffx[kXQ];
+    constexpr int kPerTile = kXQ + (RES ? 2 : 0) + (LNF ? 1 : 0);      // loads of one tile in a requesting wave's queue
+    int soffx[kXQ], soffr[2] = {0, 0};
 #pragma unroll
     for (int i = 0; i < kXQ; ++i) {
         const int n = (i * 4 + (wave & 3)) * 64 + lane;
         const int r = n / kGPR, p = n - r * kGPR;
-        soffx[i] = r * d.lda + (p ^ (r & 15)) * 8;               // destination slot (r, p) <- source granule p ^ (r & 15)
+        soffx[i] = (r * d.lda + (p ^ (r & 15)) * 8) * 2;         // bytes
     }
-    const int x_issues = (LNF && wave == 0) ? 6 : 5;
-    // residual slice: slot n = row n / 33, granule n % 33 (32 = padding); instruction q belongs to wave (q + 1) % 4
-    const bf16* __restrict__ Rp = (const bf16*)d.res1;
-    constexpr int kRQ = 3;
-    int soffr[kRQ] = {-2, -2, -2};
-    int rq_[kRQ] = {-1, -1, -1};
     if constexpr (RES) {
 #pragma unroll
-        for (int k = 0; k < kRQ; ++k) {
-            const int q = ((wave + 3) & 3) + 4 * k;              // q with (q + 1) % 4 == wave
-            if (q < kOI) {
-                rq_[k] = q;
-                const int n = q * 64 + lane;
-                const int r = n / kOGPR, g = n - r * kOGPR;
-                soffr[k] = (r < kP && g < kSlice / 8 && ch0 + g * 8 < d.N) ? r * d.ldr1 + ch0 + g * 8 : (r < kP ? -1 : -2);
-            }
+        for (int k = 0; k < 2; ++k) {
+            const int n = (k * 4 + (wave & 3)) * 64 + lane;
+            const int r = n >> 5, p = n & 31;
+            const int g = (p & 16) | ((p & 15) ^ r);
+            soffr[k] = (r * d.ldr1 + min(ch0 + g * 8, d.N - 8)) * 2;
         }
     }
-    const int r_issues = RES ? (wave == 1 ? 3 : 2) : 0;
-    const int per_tile = x_issues + r_issues;                    // loads of one tile in this wave's queue (waves 0..3)
     const bool sums_in = LNF && d.ln_sums != nullptr;            // else d.ln_stats (floats)
-    auto stage = [&](int i, int xb, int ob) {
-        if (!dma_wave) return;
-        const int64_t pix0 = (int64_t)(pt0 + i * lanes) * kP;
-        const bf16* xbase = Ap + pix0 * d.lda;
-        char* const xd = sXr + xb * kXBuf;
+    const char* const Ab = (const char*)d.A;
+    const char* const Rb = (const char*)d.res1;
+    const char* const Sb = sums_in ? (const char*)d.ln_sums : (const char*)d.ln_stats;
+    const int64_t tile_rows = (int64_t)lanes * kP;               // consecutive tiles of this workgroup are `lanes` tiles apart
+    const int64_t x_step = tile_rows * d.lda * 2, r_step = tile_rows * d.ldr1 * 2, o_step = tile_rows * d.ldc * 2;
+    const int s_step = (int)tile_rows * (sums_in ? 16 : 8);
+    int64_t st_x = (int64_t)pt0 * kP * d.lda * 2, st_r = RES ? (int64_t)pt0 * kP * d.ldr1 * 2 : 0, st_s = (int64_t)pt0 * kP * (sums_in ? 16 : 8);
+    // statistics: 16 rows x 16 B (sums) or 8 B (mean, rstd): wave w fetches lanes 0..3 -> bytes [64 w, 64 w + 64) of the 256 (128: waves 0, 1)
+    const int soffs = min((wave & 3) * 64 + (lane & 3) * 16, (sums_in ? 256 : 128) - 16);
+    int st_xs = 0, st_os = 0;                                    // ring slots of the tile being requested
+    auto stage_next = [&]() {
+        if (dma_wave) {
+            char* const xd = sXr + st_xs * kXBuf;
 #pragma unroll
-        for (int q = 0; q < kXQ; ++q) glds16(xbase + soffx[q], xd + (q * 4 + wave) * 1024);
-        if constexpr (LNF) {
-            if (wave == 0 && lane < (sums_in ? 16 : 8)) {        // the statistics of the tile's rows: 16 x 16 B / 8 x 16 B behind the rows
-                const void* src = sums_in ? (const void*)(d.ln_sums + 2 * (pix0 + lane)) : (const void*)(d.ln_stats + 2 * (pix0 + 2 * lane));
-                glds16(src, xd + kStatOff);
+            for (int q = 0; q < kXQ; ++q) glds16(Ab + st_x + soffx[q], xd + (q * 4 + wave) * 1024);
+            if constexpr (LNF) {
+                if (lane < 4) glds16(Sb + st_s + soffs, xd + kStatOff + wave * 64);
+            }
+            if constexpr (RES) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) glds16(Rb + st_r + soffr[k], sOr + st_os * kOBuf + (k * 4 + wave) * 1024);
             }
         }
-        if constexpr (RES) {
-            const bf16* rbase = Rp + pix0 * d.ldr1;
-            char* const rd = sOr + ob * kOBuf;
-#pragma unroll
-            for (int k = 0; k < kRQ; ++k)
-                if (rq_[k] >= 0) {                               // wave-uniform
-                    if (soffr[k] != -2) glds16(soffr[k] >= 0 ? (const void*)(rbase + soffr[k]) : (const void*)g_zero_page_6, rd + rq_[k] * 1024);
-                }
-        }
+        st_x += x_step;
+        st_r += r_step;
+        st_s += s_step;
+        st_xs = st_xs == kRX - 1 ? 0 : st_xs + 1;
+        st_os = st_os == (RES ? kROres : kROplain) - 1 ? 0 : st_os + 1;
     };
+    auto wait_later = [&](int later) {                            // at most the loads of `later` (<= kRX - 2) newer tiles may be outstanding
+        if (later >= 3) l6_vmcnt<3 * kPerTile>();
+        else if (later == 2) l6_vmcnt<2 * kPerTile>();
+        else if (later == 1) l6_vmcnt<kPerTile>();
+        else l6_vmcnt<0>();
+    };
+    static_assert(kRX - 2 == 3, "wait_later covers three tiles in flight behind the awaited one");
 
     // ---- the weight rows of this wave: A-operand fragments, resident for the whole kernel; bias (and colsum) of the lane's 2 x 4 channels ----
     bf16x8 wf[2][kKS];
@@ -185,42 +169,48 @@ __global__ __launch_bounds__(kNT, 1) void lin640s_kernel(const CcGemmDesc d, int
     int xlane[4];                                               // B fragment of k-step ks: xlane[ks & 3] + (ks >> 2) * 256
 #pragma unroll
     for (int m = 0; m < 4; ++m) xlane[m] = c16 * kRS + (((4 * m + g4) ^ c16) << 4);
-    const int olane = c16 * kORS + (32 * wave + 4 * g4) * 2;    // C cell (pixel, 4 channels) of channel tile ti: + ti * 32
+    // C cell (pixel c16, channels 32 w + 16 ti + 4 g4 .. + 3) = half (g4 & 1) of granule 4 w + 2 ti + (g4 >> 1), at its swizzled position
+    int olane[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int gr = 4 * wave + 2 * ti + (g4 >> 1);
+        olane[ti] = c16 * kORS + (((gr & 16) | ((gr & 15) ^ c16)) << 4) + (g4 & 1) * 8;
+    }
     // output pass (waves 4..7): thread t - 256 takes 16-byte granule t % 32 of rows t / 32 and t / 32 + 8 of the tile (16 rows x 32 granules)
     const int ot0 = tid & 255;
-    const int olds = (ot0 >> 5) * kORS + (ot0 & 31) * 16;
-    const int64_t oout = (int64_t)(ot0 >> 5) * d.ldc + ch0 + (ot0 & 31) * 8;
-    const bool ost = !dma_wave && ch0 + (ot0 & 31) * 8 < d.N;
+    const int ogr = ot0 & 31, orow = ot0 >> 5;
+    const int olds0 = orow * kORS + (((ogr & 16) | ((ogr & 15) ^ orow)) << 4);
+    const int olds1 = (orow + 8) * kORS + (((ogr & 16) | ((ogr & 15) ^ (orow + 8))) << 4);
+    const int oout = (orow * d.ldc + ch0 + ogr * 8) * 2;        // bytes; second row: + 8 ldc
+    const int oout8 = 8 * d.ldc * 2;
+    const bool ost = !dma_wave && ch0 + ogr * 8 < d.N;
+    char* const Ob = (char*)d.out;
+    int64_t so_off = (int64_t)pt0 * kP * d.ldc * 2;              // output cursor: the tile stored at step i is i - 1
+    int64_t so_rows = (int64_t)pt0 * kP;                         // ... its first row (row sums)
 
-    int xs = 0, os = 0, staged = 0;                              // ring slots the NEXT staged tile goes to
-    for (; staged < kRX - 1 && staged < ntile; ++staged) {
-        stage(staged, xs, os);
-        xs = xs == kRX - 1 ? 0 : xs + 1;
-        os = os == RO - 1 ? 0 : os + 1;
-    }
-    if (dma_wave) l6_vmcnt_n((staged - 1) * per_tile);          // tile 0 has landed (this wave's part)
+    int staged = 0;
+    for (; staged < kRX - 1 && staged < ntile; ++staged) stage_next();
+    if (dma_wave) wait_later(staged - 1);                        // tile 0 has landed (this wave's part)
     int xb = 0, ob = 0, obp = 0;                                 // slots of tile i / of tile i - 1's output
     const double inv_k = 1.0 / kK;
     for (int i = 0; i < ntile; ++i) {
         lds_barrier();      // tile i is in LDS for every wave; output tile i-1 and its row sums are complete; the X slot of tile i-1 and the O slot of tile i-2 are free
         if (staged < ntile) {
-            stage(staged, xs, os);
+            stage_next();
             ++staged;
-            xs = xs == kRX - 1 ? 0 : xs + 1;
-            os = os == RO - 1 ? 0 : os + 1;
         }
         const char* const xt = sXr + xb * kXBuf;
         char* const ot = sOr + ob * kOBuf;
         // output pass of tile i - 1, first half: its row pieces out of LDS; its row sums to memory
         bf16x8 ov[2];
         if (i > 0 && !dma_wave) {
-            ov[0] = *(const bf16x8*)(sOr + obp * kOBuf + olds);
-            ov[1] = *(const bf16x8*)(sOr + obp * kOBuf + olds + 8 * kORS);
+            ov[0] = *(const bf16x8*)(sOr + obp * kOBuf + olds0);
+            ov[1] = *(const bf16x8*)(sOr + obp * kOBuf + olds1);
             if (rsum && wave == 5 && lane < 2 * kP) {
                 double* const acc2 = sSum + ((i - 1) & 1) * 2 * kP + lane;
                 const double v = *acc2;
                 *acc2 = 0.0;
-                unsafeAtomicAdd(d.row_sums + 2 * ((int64_t)(pt0 + (i - 1) * lanes) * kP) + lane, v);
+                unsafeAtomicAdd(d.row_sums + 2 * so_rows + lane, v);
             }
         }
         // accumulators start from the bias (+ the residual cell) — or b' / rstd - mean colsum for the folded LayerNorm
@@ -250,7 +240,7 @@ __global__ __launch_bounds__(kNT, 1) void lin640s_kernel(const CcGemmDesc d, int
             for (int ti = 0; ti < 2; ++ti) {
                 acc[ti] = bq[ti];
                 if constexpr (RES) {
-                    const bf16x4 r = *(const bf16x4*)(ot + olane + ti * 32);
+                    const bf16x4 r = *(const bf16x4*)(ot + olane[ti]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[ti][e] += bf2f(r[e]);
                 }
@@ -271,16 +261,16 @@ __global__ __launch_bounds__(kNT, 1) void lin640s_kernel(const CcGemmDesc d, int
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks == 3 && i > 0 && ost) {
                     // output pass of tile i - 1, second half: to memory while the matrix pipe is busy
-                    bf16* const op = (bf16*)d.out + (int64_t)(pt0 + (i - 1) * lanes) * kP * d.ldc + oout;
+                    char* const op = Ob + so_off + oout;
                     *(bf16x8*)op = ov[0];
-                    *(bf16x8*)(op + 8 * (int64_t)d.ldc) = ov[1];
+                    *(bf16x8*)(op + oout8) = ov[1];
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         } else if (i > 0 && ost) {
-            bf16* const op = (bf16*)d.out + (int64_t)(pt0 + (i - 1) * lanes) * kP * d.ldc + oout;
+            char* const op = Ob + so_off + oout;
             *(bf16x8*)op = ov[0];
-            *(bf16x8*)(op + 8 * (int64_t)d.ldc) = ov[1];
+            *(bf16x8*)(op + oout8) = ov[1];
         }
         // bf16 cells of this wave's 32 channels into the output tile; row sums of the rounded values
         if (live) {
@@ -295,7 +285,7 @@ __global__ __launch_bounds__(kNT, 1) void lin640s_kernel(const CcGemmDesc d, int
                     s += v;
                     q += v * v;
                 }
-                *(bf16x4*)(ot + olane + ti * 32) = o;
+                *(bf16x4*)(ot + olane[ti]) = o;
             }
             if (rsum) {
                 s += __shfl_xor(s, 16);
@@ -310,20 +300,23 @@ __global__ __launch_bounds__(kNT, 1) void lin640s_kernel(const CcGemmDesc d, int
             }
         }
         // tile i + 1 must have landed (this wave's part) before the next barrier: at most the loads of the tiles after it may be outstanding
-        if (i + 1 < ntile && dma_wave) l6_vmcnt_n((staged - (i + 2)) * per_tile);
+        if (i + 1 < ntile && dma_wave) wait_later(staged - (i + 2));
+        if (i > 0) {                                             // the output cursor follows one tile behind
+            so_off += o_step;
+            so_rows += tile_rows;
+        }
         obp = ob;
         xb = xb == kRX - 1 ? 0 : xb + 1;
         ob = ob == RO - 1 ? 0 : ob + 1;
     }
     lds_barrier();
     {
-        const int64_t pix0 = (int64_t)(pt0 + (ntile - 1) * lanes) * kP;
         if (ost) {
-            bf16* const op = (bf16*)d.out + pix0 * d.ldc + oout;
-            *(bf16x8*)op = *(const bf16x8*)(sOr + obp * kOBuf + olds);
-            *(bf16x8*)(op + 8 * (int64_t)d.ldc) = *(const bf16x8*)(sOr + obp * kOBuf + olds + 8 * kORS);
+            char* const op = Ob + so_off + oout;
+            *(bf16x8*)op = *(const bf16x8*)(sOr + obp * kOBuf + olds0);
+            *(bf16x8*)(op + oout8) = *(const bf16x8*)(sOr + obp * kOBuf + olds1);
         }
-        if (rsum && wave == 5 && lane < 2 * kP) unsafeAtomicAdd(d.row_sums + 2 * pix0 + lane, sSum[((ntile - 1) & 1) * 2 * kP + lane]);
+        if (rsum && wave == 5 && lane < 2 * kP) unsafeAtomicAdd(d.row_sums + 2 * so_rows + lane, sSum[((ntile - 1) & 1) * 2 * kP + lane]);
     }
 }
 
