@@ -318,7 +318,7 @@ def main():
                     achieved=dom["tflops"] if dom_mfma else dom["gbytes_per_s"],
                     peak=MFMA_PEAK_TFLOPS if dom_mfma else HBM_PEAK_GBS, unit="TFLOP/s" if dom_mfma else "GB/s",
                     frac=dom["frac"], traffic=None, algorithmic_bytes_per_launch=dom["alg_bytes_per_launch"],
-                    family="ccedit_gemm + ccedit_ff320 (g8_kernel, conv_halo_kernel, tap_gemm_kernel, lin320s_kernel / lin320_kernel, lin640s_kernel, ff320_kernel, small_conv3x3_kernel)",
+                    family="ccedit_gemm + ccedit_ff320 (g8_kernel, conv_halo_kernel, tap_gemm_kernel, lin320s_kernel / lin320_kernel, lin640s_kernel, temp320s_kernel, ff320_kernel, small_conv3x3_kernel)",
                     family_achieved=round(ach, 1), family_frac=round(ach / MFMA_PEAK_TFLOPS, 4), family_launches=g["launches"],
                     family_avg_launch_us=round(g["avg_us"], 2), algorithmic_flops_per_step=g["flops"], by_kernel=by_kernel)
         # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 PMC passes of this
