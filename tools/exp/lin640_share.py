@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""lin640s: do the channel slices of a layer share the activation tiles through the XCD's L2?  (CCEDIT_L640_FLAGS experiments)"""
+"""lin640s at 1, 2, 5 and 15 channel slices: time per tile and the traffic it implies if every slice fetched its own copy of the
+activations.  (The experiments of DESIGN.md section 3.3 — start skew, leader / follower slices, re-reading L2-resident tiles — ran
+this script against builds with temporary switches that have been removed.)"""
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 import torch

@@ -34,7 +34,7 @@ x = torch.randn(B * T, H, W, C, device="cuda").to(BF)
 r = torch.randn(B * T * H * W, C, device="cuda").to(BF)
 pw = pack_weight(torch.randn(C, C, 3) * (3 * C) ** -0.5, torch.randn(C)).to("cuda")
 fl = 2.0 * B * T * H * W * C * C * 3
-for tile in (14,):
+for tile in (14, 0, 1, 2, 3, 4, 5, 6, 11, 12, 13):
     try:
         t = timeit(lambda: ops.conv_temporal(x, T, pw, res1=r, tile=tile))
         print(f"tile {tile:2d}: {t:7.1f} us  {fl / t / 1e6:6.0f} TF/s   [{hip.lib().ccedit_last_kernel().decode()}]", flush=True)
