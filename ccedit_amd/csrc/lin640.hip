@@ -212,6 +212,13 @@ __global__ __launch_bounds__(kNT, 1) void lin640s_kernel(const CcGemmDesc d, int
                 *acc2 = 0.0;
                 unsafeAtomicAdd(d.row_sums + 2 * so_rows + lane, v);
             }
+            // stored right away, while the requesting waves issue their DMA (inside the MFMA loop the store would wait for `ov`
+            // behind the fragment prefetch in the LDS queue: temp320.hip measured the storing waves 350 cycles per step behind)
+            if (ost) {
+                char* const op = Ob + so_off + oout;
+                *(bf16x8*)op = ov[0];
+                *(bf16x8*)(op + oout8) = ov[1];
+            }
         }
         // accumulators start from the bias (+ the residual cell) — or b' / rstd - mean colsum for the folded LayerNorm
         f32x4 acc[2];
@@ -259,18 +266,7 @@ __global__ __launch_bounds__(kNT, 1) void lin640s_kernel(const CcGemmDesc d, int
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti) acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ti][ks], xq[ks % kXD], acc[ti], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks == 3 && i > 0 && ost) {
-                    // output pass of tile i - 1, second half: to memory while the matrix pipe is busy
-                    char* const op = Ob + so_off + oout;
-                    *(bf16x8*)op = ov[0];
-                    *(bf16x8*)(op + oout8) = ov[1];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
             }
-        } else if (i > 0 && ost) {
-            char* const op = Ob + so_off + oout;
-            *(bf16x8*)op = ov[0];
-            *(bf16x8*)(op + oout8) = ov[1];
         }
         // bf16 cells of this wave's 32 channels into the output tile; row sums of the rounded values
         if (live) {

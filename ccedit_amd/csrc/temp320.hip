@@ -266,8 +266,11 @@ __global__ __launch_bounds__(kNT, 1) void temp320s_kernel(const CcGemmDesc d, in
         bf16x8 ov;
         const bool have_out = s >= 3;
         if (have_out && !dma_wave) {
+            // (stored right away, while the requesting waves issue their DMA: a store inside the MFMA loop waits for `ov` with the
+            //  fragment prefetch already in the LDS queue — the storing waves were 350 cycles per step behind the others)
             ov = *(const bf16x8*)(sR1 + sr * kOBuf + olds);
             flush_stats((s - 3) & 1, so_frame);
+            if (ost) *(bf16x8*)((char*)d.out + so_off + oout) = ov;
         }
         // epilogue of output s - 2, first half: its residual cells
         const bool have_fin = s >= 2 && live;
@@ -302,10 +305,6 @@ __global__ __launch_bounds__(kNT, 1) void temp320s_kernel(const CcGemmDesc d, in
                 if constexpr (HP) accp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][ks], xq[ks % kXD], accp, 0, 0, 0);      // x[t] is the t + 1 neighbour of output t - 1
                 if constexpr (HN) accn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ks], xq[ks % kXD], accn, 0, 0, 0);      // ... the t - 1 neighbour of output t + 1
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks == 1 && have_out) {
-                    if (ost) *(bf16x8*)((char*)d.out + so_off + oout) = ov;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 if (ks == 5 && have_fin) {
                     finish(s & 1, accd, rc1, rc2, o_fin);
                     __builtin_amdgcn_sched_barrier(0);
@@ -319,7 +318,6 @@ __global__ __launch_bounds__(kNT, 1) void temp320s_kernel(const CcGemmDesc d, in
             else if (has_next) taps(N_{}, Y{});
             else taps(Y{}, N_{});                                 // (T >= 2: the last frame of a column has a predecessor)
         } else {
-            if (have_out && ost) *(bf16x8*)((char*)d.out + so_off + oout) = ov;
             if (have_fin) finish(s & 1, accd, rc1, rc2, o_fin);
         }
         // tile s + 1 must have landed (this wave's part): at most the loads of the tiles requested after it may be outstanding
