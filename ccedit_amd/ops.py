@@ -250,11 +250,17 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, ups
     if out_hw is not None:          # asymmetric padding (VAE Downsample, model.py:74-93: pad right/bottom only, conv pad 0):
         hout, wout = out_hw         # taps that fall outside the source read zeros, so only the output size changes
     a2 = None if x2 is None else x2.reshape(-1, x2.shape[-1])
+    if pw.ksize == 1 and pw.taps == 1 and stride == 1 and not upsample and out_hw is None and not vpad and CONV1X1_LINEAR:
+        # a 1 x 1 convolution is a Linear over the pixels (zero convs, skip connections): the Linear dispatch reaches the streaming
+        # K = 320 / 640 kernels and the persistent GEMM, the convolution modes do not
+        out = gemm(x.reshape(-1, c), pw, mode=GEMM_LINEAR, a2=a2, gn_rows=hout * wout if gn else 0, **kw)
+        return carry_gn_stats(out, out.view(n, hout, wout, out.shape[-1]))
     out = gemm(x.reshape(-1, c), pw, mode=GEMM_CONV2D, m=n * hout * wout, hin=h, win=w, hout=hout, wout=wout,
                stride=stride, pad=pad, upsample=upsample, a2=a2, gn_rows=hout * wout if gn else 0, **kw)
     return carry_gn_stats(out, out.view(n, hout, wout, out.shape[-1]))
 
 
+CONV1X1_LINEAR = os.environ.get("CCEDIT_CONV1X1_LINEAR", "1") != "0"      # 0: 1 x 1 convs through the convolution mode (A/B)
 SUBPIX = os.environ.get("CCEDIT_SUBPIX", "1") != "0"      # 0: upsample + 3x3 conv through the nine-tap gather (A/B)
 
 
