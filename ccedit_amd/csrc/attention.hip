@@ -394,15 +394,12 @@ extern "C" int ccedit_attention(const CcAttnDesc* desc, void* stream) {
     CC_UNSUPPORTED(((int64_t)a.batches * a.heads + 8) * ((a.Lq + 31) / 32) > 2147483647LL, "ccedit_attention: grid too large");
     hipStream_t s = (hipStream_t)stream;
     // temporal self-attention (T <= 32 keyframes per pixel): HBM-bound, own kernel organised around whole-row loads
-    static const int short_env = getenv("CCEDIT_ATTN_SHORT") ? atoi(getenv("CCEDIT_ATTN_SHORT")) : 1;   // 0: A/B against attn_kernel
     const bool plain_q = !(a.flags & CCEDIT_ATTN_Q_LOG2);       // the two kernels below apply `scale` themselves
-    if (short_env && plain_q && cc_attn_short_applicable(a)) return cc_attn_short_launch(a, s);
+    if (cc_policy().attn_short && plain_q && cc_attn_short_applicable(a)) return cc_attn_short_launch(a, s);
     // text cross-attention (<= 96 keys shared by the frames of a clip): bound by streaming the query rows, own kernel (attntext.hip)
-    static const int text_env = getenv("CCEDIT_ATTN_TEXT") ? atoi(getenv("CCEDIT_ATTN_TEXT")) : 1;      // 0: A/B against attn_kernel
-    if (text_env && plain_q && cc_attn_text_applicable(a)) return cc_attn_text_launch(a, s);
+    if (cc_policy().attn_text && plain_q && cc_attn_text_applicable(a)) return cc_attn_text_launch(a, s);
     // long self-attention at d = 40 (the 64x96 level): the softmax arithmetic is the bound, own kernel (attnspatial.hip)
-    static const int spatial_env = getenv("CCEDIT_ATTN_SPATIAL") ? atoi(getenv("CCEDIT_ATTN_SPATIAL")) : 1;   // 0: A/B against attn_kernel
-    if (spatial_env && cc_attn_spatial_applicable(a)) return cc_attn_spatial_launch(a, s);
+    if (cc_policy().attn_spatial && cc_attn_spatial_applicable(a)) return cc_attn_spatial_launch(a, s);
     switch (a.d) {
         case 8: return dispatch_nw<8>(a, s);
         case 16: return dispatch_nw<16>(a, s);

@@ -477,8 +477,8 @@ bool cc_attn_spatial_applicable(const CcAttnDesc& a) {
 }
 
 int cc_attn_spatial_launch(const CcAttnDesc& a, hipStream_t s) {
-    // CCEDIT_ATTN_PV16=0: the PV product in 32x32x16 tiles (A/B; same sums in a different order: results differ in the last bit)
-    static const int pv16 = getenv("CCEDIT_ATTN_PV16") ? atoi(getenv("CCEDIT_ATTN_PV16")) : 1;
+    // policy attn_pv16 = 0: the PV product in 32x32x16 tiles (A/B; same sums in a different order: results differ in the last bit)
+    const int pv16 = cc_policy().attn_pv16;
     if (pv16) return (a.flags & CCEDIT_ATTN_Q_LOG2) ? launch_spatial<40, true, true>(a, s) : launch_spatial<40, false, true>(a, s);
     return (a.flags & CCEDIT_ATTN_Q_LOG2) ? launch_spatial<40, true, false>(a, s) : launch_spatial<40, false, false>(a, s);
 }

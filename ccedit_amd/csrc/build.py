@@ -65,18 +65,27 @@ def check_isa(obj: str) -> int:
     return n
 
 
+def _headers():
+    return ([os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")]
+            + [os.path.join(HERE, "..", "..", "include", "ccedit_hip.h"), os.path.abspath(__file__)])
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
     objs = []
     t0 = time.time()
     procs = []
+    hdr_t = max(os.path.getmtime(h) for h in _headers())
     for s in SOURCES:
         o = os.path.join(HERE, s.rsplit(".", 1)[0] + ".o")
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *EXTRA_FLAGS.get(s, []), "-x", "hip", "-c",
-               os.path.join(HERE, s), "-o", o]
-        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(o)
+        src = os.path.join(HERE, s)
+        # per-file incremental: an object newer than its source and every header is kept (a forced build recompiles all)
+        if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(src), hdr_t):
+            continue
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *EXTRA_FLAGS.get(s, []), "-x", "hip", "-c", src, "-o", o]
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     ok = True
     for s, p in procs:
         out, _ = p.communicate()
@@ -87,8 +96,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
             sys.stderr.write(out)
     if not ok:
         raise RuntimeError("hipcc failed")
+    rebuilt = {s for s, _ in procs}
     for s, o in zip(SOURCES, objs):
-        if s.endswith(".hip"):
+        if s.endswith(".hip") and s in rebuilt:      # (kept objects passed the check when they were built)
             n = check_isa(o)
             if n:
                 raise RuntimeError(f"{s}: {n} packed-fp32 instruction(s) with a low-lane read of a high half (op_sel:[..1..]) — "

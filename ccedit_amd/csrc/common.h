@@ -55,6 +55,29 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// The library's dispatch policy: ONE table of named integer switches (core.cpp), all defaulting to the fast path.  Nothing in the
+// library reads the environment: the host sets entries through ccedit_policy_set (ccedit_amd/policy.py reads CCEDIT_POLICY once and
+// pushes it).  Every switch selects between kernels that compute the same fp32 sums in a different order — A/B and test arms
+// ("specialised kernels reproduce the generic ones", tests/test_fullsize_gpu.py), never a change of arithmetic.
+struct CcPolicy {
+    int conv_halo = 1;      // 3x3 stride-1 convs on the LDS-halo kernel (0: tap-gather)
+    int g8 = 1;             // persistent eight-phase GEMM for long Linears (0: the tap_gemm block shapes)
+    int g8_conv = 1;        // ... its tap-gather mode for 3x3 convs onto >= 1024 channels
+    int g8_temporal = 1;    // ... and for Conv1d k3 over T at >= 640 channels
+    int g8_split = -1;      // split-K at the 8x12 level: -1 auto, 0 off, n fixed
+    int lin320 = 1;         // register-resident-weight K = 320 Linears (0: tap_gemm)
+    int lin320s = 1;        // ... the streaming deep-ring variant (0: the K-split kernel)
+    int lin640 = 1;         // streaming K = 640 Linears (0: g8)
+    int temp320 = 1;        // streaming Conv1d k3 at 320 channels (0: tap_gemm)
+    int attn_short = 1;     // temporal attention kernel (0: the general flash kernel)
+    int attn_text = 1;      // text cross-attention kernel
+    int attn_spatial = 1;   // d = 40 long self-attention kernel
+    int attn_pv16 = 1;      // ... its PV product in 16x16x32 tiles (0: 32x32x16)
+    int gn_flat = 1;        // flat thread mapping of the temporal GroupNorm at the two large levels
+    int block_tail = 1;     // ff320 with the to_out prologue / proj_out epilogue GEMMs (0: three launches)
+};
+const CcPolicy& cc_policy();
+
 void cc_set_error(const char* fmt, ...);
 void cc_note_kernel(const char* fmt, ...);      // which kernel template the entry point dispatched to (ccedit_last_kernel)
 

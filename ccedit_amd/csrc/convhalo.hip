@@ -246,9 +246,8 @@ int cc_conv_halo_launch(const CcGemmDesc& d, hipStream_t s) {
         const int ng = (int)((ct_n + q - 1) / q);
         dd.cgroup = (int)((ct_n + ng - 1) / ng);
     }
-    static const int narrow_env = getenv("CCEDIT_CONV_NARROW") ? atoi(getenv("CCEDIT_CONV_NARROW")) : 1;     // 0: A/B with the padded tile
     cc_note_kernel("conv_halo_kernel");
     hipLaunchKernelGGL((conv_halo_kernel<WM, WN, TI, TJ>), dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, dd,
-                       tw_log2 | (narrow_env ? 1 << 8 : 0));
+                       tw_log2 | (1 << 8));
     return cc_launch_status("conv_halo_kernel");
 }

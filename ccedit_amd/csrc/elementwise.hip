@@ -359,7 +359,10 @@ extern "C" int ccedit_cat_add_gn(const void* a, const void* b, const void* c, vo
     RS = RS < 1 ? 1 : (RS > 4 ? 4 : RS);
     int ppb = 256;                           // rows per workgroup: as many as still leave ~2000 workgroups
     while (ppb > 8 * RS && (int64_t)((hw + ppb - 1) / ppb) * frames < 2048) ppb >>= 1;
-    hipLaunchKernelGGL(cat_add_gn_kernel, dim3((hw + ppb - 1) / ppb, frames), dim3(gt * RS), 2 * RS * C * sizeof(float),
+    // at least 64 threads: the final per-(group, sum | sum of squares) reduction is done by threads 0..63 (C = 64 / 96 give only
+    // 32 / 48 column threads; the body is guarded by rs < RS, the extra threads only take part in the reduction)
+    const int threads = gt * RS < 64 ? 64 : gt * RS;
+    hipLaunchKernelGGL(cat_add_gn_kernel, dim3((hw + ppb - 1) / ppb, frames), dim3(threads), 2 * RS * C * sizeof(float),
                        (hipStream_t)stream, (const bf16*)a, (const bf16*)b, (const bf16*)c, (bf16*)out, stats, hw, C1, C2, ppb, RS);
     return cc_launch_status("cat_add_gn");
 }

@@ -374,24 +374,20 @@ int launch(const CcGemmDesc& d, hipStream_t s) {
     // (atile shrinks by the tap re-use of a 3x3 / temporal gather).
     CcGemmDesc dd = d;
     dd.cgroup = 0;
-    static const int cg_env = getenv("CCEDIT_CGROUP") ? atoi(getenv("CCEDIT_CGROUP")) : -1;    // tuning: -1 auto, 0 off, n fixed
     const double wbytes = (double)ct_n * BMC * d.Kpad * 2.0;
-    if (cg_env != 0 && ct_n > 4 && wbytes > 3.0 * 1024 * 1024) {
+    if (ct_n > 4 && wbytes > 3.0 * 1024 * 1024) {
         const double resident = (lds <= 80 * 1024 ? 2.0 : 1.0) * 32.0;
         const double a_over_w = (double)BNP / ((double)BMC * d.taps);
-        int q = cg_env > 0 ? cg_env : (int)(sqrt(resident * a_over_w) + 0.5);
+        int q = (int)(sqrt(resident * a_over_w) + 0.5);
         q = q < 2 ? 2 : q;
         if (q < ct_n) {
             const int ng = (int)((ct_n + q - 1) / q);
             dd.cgroup = (int)((ct_n + ng - 1) / ng);
         }
     }
-    static const int krot_env = getenv("CCEDIT_KROT") ? atoi(getenv("CCEDIT_KROT")) : 1;     // 0: A/B without the K rotation
-    if (krot_env && d.Kpad <= 640) dd.cgroup |= 1 << 16;                                         // short K only: measured neutral or -3 % at K = 1280
-    static const int tord_env = getenv("CCEDIT_TEMPORAL_ORDER") ? atoi(getenv("CCEDIT_TEMPORAL_ORDER")) : 1;   // 0: frames-outermost tile order
-    if (MODE == M_TEMPORAL && tord_env && d.HW % BNP == 0 && d.M % d.HW == 0) dd.cgroup |= 1 << 17;
-    static const int bal_env = getenv("CCEDIT_BALANCED") ? atoi(getenv("CCEDIT_BALANCED")) : 1;      // 0: A/B against pixel-tile cuts
-    if (bal_env && (dd.cgroup & 0xFFFF) == 0 && !((dd.cgroup >> 17) & 1)) {
+    if (d.Kpad <= 640) dd.cgroup |= 1 << 16;            // K rotation, short K only: measured neutral or -3 % at K = 1280
+    if (MODE == M_TEMPORAL && d.HW % BNP == 0 && d.M % d.HW == 0) dd.cgroup |= 1 << 17;      // frame-minor tile order
+    if ((dd.cgroup & 0xFFFF) == 0 && !((dd.cgroup >> 17) & 1)) {       // XCD ranges cut at workgroup granularity
         dd.cgroup |= 1 << 18;
         nblk = 8 * ((pt_n * ct_n + 7) / 8);
     }
@@ -420,8 +416,7 @@ int launch_tile(const CcGemmDesc& d, int tile, hipStream_t s) {
 extern "C" int64_t ccedit_gemm_workspace_bytes(const CcGemmDesc* desc) {
     if (!desc || desc->M <= 0 || desc->N <= 0 || desc->Kpad <= 0) return 0;
     if (!(desc->tile == 0 || desc->tile == 11 || desc->tile == 12)) return 0;
-    static const int g8_env = getenv("CCEDIT_G8") ? atoi(getenv("CCEDIT_G8")) : 1;
-    return g8_env ? cc_g8_workspace_bytes(*desc, 0) : 0;
+    return cc_policy().g8 ? cc_g8_workspace_bytes(*desc, 0) : 0;
 }
 
 extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
@@ -494,19 +489,18 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         return cc_lin320_launch(d, s);
     }
     // Conv1d k3 over T at 320 input channels over many pixels (the 64x96 level): all three taps' weights in registers, pixel columns
-    // streamed frame by frame (temp320.hip).  CCEDIT_TEMP320=0: A/B against the tiled kernels.
-    static const int t320_env = getenv("CCEDIT_TEMP320") ? atoi(getenv("CCEDIT_TEMP320")) : 1;
-    if ((d.tile == 0 && t320_env && d.M >= 100000) || d.tile == 14) {
+    // streamed frame by frame (temp320.hip).  Policy temp320 = 0: A/B against the tiled kernels.
+    const CcPolicy& pol = cc_policy();
+    if ((d.tile == 0 && pol.temp320 && d.M >= 100000) || d.tile == 14) {
         if (cc_temp320_applicable(d)) return cc_temp320_launch(d, s);
         CC_UNSUPPORTED(d.tile == 14, "ccedit_gemm: tile 14 (streaming Conv1d k3, 320 input channels) does not apply to this descriptor");
     }
     // K = 640 Linear over many whole 16-pixel tiles (the 32x48 level): weights resident in registers, activations streamed once
-    // (lin640.hip) — bias, one residual, row_sums, or the folded LayerNorm (ln_stats / ln_sums).  CCEDIT_LIN640=0: A/B against gemm8p.
-    static const int l640_env = getenv("CCEDIT_LIN640") ? atoi(getenv("CCEDIT_LIN640")) : 1;
+    // (lin640.hip) — bias, one residual, row_sums, or the folded LayerNorm (ln_stats / ln_sums).  Policy lin640 = 0: A/B against gemm8p.
     // (at 52224 rows, lin640s / gemm8p: 1920 channels 147 / 220 us, 1280: 105 / 140; at 640 the three slices — the third half empty —
     //  fetch the activations three times: plain 63 / 68, residual 66 / 75, with row_sums 74 / 82, but with the folded LayerNorm
     //  67 / 65 — that one stays on gemm8p below 1024 channels)
-    if ((d.tile == 0 && l640_env && d.M >= 16384 && (d.N >= 1024 || (!d.ln_stats && !d.ln_sums))) || d.tile == 10) {
+    if ((d.tile == 0 && pol.lin640 && d.M >= 16384 && (d.N >= 1024 || (!d.ln_stats && !d.ln_sums))) || d.tile == 10) {
         if (cc_lin640_applicable(d)) return cc_lin640_launch(d, s);
         CC_UNSUPPORTED(d.tile == 10, "ccedit_gemm: tile 10 (register-resident weights, K = 640) does not apply to this descriptor");
     }
@@ -529,23 +523,19 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     // 3x3 convs onto >= 1024 channels (the 16x24 level): 29-59 MB of weights do not fit an XCD's L2 and the 128 x 128 tiles of the LDS-halo
     // kernel re-stream them per pixel tile (450 MB fetched for 63 MB of operands, round 2).  The persistent 256 x 256 tap-gather loop
     // halves the weight bytes per FLOP: cold sweep 1280->1280 1162 / 843, 2560->1280 1220 / 895, 640->1280 1067 / 729 TF/s.  At 640
-    // channels and below the halo re-use wins (32x48 640->640: 890 / 925) and those stay.  CCEDIT_G8_CONV=0 for the A/B.
-    static const int g8c_env = getenv("CCEDIT_G8_CONV") ? atoi(getenv("CCEDIT_G8_CONV")) : 1;
-    static const int g8_env0 = getenv("CCEDIT_G8") ? atoi(getenv("CCEDIT_G8")) : 1;
-    if (d.tile == 0 && g8c_env && g8_env0 && !d.vpad && d.mode == CCEDIT_GEMM_CONV2D && d.N >= 1024 && d.M >= 12000 && cc_g8_applicable(d, 1))
+    // channels and below the halo re-use wins (32x48 640->640: 890 / 925) and those stay.  Policy g8_conv = 0 for the A/B.
+    if (d.tile == 0 && pol.g8_conv && pol.g8 && !d.vpad && d.mode == CCEDIT_GEMM_CONV2D && d.N >= 1024 && d.M >= 12000 && cc_g8_applicable(d, 1))
         return cc_g8_launch(d, s, 1);
     // Few tiles, long K (the 8x12 level: 3264 pixels x 1280 channels = 65 tiles of 256 x 256, K loops of 60-360 K tiles — a quarter of the
     // chip busy for the whole loop on any block shape): split-K in the persistent kernel when the caller lent a workspace.
-    if (d.tile == 0 && g8_env0 && !d.subpix && !d.vpad && d.workspace && cc_g8_split(d, 0) > 1 && d.workspace_bytes >= cc_g8_workspace_bytes(d, 0))
+    if (d.tile == 0 && pol.g8 && !d.subpix && !d.vpad && d.workspace && cc_g8_split(d, 0) > 1 && d.workspace_bytes >= cc_g8_workspace_bytes(d, 0))
         return cc_g8_launch(d, s, 1);
-    static const int halo_env = getenv("CCEDIT_CONV_HALO") ? atoi(getenv("CCEDIT_CONV_HALO")) : 1;   // 0: A/B against the gather path
-    if ((d.tile == 0 && halo_env && !d.vpad) || d.tile == 8) {
+    if ((d.tile == 0 && pol.conv_halo && !d.vpad) || d.tile == 8) {
         if (!d.vpad && cc_conv_halo_applicable(d)) return cc_conv_halo_launch(d, s);
         CC_UNSUPPORTED(d.tile == 8, "ccedit_gemm: tile 8 (LDS-halo 3x3 conv) does not apply to this descriptor");
     }
     // K = 320 Linear over many pixels: weights resident in registers, activations streamed once (lin320.hip)
-    static const int l320_env = getenv("CCEDIT_LIN320") ? atoi(getenv("CCEDIT_LIN320")) : 1;    // 0: A/B against tap_gemm
-    if ((d.tile == 0 && l320_env && d.M >= 32768) || d.tile == 9) {
+    if ((d.tile == 0 && pol.lin320 && d.M >= 32768) || d.tile == 9) {
         if (cc_lin320_applicable(d)) return cc_lin320_launch(d, s);
         CC_UNSUPPORTED(d.tile == 9, "ccedit_gemm: tile 9 (register-resident weights, K = 320) does not apply to this descriptor");
     }
@@ -560,14 +550,12 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
     //   13056 x 1280 <- 5120 + res 1171 / 904   13056 x 1280 <- 1280 + res 814 / 553      52224 x 640 <- 640 + res 582 / 525
     // and the single CFG halves (two-stream execution): 26112 x 5120 <- 640 GEGLU 945 / 588, 6528 x 10240 <- 1280 GEGLU 964 / 677.
     // Not below 4096 rows (fewer than ~100 tiles: most CUs idle) and not for K = 320 (lin320 / ff320 own those).
-    static const int g8_env = getenv("CCEDIT_G8") ? atoi(getenv("CCEDIT_G8")) : 1;      // 0: A/B against the older block shapes
-    if (d.tile == 0 && g8_env && !d.subpix && d.M >= 4096 && d.Kpad >= 640 && d.N >= 640 && cc_g8_applicable(d, 0)) {
+    if (d.tile == 0 && pol.g8 && !d.subpix && d.M >= 4096 && d.Kpad >= 640 && d.N >= 640 && cc_g8_applicable(d, 0)) {
         // Conv1d k3 over T: the same K loop with the activation rows gathered HW rows away (cold sweep, + residual, against the
         // best older shape: 32x48 640->640 746 / 703, 1280->1280 1034 / 883; 16x24 1280->1280 981 / 917; 64x96 640->640 801 / 692 —
         // and 507 / 519 at 320->320, where three 128-channel tiles re-read every activation row: those stay on tap_gemm, N >= 640 above).
         // Below ~200 tiles the persistent grid is mostly idle: the 8x12 level (3264 rows) and single CFG halves of 16x24 stay too.
-        static const int g8t_env = getenv("CCEDIT_G8_TEMPORAL") ? atoi(getenv("CCEDIT_G8_TEMPORAL")) : 1;      // 0: A/B
-        if (d.mode == CCEDIT_GEMM_LINEAR || (d.mode == CCEDIT_GEMM_TEMPORAL && g8t_env && d.M >= 12000)) return cc_g8_launch(d, s, 0);
+        if (d.mode == CCEDIT_GEMM_LINEAR || (d.mode == CCEDIT_GEMM_TEMPORAL && pol.g8_temporal && d.M >= 12000)) return cc_g8_launch(d, s, 0);
     }
     CC_UNSUPPORTED(d.tile == 6 && d.N % 320 != 0, "ccedit_gemm: tile 6 (320-channel block shape) needs N %% 320 == 0 (N=%d)", d.N);
     int tile = d.tile;
@@ -588,19 +576,17 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         //   long K with Cout % 320 == 0 (every UNet width): 320ch x 128pix, K tiles of 32, still two workgroups per CU
         //   (t6: 91 FLOP per staged byte against 64 for t1; cold sweep +4 % at 1280 -> 1280 / 3840 / 10240 and +8 % at
         //   1280 -> 320 on 209k pixels, +22 % on the 1280-channel temporal conv; slower for K <= 640 and below 8k pixels;
-        //   in the network +0.6 % per step, CCEDIT_T6=0 switches it off for A/B)
-        static const int t6_env = getenv("CCEDIT_T6") ? atoi(getenv("CCEDIT_T6")) : 1;
-        if (t6_env && d.N % 320 == 0 && !d.gn_stats && d.M >= 8192 &&
+        //   in the network +0.6 % per step)
+        if (d.N % 320 == 0 && !d.gn_stats && d.M >= 8192 &&
             ((d.mode == CCEDIT_GEMM_LINEAR && d.Kpad >= 1280) || (d.mode == CCEDIT_GEMM_TEMPORAL && d.Kpad >= 3840)))
             tile = 6;
         //   16x24-level Linears onto 1280 channels: 256ch x 256pix (t4).  With the workgroup-granular XCD cut (cgroup bit 18)
         //   13056 pixels x 1280 channels is 255 workgroups = one round of the chip: 706 / 906 / 954 TF/s at K = 1280 / 5120 /
         //   11520 against 644 / 817 / 846 for t6 (tools/exp/gemm_vs_vendor.py; the same shapes cut at pixel-tile granularity
-        //   ran 374 / 540 / 591).  CCEDIT_T4=0 switches it off for A/B.
+        //   ran 374 / 540 / 591).
         //   Only with BOTH CFG halves in the launch: at 6528 pixels (one half, the default two-stream execution) it is 130
         //   workgroups and loses to t1 (383 / 544 against 454 / 577 TF/s at K = 1280 / 5120; -0.6 ms per step in the A/B).
-        static const int t4_env = getenv("CCEDIT_T4") ? atoi(getenv("CCEDIT_T4")) : 1;
-        if (t4_env && d.mode == CCEDIT_GEMM_LINEAR && d.N % 256 == 0 && d.N <= 2560 && d.act != CCEDIT_ACT_GEGLU && !d.gn_stats &&
+        if (d.mode == CCEDIT_GEMM_LINEAR && d.N % 256 == 0 && d.N <= 2560 && d.act != CCEDIT_ACT_GEGLU && !d.gn_stats &&
             d.Kpad >= 1280 && d.M >= 12000 && d.M <= 16384)
             tile = 4;
         if (d.gn_stats && d.gn_rows % 256 != 0) tile = 1;     // a block must not straddle two frames

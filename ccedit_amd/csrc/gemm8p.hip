@@ -837,10 +837,9 @@ int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu, int split_k = 
     }
     // channel-tile groups when the weight matrix does not fit an XCD's 4 MB L2 beside the activation tiles in flight: the largest
     // group of at most ~2 MB of weight rows, evened out over the groups
-    static const int cg_env = getenv("CCEDIT_CGROUP") ? atoi(getenv("CCEDIT_CGROUP")) : -1;     // tuning: -1 auto, 0 off, n fixed
     const double tile_bytes = (double)BM * d.Kpad * 2.0;
-    if (cg_env != 0 && ct_n * tile_bytes > 3.0 * 1024 * 1024) {
-        int q = cg_env > 0 ? cg_env : (int)(2.0 * 1024 * 1024 / tile_bytes);
+    if (ct_n * tile_bytes > 3.0 * 1024 * 1024) {
+        int q = (int)(2.0 * 1024 * 1024 / tile_bytes);
         q = q < 2 ? 2 : q;
         if (q < ct_n) {
             const int ng = (int)((ct_n + q - 1) / q);
@@ -906,7 +905,7 @@ bool cc_g8_applicable(const CcGemmDesc& d, int shape) {
 // long enough to share — as many splits as fit one round of the chip, at least 8 K tiles each, at most 8.  The caller's workspace
 // decides: without one (or with one too small) there is no split.  n_cu = 0: the 256 CUs of an MI355X (size queries without a GPU).
 int cc_g8_split(const CcGemmDesc& d, int n_cu) {
-    static const int env = getenv("CCEDIT_G8_SPLIT") ? atoi(getenv("CCEDIT_G8_SPLIT")) : -1;       // tuning: 0 off, n fixed
+    const int env = cc_policy().g8_split;       // -1 auto, 0 off, n fixed
     if (env == 0 || d.act == CCEDIT_ACT_GEGLU || !cc_g8_applicable(d, 1)) return 1;
     const int wgs = (n_cu > 0 ? n_cu : 256) / 8 * 8;
     const int64_t tiles = ((d.M + 255) / 256) * ((d.N + 255) / 256);

@@ -578,9 +578,8 @@ int cc_lin320_launch(const CcGemmDesc& d, hipStream_t s) {
         cc_set_error("ccedit_gemm: grid too large");
         return CCEDIT_EUNSUPPORTED;
     }
-    // whole tiles and no GEGLU: the deep-ring variant.  CCEDIT_LIN320S=0 for the A/B against the K-split kernel.
-    static const int s_env = getenv("CCEDIT_LIN320S") ? atoi(getenv("CCEDIT_LIN320S")) : 1;
-    if (s_env && !geglu && d.M % kP == 0) {
+    // whole tiles and no GEGLU: the deep-ring variant (policy lin320s = 0: A/B against the K-split kernel)
+    if (cc_policy().lin320s && !geglu && d.M % kP == 0) {
         const int lds_s = kBufsS * kXBuf;
         static unsigned long long attr_s[3] = {0, 0, 0};
         if (int rc = cc_max_dynamic_lds((const void*)lin320s_kernel<false, false>, lds_s, &attr_s[0], "lin320s")) return rc;

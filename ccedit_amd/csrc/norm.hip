@@ -187,29 +187,36 @@ __global__ __launch_bounds__(256) void gn_spatial_onepass_kernel(const bf16* __r
         off[k] = u < units ? pix * C + gr * 8 : -1;
         if (off[k] >= 0) v[k] = *(const bf16x8*)(xf + off[k]);
     }
-    float s = 0.f, q = 0.f;
+    // Two passes over the REGISTER-resident values (no extra memory traffic): the mean first, then the sum of squared deviations from
+    // it — no E[x^2] - mean^2 cancellation when |mean| >> std (the other spatial paths accumulate raw moments in double; this one keeps
+    // fp32 lanes but never subtracts two large numbers).  Wave partials meet in double, in wave-index order.
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kGnOneUnits; ++k)
+        if (off[k] >= 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += bf2f(v[k][e]);
+        }
+    s = wave_sum(s);
+    if (lane == 0) s_part[wave][0] = s;
+    __syncthreads();
+    const double inv_n = 1.0 / ((double)cpg * (double)hw);
+    const float mean = (float)((((double)s_part[0][0] + (double)s_part[1][0]) + ((double)s_part[2][0] + (double)s_part[3][0])) * inv_n);
+    float q = 0.f;
 #pragma unroll
     for (int k = 0; k < kGnOneUnits; ++k)
         if (off[k] >= 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float f = bf2f(v[k][e]);
-                s += f;
-                q += f * f;
+                const float dv = bf2f(v[k][e]) - mean;
+                q = fmaf(dv, dv, q);
             }
         }
-    s = wave_sum(s);
     q = wave_sum(q);
-    if (lane == 0) {
-        s_part[wave][0] = s;
-        s_part[wave][1] = q;
-    }
+    if (lane == 0) s_part[wave][1] = q;
     __syncthreads();
-    const float ts = (s_part[0][0] + s_part[1][0]) + (s_part[2][0] + s_part[3][0]);
-    const float tq = (s_part[0][1] + s_part[1][1]) + (s_part[2][1] + s_part[3][1]);
-    const float inv_n = 1.0f / ((float)cpg * (float)hw);
-    const float mean = ts * inv_n;
-    const float rstd = rsqrtf(fmaxf(tq * inv_n - mean * mean, 0.f) + eps);
+    const double tq = ((double)s_part[0][1] + (double)s_part[1][1]) + ((double)s_part[2][1] + (double)s_part[3][1]);
+    const float rstd = rsqrtf((float)(tq * inv_n) + eps);
 #pragma unroll
     for (int k = 0; k < kGnOneUnits; ++k)
         if (off[k] >= 0) {
@@ -801,7 +808,7 @@ extern "C" int ccedit_groupnorm_temporal(const void* x, void* y, const float* ga
     dim3 grid((unsigned)((waves + 3) / 4));
     int nsl = 1;                                   // channel slices: whole groups, at most 512 channels each
     while (nsl < 32 && C / nsl > 512) nsl <<= 1;
-    static const int flat_env = getenv("CCEDIT_GN_FLAT") ? atoi(getenv("CCEDIT_GN_FLAT")) : 1;      // 0: A/B against the wave-per-slice mapping
+    const int flat_env = cc_policy().gn_flat;      // 0: A/B against the wave-per-slice mapping
     // (measured, 2 x 17 frames: 70 / 38 us against 73 / 40 at 64x96 / 32x48; the small levels — a few hundred workgroups — are
     //  1 - 2 us better with the wave-per-slice mapping's larger grid)
     if (flat_env && T <= kGtCacheT && C % 320 == 0 && C <= 1280 && waves * (C >> 3) >= 700 * kGtFlatThreads) {

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the library is loaded: to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCEDIT_HIP_LIB") or os.path.join(_HERE, "libccedit_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 ATTN_Q_LOG2 = 1          # CcAttnDesc.flags: CCEDIT_ATTN_Q_LOG2
 
 GEMM_LINEAR, GEMM_CONV2D, GEMM_TEMPORAL = 0, 1, 2
@@ -72,6 +72,9 @@ _SIGS = {
     "ccedit_last_error": (C.c_char_p, []),
     "ccedit_last_kernel": (C.c_char_p, []),
     "ccedit_device_info": (C.c_int, [C.c_char_p, C.c_int]),
+    "ccedit_policy_set": (C.c_int, [C.c_char_p, C.c_int32]),
+    "ccedit_policy_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
+    "ccedit_policy_names": (C.c_char_p, []),
     "ccedit_gemm": (C.c_int, [C.POINTER(CcGemmDesc), C.c_void_p]),
     "ccedit_gemm_workspace_bytes": (C.c_int64, [C.POINTER(CcGemmDesc)]),
     "ccedit_ff320": (C.c_int, [C.POINTER(CcFf320Desc), C.c_void_p]),
@@ -140,6 +143,8 @@ def lib() -> C.CDLL:
     if v != ABI_VERSION:
         raise HipLibraryError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
     _lib = l
+    from . import policy
+    policy.push_to_library(l)          # the library never reads the environment: the one policy table is pushed here
     return l
 
 

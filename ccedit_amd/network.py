@@ -25,7 +25,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, policy
 from .hip import ACT_SILU
 from .layers import PACK_GENERATION, Conv, Linear, Norm, Slot, pack_tree
 from .packing import pack_concat
@@ -60,6 +60,9 @@ def sconv3(x, pw, geo: Geometry, stride: int = 1, **kw):
     rs = geo.rows
     if rs is None:
         return ops.conv2d(x, pw, stride=stride, **kw)
+    if stride == 2 and x.shape[1] % 2:
+        raise ValueError(f"row-sharded stride-2 convolution on {x.shape[1]} local rows: the local height must be even at every level "
+                         f"(RowShard.check_latent)")
     return ops.conv2d(rs.halo_rows(x, below=stride == 1), pw, stride=stride, vpad=True, **kw)
 
 
@@ -198,12 +201,15 @@ class CrossAttention(nn.Module):
         self.kv = None
         self.q_log2 = False
 
+    def wants_q_log2(self) -> bool:
+        return self.self_attn and self.dim_head == 40 and ops.ATTN_Q_LOG2
+
     def post_pack(self, device):
         if self.self_attn:
             # d = 40 (the 64x96 level, 6144 keys): softmax scale * log2(e) rides in the packed to_q rows — the attention kernel
             # then exponentiates q.k directly (CCEDIT_ATTN_Q_LOG2), and q is rounded to bf16 once, as in the reference's
             # `q = self.to_q(x)` (attention.py:404), instead of a second time after an in-kernel multiply
-            self.q_log2 = self.dim_head == 40 and ops.ATTN_Q_LOG2
+            self.q_log2 = self.wants_q_log2()
             qw = self.to_q.weight * (self.dim_head ** -0.5 * LOG2E) if self.q_log2 else self.to_q.weight
             self.qkv = pack_concat([qw, self.to_k.weight, self.to_v.weight], device=device)
         self.kv = pack_concat([self.to_k.weight, self.to_v.weight], device=device)
@@ -295,7 +301,8 @@ class BasicTransformerBlock(nn.Module):
                               q_log2=a1.q_log2)
         tok = linear_ln_producer(o, a1.to_out[0].pw, res1=tok)
         q = ln_linear(tok, self.norm2, a2.to_q.pw, self.q2_ln)
-        kv = ops.linear(ctx_kv_src, a2.kv)                     # [B*L, 2C]: once per clip, shared by its T frames
+        # [B*L, 2C]: once per clip, shared by its T frames; normally a column slice of the network's batched projection (TextKV)
+        kv = ctx_kv_src.of(self) if isinstance(ctx_kv_src, TextKV) else ops.linear(ctx_kv_src, a2.kv)
         o = ops.attention(q, kv[:, :c], kv[:, c:], a2.heads, a2.dim_head, batches=frames, lq=hw, lk=ctx_len,
                           kv_div=frames_per_clip)
         tok = linear_ln_producer(o, a2.to_out[0].pw, res1=tok)
@@ -308,7 +315,10 @@ class BasicTransformerBlock(nn.Module):
         self.ff.pack_fused(self.norm3, device)
         self.q2_ln = _fold_ln([self.attn2.to_q.weight], self.norm2, device)
         a1 = self.attn1
-        assert not (a1.q_log2 and a1.to_q.weight.shape[1] in (640, 1280))      # (the folded-norm pack below carries no scale)
+        if a1.wants_q_log2() and a1.to_q.weight.shape[1] in (640, 1280):      # (asked of the child directly: pack order does not matter)
+            # the folded-norm pack below carries no softmax scale: a d = 40 head at 640 / 1280 channels would be attended un-scaled
+            raise NotImplementedError("CrossAttention: q_log2 (d = 40) together with the folded LayerNorm of the 640 / 1280-channel "
+                                      "projections is not packed; extend _fold_ln with the q scale before enabling this width")
         self.qkv_ln = _fold_ln([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], self.norm1, device, dims=(640, 1280))
 
 
@@ -643,6 +653,27 @@ class EmbOut:
         return self.e_all[:, sl[0]:sl[0] + sl[1]]
 
 
+class TextKV:
+    """Text-conditioning keys / values of one network evaluation.  Every BasicTransformerBlock projects the SAME (B * 77, 768) context
+    with its own to_k / to_v (attention.py:392-467; 16 blocks in the UNet, 7 in a ControlNet): they run as ONE GEMM against the
+    row-concatenated weights (`UNetModel._pack_text_kv`), `of(block)` is that block's (B * L, 2C) column slice [K | V] — the attention
+    kernels take the row stride of the fused buffer.  The projections depend only on the conditioning tensor, which is constant over
+    the evaluations of a clip: the wrapper keeps the result per (network, context tensor) while its per-clip caches are on
+    (OpenAIWrapperControlLDM3DTV2V._text_kv).  A block outside the packed projection falls back to its own Linear."""
+
+    def __init__(self, ctx2d: torch.Tensor, kv_all: Optional[torch.Tensor] = None):
+        self.ctx2d, self.kv_all = ctx2d, kv_all
+
+    def of(self, block) -> torch.Tensor:
+        sl = getattr(block, "_tkv_slice", None)
+        if self.kv_all is None or sl is None or sl[0] + sl[1] > self.kv_all.shape[1]:
+            return ops.linear(self.ctx2d, block.attn2.kv)
+        return self.kv_all[:, sl[0]:sl[0] + sl[1]]
+
+
+TEXT_KV_BATCHED = policy.on("text_kv_batched")      # 0: one K/V projection launch per transformer block (A/B)
+
+
 class UNetModel(nn.Module):
     """Block wiring of sgm UNetModel.__init__ (openaimodel.py:1033-1527) for the supported options."""
 
@@ -741,8 +772,29 @@ class UNetModel(nn.Module):
                 return not (name.startswith("controlnet.") or name.startswith("controlnet_img."))
         return False
 
+    def _pack_text_kv(self, device):
+        blocks = [m for m in self.modules() if isinstance(m, BasicTransformerBlock) and self._owns(m)]
+        off = 0
+        for m in blocks:
+            m._tkv_slice = (off, 2 * m.attn2.inner)
+            off += 2 * m.attn2.inner
+        self._text_kv_all = None
+        if blocks and TEXT_KV_BATCHED:
+            ws = []
+            for m in blocks:
+                ws += [m.attn2.to_k.weight, m.attn2.to_v.weight]
+            self._text_kv_all = pack_concat(ws, device=device)
+
+    def text_kv(self, ctx2d) -> Optional["TextKV"]:
+        """One GEMM for the text K / V projections of every transformer block of this network (see TextKV)."""
+        if ctx2d is None or isinstance(ctx2d, TextKV):
+            return ctx2d
+        pw = getattr(self, "_text_kv_all", None)
+        return TextKV(ctx2d, None if pw is None else ops.linear(ctx2d, pw))
+
     def post_pack(self, device):
         self._pack_emb(device)
+        self._pack_text_kv(device)
 
     def pack(self, device=None):
         device = torch.device("cuda") if device is None else device
@@ -802,6 +854,7 @@ class ControlNet2D(UNetModel):
 
     def post_pack(self, device):
         self._pack_emb(device)
+        self._pack_text_kv(device)
         if self.control_scales != 1.0:       # `c * scale` (controlmodel.py:311-312) folded into the zero convs
             for zc in list(self.zero_convs) + [self.middle_block_out]:
                 zc[0].pack(device, scale=self.control_scales)
@@ -820,6 +873,7 @@ class ControlNet2D(UNetModel):
         controlnet_img (no_add_x + identity hint block): x_nhwc is ignored and `guided` is the 8-channel-padded
         reference latent; the first block's output is input_blocks[0](guided) (controlmodel.py:283-299)."""
         emb_silu = self._emb_silu(timesteps)
+        ctx2d = self.text_kv(ctx2d)
         outs = []
         h = x_nhwc
         for i, (block, zc) in enumerate(zip(self.input_blocks, self.zero_convs)):
@@ -875,6 +929,7 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
         residuals added in place to the centre frame T//2 of every clip (controlmodel.py:529-535)
         -> eps (B*T, h, w, out) fp32."""
         emb_silu = self._emb_silu(timesteps)
+        ctx2d = self.text_kv(ctx2d)
 
         def add_center(hh):
             if img_control is not None:
@@ -965,7 +1020,7 @@ class IdentityWrapper(nn.Module):
 # and the default.  Round 3: the persistent eight-phase GEMM (gemm8p.hip) owns every CU while it runs (128-160 KB of LDS per
 # workgroup), so there is little left to overlap, and the batched pass gives it twice the tiles per launch — same-box A/B
 # 115.2 (batched) vs 116.3 ms (two streams).  Batched is the default now; CCEDIT_SPLIT_CFG=1 restores the two-stream halves.
-_SPLIT_CFG = os.environ.get("CCEDIT_SPLIT_CFG", "0") == "1"
+_SPLIT_CFG = policy.on("split_cfg")
 
 
 class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
@@ -980,7 +1035,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     _hint_val = None
     _hint_slices = None
     _hint_dup = None
-    dedup_hint = os.environ.get("CCEDIT_HINT_DEDUP", "1") != "0"      # 0: evaluate the hint stem on both CFG halves (A/B)
+    dedup_hint = policy.on("hint_dedup")      # 0: evaluate the hint stem on both CFG halves (A/B)
     frame_shard = None          # parallel.FrameShard: split the T keyframes of each clip over the ranks (config 4)
     row_shard = None            # parallel.RowShard: split the latent ROWS of every frame over the ranks (config 4, balanced)
     # The ControlNet's residuals are first needed after the UNet's middle block: with overlap_controlnet the ControlNet
@@ -994,7 +1049,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     # block shapes 1 / 2 / 3 / 6, never when idle, never with the scalar build of the same kernel).  csrc/build.py compiles
     # the two files that had the form without the SLP vectoriser and refuses it in any object (check_isa), which restored
     # run-to-run bit-equality with the side stream on; CCEDIT_OVERLAP_CONTROLNET=0 keeps everything on one stream.
-    overlap_controlnet = os.environ.get("CCEDIT_OVERLAP_CONTROLNET", "1") != "0"
+    overlap_controlnet = policy.on("overlap_controlnet")
     _side_stream = None
     _half_stream = None
 
@@ -1010,6 +1065,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         self._hint_val = None
         self._hint_slices = None
         self._hint_dup = None
+        self._tkv_val = None
         self._graphs = None
 
     def _guided_hint(self, hint5d: torch.Tensor, rows=None):
@@ -1046,6 +1102,23 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             self._hint_val[key] = (hint5d, g)
         return g
 
+    _tkv_val = None
+
+    def _text_kv(self, net, context: torch.Tensor, ctx2d: torch.Tensor) -> "TextKV":
+        """net.text_kv(ctx2d), kept per (network, conditioning tensor) while the per-clip caches are on (`cache_hint_stem`): the text
+        K / V projections are constant over the 59 evaluations of a clip (the reference recomputes them every time).  Same
+        keying discipline as _guided_hint: identity + version of the source tensor, which the entry pins."""
+        if not self.cache_hint_stem:
+            return net.text_kv(ctx2d)
+        key = (id(net),) + self._tensor_key(context) + (PACK_GENERATION[0],)
+        if isinstance(self._tkv_val, dict) and key in self._tkv_val:
+            return self._tkv_val[key][1]
+        tkv = net.text_kv(ctx2d)
+        if not isinstance(self._tkv_val, dict) or len(self._tkv_val) >= 6:
+            self._tkv_val = {}
+        self._tkv_val[key] = (context, tkv)
+        return tkv
+
     # One network evaluation is ~560 kernel launches issued from Python; where the kernels are short (the 16x24 / 8x12 levels, the
     # norm passes) the GPU outruns the launching thread: 150 gaps of 5-10 us, 1.3 ms per step in the kernel trace
     # (tools/exp/gaps.py).  The 59 evaluations of a clip have identical shapes and conditioning tensors, so the launch sequence is
@@ -1056,7 +1129,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     # (tests/test_network_gpu.py).  CCEDIT_GRAPH=0 disables; sharded / profiled / traced evaluations are always eager, and so are
     # the two-stream CFG halves (CCEDIT_SPLIT_CFG=1: capturing four streams that fork and join inside each other crashed the
     # runtime on ROCm 7.2 — not pursued, the batched pass is the default).
-    use_graph = os.environ.get("CCEDIT_GRAPH", "1") != "0" and not _SPLIT_CFG
+    use_graph = policy.on("graph") and not _SPLIT_CFG
     _graphs = None
     _graph_failed = False
 
@@ -1099,6 +1172,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                         ops.reset_stream_scratch()
                 ent["graph"] = g
                 ent["pins"].append(dict(self._hint_val) if isinstance(self._hint_val, dict) else None)   # the cached stem output it reads
+                ent["pins"].append(dict(self._tkv_val) if isinstance(self._tkv_val, dict) else None)     # ... and the cached text K / V
             except Exception as e:                              # capture is an optimisation: report once, keep evaluating eagerly
                 import warnings
                 OpenAIWrapperControlLDM3DTV2V._graph_failed = True
@@ -1161,6 +1235,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         if rs is not None:             # keep this rank's latent rows of every frame (and the 8x finer hint rows that feed them)
             if sh is not None:
                 raise ValueError("frame_shard and row_shard are alternative decompositions of one clip")
+            rs.check_latent(lh)
             r0, r1 = rs.rows(lh)
             x = x[:, :, :, r0:r1]
             hk = self._tensor_key(c["control_hint"]) + ("rows", r0, r1)
@@ -1186,7 +1261,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             side.wait_stream(main)                      # x8 / ctx2d / t are ready
             with torch.cuda.stream(side):
                 guided = self._guided_hint(hint5)
-                control = net.controlnet.run(x8, guided, t, ctx2d, context.shape[1], geo)
+                control = net.controlnet.run(x8, guided, t, self._text_kv(net.controlnet, context, ctx2d), context.shape[1], geo)
                 control_ready = torch.cuda.Event()
                 control_ready.record(side)
             for tns in (x8, ctx2d):
@@ -1195,14 +1270,14 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                 tns.record_stream(main)                 # and vice versa
         else:
             guided = self._guided_hint(hint5, rows=rs)
-            control = net.controlnet.run(x8, guided, t, ctx2d, context.shape[1], geo)
+            control = net.controlnet.run(x8, guided, t, self._text_kv(net.controlnet, context, ctx2d), context.shape[1], geo)
         img_control = None
         if cond_feat is not None and (sh is None or sh.owner_of(nt // 2) == sh.rank):
             # TVI2V (wrappers.py:176-190): controlnet_img on the reference latent; its residuals only touch keyframe T//2,
             # so under frame sharding only the rank holding that keyframe evaluates it
             cf8 = ops.ncthw_to_nhwc(cond_feat.float()[:, :, None].contiguous(), 8)
             img_control = net.controlnet_img.run(None, cf8, t, None, 0, Geometry(b, 1, rows=rs))
-        eps = net.run(x8, t, ctx2d, context.shape[1], control, geo, img_control, control_ready=control_ready)
+        eps = net.run(x8, t, self._text_kv(net, context, ctx2d), context.shape[1], control, geo, img_control, control_ready=control_ready)
         if sh is not None:             # all ranks get the full (B, C, T, h, w) prediction (1.6 MB at 17x64x96)
             eps = sh.gather_pixels(eps.view(-1, eps.shape[-1]), b, lh * lw) if sh.mode == "a2a" else sh.gather_frames(eps, b)
             eps = eps.view(b * nt, lh, lw, -1)

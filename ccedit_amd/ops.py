@@ -13,7 +13,7 @@ from typing import Optional
 
 import torch
 
-from . import hip
+from . import hip, policy
 from .hip import (ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, CcAttnDesc, CcFf320Desc, CcGemmDesc, GEMM_CONV2D, GEMM_LINEAR,
                   GEMM_TEMPORAL)
 from .packing import PackedFF320, PackedWeight
@@ -194,7 +194,7 @@ def linear(x2d, pw, **kw):
     return gemm(x2d, pw, mode=GEMM_LINEAR, **kw)
 
 
-LN320 = os.environ.get("CCEDIT_LN320", "1") != "0"      # 0: separate LayerNorm pass in front of the K = 320 projections
+LN320 = policy.on("ln320")      # 0: separate LayerNorm pass in front of the K = 320 projections
 
 
 def ln320_applicable(m, pw, act=ACT_NONE, res1=None, res2=None, group_bias=None, out_f32=False, gn_rows=0) -> bool:
@@ -206,8 +206,8 @@ def ln320_applicable(m, pw, act=ACT_NONE, res1=None, res2=None, group_bias=None,
             and gn_rows == 0)
 
 
-ATTN_Q_LOG2 = os.environ.get("CCEDIT_ATTN_Q_LOG2", "1") != "0"      # 0: softmax scale applied inside the attention kernels (A/B)
-FF320 = os.environ.get("CCEDIT_FF320", "1") != "0"      # 0: LayerNorm + two GEMMs instead of the fused dim-320 feed-forward
+ATTN_Q_LOG2 = policy.on("attn_q_log2")      # 0: softmax scale applied inside the attention kernels (A/B)
+FF320 = policy.on("ff320")      # 0: LayerNorm + two GEMMs instead of the fused dim-320 feed-forward
 
 
 def ff320(x2d: torch.Tensor, pk: PackedFF320, eps: float = 1e-5, ln: bool = True, out: Optional[torch.Tensor] = None,
@@ -260,8 +260,8 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, ups
     return carry_gn_stats(out, out.view(n, hout, wout, out.shape[-1]))
 
 
-CONV1X1_LINEAR = os.environ.get("CCEDIT_CONV1X1_LINEAR", "1") != "0"      # 0: 1 x 1 convs through the convolution mode (A/B)
-SUBPIX = os.environ.get("CCEDIT_SUBPIX", "1") != "0"      # 0: upsample + 3x3 conv through the nine-tap gather (A/B)
+CONV1X1_LINEAR = policy.on("conv1x1_linear")      # 0: 1 x 1 convs through the convolution mode (A/B)
+SUBPIX = policy.on("subpix")      # 0: upsample + 3x3 conv through the nine-tap gather (A/B)
 
 
 def conv2d_upsampled(x: torch.Tensor, pws, vpad: bool = False) -> torch.Tensor:
@@ -304,7 +304,7 @@ def conv_temporal_sharded(x_ext: torch.Tensor, b: int, t_local: int, t0: int, t_
 _ws_cache = {}
 
 
-SPLIT_K = os.environ.get("CCEDIT_G8_SPLIT", "1") != "0"
+SPLIT_K = policy.get("g8_split") != 0
 _splitk_cache = {}
 
 
@@ -365,7 +365,7 @@ def zero_stats(frames: int, device) -> torch.Tensor:
     return _ZEROS.take(frames * 64, device).view(frames, 32, 2)
 
 
-FUSE_GN_STATS = os.environ.get("CCEDIT_FUSE_GN_STATS", "1") != "0"      # 0: always the two-pass GroupNorm
+FUSE_GN_STATS = policy.on("fuse_gn_stats")      # 0: always the two-pass GroupNorm
 
 
 def gn_stats_of(x: torch.Tensor, hw: int):
@@ -464,7 +464,7 @@ def row_stats(x2d: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     return st
 
 
-LNF = os.environ.get("CCEDIT_LNF", "1") != "0"       # 0: LayerNorm passes in front of the 640 / 1280-channel projections (A/B)
+LNF = policy.on("lnf")       # 0: LayerNorm passes in front of the 640 / 1280-channel projections (A/B)
 
 
 def ln_sums_of(x: torch.Tensor):
@@ -477,7 +477,7 @@ def row_sums_applicable(m: int, pw, act: int = ACT_NONE) -> bool:
     return LNF and LN_SUMS and m >= 4096 and pw.kpad >= 640 and pw.n >= 640 and pw.taps == 1 and not pw.geglu and act == ACT_NONE
 
 
-LN_SUMS = os.environ.get("CCEDIT_LN_SUMS", "1") != "0"   # 0: statistics by ccedit_row_stats instead of the producer's epilogue (A/B)
+LN_SUMS = policy.on("ln_sums")   # 0: statistics by ccedit_row_stats instead of the producer's epilogue (A/B)
 
 
 def lnf_applicable(m: int, pw) -> bool:

@@ -136,29 +136,33 @@ class _ShardComm:
         self.bytes_sent += t.numel() * t.element_size()
         return t
 
-    def _neighbours(self, to_prev: torch.Tensor, to_next: torch.Tensor, kind: str):
+    def _neighbours(self, to_prev: torch.Tensor, to_next: torch.Tensor, kind: str, from_next: bool = True):
         """Send `to_prev` to rank - 1 and `to_next` to rank + 1; return (received from rank - 1, received from rank + 1), None at
-        the ends of the rank list.  Contiguous tensors of identical shape; point-to-point, both directions in one batch."""
+        the ends of the rank list.  Contiguous tensors of identical shape; point-to-point, both directions in one batch.
+        from_next=False: only the downward direction (every rank sends `to_next` and receives from rank - 1 — what a stride-2
+        convolution needs); `to_prev` is then neither sent nor counted."""
         dist = self.dist
-        dev = to_prev.device
+        dev = to_next.device
         ops_, prev_buf, next_buf = [], None, None
-        ev = self._tick(to_prev, kind)
-        f_out, l_out = self._out(to_prev), self._out(to_next)
+        ev = self._tick(to_next, kind)
+        f_out, l_out = (self._out(to_prev) if from_next else None), self._out(to_next)
         if self.rank > 0:
-            prev_buf = torch.empty_like(f_out)
+            prev_buf = torch.empty_like(l_out)
             peer = self._global_rank(self.rank - 1)      # P2POp peers are GLOBAL ranks, also inside a sub-group
-            ops_.append(dist.P2POp(dist.isend, f_out, peer, self.group))
+            if from_next:
+                ops_.append(dist.P2POp(dist.isend, f_out, peer, self.group))
             ops_.append(dist.P2POp(dist.irecv, prev_buf, peer, self.group))
         if self.rank < self.world - 1:
-            next_buf = torch.empty_like(l_out)
             peer = self._global_rank(self.rank + 1)
             ops_.append(dist.P2POp(dist.isend, l_out, peer, self.group))
-            ops_.append(dist.P2POp(dist.irecv, next_buf, peer, self.group))
+            if from_next:
+                next_buf = torch.empty_like(l_out)
+                ops_.append(dist.P2POp(dist.irecv, next_buf, peer, self.group))
         if ops_:
             for r in dist.batch_isend_irecv(ops_):
                 r.wait()
         self._tock(ev)
-        self.bytes_sent += (int(self.rank > 0) + int(self.rank < self.world - 1)) * to_prev.numel() * to_prev.element_size()
+        self.bytes_sent += ((int(self.rank > 0) if from_next else 0) + int(self.rank < self.world - 1)) * to_next.numel() * to_next.element_size()
         prev = None if prev_buf is None else prev_buf.to(dev)
         nxt = None if next_buf is None else next_buf.to(dev)
         return prev, nxt
@@ -194,11 +198,19 @@ class RowShard(_ShardComm):
         n = h // self.world
         return self.rank * n, (self.rank + 1) * n
 
+    def check_latent(self, h: int):
+        """The latent height must split evenly at EVERY level of the networks (h, h/2, h/4, h/8 rows): h % (8 * world) == 0.  `rows`
+        alone would accept 48 rows over 4 ranks and fail two levels down with an odd local height."""
+        if h % (8 * self.world):
+            raise ValueError(f"{h} latent rows cannot be row-sharded over {self.world} ranks: the deepest level has {h // 8} rows "
+                             f"(the frame height must be a multiple of {64 * self.world} pixels)")
+        return row_sharding_efficiency(h, self.world)
+
     def halo_rows(self, x: torch.Tensor, below: bool = True) -> torch.Tensor:
         """x (n, h_local, w, C) -> (n, 1 + h_local + below, w, C): the last row of rank - 1 on top, the first row of rank + 1 at the
         bottom (`below`; a stride-2 convolution reads only upwards), zero rows at the ends of the frame."""
         n, h, w, c = x.shape
-        up, down = self._neighbours(x[:, 0].contiguous(), x[:, h - 1].contiguous(), "halo_rows")
+        up, down = self._neighbours(x[:, 0].contiguous() if below else None, x[:, h - 1].contiguous(), "halo_rows", from_next=below)
         top = up if up is not None else x.new_zeros((n, w, c))
         pieces = [top.view(n, 1, w, c), x]
         if below:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCEDIT_ABI_VERSION 9
+#define CCEDIT_ABI_VERSION 10
 
 #define CCEDIT_OK 0
 #define CCEDIT_EINVAL (-1)       /* null pointer / bad size */
@@ -42,6 +42,16 @@ const char* ccedit_last_error(void);
 const char* ccedit_last_kernel(void);
 /* fills name with hipDeviceProp_t.gcnArchName of the current device; returns CU count or <0 */
 int ccedit_device_info(char* name, int name_len);
+
+/* Dispatch policy: ONE table of named integer switches that choose between kernels computing the same fp32 sums in a different order
+ * (A/B arms and the "specialised kernels reproduce the generic ones" tests).  All default to the fast path.  The library never reads
+ * the environment; the host sets entries before launching (process-wide, not thread-safe against concurrent launches).  Names:
+ *   conv_halo g8 g8_conv g8_temporal g8_split lin320 lin320s lin640 temp320 attn_short attn_text attn_spatial attn_pv16 gn_flat
+ *   block_tail     (ccedit_policy_names() returns them comma-separated; semantics in csrc/common.h: CcPolicy)
+ * Unknown name: CCEDIT_EINVAL. */
+int ccedit_policy_set(const char* name, int32_t value);
+int ccedit_policy_get(const char* name, int32_t* value);
+const char* ccedit_policy_names(void);
 
 /* ------------------------------------------------------------------------------------------
  * Tap-gather GEMM on MFMA: out[m][n] = epilogue( sum_{tap,c} W[n][tap][c] * A[src(m,tap)][c] )

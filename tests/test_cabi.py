@@ -29,7 +29,7 @@ def test_header_symbols_exported(libpath):
         assert hasattr(lib, n), f"{n} declared in include/ccedit_hip.h but not exported"
     lib.ccedit_abi_version.restype = ctypes.c_int
     from ccedit_amd import hip
-    assert lib.ccedit_abi_version() == 9 == hip.ABI_VERSION
+    assert lib.ccedit_abi_version() == 10 == hip.ABI_VERSION
 
 
 def test_binding_matches_header(libpath):

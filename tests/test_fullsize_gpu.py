@@ -20,10 +20,13 @@ import torch
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-GENERIC = dict(CCEDIT_T6="0", CCEDIT_CONV_HALO="0", CCEDIT_ATTN_SHORT="0", CCEDIT_SPLIT_CFG="0", CCEDIT_OVERLAP_CONTROLNET="0",
-               CCEDIT_KROT="0", CCEDIT_CGROUP="0", CCEDIT_FUSE_GN_STATS="0", CCEDIT_TEMPORAL_ORDER="0", CCEDIT_LIN320="0",
-               CCEDIT_FF320="0", CCEDIT_LN320="0", CCEDIT_T4="0", CCEDIT_BALANCED="0", CCEDIT_CONV_NARROW="0", CCEDIT_G8="0",
-               CCEDIT_GRAPH="0", CCEDIT_LNF="0", CCEDIT_ATTN_TEXT="0", CCEDIT_G8_SPLIT="0")
+from ccedit_amd import policy
+
+# Every switch of the ONE policy table (ccedit_amd/policy.py) off: specialised kernels, fusions, overlap, graph replay — including the
+# round-4 and round-5 ones (spatial attention kernel, streaming K = 320 / 640 kernels, parity up-sampling convs, 1 x 1 convs on the
+# Linear dispatch, hint dedup, batched text K/V, block-tail fusion, GroupNorm apply in the consumer ...).  `policy.generic()` is
+# derived from the table, so a switch added later is part of the generic arm without editing this test.
+GENERIC = dict(CCEDIT_POLICY=policy.generic())
 
 
 def _rel(a, b):
@@ -34,8 +37,9 @@ def _rel(a, b):
 def _run(tmp_path, name, extra_env, workload=None):
     out = os.path.join(str(tmp_path), name + ".npz")
     env = dict(os.environ)
-    for k in GENERIC:
-        env.pop(k, None)
+    for k in list(env):
+        if k == "CCEDIT_POLICY" or (k.startswith("CCEDIT_") and k[7:].lower() in policy.TABLE):
+            env.pop(k)
     env.update(extra_env)
     r = subprocess.run([sys.executable, os.path.join(HERE, "_fullsize_eval.py"), out] + ([workload] if workload else []), env=env,
                        capture_output=True, text=True, timeout=900)
@@ -57,10 +61,10 @@ def test_full_size_properties(tmp_path):
     for k in ("eps", "eps_same", "eps_other", "frames"):
         assert np.array_equal(fast[k], again[k]), f"{k}: two runs of the same evaluation differ"
     # (2) identical CFG halves give identical predictions: bit for bit when each half is its own launch sequence (two streams,
-    #     CCEDIT_SPLIT_CFG=1); in the batched default the halves are different tiles of one launch and the short-K Linears start
+    #     policy split_cfg=1); in the batched default the halves are different tiles of one launch and the short-K Linears start
     #     their K loops at tile-dependent positions, so there they agree to the summation-order noise floor.  (3) clips do not
     #     interact: half 0 does not change when half 1 is another clip (same tiles, same order: bit-exact in both modes).
-    split = _run(tmp_path, "split", dict(CCEDIT_SPLIT_CFG="1"))
+    split = _run(tmp_path, "split", dict(CCEDIT_POLICY="split_cfg=1"))
     assert np.array_equal(split["eps_same"][0], split["eps_same"][1])
     assert _rel(fast["eps_same"][0], fast["eps_same"][1]) < 3.5e-2
     assert np.array_equal(fast["eps_other"][0], fast["eps"][0]) and np.array_equal(split["eps_other"][0], split["eps"][0])
@@ -87,7 +91,7 @@ def test_full_size_tvi2v_properties(tmp_path):
     assert fast["eps"].shape == (2, 4, 17, 64, 96) and np.isfinite(fast["eps"]).all() and np.isfinite(gen["eps"]).all()
     for k in ("eps", "eps_same", "eps_ref"):
         assert np.array_equal(fast[k], again[k]), f"{k}: two runs of the same evaluation differ"
-    assert _rel(fast["eps_same"][0], fast["eps_same"][1]) < 3.5e-2          # (bit-equal with CCEDIT_SPLIT_CFG=1, see above)
+    assert _rel(fast["eps_same"][0], fast["eps_same"][1]) < 3.5e-2          # (bit-equal with policy split_cfg=1, see above)
     assert np.array_equal(fast["eps_ref"][0], fast["eps"][0])
     assert _rel(fast["eps_ref"][1], fast["eps"][1]) > 1e-2          # the reference latent does condition the prediction
     e = _rel(fast["eps"], gen["eps"])

@@ -666,10 +666,11 @@ def test_gemm_fused_groupnorm_statistics(tile, cout):
         assert torch.allclose(ops.gn_stats_of(y3, 384)[..., 0].float(), y3f.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
 
 
-def test_cat_add_fused_groupnorm_statistics():
+@pytest.mark.parametrize("c1,c2", [(640, 320), (32, 32), (64, 32), (320, 320)])      # 32 + 32 / 64 + 32: fewer column threads than
+def test_cat_add_fused_groupnorm_statistics(c1, c2):                               # reduction threads
     _dev()
     from ccedit_amd import ops
-    n, h, w, c1, c2 = 3, 12, 9, 640, 320
+    n, h, w = 3, 12, 9
     a, bb, cc = _rnd(n, h, w, c1, seed=1), _rnd(n, h, w, c2, seed=2), _rnd(n, h, w, c2, seed=3)
     o = ops.cat_add(a.to(BF).cuda(), bb.to(BF).cuda(), cc.to(BF).cuda(), gn=True)
     plain = ops.cat_add(a.to(BF).cuda(), bb.to(BF).cuda(), cc.to(BF).cuda())
@@ -718,6 +719,20 @@ def test_groupnorm_spatial(c, h, w, eps, silu):
     if silu:
         ref = F.silu(ref)
     _close(_nchw(y), ref, rel=2.0 ** -6, what=f"GN spatial C={c}")
+
+
+@pytest.mark.parametrize("h,w", [(8, 12), (16, 24)])
+def test_groupnorm_spatial_onepass_large_mean(h, w):
+    """The one-pass kernel (C % 256 == 0, small frames: 8x12 and 16x24 at 1280 channels) with |mean| >> std: the variance is the sum
+    of squared deviations from the mean over the register-resident values, not E[x^2] - mean^2."""
+    _dev()
+    from ccedit_amd import ops
+    c = 1280
+    x = (_rnd(2, c, h, w, seed=1) * 0.25 + 48.0).to(BF).float()
+    g, b = _rnd(c, seed=2) * 0.1 + 1, _rnd(c, seed=3) * 0.1
+    y = ops.groupnorm_spatial(_nhwc(x), g.cuda(), b.cuda(), 1e-5, False)
+    ref = F.group_norm(x.double(), 32, g.double(), b.double(), 1e-5).float()
+    _close(_nchw(y), ref, rel=2.0 ** -6, what=f"GN one-pass {h}x{w}, mean >> std")
 
 
 @pytest.mark.parametrize("c,t,eps,silu", [(320, 17, 1e-5, True), (1280, 3, 1e-6, False), (160, 4, 1e-5, True)])
