@@ -74,7 +74,6 @@ struct CcPolicy {
     int attn_spatial = 1;   // d = 40 long self-attention kernel
     int attn_pv16 = 1;      // ... its PV product in 16x16x32 tiles (0: 32x32x16)
     int gn_flat = 1;        // flat thread mapping of the temporal GroupNorm at the two large levels
-    int block_tail = 1;     // ff320 with the to_out prologue / proj_out epilogue GEMMs (0: three launches)
 };
 const CcPolicy& cc_policy();
 

@@ -2,7 +2,7 @@
 //
 //     out = x + W2 . GEGLU( W1 . LayerNorm(x) + b1 ) + b2          (attention.py:115-141, 695-716 / 758-761)
 //
-// in ONE kernel that reads x once and writes out once.  The 4C = 1280-wide hidden activation (535 MB per call at
+// in ONE kernel that reads x once and writes out once (and, round 5, the two projections around it: "Block tail" below).  The 4C = 1280-wide hidden activation (535 MB per call at
 // 34 x 64 x 96 tokens) never exists in memory, LayerNorm is applied to the operand registers, and the residual is folded
 // into the accumulator initialisation.
 //
@@ -32,9 +32,22 @@
 // (conflict-free) and every global_load_lds moves 1 KB contiguous; two chunk buffers, one barrier per chunk.  Every
 // weight byte staged serves 128 tokens: 64 KB per ~2800 cycles = the ~23 B/clk a CU's L2 -> LDS path sustains, i.e. the
 // weight stream and the MFMA + exposed VALU time are co-limiting.
+//
+// Block tail (round 5).  The transformer blocks of this level end  tok = to_out(attn) + tok;  tok = FF(LN(tok)) + tok;
+// out = proj_out(tok) + x_in  (attention.py:695-716 / 758-761, 865-889, 1141-1208): two K = 320 Linears around the feed-forward, each
+// of which is a 134 MB read + 134 MB residual read + 134 MB write that runs AT its HBM roofline as a launch of its own.  With
+// PRO / EPI the kernel owns the whole tail on the row tile it already holds:
+//   PRO   x is not read: the wave loads its 32 rows of the attention output as B fragments, 4 stream chunks of 50 A-fragments
+//         (5 k-steps x 10 output tiles of W_o, rows permuted like W2's) accumulate  b_o + W_o . attn  in the 160 accumulator registers,
+//         the residual rows (requested at the top of the round, so their latency hides behind the 200 MFMAs) are added in fp32 and the
+//         bf16 rounding of the sum IS the X fragment set of the feed-forward — same register mapping as GEMM2's output, no shuffle;
+//   EPI   the feed-forward's result is rounded to bf16 into the same fragment registers, 4 more chunks accumulate
+//         b_p + W_p . tok, the x_in rows (requested when the epilogue starts) are added and the sum is stored.
+// The chunk machinery (64 KB chunks, two LDS buffers, barrier A / B, the fragment read ring) is the feed-forward's; a round is
+// [P0..P3] F0..F41 [E0..E3].  Ring depth 5 divides both chunk lengths (50 and 60 fragments), so the ring runs across all of them.
 #include "common.h"
 #ifndef KD_VALUE
-#define KD_VALUE 6
+#define KD_VALUE 5
 #endif
 #include <stdlib.h>
 #include <utility>
@@ -44,12 +57,14 @@ namespace {
 constexpr int kC = 320;                 // model width
 constexpr int kKS = kC / 16;            // 20 k-steps of 16
 constexpr int kOT = kC / 32;            // 10 output-channel tiles of 32
-constexpr int kIters = 1280 / 32 + 2;   // 40 hidden chunks of 32, software-pipelined (three stages) over 42 iterations
+constexpr int kFF = 1280 / 32 + 2;      // 40 hidden chunks of 32, software-pipelined (three stages) over 42 iterations
+constexpr int kPE = 50;                 // fragments of a prologue / epilogue chunk: 5 k-steps x 10 output tiles
+constexpr int kPEChunks = 4;            // 4 x 5 = the 20 k-steps of a 320 x 320 projection
 constexpr int kAuxOff = 60 * 1024;      // 40 GEMM1 + 20 GEMM2 fragments of 1 KB, then b1'
-constexpr int kChunkBytes = 64 * 1024;  // every wave issues exactly 16 DMA instructions per chunk
+constexpr int kChunkBytes = 64 * 1024;  // every wave issues at most 16 DMA instructions per chunk
 constexpr int kWavePix = 32;
-constexpr int kD = KD_VALUE;            // fragment reads in flight ahead of their use (divides 60: the ring runs across chunks)
-static_assert(60 % kD == 0, "ring depth");
+constexpr int kD = KD_VALUE;            // fragment reads in flight ahead of their use (divides 60 and 50: the ring runs across chunks)
+static_assert(60 % kD == 0 && kPE % kD == 0, "ring depth");
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
@@ -111,8 +126,8 @@ struct GeluPipe {
     }
 };
 
-// ABL (tuning only, CCEDIT_FF320_ABL, bit mask): 1 = no weight stream after the first chunk; 2 = GEGLU replaced by an add; 32 = phase
-// cycle counters into d.dbg.  Results are wrong for ABL & 3.
+// ABL (tuning only, CCEDIT_FF320_ABL, bit mask; PRO = EPI = false only): 1 = no weight stream after the first chunk; 2 = GEGLU replaced
+// by an add; 32 = phase cycle counters into d.dbg.  Results are wrong for ABL & 3.
 //
 // Software pipeline over the 40 hidden chunks, three stages deep: iteration c = 0 .. 41 works on stream chunk
 // c = [W1'(c) | W2(c-2) | b1'(c)], its 60 fragments interleaved per k-step s as (value_s, gate_s, W2 fragment s):
@@ -120,11 +135,30 @@ struct GeluPipe {
 //            GEMM2 of chunk c-2 (twenty different accumulators)
 //     VALU   GEGLU of chunk c-1, one accumulator register (one hidden row of the lane's token) per k-step
 // Chunks -2, -1, 40, 41 do not exist: the packer supplies zero fragments / biases, so those MFMAs add zeros.
-// The fragment ring runs across iterations: barrier B (step 58 - kD, after the wait for the next chunk's DMA) lets the last
+// The fragment ring runs across iterations: barrier B (step NF - 2 - kD, after the wait for the next chunk's DMA) lets the last
 // steps prefetch the next chunk; barrier A (iteration top) lets the DMA overwrite the buffer every wave has left.
-template <int ABL>
+//
+// One chunk of the round, as a compile-time description: KIND (0 prologue GEMM, 1 feed-forward, 2 epilogue GEMM), Q (index of a
+// prologue / epilogue chunk: k-steps 5 Q .. 5 Q + 4), PAR (LDS buffer = stream index & 1), HAS_BQ (the chunk before this one read
+// b1' rows ahead: they are retired — and, in a feed-forward chunk, used — at step 0), NEXT_BQ (read the next chunk's b1' ahead),
+// NISS (DMA instructions per wave that move the next chunk: 16 for a feed-forward chunk with its b1' rows, 13 for 50 fragments).
+template <int KIND_, int Q_, int PAR_, bool HAS_BQ_, bool NEXT_BQ_, int NISS_>
+struct Chunk {
+    static constexpr int KIND = KIND_, Q = Q_, PAR = PAR_, NISS = NISS_;
+    static constexpr bool HAS_BQ = HAS_BQ_, NEXT_BQ = NEXT_BQ_;
+    static constexpr int NF = KIND_ == 1 ? 60 : kPE;
+};
+
+template <int ABL, bool PRO, bool EPI>
 __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int n_rounds) {
+    static_assert(ABL == 0 || (!PRO && !EPI), "ablations exist for the plain feed-forward only");
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][kChunkBytes]
+    constexpr int cF = PRO ? kPEChunks : 0;                              // stream index of the first feed-forward chunk
+    constexpr int cE = cF + kFF;                                         // ... of the first epilogue chunk
+    constexpr int NCH = cE + (EPI ? kPEChunks : 0);                      // chunks of one round
+    static_assert(NCH % 2 == 0 && cF % 2 == 0 && cE % 2 == 0, "a chunk's buffer is its stream index & 1 in every round");
+    constexpr bool FIRST_BQ = !PRO;                                      // the first chunk of a round is a feed-forward chunk
+    constexpr bool FIRST_HAS_BQ = PRO ? !EPI : true;                     // ... or retires the b1' rows the last chunk of a round reads ahead
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
     const f32x4* __restrict__ b2p = (const f32x4*)d.b2p;                 // [kOT][2 lane halves][16 registers]
     const int lane16 = lane * 16;
 
-    // DMA share of this wave: fragments wave, wave + 4, ... (16 per chunk); uniform base + lane offset
+    // DMA share of this wave: fragments wave, wave + 4, ... (at most 16 per chunk); uniform base + lane offset
     auto issue_frag = [&](int c, int buf, int k) {
         const char* src = wstream + ((size_t)c * kChunkBytes + (size_t)(k * 4 + wave) * 1024);     // wave-uniform
         glds16(src + lane16, smem + buf * kChunkBytes + (k * 4 + wave) * 1024);
@@ -148,41 +182,187 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
     for (int k = 0; k < 16; ++k) issue_frag(0, 0, k);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // the read stream starts: b1' of chunk 0 and its first kD fragments
+    // the read stream starts: the first kD fragments of chunk 0 (and its b1' when it is a feed-forward chunk)
     f32x4 bq[2][4];                      // b1' (value, gate) of the chunk GEMM1 starts next, in accumulator order
     bf16x8 ring[kD];
     FF_DS_READ(ring[0], la0, 0);          // same order as in the steady state: fragment 0, b1', fragments 1 .. kD - 1
+    if constexpr (FIRST_HAS_BQ) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) FF_DS_READ(bq[k][q4], lx0, k * 128 + q4 * 16);
+            for (int q4 = 0; q4 < 4; ++q4) FF_DS_READ(bq[k][q4], lx0, k * 128 + q4 * 16);
+    }
 #pragma unroll
     for (int j = 1; j < kD; ++j) FF_DS_READ(ring[j], la0, j * 1024);
 
     f32x16 acc1[2][2];                   // [chunk parity][value, gate]
     bf16x8 hf[2][2];                     // [chunk parity][kappa]: GEGLU outputs = GEMM2 B operands
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
+    // What the software pipeline reads before writing it — the GEGLU input of "chunk -1" and the GEMM2 operand of "chunk -2" (the
+    // fragments they meet are zeros).  Plain feed-forward: set once, the values that cross a round boundary are as harmless.  Block
+    // tail: set every round, so that nothing of the pipeline is live across the prologue / epilogue GEMMs.
+    auto pipeline_reset = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hf[k][q][e] = f2bf(0.f);
+            for (int e = 0; e < 8; ++e) hf[0][q][e] = f2bf(0.f);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[k][q][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc1[1][q][r] = 0.f;
         }
+    };
+    if constexpr (!PRO) pipeline_reset();
 
     for (int round = blockIdx.x; round < n_rounds; round += gdim) {
         const int64_t p = ((int64_t)round * 4 + wave) * kWavePix + n;
-        // ---- this wave's tokens: raw x as B-operand fragments (rows past M repeat the last row; never stored) ----
+        const int64_t pr = p < d.M ? p : d.M - 1;                         // rows past M repeat the last row; never stored
+        const bool last_round = round + gdim >= n_rounds;
+        // ---- this wave's tokens as B-operand fragments: x (plain) or the attention output (PRO); with PRO also the residual rows,
+        //      which are only needed after the 200 prologue MFMAs ----
         bf16x8 xf[kKS];
+        bf16x8 rf[kKS];                  // PRO: residual rows of the prologue; EPI: x_in rows of the epilogue (see add_rows)
         {
-            const bf16* row = xp + (p < d.M ? p : d.M - 1) * d.ldx + hi * 8;
+            const bf16* row = (PRO ? (const bf16*)d.a + pr * d.lda : xp + pr * d.ldx) + hi * 8;
 #pragma unroll
             for (int s = 0; s < kKS; ++s) xf[s] = *(const bf16x8*)(row + s * 16);
+            if constexpr (PRO) {
+                const bf16* rrow = (const bf16*)d.res + pr * d.ldr + hi * 8;
+#pragma unroll
+                for (int s = 0; s < kKS; ++s) rf[s] = *(const bf16x8*)(rrow + s * 16);
+            }
+        }
+        f32x16 acc2[kOT];                // the 320 x 32 accumulator tile of whichever GEMM is running (prologue, GEMM2, epilogue)
+        auto init_acc = [&](const f32x4* __restrict__ bias, bool add_x) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < kOT; ++t) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 bv = bias[(t * 2 + hi) * 4 + q4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = q4 * 4 + e;
+                        acc2[t][r] = add_x ? bv[e] + bf2f(xf[2 * t + (r >> 3)][r & 7]) : bv[e];
+                    }
+                }
+            }
+        };
+        // registers 0..7 / 8..15 of accumulator tile t are channels 32 t + 8 hi .. / 32 t + 16 + 8 hi .. of token n = the channels of
+        // fragments 2 t / 2 t + 1 of the same lane: accumulator -> bf16 -> the next GEMM's B operand
+        auto acc_to_frags = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < kOT; ++t)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xf[2 * t][e] = f2bf(acc2[t][e]);
+                    xf[2 * t + 1][e] = f2bf(acc2[t][8 + e]);
+                }
+        };
+
+        unsigned long long tacc[2] = {0, 0};            // ABL & 32: cycles in [barrier A, the 60 steps]
+        // one chunk; `c` = its stream index (run time for the feed-forward chunks), CH = Chunk<...>
+        auto iteration = [&](auto chunk, int c, bool final_chunk) __attribute__((always_inline)) {
+            using CH = decltype(chunk);
+            constexpr int PAR = CH::PAR, NF = CH::NF, KIND = CH::KIND;
+            unsigned long long tm0 = 0, tm1 = 0;
+            if constexpr (ABL & 32) tm0 = __builtin_amdgcn_s_memtime();
+            // barrier A: every wave has left the other buffer (chunk c - 1) -> the DMA of chunk c + 1 may overwrite it
+            __builtin_amdgcn_s_barrier();
+            if constexpr (ABL & 32) tm1 = __builtin_amdgcn_s_memtime();
+            const bool last = final_chunk && last_round;
+            const bool issue_next = !last && !((ABL & 1) && (c > 0 || round != (int)blockIdx.x));
+            int cn = final_chunk ? 0 : c + 1;
+            // (opaque to the optimiser: with the compile-time stream indices of the prologue / epilogue chunks hipcc precomputes the 13
+            //  DMA source addresses of every one of them before the round loop — 200 registers — and spills them)
+            asm volatile("" : "+s"(cn));
+            const unsigned la = la0 + PAR * kChunkBytes, lan = la0 + (1 - PAR) * kChunkBytes;
+            const unsigned lxn = lx0 + (1 - PAR) * kChunkBytes;
+
+            GeluPipe gp;
+            auto step = [&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                // younger reads that may stay in flight: the kD - 1 fragments behind this one, + the 8 b1' reads slipped in
+                // behind fragment NF (= fragment 0 of the next chunk, read at step NF - kD) while that one is among them
+                constexpr int young8 = kD - 1 + 8 > 15 ? 15 : kD - 1 + 8;                              // (lgkmcnt is a 4-bit counter)
+                FF_WAIT(ring[j % kD], (CH::NEXT_BQ && j >= NF + 1 - kD ? young8 : kD - 1));
+                if constexpr (j == 0 && CH::HAS_BQ) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) FF_WAIT(bq[k][q4], kD - 1);      // older than fragment 1: retired with fragment 0
+                }
+                if constexpr (KIND == 1) {
+                    constexpr int s = j / 3, role = j % 3;                        // k-step, (value, gate, GEMM2) fragment
+                    if constexpr (role < 2) {        // GEMM1 of chunk c: value / gate tile, C operand of the first k-step = b1'
+                        if constexpr (s == 0) {
+                            f32x16 c0;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) c0[r] = bq[role][r >> 2][r & 3];
+                            acc1[PAR][role] = mfma32(ring[j % kD], xf[s], c0);
+                        } else {
+                            acc1[PAR][role] = mfma32(ring[j % kD], xf[s], acc1[PAR][role]);
+                        }
+                    } else {                         // GEMM2 of chunk c - 2: fragment s = (kappa = s / 10, out tile s % 10)
+                        acc2[s % kOT] = mfma32(ring[j % kD], hf[PAR][s / kOT], acc2[s % kOT]);
+                    }
+                } else {                             // prologue / epilogue GEMM: fragment j = (k-step 5 Q + j / 10, out tile j % 10)
+                    acc2[j % kOT] = mfma32(ring[j % kD], xf[CH::Q * (kPE / kOT) + j / kOT], acc2[j % kOT]);
+                }
+                // the ring continues into the next chunk's buffer behind barrier B
+                if constexpr (j + kD < NF) FF_DS_READ(ring[j % kD], la, (j + kD) * 1024);
+                else FF_DS_READ(ring[j % kD], lan, (j + kD - NF) * 1024);
+                if constexpr (CH::NEXT_BQ && j == NF - kD) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) FF_DS_READ(bq[k][q4], lxn, k * 128 + q4 * 16);
+                }
+                if constexpr (j < 32 && (j & 1) == 0 && (j >> 1) < CH::NISS) {
+                    if (issue_next) issue_frag(cn, 1 - PAR, j >> 1);          // the next chunk's DMA, spread over the MFMA steps
+                }
+                if constexpr (j == NF - 2 - kD) {    // barrier B: chunk c + 1 has landed for every wave
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                if constexpr (KIND == 1) {
+                    // GEGLU of chunk c - 1: registers 0..7 in steps 2..17 + 18 (stages 0..15, then the bf16 pack), registers 8..15 in
+                    // steps 20..35 + 36 — one stage of eight independent VALU instructions beside each step's MFMA
+                    if constexpr (j >= 2 && j < 2 + GeluPipe::kStages) gp.template stage<j - 2>(acc1[1 - PAR][0], acc1[1 - PAR][1], 0, (ABL & 2) != 0);
+                    if constexpr (j >= 20 && j < 20 + GeluPipe::kStages) gp.template stage<j - 20>(acc1[1 - PAR][0], acc1[1 - PAR][1], 8, (ABL & 2) != 0);
+                    if constexpr (j == 18 || j == 36) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) hf[1 - PAR][j == 18 ? 0 : 1][i] = f2bf(gp.p[i]);
+                    }
+                }
+            };
+            for_seq(step, std::make_integer_sequence<int, NF>{});
+            if constexpr (ABL & 32) {
+                const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
+                tacc[0] += tm1 - tm0;
+                tacc[1] += tm2 - tm1;
+            }
+        };
+
+        // the residual rows of a projection, requested when its first chunk starts and added (fp32) when that chunk ends: their latency
+        // hides behind 50 MFMAs and they occupy registers for one chunk only
+        auto add_rows = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < kOT; ++t)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    acc2[t][e] += bf2f(rf[2 * t][e]);
+                    acc2[t][8 + e] += bf2f(rf[2 * t + 1][e]);
+                }
+        };
+        // ---- prologue GEMM: tok = W_o . attn + b_o + residual, left in xf as the feed-forward's input ----
+        if constexpr (PRO) {
+            init_acc((const f32x4*)d.bop, false);
+            iteration(Chunk<0, 0, 0, !EPI, false, 13>{}, 0, false);      // (the round before ended with a feed-forward chunk iff !EPI)
+            add_rows();
+            iteration(Chunk<0, 1, 1, false, false, 13>{}, 1, false);
+            iteration(Chunk<0, 2, 0, false, false, 13>{}, 2, false);
+            iteration(Chunk<0, 3, 1, false, true, 16>{}, 3, false);
+            acc_to_frags();
         }
         // ---- LayerNorm statistics (two passes over the registers, the two lanes of a token meet once); the accumulators of the
         //      second GEMM start from b2 + x; then the fragments are normalised in place ----
-        f32x16 acc2[kOT];
         {
             float sm = 0.f;
 #pragma unroll
@@ -202,101 +382,19 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
             sq += __shfl_xor(sq, 32);
             const float rs = d.ln ? rsqrtf(sq * (1.0f / kC) + d.eps) : 1.f;
             const float rm = d.ln ? rs * mu : 0.f;
-#pragma unroll
-            for (int t = 0; t < kOT; ++t) {
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const f32x4 bv = b2p[(t * 2 + hi) * 4 + q4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = q4 * 4 + e;
-                        acc2[t][r] = bv[e] + bf2f(xf[2 * t + (r >> 3)][r & 7]);
-                    }
-                }
-            }
+            init_acc(b2p, true);
 #pragma unroll
             for (int s = 0; s < kKS; ++s)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) xf[s][e] = f2bf(fmaf(rs, bf2f(xf[s][e]), -rm));
         }
 
-        unsigned long long tacc[2] = {0, 0};            // ABL & 32: cycles in [barrier A, the 60 steps]
-        // one iteration; PAR = c & 1 selects the register sets (static indices: the loop below is unrolled by two)
-        auto iteration = [&](auto parc, int c) __attribute__((always_inline)) {
-            constexpr int PAR = decltype(parc)::value;
-            unsigned long long tm0 = 0, tm1 = 0;
-            if constexpr (ABL & 32) tm0 = __builtin_amdgcn_s_memtime();
-            // barrier A: every wave has left the other buffer (chunk c - 1) -> the DMA of chunk c + 1 may overwrite it
-            __builtin_amdgcn_s_barrier();
-            if constexpr (ABL & 32) tm1 = __builtin_amdgcn_s_memtime();
-            const bool last = (c == kIters - 1) && (round + gdim >= n_rounds);
-            const bool issue_next = !last && !((ABL & 1) && (c > 0 || round != (int)blockIdx.x));
-            const int cn = c + 1 == kIters ? 0 : c + 1;
-            const unsigned la = la0 + PAR * kChunkBytes, lan = la0 + (1 - PAR) * kChunkBytes;       // kIters is even: chunk c sits in buffer c & 1
-            const unsigned lxn = lx0 + (1 - PAR) * kChunkBytes;
-
-            GeluPipe gp;
-            auto step = [&](auto jc) __attribute__((always_inline)) {
-                constexpr int j = decltype(jc)::value;
-                constexpr int s = j / 3, role = j % 3;                        // k-step, (value, gate, GEMM2) fragment
-                // younger reads that may stay in flight: the kD - 1 fragments behind this one, + the 8 b1' reads slipped in
-                // behind fragment 60 (= fragment 0 of the next chunk, read at step 60 - kD) while that one is among them
-                FF_WAIT(ring[j % kD], (j >= 61 - kD ? (kD - 1 + 8 > 15 ? 15 : kD - 1 + 8) : kD - 1));      // (lgkmcnt is a 4-bit counter)
-                if constexpr (j == 0) {
-                    FF_WAIT(ring[0], (kD - 1 + 8 > 15 ? 15 : kD - 1 + 8));                             // (fragment 0 itself: the b1' reads behind it may still fly)
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) FF_WAIT(bq[k][q4], kD - 1);      // older than fragment 1
-                }
-                if constexpr (role < 2) {        // GEMM1 of chunk c: value / gate tile, C operand of the first k-step = b1'
-                    if constexpr (s == 0) {
-                        f32x16 c0;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) c0[r] = bq[role][r >> 2][r & 3];
-                        acc1[PAR][role] = mfma32(ring[j % kD], xf[s], c0);
-                    } else {
-                        acc1[PAR][role] = mfma32(ring[j % kD], xf[s], acc1[PAR][role]);
-                    }
-                } else {                         // GEMM2 of chunk c - 2: fragment s = (kappa = s / 10, out tile s % 10)
-                    acc2[s % kOT] = mfma32(ring[j % kD], hf[PAR][s / kOT], acc2[s % kOT]);
-                }
-                // the ring continues into the next chunk's buffer behind barrier B
-                if constexpr (j + kD < 60) FF_DS_READ(ring[j % kD], la, (j + kD) * 1024);
-                else FF_DS_READ(ring[j % kD], lan, (j + kD - 60) * 1024);
-                if constexpr (j == 60 - kD) {
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) FF_DS_READ(bq[k][q4], lxn, k * 128 + q4 * 16);
-                }
-                if constexpr (j < 32 && (j & 1) == 0) {
-                    if (issue_next) issue_frag(cn, 1 - PAR, j >> 1);          // the next chunk's DMA, spread over the MFMA steps
-                }
-                if constexpr (j == 58 - kD) {    // barrier B: chunk c + 1 has landed for every wave
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
-                // GEGLU of chunk c - 1: registers 0..7 in steps 2..17 + 18 (stages 0..15, then the bf16 pack), registers 8..15 in
-                // steps 20..35 + 36 — one stage of eight independent VALU instructions beside each step's MFMA
-                if constexpr (j >= 2 && j < 2 + GeluPipe::kStages) gp.template stage<j - 2>(acc1[1 - PAR][0], acc1[1 - PAR][1], 0, (ABL & 2) != 0);
-                if constexpr (j >= 20 && j < 20 + GeluPipe::kStages) gp.template stage<j - 20>(acc1[1 - PAR][0], acc1[1 - PAR][1], 8, (ABL & 2) != 0);
-                if constexpr (j == 18 || j == 36) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) hf[1 - PAR][j == 18 ? 0 : 1][i] = f2bf(gp.p[i]);
-                }
-            };
-            for_seq(step, std::make_integer_sequence<int, 60>{});
-            if constexpr (ABL & 32) {
-                const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
-                tacc[0] += tm1 - tm0;
-                tacc[1] += tm2 - tm1;
-            }
-        };
-        static_assert(kIters % 2 == 0, "the iteration loop is unrolled by two");
-        for (int c = 0; c < kIters; c += 2) {
-            iteration(std::integral_constant<int, 0>{}, c);
-            iteration(std::integral_constant<int, 1>{}, c + 1);
+        // ---- feed-forward: 42 chunks, unrolled by two (PAR selects the register sets with static indices) ----
+        if constexpr (PRO) pipeline_reset();
+        static_assert(kFF % 2 == 0, "the iteration loop is unrolled by two");
+        for (int c = 0; c < kFF; c += 2) {
+            iteration(Chunk<1, 0, 0, true, true, 16>{}, cF + c, false);
+            iteration(Chunk<1, 0, 1, true, true, 16>{}, cF + c + 1, !EPI && c + 2 == kFF);
         }
         if constexpr (ABL & 32) {
             if (round == (int)blockIdx.x && lane == 0 && d.dbg) {
@@ -305,6 +403,26 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
                 o[1] = tacc[1];
                 o[2] = o[3] = 0;
             }
+        }
+
+        // ---- epilogue GEMM: out = W_p . tok + b_p + x_in ----
+        if constexpr (EPI) {
+            acc_to_frags();
+            {
+                const bf16* rrow = (const bf16*)d.res2 + pr * d.ldr2 + hi * 8;
+#pragma unroll
+                for (int s = 0; s < kKS; ++s) rf[s] = *(const bf16x8*)(rrow + s * 16);
+            }
+            init_acc((const f32x4*)d.bpp, false);
+            iteration(Chunk<2, 0, 0, true, false, 13>{}, cE, false);     // (retires the b1' rows the last feed-forward chunk read ahead)
+            add_rows();
+            iteration(Chunk<2, 1, 1, false, false, 13>{}, cE + 1, false);
+            iteration(Chunk<2, 2, 0, false, false, 13>{}, cE + 2, false);
+            iteration(Chunk<2, 3, 1, false, FIRST_BQ, FIRST_BQ ? 16 : 13>{}, cE + 3, true);
+        }
+        if (last_round) {    // the reads issued ahead for a chunk that does not exist: retire them before their registers are reused
+#pragma unroll
+            for (int j = 0; j < kD; ++j) FF_WAIT(ring[j], 0);
         }
 
         // ---- store: registers 0..7 / 8..15 of accumulator tile t are channels 32 t + 8 hi .. / 32 t + 16 + 8 hi .. of token n ----
@@ -331,10 +449,25 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
 extern "C" int ccedit_ff320(const CcFf320Desc* desc, void* stream) {
     CC_CHECK_ARG(desc != nullptr, "ccedit_ff320: null descriptor");
     const CcFf320Desc d = *desc;
-    CC_CHECK_ARG(d.x && d.out && d.wstream && d.b2p, "ccedit_ff320: null x/out/wstream/b2p");
+    CC_CHECK_ARG(d.out && d.wstream && d.b2p, "ccedit_ff320: null out/wstream/b2p");
     CC_CHECK_ARG(d.M > 0, "ccedit_ff320: M=%lld", (long long)d.M);
     CC_UNSUPPORTED(d.dim != kC || d.inner != 1280, "ccedit_ff320: only dim 320 / inner 1280 (got %d / %d)", d.dim, d.inner);
-    CC_UNSUPPORTED(d.ldx % 8 != 0 || d.ldo % 8 != 0 || d.ldx < kC || d.ldo < kC, "ccedit_ff320: ldx=%d / ldo=%d", d.ldx, d.ldo);
+    const bool pro = d.a != nullptr, epi = d.res2 != nullptr;
+    if (pro) {
+        CC_CHECK_ARG(d.res && d.bop, "ccedit_ff320: the prologue GEMM (a) needs its residual (res) and bias (bop)");
+        CC_UNSUPPORTED(d.lda % 8 != 0 || d.ldr % 8 != 0 || d.lda < kC || d.ldr < kC, "ccedit_ff320: lda=%d / ldr=%d", d.lda, d.ldr);
+    } else {
+        CC_CHECK_ARG(d.x != nullptr && !d.res && !d.bop, "ccedit_ff320: null x (or res / bop without a)");
+        CC_UNSUPPORTED(d.ldx % 8 != 0 || d.ldx < kC, "ccedit_ff320: ldx=%d", d.ldx);
+    }
+    if (epi) {
+        CC_CHECK_ARG(d.bpp != nullptr, "ccedit_ff320: the epilogue GEMM (res2) needs its bias (bpp)");
+        CC_UNSUPPORTED(d.ldr2 % 8 != 0 || d.ldr2 < kC, "ccedit_ff320: ldr2=%d", d.ldr2);
+    } else {
+        CC_CHECK_ARG(!d.bpp, "ccedit_ff320: bpp without res2");
+    }
+    CC_UNSUPPORTED(epi && !pro, "ccedit_ff320: the epilogue GEMM is built together with the prologue GEMM only");
+    CC_UNSUPPORTED(d.ldo % 8 != 0 || d.ldo < kC, "ccedit_ff320: ldo=%d", d.ldo);
     const int64_t rounds = (d.M + 4 * kWavePix - 1) / (4 * kWavePix);
     CC_UNSUPPORTED(rounds > 2147483647LL, "ccedit_ff320: M too large");
 #ifdef CCEDIT_TUNING      // probe builds only (-DCCEDIT_TUNING): the product library never reads a switch that changes results
@@ -342,16 +475,21 @@ extern "C" int ccedit_ff320(const CcFf320Desc* desc, void* stream) {
 #else
     constexpr int abl = 0;
 #endif
-    void (*kern)(const CcFf320Desc, int) = ff320_kernel<0>;
-    switch (abl) {        // tuning only (bit mask, see the kernel); results are wrong for abl != 0
-        case 1: kern = ff320_kernel<1>; break;
-        case 2: kern = ff320_kernel<2>; break;
-        case 3: kern = ff320_kernel<3>; break;
-        case 32: kern = ff320_kernel<32>; break;
+    void (*kern)(const CcFf320Desc, int) = ff320_kernel<0, false, false>;
+    int slot = 0;
+    if (pro && epi) kern = ff320_kernel<0, true, true>, slot = 1;
+    else if (pro) kern = ff320_kernel<0, true, false>, slot = 2;
+#ifdef CCEDIT_TUNING
+    if (!pro) switch (abl) {        // tuning only (bit mask, see the kernel); results are wrong for abl != 0
+        case 1: kern = ff320_kernel<1, false, false>; slot = 3; break;
+        case 2: kern = ff320_kernel<2, false, false>; slot = 4; break;
+        case 3: kern = ff320_kernel<3, false, false>; slot = 5; break;
+        case 32: kern = ff320_kernel<32, false, false>; slot = 6; break;
         default: break;
     }
-    static unsigned long long attr_done[64] = {0};
-    if (int rc = cc_max_dynamic_lds((const void*)kern, 2 * kChunkBytes, &attr_done[abl & 63], "ff320")) return rc;
+#endif
+    static unsigned long long attr_done[8] = {0};
+    if (int rc = cc_max_dynamic_lds((const void*)kern, 2 * kChunkBytes, &attr_done[slot], "ff320")) return rc;
     int cus = 256;
     {
         int dev = 0;
@@ -365,7 +503,7 @@ extern "C" int ccedit_ff320(const CcFf320Desc* desc, void* stream) {
         }
     }
     const int grid = (int)(rounds < cus ? rounds : cus);
-    cc_note_kernel("ff320_kernel");
+    cc_note_kernel(pro && epi ? "ff320_kernel (block tail: to_out + FF + proj_out)" : pro ? "ff320_kernel (to_out + FF)" : "ff320_kernel");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 2 * kChunkBytes, (hipStream_t)stream, d, (int)rounds);
     return cc_launch_status("ff320_kernel");
 }

@@ -58,6 +58,8 @@ class CcFf320Desc(C.Structure):
         ("M", C.c_int64), ("dim", C.c_int32), ("inner", C.c_int32), ("ldx", C.c_int32), ("ldo", C.c_int32),
         ("eps", C.c_float), ("ln", C.c_int32),
         ("x", C.c_void_p), ("out", C.c_void_p), ("wstream", C.c_void_p), ("b2p", C.c_void_p), ("dbg", C.c_void_p),
+        ("a", C.c_void_p), ("res", C.c_void_p), ("res2", C.c_void_p), ("bop", C.c_void_p), ("bpp", C.c_void_p),
+        ("lda", C.c_int32), ("ldr", C.c_int32), ("ldr2", C.c_int32), ("pad_", C.c_int32),
     ]
 
 

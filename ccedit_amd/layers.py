@@ -84,7 +84,7 @@ def pack_tree(module: nn.Module, device) -> None:
     for m in module.modules():
         if isinstance(m, (Conv, Linear, Norm)) and not getattr(m, "_packed_by_parent", False):
             m.pack(device)
-    for m in module.modules():
+    for m in reversed(list(module.modules())):          # children before their parents: a parent's post_pack may build on theirs
         post = getattr(m, "post_pack", None)
         if post is not None:
             post(device)

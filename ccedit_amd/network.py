@@ -269,6 +269,19 @@ class FeedForward(nn.Module):
             self.proj_ln = _fold_ln([p.weight], norm, device, biases=[p.bias], geglu=True, dims=(640, 1280))
 
     proj_ln = None
+    _tails = None
+
+    def tail_pack(self, to_out: "Linear", proj: Optional["Conv"], device):
+        """Weight stream of the block-tail launch (to_out prologue GEMM [+ proj_out epilogue GEMM] around the fused feed-forward),
+        built on first use and kept until the next pack (a captured graph holds its address: PACK_GENERATION keys the cache)."""
+        key = (id(to_out), None if proj is None else id(proj), PACK_GENERATION[0])
+        if self._tails is None or next(iter(self._tails))[2] != PACK_GENERATION[0]:
+            self._tails = {}
+        if key not in self._tails:
+            from .packing import pack_ff320_tail
+            self._tails[key] = pack_ff320_tail(self.fused, to_out.weight, to_out.bias, None if proj is None else proj.weight,
+                                               None if proj is None else proj.bias, device=device)
+        return self._tails[key]
 
     def run(self, tok, norm: "Norm"):
         """tok + FF(LayerNorm(tok)) (attention.py:695-716 `x = self.ff(self.norm3(x)) + x`)."""
@@ -276,6 +289,23 @@ class FeedForward(nn.Module):
             return ops.ff320(tok, self.fused, eps=self.fused_eps)
         g = ln_linear(tok, norm, self.net[0].proj.pw, self.proj_ln)
         return ops.linear(g, self.net[2].pw, res1=tok)
+
+
+def transformer_tail(ff: "FeedForward", norm: "Norm", to_out: "Linear", o, tok, proj: "Conv", x2d, gn_rows: int = 0):
+    """What every transformer of the networks ends with:  tok = to_out(o) + tok;  tok = FF(LN(tok)) + tok;  y = proj_out(tok) + x
+    (attention.py:695-716 / 758-761 and the proj_out of :865-889 / :1141-1208).  At dim 320 (the 64x96 level) ONE launch
+    (csrc/ff320.hip, block tail): each of the two projections alone is a read + residual read + write of the whole activation at
+    its HBM roofline.  When the consumer wants the GroupNorm statistics of y from the producer's epilogue (gn_rows), only to_out is
+    fused and proj_out stays a launch of its own."""
+    m = tok.shape[0]
+    if (ops.BLOCK_TAIL and ff.fused is not None and m >= 1024 and proj.k == 1 and proj.cin == 320 and proj.cout == 320
+            and to_out.cin == 320 and to_out.cout == 320 and tok.is_contiguous() and x2d.is_contiguous() and o.stride(-1) == 1):
+        if gn_rows == 0:
+            return ops.ff320(None, ff.tail_pack(to_out, proj, tok.device), eps=ff.fused_eps, a=o, res=tok, res2=x2d)
+        t2 = ops.ff320(None, ff.tail_pack(to_out, None, tok.device), eps=ff.fused_eps, a=o, res=tok)
+        return ops.linear(t2, proj.pw, res1=x2d, gn_rows=gn_rows)
+    tok = linear_ln_producer(o, to_out.pw, res1=tok)
+    return ops.linear(ff.run(tok, norm), proj.pw, res1=x2d, gn_rows=gn_rows)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -288,7 +318,8 @@ class BasicTransformerBlock(nn.Module):
         self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head)
         self.norm1, self.norm2, self.norm3 = Norm(dim, 1e-5), Norm(dim, 1e-5), Norm(dim, 1e-5)
 
-    def run(self, tok, frames: int, hw: int, ctx_kv_src, ctx_len: int, frames_per_clip: int, geo: Optional[Geometry] = None):
+    def run(self, tok, frames: int, hw: int, ctx_kv_src, ctx_len: int, frames_per_clip: int, geo: Optional[Geometry] = None, tail=None):
+        """tail = (proj_out Conv, x2d, gn_rows): also apply the owning transformer's proj_out + residual (transformer_tail)."""
         a1, a2 = self.attn1, self.attn2
         c = a1.inner
         qkv = ln_linear(tok, self.norm1, a1.qkv, self.qkv_ln)      # (dim 320, 3 slices: folding the norm into lin320 does not pay)
@@ -305,6 +336,8 @@ class BasicTransformerBlock(nn.Module):
         kv = ctx_kv_src.of(self) if isinstance(ctx_kv_src, TextKV) else ops.linear(ctx_kv_src, a2.kv)
         o = ops.attention(q, kv[:, :c], kv[:, c:], a2.heads, a2.dim_head, batches=frames, lq=hw, lk=ctx_len,
                           kv_div=frames_per_clip)
+        if tail is not None:
+            return transformer_tail(self.ff, self.norm3, a2.to_out[0], o, tok, *tail)
         tok = linear_ln_producer(o, a2.to_out[0].pw, res1=tok)
         return self.ff.run(tok, self.norm3)
 
@@ -331,7 +364,14 @@ class BasicTransformerSingleLayerBlock(nn.Module):
         self.ff = FeedForward(dim)
         self.norm1, self.norm2 = Norm(dim, 1e-5), Norm(dim, 1e-5)
 
-    def run_frames(self, tok, frames: int, hw: int, anchor_t: Optional[int] = None, frames_per_clip: int = 1, shard=None, geo=None):
+    def _finish(self, o, tok, tail):
+        if tail is not None:
+            return transformer_tail(self.ff, self.norm2, self.attn1.to_out[0], o, tok, *tail)
+        tok = linear_ln_producer(o, self.attn1.to_out[0].pw, res1=tok)
+        return self.ff.run(tok, self.norm2)
+
+    def run_frames(self, tok, frames: int, hw: int, anchor_t: Optional[int] = None, frames_per_clip: int = 1, shard=None, geo=None,
+                   tail=None):
         """Per-frame attention with K/V from the un-normalised tokens.  anchor_t is None: plain self-attention
         (controlnet_img's SpatialTransformer, disable_text_ca).  Otherwise the keys are
         [tokens of frame anchor_t of the same clip ; own tokens] — SpatialTransformer3DCA 'center_self'."""
@@ -369,8 +409,7 @@ class BasicTransformerSingleLayerBlock(nn.Module):
             o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=frames, lq=hw, lk=2 * hw,
                               kv_outer_rows=hw, seg1_len=hw, seg1_div=frames_per_clip, seg1_mul=frames_per_clip,
                               seg1_add=anchor_t)
-        tok = linear_ln_producer(o, a.to_out[0].pw, res1=tok)
-        return self.ff.run(tok, self.norm2)
+        return self._finish(o, tok, tail)
 
     q_ln = None
 
@@ -378,7 +417,7 @@ class BasicTransformerSingleLayerBlock(nn.Module):
         self.ff.pack_fused(self.norm2, device)
         self.q_ln = _fold_ln([self.attn1.to_q.weight], self.norm1, device)
 
-    def run_temporal(self, tok, geo: Geometry, hw: int):
+    def run_temporal(self, tok, geo: Geometry, hw: int, tail=None):
         a = self.attn1
         c = a.inner
         q = ln_linear(tok, self.norm1, a.to_q.pw, self.q_ln)
@@ -390,8 +429,7 @@ class BasicTransformerSingleLayerBlock(nn.Module):
         o = ops.attention(q, kv[:, :c], kv[:, c:], a.heads, a.dim_head, batches=geo.b * hw, lq=t, lk=tk,
                           q_inner=hw, q_outer_rows=t * hw, q_inner_rows=1, q_seq_rows=hw,
                           kv_inner=hw, kv_outer_rows=tk * hw, kv_inner_rows=1, kv_seq_rows=hw)
-        tok = linear_ln_producer(o, a.to_out[0].pw, res1=tok)
-        return self.ff.run(tok, self.norm2)
+        return self._finish(o, tok, tail)
 
 
 class SpatialTransformer(nn.Module):
@@ -415,12 +453,17 @@ class SpatialTransformer(nn.Module):
         n, h, w, c = x.shape
         a = sgn(x, self.norm, geo, False) if geo is not None else ops.groupnorm_spatial(x, self.norm.g, self.norm.b, self.norm.eps, False)
         tok = linear_ln_producer(a.view(-1, c), self.proj_in.pw)
+        tail = (self.proj_out, x.view(-1, c), h * w if (gn and self.gn_out) else 0)
         if self.disable_text_ca:
-            tok = self.transformer_blocks[0].run_frames(tok, n, h * w, geo=geo)
+            y = self.transformer_blocks[0].run_frames(tok, n, h * w, geo=geo, tail=tail)
         else:
-            tok = self.transformer_blocks[0].run(tok, n, h * w, ctx2d, ctx_len, frames_per_clip, geo=geo)
-        y = ops.linear(tok, self.proj_out.pw, res1=x.view(-1, c), gn_rows=h * w if gn else 0)
+            y = self.transformer_blocks[0].run(tok, n, h * w, ctx2d, ctx_len, frames_per_clip, geo=geo, tail=tail)
         return ops.carry_gn_stats(y, y.view(n, h, w, c))
+
+    # Does the consumer of this transformer's output read GroupNorm statistics from the producer's epilogue?  True unless the owning
+    # network knows better (UNetModel._mark_gn_consumers: a Downsample or the decoder's concatenation follows) — then the statistics
+    # are not accumulated, and at dim 320 proj_out can ride in the block-tail launch.
+    gn_out = True
 
     def run(self, x, geo, ctx2d, ctx_len):
         return self.run_spatial(x, ctx2d, ctx_len, geo.t, gn=True, geo=geo)      # the next block opens with a GroupNorm
@@ -455,9 +498,12 @@ class SpatialTransformer3D(SpatialTransformer):
             return sh.to_frames(z, geo.b, h * w).view(n, h, w, c)
         a = temporal_gn(y, self.norm_temporal, geo, False)
         tok = ops.linear(a.view(-1, c), self.proj_in_temporal.pw)
-        tok = self.transformer_blocks_temporal[0].run_temporal(tok, geo, h * w)
-        z = ops.linear(tok, self.proj_out_temporal.pw, res1=y.view(-1, c), gn_rows=h * w)
+        z = self.transformer_blocks_temporal[0].run_temporal(tok, geo, h * w, tail=(self.proj_out_temporal, y.view(-1, c),
+                                                                                   h * w if self.gn_out_3d() else 0))
         return ops.carry_gn_stats(z, z.view(n, h, w, c))
+
+    def gn_out_3d(self) -> bool:
+        return self.gn_out
 
 
 class SpatialTransformer3DCA(SpatialTransformer3D):
@@ -477,6 +523,9 @@ class SpatialTransformer3DCA(SpatialTransformer3D):
         self.transformer_blocks_temporal_ca = nn.ModuleList([BasicTransformerSingleLayerBlock(inner, n_heads, d_head)])
         self.proj_out_temporal_ca = Conv(inner, in_channels, 1)
 
+    def gn_out_3d(self) -> bool:
+        return True            # the 3-D transformer's output feeds this class's own GroupNorm (norm_temporal_ca): statistics wanted
+
     def run(self, x, geo, ctx2d, ctx_len):
         y = super().run(x, geo, ctx2d, ctx_len)
         n, h, w, c = y.shape
@@ -484,9 +533,9 @@ class SpatialTransformer3DCA(SpatialTransformer3D):
         a = sgn(y, nc, geo, False)
         tok = ops.linear(a.view(-1, c), self.proj_in_temporal_ca.pw)
         t_glob = geo.t if geo.shard is None else geo.shard.t_glob
-        tok = self.transformer_blocks_temporal_ca[0].run_frames(tok, n, h * w, anchor_t=t_glob // 2, frames_per_clip=geo.t,
-                                                                shard=geo.shard, geo=geo)
-        z = ops.linear(tok, self.proj_out_temporal_ca.pw, res1=y.view(-1, c), gn_rows=h * w)
+        z = self.transformer_blocks_temporal_ca[0].run_frames(tok, n, h * w, anchor_t=t_glob // 2, frames_per_clip=geo.t,
+                                                              shard=geo.shard, geo=geo,
+                                                              tail=(self.proj_out_temporal_ca, y.view(-1, c), h * w if self.gn_out else 0))
         return ops.carry_gn_stats(z, z.view(n, h, w, c))
 
 
@@ -792,9 +841,27 @@ class UNetModel(nn.Module):
         pw = getattr(self, "_text_kv_all", None)
         return TextKV(ctx2d, None if pw is None else ops.linear(ctx2d, pw))
 
+    def _mark_gn_consumers(self):
+        """SpatialTransformer.gn_out: is the transformer's output read next by a GroupNorm that takes its statistics from the
+        producer's epilogue?  Encoder: yes iff a ResBlock follows (not a Downsample).  Decoder: the concatenation recomputes them
+        (cat_add_gn) and an Upsample is a convolution — only the last block, whose output meets `out.0`, wants them."""
+        def first_is_res(seq):
+            return isinstance(seq[0], (ResBlock, ResBlock3D))
+        blocks = list(self.input_blocks)
+        for i, blk in enumerate(blocks):
+            if isinstance(blk[-1], SpatialTransformer):
+                nxt = blocks[i + 1] if i + 1 < len(blocks) else self.middle_block
+                blk[-1].gn_out = first_is_res(nxt)
+        outs = list(getattr(self, "output_blocks", []))
+        for i, blk in enumerate(outs):
+            for j, layer in enumerate(blk):
+                if isinstance(layer, SpatialTransformer):
+                    layer.gn_out = (i == len(outs) - 1 and j == len(blk) - 1)
+
     def post_pack(self, device):
         self._pack_emb(device)
         self._pack_text_kv(device)
+        self._mark_gn_consumers()
 
     def pack(self, device=None):
         device = torch.device("cuda") if device is None else device
@@ -855,6 +922,7 @@ class ControlNet2D(UNetModel):
     def post_pack(self, device):
         self._pack_emb(device)
         self._pack_text_kv(device)
+        self._mark_gn_consumers()
         if self.control_scales != 1.0:       # `c * scale` (controlmodel.py:311-312) folded into the zero convs
             for zc in list(self.zero_convs) + [self.middle_block_out]:
                 zc[0].pack(device, scale=self.control_scales)

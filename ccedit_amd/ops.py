@@ -27,12 +27,16 @@ class LaunchProfile:
 
     def __init__(self):
         self.records = {}          # family -> list of (start_event, end_event, algorithmic_flops, algorithmic_bytes)
+        self.executed = 0.0        # sum of executed FLOPs over all recorded launches
 
-    def add(self, family, e0, e1, flops, nbytes, shape=None, kernel=None):
+    def add(self, family, e0, e1, flops, nbytes, shape=None, kernel=None, exec_flops=None):
         if kernel is None:
             k = hip.lib().ccedit_last_kernel()           # the kernel template the entry point just dispatched to
             kernel = k.decode() if k else "?"
         self.records.setdefault(family, []).append((e0, e1, flops, nbytes, shape, kernel))
+        # FLOPs the matrix pipe really retires for this launch where that differs from the algorithmic count (the parity form of
+        # upsample + conv executes 4/9 of the reference convolution's multiply-adds)
+        self.executed += flops if exec_flops is None else exec_flops
 
     def by_kernel(self, families=("tap_gemm", "attention", "memory")):
         """[{kernel, launches, ms, tflops, gbytes_per_s}] over the given families, sorted by time (gbytes_per_s: algorithmic bytes
@@ -184,7 +188,8 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
                      + m * out.shape[1] * out.element_size() + nres * m * pw.n * 2 + pw.n * pw.kpad * 2)   # out, residuals, W
         PROFILE.add("tap_gemm", e0, e1, pw.flops_per_row * m, float(alg_bytes),
                     (("lin", "conv", "temp")[mode] + ("+up" if upsample else "") + ("+up(parity)" if subpix else ""), m, pw.n, pw.taps * pw.cin, stride,
-                     int(res1 is not None) + int(res2 is not None), d.act))
+                     int(res1 is not None) + int(res2 is not None), d.act),
+                    exec_flops=pw.flops_per_row * m * (4.0 / 9.0) if subpix else None)
         return out
     hip.check(hip.lib().ccedit_gemm(C.byref(d), _stream()), "ccedit_gemm")
     return out
@@ -208,26 +213,51 @@ def ln320_applicable(m, pw, act=ACT_NONE, res1=None, res2=None, group_bias=None,
 
 ATTN_Q_LOG2 = policy.on("attn_q_log2")      # 0: softmax scale applied inside the attention kernels (A/B)
 FF320 = policy.on("ff320")      # 0: LayerNorm + two GEMMs instead of the fused dim-320 feed-forward
+BLOCK_TAIL = policy.on("block_tail") and FF320      # to_out / proj_out of the dim-320 transformer tails inside the ff320 launch
 
 
-def ff320(x2d: torch.Tensor, pk: PackedFF320, eps: float = 1e-5, ln: bool = True, out: Optional[torch.Tensor] = None,
-          dbg: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = x + W2 . GEGLU(W1 . LayerNorm(x) + b1) + b2 for dim 320 in one kernel (csrc/ff320.hip).  x2d: [tokens, 320]."""
-    assert x2d.dtype == BF16 and x2d.is_cuda and x2d.stride(-1) == 1 and x2d.shape[1] == 320
+def ff320(x2d: Optional[torch.Tensor], pk: PackedFF320, eps: float = 1e-5, ln: bool = True, out: Optional[torch.Tensor] = None,
+          dbg: Optional[torch.Tensor] = None, a: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+          res2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = x + W2 . GEGLU(W1 . LayerNorm(x) + b1) + b2 for dim 320 in one kernel (csrc/ff320.hip).  x2d: [tokens, 320].
+    Block tail (pk from packing.pack_ff320_tail): x2d is None and x = W_o . a + b_o + res is computed by the kernel's prologue GEMM;
+    with res2 (and an epilogue pack) the result is W_p . (x + FF(LN(x))) + b_p + res2."""
+    tail = a is not None
+    src = a if tail else x2d
+    assert src.dtype == BF16 and src.is_cuda and src.stride(-1) == 1 and src.shape[1] == 320
+    m = src.shape[0]
     if out is None:
-        out = torch.empty((x2d.shape[0], 320), dtype=BF16, device=x2d.device)
-    assert out.dtype == BF16 and out.stride(-1) == 1 and out.shape == (x2d.shape[0], 320) and out.data_ptr() != x2d.data_ptr()
+        out = torch.empty((m, 320), dtype=BF16, device=src.device)
+    assert out.dtype == BF16 and out.stride(-1) == 1 and out.shape == (m, 320) and out.data_ptr() != src.data_ptr()
     d = CcFf320Desc()
-    d.M, d.dim, d.inner, d.ldx, d.ldo, d.eps, d.ln = x2d.shape[0], 320, 1280, x2d.stride(0), out.stride(0), eps, int(ln)
-    d.x, d.out, d.wstream, d.b2p = x2d.data_ptr(), out.data_ptr(), pk.stream.data_ptr(), pk.b2p.data_ptr()
+    d.M, d.dim, d.inner, d.ldo, d.eps, d.ln = m, 320, 1280, out.stride(0), eps, int(ln)
+    d.out, d.wstream, d.b2p = out.data_ptr(), pk.stream.data_ptr(), pk.b2p.data_ptr()
     d.dbg = None if dbg is None else dbg.data_ptr()
+    nbytes = 2.0 * m * 320 * 2 + pk.stream.numel()
+    if tail:
+        if pk.bop is None or res is None or x2d is not None:
+            raise ValueError("ff320: the block-tail form needs a packing.pack_ff320_tail pack, `a` and `res`, and no x2d")
+        if (res2 is not None) != (pk.bpp is not None):
+            raise ValueError("ff320: res2 goes with an epilogue pack (pack_ff320_tail(..., wp=...)), and only with one")
+        for t_ in (res, res2):
+            if t_ is not None:
+                assert t_.dtype == BF16 and t_.is_cuda and t_.stride(-1) == 1 and tuple(t_.shape) == (m, 320) and t_.data_ptr() != out.data_ptr()
+        d.a, d.lda, d.res, d.ldr, d.bop = a.data_ptr(), a.stride(0), res.data_ptr(), res.stride(0), pk.bop.data_ptr()
+        nbytes += 2.0 * m * 320
+        if res2 is not None:
+            d.res2, d.ldr2, d.bpp = res2.data_ptr(), res2.stride(0), pk.bpp.data_ptr()
+            nbytes += 2.0 * m * 320
+    else:
+        if pk.bop is not None:
+            raise ValueError("ff320: a block-tail pack needs `a` / `res` (use pk.tail_of for the plain feed-forward)")
+        d.x, d.ldx = x2d.data_ptr(), x2d.stride(0)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         hip.check(hip.lib().ccedit_ff320(C.byref(d), _stream()), "ccedit_ff320")
         e1.record()
-        m = x2d.shape[0]
-        PROFILE.add("tap_gemm", e0, e1, pk.flops_per_row * m, float(2 * m * 320 * 2 + pk.stream.numel()), ("ff320", m, 320, 1280, 1, 1, 2))
+        PROFILE.add("tap_gemm", e0, e1, pk.flops_per_row * m, float(nbytes),
+                    ("ff320" + ("+to_out" if tail else "") + ("+proj_out" if res2 is not None else ""), m, 320, 1280, 1, 1, 2))
         return out
     hip.check(hip.lib().ccedit_ff320(C.byref(d), _stream()), "ccedit_ff320")
     return out

@@ -160,6 +160,10 @@ class PackedFF320:
     stream: torch.Tensor            # uint8 [42 * 65536]: per pipeline iteration 40 GEMM1 + 20 GEMM2 MFMA A-fragments + b1'
     b2p: torch.Tensor               # fp32 [320]: b2 in accumulator order [tile 10][lane half 2][register 16]
     flops_per_row: float = 2.0 * 320 * 2560 + 2.0 * 1280 * 320
+    # block tail (pack_ff320_tail): stream = [4 prologue chunks | 42 | 4 epilogue chunks]; bop / bpp = b_o / b_p in accumulator order
+    bop: Optional[torch.Tensor] = None
+    bpp: Optional[torch.Tensor] = None
+    tail_of: Optional["PackedFF320"] = None     # the plain pack these chunks were built around (kept for the fallback launch)
 
 
 def ff320_acc_row(r: torch.Tensor, hi: torch.Tensor) -> torch.Tensor:
@@ -231,3 +235,51 @@ def pack_ff320(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.T
     b2p = b2[32 * tt + torch.where(rr < 8, 8 * hh + rr, 16 + 8 * hh + rr - 8)].reshape(-1).contiguous()
     dev = device if device is not None else torch.device("cpu")
     return PackedFF320(stream.reshape(-1).to(dev), b2p.to(dev))
+
+
+FF320_PE_FRAGS, FF320_PE_CHUNKS = 50, 4      # prologue / epilogue GEMM: 4 chunks of 5 k-steps x 10 output tiles
+
+
+def _ff320_acc_order(b: torch.Tensor) -> torch.Tensor:
+    """A 320-vector in the accumulator order of the kernel: [tile 10][lane half 2][register 16]."""
+    tt, hh, rr = torch.meshgrid(torch.arange(10), torch.arange(2), torch.arange(16), indexing="ij")
+    return b[32 * tt + torch.where(rr < 8, 8 * hh + rr, 16 + 8 * hh + rr - 8)].reshape(-1).contiguous()
+
+
+def _ff320_proj_chunks(w: torch.Tensor) -> torch.Tensor:
+    """A 320 x 320 projection as 4 stream chunks of 50 MFMA A-fragments: fragment j of chunk Q is (k-step 5 Q + j // 10, output tile
+    j % 10), its row for lane i the output channel ff320_out_channel(tile, i) — the row permutation that makes accumulator registers
+    0..7 / 8..15 of a lane the channels of B fragments 2 t / 2 t + 1 of the same lane — and its 8 elements input channels
+    16 s + 8 (lane >> 5) .. + 7."""
+    wb = w.detach().float().cpu().to(torch.bfloat16)
+    assert tuple(wb.shape) == (FF320_DIM, FF320_DIM)
+    lane = torch.arange(64)
+    i, hi = lane & 31, lane >> 5
+    e = torch.arange(8)
+    s = torch.arange(20)[:, None, None, None]
+    t = torch.arange(10)[None, :, None, None]
+    row = ff320_out_channel(t, i[None, None, :, None])                      # [1, t, lane, 1]
+    col = 16 * s + 8 * hi[None, None, :, None] + e[None, None, None, :]     # [s, 1, lane, e]
+    shp = (20, 10, 64, 8)
+    fr = wb[row.expand(shp), col.expand(shp)]                               # [s][t][lane][e] = stream order (s-major, tile-minor)
+    stream = torch.zeros(FF320_PE_CHUNKS, FF320_CHUNK_BYTES, dtype=torch.uint8)
+    fr = fr.reshape(FF320_PE_CHUNKS, FF320_PE_FRAGS, 64, 8).contiguous()
+    stream[:, : FF320_PE_FRAGS * 1024] = fr.view(torch.uint8).reshape(FF320_PE_CHUNKS, -1)
+    return stream
+
+
+def pack_ff320_tail(ff: PackedFF320, wo: torch.Tensor, bo: Optional[torch.Tensor], wp: Optional[torch.Tensor] = None,
+                    bp: Optional[torch.Tensor] = None, device: Optional[torch.device] = None) -> PackedFF320:
+    """The weight stream of the dim-320 BLOCK TAIL (csrc/ff320.hip, PRO / EPI):  tok = wo a + bo + res;  tok += FF(LN(tok));
+    out = wp tok + bp + res2.  wo / wp: (320, 320) reference-layout Linear or 1 x 1 Conv weights (to_out.0 and proj_out of
+    attention.py:695-716 / 758-761, 865-889, 1141-1208); wp None = no epilogue GEMM (out = the feed-forward's result)."""
+    parts = [_ff320_proj_chunks(wo.reshape(FF320_DIM, FF320_DIM)), ff.stream.detach().cpu().reshape(-1, FF320_CHUNK_BYTES)]
+    if wp is not None:
+        parts.append(_ff320_proj_chunks(wp.reshape(FF320_DIM, FF320_DIM)))
+    dev = device if device is not None else ff.stream.device
+    zero = torch.zeros(FF320_DIM)
+    bop = _ff320_acc_order(zero if bo is None else bo.detach().float().cpu())
+    bpp = None if wp is None else _ff320_acc_order(zero if bp is None else bp.detach().float().cpu())
+    extra = 2.0 * FF320_DIM * FF320_DIM * (1 if wp is None else 2)
+    return PackedFF320(torch.cat(parts).reshape(-1).to(dev), ff.b2p.to(dev), ff.flops_per_row + extra, bop.to(dev),
+                       None if bpp is None else bpp.to(dev), ff)

@@ -32,7 +32,7 @@ TABLE = {
     "subpix": (1, "py", "0: upsample + 3x3 conv through the nine-tap gather instead of four parity convs"),
     "conv1x1_linear": (1, "py", "0: 1 x 1 convs through the convolution mode instead of the Linear dispatch"),
     "attn_q_log2": (1, "py", "0: softmax scale applied inside the attention kernels instead of folded into to_q"),
-    "gn_consumer": (1, "py", "0: GroupNorm apply as its own pass in front of every consumer"),
+    "block_tail": (1, "py", "0: to_out / proj_out of the dim-320 transformer tails as their own launches, not inside ff320"),
     # ---- kernel library (csrc/common.h: CcPolicy) ----
     "conv_halo": (1, "lib", "0: 3x3 stride-1 convs on the tap-gather kernel"),
     "g8": (1, "lib", "0: long Linears on the tap_gemm block shapes"),
@@ -48,7 +48,6 @@ TABLE = {
     "attn_spatial": (1, "lib", "0: the 6144-key self-attention through the general flash kernel"),
     "attn_pv16": (1, "lib", "0: PV product of the spatial attention in 32x32x16 tiles"),
     "gn_flat": (1, "lib", "0: temporal GroupNorm through the per-pixel kernels at the two large levels"),
-    "block_tail": (1, "lib", "0: to_out / proj_out of the dim-320 transformer tails as their own launches"),
 }
 
 _values: Dict[str, int] = {}

@@ -47,7 +47,7 @@ int ccedit_device_info(char* name, int name_len);
  * (A/B arms and the "specialised kernels reproduce the generic ones" tests).  All default to the fast path.  The library never reads
  * the environment; the host sets entries before launching (process-wide, not thread-safe against concurrent launches).  Names:
  *   conv_halo g8 g8_conv g8_temporal g8_split lin320 lin320s lin640 temp320 attn_short attn_text attn_spatial attn_pv16 gn_flat
- *   block_tail     (ccedit_policy_names() returns them comma-separated; semantics in csrc/common.h: CcPolicy)
+ *   (ccedit_policy_names() returns them comma-separated; semantics in csrc/common.h: CcPolicy)
  * Unknown name: CCEDIT_EINVAL. */
 int ccedit_policy_set(const char* name, int32_t value);
 int ccedit_policy_get(const char* name, int32_t* value);
@@ -195,9 +195,21 @@ typedef struct CcFf320Desc {
     int32_t ln;           /* 1: LayerNorm folded in (statistics computed in the kernel) */
     const void* x;        /* bf16 [M][ldx] */
     void* out;            /* bf16 [M][ldo]; may NOT alias x (other workgroups' reads are not ordered against the stores) */
-    const void* wstream;  /* packed weights, 42 * 65536 bytes */
+    const void* wstream;  /* packed weights, 42 * 65536 bytes (block tail: 46 or 50 chunks, see below) */
     const float* b2p;     /* float[320] in accumulator order */
     void* dbg;            /* null (tuning builds only: per-wave phase cycle counters) */
+    /* Block tail (ABI 10; all null / 0 = the plain feed-forward above).  With `a` the kernel computes the whole tail of a dim-320
+     * transformer block on the row tile it holds (attention.py:695-716 / 758-761 and the proj_out of :865-889 / :1141-1208):
+     *     tok = W_o a + b_o + res;   tok = tok + W2 GEGLU(W1 LayerNorm(tok) + b1) + b2;   out = W_p tok + b_p + res2   (with res2)
+     * x is not read.  wstream then is [4 prologue chunks | the 42 feed-forward chunks | 4 epilogue chunks] of 65536 bytes
+     * (packing.pack_ff320_tail: 50 A-fragments of W_o / W_p per chunk, rows permuted like W2's); bop / bpp: b_o / b_p in accumulator
+     * order like b2p.  res2 requires a.  tok and the feed-forward output are rounded to bf16 where the separate launches store them. */
+    const void* a;        /* bf16 [M][lda]: input of the prologue projection (the attention output) */
+    const void* res;      /* bf16 [M][ldr]: residual added to the prologue projection */
+    const void* res2;     /* bf16 [M][ldr2]: residual added to the epilogue projection (null: no epilogue GEMM, out = the feed-forward's) */
+    const float* bop;     /* float[320] */
+    const float* bpp;     /* float[320] */
+    int32_t lda, ldr, ldr2, pad_;
 } CcFf320Desc;
 
 int ccedit_ff320(const CcFf320Desc* desc, void* stream);

@@ -11,7 +11,7 @@ import math
 import numpy as np
 import torch
 
-from ccedit_amd.packing import FF320_CHUNK_BYTES, pack_ff320
+from ccedit_amd.packing import FF320_CHUNK_BYTES, pack_ff320, pack_ff320_tail
 
 L = np.arange(64)
 N_, HI_ = L & 31, L >> 5
@@ -39,13 +39,72 @@ def gelu(v):
     return 0.5 * v * (1.0 + np.vectorize(math.erf)(v / np.sqrt(2.0)))
 
 
-def emulate_wave(stream, b2p, x32, eps, ln=True):
-    """x32: [32][320] bf16-representable floats.  Returns [32][320]."""
-    stream = stream.numpy().reshape(42, FF320_CHUNK_BYTES)
-    xf = np.zeros((20, 64, 8))                        # xf[s][lane][e] = x[lane & 31][16 s + 8 hi + e]
+def to_frags(x32):
+    """B-operand fragments of a wave's 32 rows: xf[s][lane][e] = x[lane & 31][16 s + 8 hi + e]."""
+    xf = np.zeros((20, 64, 8))
     for s in range(20):
         for l in range(64):
             xf[s, l] = x32[l & 31, 16 * s + 8 * (l >> 5): 16 * s + 8 * (l >> 5) + 8]
+    return xf
+
+
+def acc_rows(acc2):
+    """Accumulator tile registers -> [32 tokens][320 channels] (the kernel's store / the fragment layout of the next GEMM)."""
+    out = np.zeros((32, 320))
+    for t in range(10):
+        for l in range(64):
+            n, hi = l & 31, l >> 5
+            out[n, 32 * t + 8 * hi: 32 * t + 8 * hi + 8] = acc2[t, l, :8]
+            out[n, 32 * t + 16 + 8 * hi: 32 * t + 16 + 8 * hi + 8] = acc2[t, l, 8:]
+    return out
+
+
+def emulate_proj(chunks, bias_p, xf, res32):
+    """Prologue / epilogue GEMM of the block tail: 4 chunks of 50 fragments (k-step 5 Q + j // 10, out tile j % 10), accumulators
+    from the bias in accumulator order, residual rows added after the first chunk.  Returns the accumulators [10][64][16]."""
+    b = bias_p.numpy().reshape(10, 2, 16)
+    acc = np.zeros((10, 64, 16))
+    for t in range(10):
+        acc[t] = b[t][HI_]
+    rfr = to_frags(res32)
+    for q in range(4):
+        fr = torch.from_numpy(chunks[q][: 50 * 1024].copy()).view(torch.bfloat16).float().numpy().reshape(50, 64, 8)
+        for j in range(50):
+            acc[j % 10] = mfma32(fr[j], xf[5 * q + j // 10], acc[j % 10])
+        if q == 0:
+            for t in range(10):
+                acc[t][:, :8] += rfr[2 * t]
+                acc[t][:, 8:] += rfr[2 * t + 1]
+    return acc
+
+
+def acc_to_frags(acc):
+    xf = np.zeros((20, 64, 8))
+    for t in range(10):
+        xf[2 * t] = bf16_round(acc[t][:, :8])
+        xf[2 * t + 1] = bf16_round(acc[t][:, 8:])
+    return xf
+
+
+def emulate_tail(pk, a32, res32, res2_32, eps):
+    """The block-tail launch on one wave, statement by statement (csrc/ff320.hip, PRO [+ EPI])."""
+    n_ch = pk.stream.numel() // FF320_CHUNK_BYTES
+    stream = pk.stream.numpy().reshape(n_ch, FF320_CHUNK_BYTES)
+    assert n_ch == (50 if pk.bpp is not None else 46)
+    xf = acc_to_frags(emulate_proj(stream[:4], pk.bop, to_frags(a32), res32))
+    acc2 = emulate_ff(stream[4:46], pk.b2p, xf, eps, True)
+    if pk.bpp is None:
+        return acc_rows(acc2)
+    return acc_rows(emulate_proj(stream[46:], pk.bpp, acc_to_frags(acc2), res2_32))
+
+
+def emulate_wave(stream, b2p, x32, eps, ln=True):
+    """x32: [32][320] bf16-representable floats.  Returns [32][320]."""
+    return acc_rows(emulate_ff(stream.numpy().reshape(42, FF320_CHUNK_BYTES), b2p, to_frags(x32), eps, ln))
+
+
+def emulate_ff(stream, b2p, xf, eps, ln):
+    """The 42 feed-forward chunks on fragments xf [20][64][8]; returns the GEMM2 accumulators."""
     sm = xf.sum(axis=(0, 2))
     mu = (sm + sm[L ^ 32]) / 320.0
     sq = ((xf - mu[None, :, None]) ** 2).sum(axis=(0, 2))
@@ -75,13 +134,7 @@ def emulate_wave(stream, b2p, x32, eps, ln=True):
             acc2[s % 10] = mfma32(fr[s, 2], hf[par, s // 10], acc2[s % 10])
         hn = bf16_round(prev[0] * gelu(prev[1]))
         hf[1 - par] = np.stack([hn[:, :8], hn[:, 8:]])
-    out = np.zeros((32, 320))
-    for t in range(10):
-        for l in range(64):
-            n, hi = l & 31, l >> 5
-            out[n, 32 * t + 8 * hi: 32 * t + 8 * hi + 8] = acc2[t, l, :8]
-            out[n, 32 * t + 16 + 8 * hi: 32 * t + 16 + 8 * hi + 8] = acc2[t, l, 8:]
-    return out
+    return acc2
 
 
 def _weights(seed):
@@ -126,3 +179,36 @@ def test_weight_stream_without_layernorm():
     h = torch.from_numpy(bf16_round((v * torch.nn.functional.gelu(gate)).numpy()))
     want = x.double() + h @ w2.to(torch.bfloat16).double().T + b2.double()
     assert np.abs(got - want.numpy()).max() < 1e-5
+
+
+def _ff_ref(xd, w1, b1, w2, b2, lg, lb):
+    hh = torch.nn.functional.layer_norm(xd, (320,), lg.double(), lb.double(), 1e-5)
+    v, gate = (hh @ w1.double().T + b1.double()).chunk(2, dim=-1)
+    return xd + (v * torch.nn.functional.gelu(gate)) @ w2.double().T + b2.double()
+
+
+def test_block_tail_stream_matches_kernel_dataflow():
+    """pack_ff320_tail: prologue chunks (to_out), the 42 feed-forward chunks, epilogue chunks (proj_out) — the row permutation that
+    turns a projection's accumulators into the next GEMM's B fragments, the accumulator-order biases and the chunk order, against
+    out = W_p (tok + FF(LN(tok))) + b_p + x_in,  tok = W_o a + b_o + res  (attention.py:695-716, 865-889) in float64."""
+    w1, b1, w2, b2, lg, lb, a = _weights(9)
+    gen = torch.Generator().manual_seed(19)
+    wo, wp = torch.randn(320, 320, generator=gen) * 0.05, torch.randn(320, 320, 1, 1, generator=gen) * 0.05
+    bo, bp = torch.randn(320, generator=gen) * 0.1, torch.randn(320, generator=gen) * 0.1
+    res, res2 = ((torch.randn(32, 320, generator=gen) * 1.2).to(torch.bfloat16).float() for _ in range(2))
+    base = pack_ff320(w1, b1, w2, b2, lg, lb)
+    for with_epi in (True, False):
+        pk = pack_ff320_tail(base, wo, bo, wp if with_epi else None, bp if with_epi else None)
+        assert pk.stream.numel() == (50 if with_epi else 46) * FF320_CHUNK_BYTES and pk.bop.shape == (320,) and pk.tail_of is base
+        got = emulate_tail(pk, a.numpy().astype(np.float64), res.numpy().astype(np.float64), res2.numpy().astype(np.float64), 1e-5)
+        tok = a.double() @ wo.double().T + bo.double() + res.double()
+        t2 = _ff_ref(tok, w1, b1, w2, b2, lg, lb)
+        ref = (t2 @ wp.reshape(320, 320).double().T + bp.double() + res2.double()) if with_epi else t2
+        rel = float(np.sqrt(((got - ref.numpy()) ** 2).mean() / (ref.numpy() ** 2).mean()))
+        assert rel < 1e-2, (with_epi, rel)          # bf16 weights / operands / two intermediate roundings apart
+        # with the SAME bf16 quantities the kernel multiplies for the projections (FF as emulated): the index maps alone
+        tokb = torch.from_numpy(bf16_round((a.double() @ wo.to(torch.bfloat16).double().T + bo.double() + res.double()).numpy()))
+        ffb = acc_rows(emulate_ff(pk.stream.numpy().reshape(-1, FF320_CHUNK_BYTES)[4:46], pk.b2p, to_frags(tokb.numpy()), 1e-5, True))
+        want = ffb if not with_epi else (torch.from_numpy(bf16_round(ffb)) @ wp.reshape(320, 320).to(torch.bfloat16).double().T
+                                         + bp.double() + res2.double()).numpy()
+        assert np.abs(got - want).max() < 1e-4, with_epi

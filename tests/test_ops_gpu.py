@@ -1049,6 +1049,59 @@ def test_ff320_equals_unfused_path():
     assert torch.equal(wide_out[:, :320], fused) and bool((wide_out[:, 320:] == 7.0).all())
 
 
+@pytest.mark.parametrize("m", [128, 4096 + 77, 33 * 1024 + 5])
+@pytest.mark.parametrize("epi", [True, False])
+def test_ff320_block_tail_vs_fp32_reference_and_three_launches(m, epi):
+    """The block-tail launch (csrc/ff320.hip PRO [+ EPI]):  tok = to_out(a) + res;  tok += FF(LN(tok));  out = proj_out(tok) + x_in
+    (attention.py:695-716 / 758-761, 865-889).  Against the fp32 formula on bf16-representable inputs (ragged M: the last round is
+    partial), against the three launches it replaces (lin320 / lin320s + ff320 + lin320: same bf16 roundings of tok and of the
+    feed-forward's result, different summation order), strided a / out rows, and bit-identical repeats."""
+    _dev()
+    from ccedit_amd import ops
+    from ccedit_amd.packing import pack_ff320, pack_ff320_tail, pack_weight
+    a = (_rnd(m, 320, seed=41, scale=1.3)).to(BF)
+    res = (_rnd(m, 320, seed=42, scale=1.5) + 0.3).to(BF)
+    xin = (_rnd(m, 320, seed=43, scale=1.1) - 0.2).to(BF)
+    wo, bo = _rnd(320, 320, seed=44, scale=320 ** -0.5), _rnd(320, seed=45, scale=0.2)
+    wp, bp = _rnd(320, 320, 1, 1, seed=46, scale=320 ** -0.5), _rnd(320, seed=47, scale=0.2)
+    w1, b1 = _rnd(2560, 320, seed=12, scale=320 ** -0.5), _rnd(2560, seed=13, scale=0.2)
+    w2, b2 = _rnd(320, 1280, seed=14, scale=1280 ** -0.5), _rnd(320, seed=15, scale=0.2)
+    g, b = 1.0 + _rnd(320, seed=16, scale=0.2), _rnd(320, seed=17, scale=0.2)
+    base = pack_ff320(w1, b1, w2, b2, g, b, device="cuda")
+    pk = pack_ff320_tail(base, wo, bo, wp if epi else None, bp if epi else None, device="cuda")
+    ac, rc, xc = a.cuda(), res.cuda(), xin.cuda()
+    y = ops.ff320(None, pk, a=ac, res=rc, res2=xc if epi else None)
+    # fp32 formula
+    tok = a.float() @ wo.t() + bo + res.float()
+    t2 = _ff_ref(tok, w1, b1, w2, b2, g, b, 1e-5, True)
+    ref = t2 @ wp.reshape(320, 320).t() + bp + xin.float() if epi else t2
+    got = y.float().cpu()
+    assert torch.isfinite(got).all()
+    rel = ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    print(f"block tail m={m} epi={epi}: rel rms vs fp32 {rel:.5f}")
+    assert rel < 8e-3, rel
+    _close(y, ref, rel=2.0 ** -6, abs_=3e-2, what=f"block tail m={m}")
+    # the three launches it replaces
+    tok3 = ops.linear(ac, pack_weight(wo, bo).to("cuda"), res1=rc)
+    t3 = ops.ff320(tok3, base)
+    y3 = ops.linear(t3, pack_weight(wp, bp).to("cuda"), res1=xc) if epi else t3
+    d3 = ((y.float() - y3.float()).pow(2).mean().sqrt() / y3.float().pow(2).mean().sqrt()).item()
+    print(f"block tail m={m} epi={epi}: rel rms vs three launches {d3:.5f}")
+    assert d3 < 6e-3, d3
+    # bit-identical repeats; strided source / destination rows
+    assert torch.equal(y, ops.ff320(None, pk, a=ac, res=rc, res2=xc if epi else None))
+    wide_a = torch.zeros(m, 960, dtype=BF, device="cuda")
+    wide_a[:, 320:640] = ac
+    wide_out = torch.full((m, 336), 7.0, dtype=BF, device="cuda")
+    ops.ff320(None, pk, a=wide_a[:, 320:640], res=rc, res2=xc if epi else None, out=wide_out[:, :320])
+    assert torch.equal(wide_out[:, :320], y) and bool((wide_out[:, 320:] == 7.0).all())
+    # a tail pack cannot be launched as the plain feed-forward, nor the other way round
+    with pytest.raises(ValueError):
+        ops.ff320(ac, pk)
+    with pytest.raises(ValueError):
+        ops.ff320(None, base, a=ac, res=rc)
+
+
 @pytest.mark.parametrize("m,n", [(32768, 320), (40000 + 13, 320)])
 def test_layernorm_folded_into_k320_linear(m, n):
     """`to_q(norm(x))` of attention.py:695-716 / 758-761 as ONE launch: lin320 normalises the rows in LDS
