@@ -152,15 +152,14 @@ def cpu_config1_end_to_end(sd, threads, wrapper=None, device=None):
                c1_workload=f"BASELINE config 1: {tt} keyframes 256x256, 5 DPMPP2SAncestral steps cfg 7.5 ({evals[0]} evaluations) + "
                            f"VAE decode, oracle fp32 on {threads} threads")
     if wrapper is not None and device is not None:
-        out["c1_hip_vs_oracle"] = hip_config1(wrapper, device, x, c, uc, noises, z, frames)
+        out["c1_hip_vs_oracle"] = hip_config1(wrapper, device, x, c, uc, noises, z, frames, vsd)
     return out
 
 
-def hip_config1(wrapper, device, x, c, uc, noises, z_ref, frames_ref):
+def hip_config1(wrapper, device, x, c, uc, noises, z_ref, frames_ref, vsd):
     """The product path on config 1 with the oracle's inputs and noise; relative RMS distance of the final latent / frames."""
     from ccedit_amd.config import instantiate_from_config
     from ccedit_amd.sgm_compat import build_vae
-    from ccedit_amd.utils.synth import fill_module_
     from ccedit_amd import ops
     dd = "sgm.modules.diffusionmodules."
     denoiser = instantiate_from_config(dict(target=dd + "denoiser.DiscreteDenoiser", params=dict(
@@ -173,7 +172,9 @@ def hip_config1(wrapper, device, x, c, uc, noises, z_ref, frames_ref):
     it = iter([n.to(device) for n in noises])
     sampler.noise_sampler = lambda v: next(it)
     vae = build_vae(device)
-    fill_module_(vae, prefix="first_stage_model.")
+    # the oracle's VAE weights (name-keyed fills differ between the CPU and the device generator: same tensors on both sides)
+    missing = vae.load_state_dict({k[len("first_stage_model."):]: v for k, v in vsd.items()}, strict=False)
+    assert not missing.missing_keys, missing.missing_keys[:4]
     vae.pack(device)
     cd = {k: v.to(device) for k, v in c.items()}
     ud = {k: v.to(device) for k, v in uc.items()}

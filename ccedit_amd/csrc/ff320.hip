@@ -49,6 +49,16 @@
 #ifndef KD_VALUE
 #define KD_VALUE 5
 #endif
+// block-tail schedule knobs (probe builds: tools/exp/build_variant.sh -DTAIL_...=0/1; the defaults are the measured best)
+#ifndef TAIL_RF_LATE
+#define TAIL_RF_LATE 1          // residual rows added after the projection's LAST chunk (0: after its first)
+#endif
+#ifndef TAIL_DMA_EARLY
+#define TAIL_DMA_EARLY 1        // prologue / epilogue chunks issue the next chunk's DMA in their first steps (0: every other step)
+#endif
+#ifndef TAIL_PREFETCH_A
+#define TAIL_PREFETCH_A 0       // next round's attention-output rows requested during the epilogue GEMM
+#endif
 #include <stdlib.h>
 #include <utility>
 
@@ -211,6 +221,20 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
     };
     if constexpr (!PRO) pipeline_reset();
 
+    // Every workgroup starts its round at the same moment and asks HBM for its 80 KB of rows at once: ~7k cycles per round when the
+    // wave has to wait for them (MI355X_MICROARCH.md, "prologue HBM burst").  The block tail reads three such row sets per round; two
+    // are requested four chunks before they are used (residual rows: `rf`), and with the epilogue GEMM present the NEXT round's
+    // attention-output rows are requested while the epilogue runs (`xnext`), so only the very first round waits for its input.
+    constexpr bool PREFETCH_A = PRO && EPI && TAIL_PREFETCH_A;
+    bf16x8 xnext[kKS];
+    auto load_rows = [&](bf16x8* dst, const bf16* base, int ld, int rnd) __attribute__((always_inline)) {
+        const int64_t q = ((int64_t)rnd * 4 + wave) * kWavePix + n;
+        const bf16* row = base + (q < d.M ? q : d.M - 1) * ld + hi * 8;                 // rows past M repeat the last row; never stored
+#pragma unroll
+        for (int s = 0; s < kKS; ++s) dst[s] = *(const bf16x8*)(row + s * 16);
+    };
+    if constexpr (PREFETCH_A) load_rows(xnext, (const bf16*)d.a, d.lda, (int)blockIdx.x);          // (grid <= rounds)
+
     for (int round = blockIdx.x; round < n_rounds; round += gdim) {
         const int64_t p = ((int64_t)round * 4 + wave) * kWavePix + n;
         const int64_t pr = p < d.M ? p : d.M - 1;                         // rows past M repeat the last row; never stored
@@ -220,9 +244,14 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
         bf16x8 xf[kKS];
         bf16x8 rf[kKS];                  // PRO: residual rows of the prologue; EPI: x_in rows of the epilogue (see add_rows)
         {
-            const bf16* row = (PRO ? (const bf16*)d.a + pr * d.lda : xp + pr * d.ldx) + hi * 8;
+            if constexpr (PREFETCH_A) {
 #pragma unroll
-            for (int s = 0; s < kKS; ++s) xf[s] = *(const bf16x8*)(row + s * 16);
+                for (int s = 0; s < kKS; ++s) xf[s] = xnext[s];
+            } else {
+                const bf16* row = (PRO ? (const bf16*)d.a + pr * d.lda : xp + pr * d.ldx) + hi * 8;
+#pragma unroll
+                for (int s = 0; s < kKS; ++s) xf[s] = *(const bf16x8*)(row + s * 16);
+            }
             if constexpr (PRO) {
                 const bf16* rrow = (const bf16*)d.res + pr * d.ldr + hi * 8;
 #pragma unroll
@@ -314,8 +343,11 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) FF_DS_READ(bq[k][q4], lxn, k * 128 + q4 * 16);
                 }
-                if constexpr (j < 32 && (j & 1) == 0 && (j >> 1) < CH::NISS) {
-                    if (issue_next) issue_frag(cn, 1 - PAR, j >> 1);          // the next chunk's DMA, spread over the MFMA steps
+                // the next chunk's DMA: spread over the MFMA steps of a feed-forward chunk (16 of 60 steps); a prologue / epilogue chunk is
+                // 50 bare MFMAs (1600 cycles) against ~2300 cycles of DMA, so there the requests go out first
+                constexpr int dma_k = (KIND != 1 && TAIL_DMA_EARLY) ? j : ((j & 1) == 0 ? (j >> 1) : 99);
+                if constexpr (dma_k < CH::NISS && j < 32) {
+                    if (issue_next) issue_frag(cn, 1 - PAR, dma_k);
                 }
                 if constexpr (j == NF - 2 - kD) {    // barrier B: chunk c + 1 has landed for every wave
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -340,8 +372,8 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
             }
         };
 
-        // the residual rows of a projection, requested when its first chunk starts and added (fp32) when that chunk ends: their latency
-        // hides behind 50 MFMAs and they occupy registers for one chunk only
+        // the residual rows of a projection, requested when its first chunk starts and added (fp32) after its last: their latency
+        // hides behind the projection's 200 MFMAs and four chunk DMAs
         auto add_rows = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < kOT; ++t)
@@ -355,10 +387,11 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
         if constexpr (PRO) {
             init_acc((const f32x4*)d.bop, false);
             iteration(Chunk<0, 0, 0, !EPI, false, 13>{}, 0, false);      // (the round before ended with a feed-forward chunk iff !EPI)
-            add_rows();
+            if constexpr (!TAIL_RF_LATE) add_rows();
             iteration(Chunk<0, 1, 1, false, false, 13>{}, 1, false);
             iteration(Chunk<0, 2, 0, false, false, 13>{}, 2, false);
             iteration(Chunk<0, 3, 1, false, true, 16>{}, 3, false);
+            if constexpr (TAIL_RF_LATE) add_rows();
             acc_to_frags();
         }
         // ---- LayerNorm statistics (two passes over the registers, the two lanes of a token meet once); the accumulators of the
@@ -415,10 +448,16 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
             }
             init_acc((const f32x4*)d.bpp, false);
             iteration(Chunk<2, 0, 0, true, false, 13>{}, cE, false);     // (retires the b1' rows the last feed-forward chunk read ahead)
-            add_rows();
+            if constexpr (!TAIL_RF_LATE) add_rows();
+            if constexpr (PREFETCH_A) {
+                // unconditional (the last round re-reads its own rows): a conditional load would keep xnext's old value — and its 80
+                // registers — alive through the whole feed-forward
+                load_rows(xnext, (const bf16*)d.a, d.lda, last_round ? round : round + gdim);
+            }
             iteration(Chunk<2, 1, 1, false, false, 13>{}, cE + 1, false);
             iteration(Chunk<2, 2, 0, false, false, 13>{}, cE + 2, false);
             iteration(Chunk<2, 3, 1, false, FIRST_BQ, FIRST_BQ ? 16 : 13>{}, cE + 3, true);
+            if constexpr (TAIL_RF_LATE) add_rows();
         }
         if (last_round) {    // the reads issued ahead for a chunk that does not exist: retire them before their registers are reused
 #pragma unroll

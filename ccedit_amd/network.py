@@ -1034,6 +1034,11 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
             h = ops.cat_add(h, hs.pop(), control.pop(), gn=True)          # cat([h, hs.pop() + control.pop()], dim=1)
             h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
             _trace(f"output_blocks.{len(self.output_blocks) - len(hs) - 1}", h)
+        return self.head(h, geo)
+
+    def head(self, h, geo: Geometry):
+        """`out` (GroupNorm + SiLU + conv3x3 -> 4 channels) and `out_temporal` (SiLU + Conv1d k3 over T, residual): the prediction,
+        fp32 (controlmodel.py:545-550, openaimodel.py:1627-1632)."""
         a = sgn(h, self.out[0], geo, True)
         n, hh, ww, _ = a.shape
         oc = self.out_channels

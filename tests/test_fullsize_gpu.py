@@ -17,6 +17,7 @@ import sys
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -117,10 +118,20 @@ def _oracle_block(O, sd, cfg, name, x5, emb, ctx):
     inputs, _, outputs = O.unet_topology(cfg)
     kind, i = name.rsplit(".", 1)
     spec = (inputs if kind == "input_blocks" else outputs)[int(i)]
-    assert spec.kind == "res" and not spec.up
+
+    def t3(key):
+        return lambda x, add: O._conv1d(sd, key, x, padding=1, add=add)
+    if spec.kind == "down":      # Downsample3D (openaimodel.py:388-394)
+        return O.stf(x5, lambda x: O._conv2d(sd, bp + ".0.op", x, stride=2, padding=1), t3(bp + ".0.conv_temporal"))
+    assert spec.kind == "res"
     h = O.resblock3d(sd, bp + ".0", x5, emb)
+    j = 1
     if spec.attn:
-        h = O.spatial_transformer3d(sd, bp + ".1", h, ctx, cfg.num_heads)
+        h = O.spatial_transformer3d(sd, f"{bp}.{j}", h, ctx, cfg.num_heads)
+        j += 1
+    if spec.up:                  # Upsample3D (openaimodel.py:254-263): nearest x(1,2,2), conv3x3, conv1d over T
+        up = F.interpolate(h, scale_factor=(1, 2, 2), mode="nearest")
+        h = O.stf(up, lambda x: O._conv2d(sd, f"{bp}.{j}.conv", x, padding=1), t3(f"{bp}.{j}.conv_temporal"))
     return h
 
 
@@ -128,10 +139,14 @@ def _oracle_block(O, sd, cfg, name, x5, emb, ctx):
 # conv-gather and the short-K Linears of the persistent kernel as the network launches them) — and a B = 2 case at 32x48 (the batched
 # default step: M = 52224 rows per launch); every case is also held to the oracle's fp32 mode (the mode the reference goldens pin).
 @pytest.mark.timeout(3000)
+# Round 5: an Upsample3D block (`output_blocks.8`: the parity convs 32x48 -> 64x96 at 640 channels), a Downsample3D
+# (`input_blocks.3`: the stride-2 gather), and level 0 at B = 2 (`input_blocks.1` at M = 208896: the launches of the batched default
+# step — lin320s, the block-tail ff320 and the spatial attention kernel over 34 frames).
 @pytest.mark.parametrize("name,cin,hh,ww,b", [("input_blocks.1", 320, 64, 96, 1), ("input_blocks.4", 320, 32, 48, 1),
                                               ("input_blocks.7", 640, 16, 24, 1), ("output_blocks.11", 640, 64, 96, 1),
                                               ("middle_block", 1280, 8, 12, 2), ("output_blocks.1", 2560, 8, 12, 2),
-                                              ("input_blocks.5", 640, 32, 48, 2)])
+                                              ("input_blocks.5", 640, 32, 48, 2), ("output_blocks.8", 960, 32, 48, 1),
+                                              ("input_blocks.3", 320, 64, 96, 1), ("input_blocks.1", 320, 64, 96, 2)])
 def test_full_size_block_teacher_forced_vs_bf16_emulating_oracle(name, cin, hh, ww, b):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -166,10 +181,76 @@ def test_full_size_block_teacher_forced_vs_bf16_emulating_oracle(name, cin, hh, 
     ctx2d = ctx.to(torch.bfloat16).reshape(-1, 768).contiguous().cuda()
     got = blk.run(x_hip, net._emb_silu(tt.cuda()), network.Geometry(b, t), ctx2d, 77)
     torch.cuda.synchronize()
-    got5 = got.float().cpu().view(b, t, hh, ww, -1).permute(0, 4, 1, 2, 3)
+    got5 = got.float().cpu().view(b, t, got.shape[1], got.shape[2], -1).permute(0, 4, 1, 2, 3)
     assert got5.shape == want.shape
     r = _rel(got5.numpy(), want.numpy())
     r32 = _rel(got5.numpy(), want32.numpy())
     print(f"full-size {name} ({cin} ch in, B={b}, T=17, {hh}x{ww}): HIP vs bf16-emulating oracle, teacher-forced: {r:.4f}; vs the fp32 oracle: {r32:.4f}")
     assert np.isfinite(r) and r < 9e-3, f"{name}: {r}"       # the small-size budget for blocks with attention (test_network_gpu.py)
     assert np.isfinite(r32) and r32 < 1.5e-2, f"{name} vs fp32 oracle: {r32}"
+
+
+@pytest.mark.timeout(3000)
+@pytest.mark.parametrize("piece", ["out_head", "hint_stem", "controlnet_block1"])
+def test_full_size_pieces_vs_oracle(piece):
+    """The remaining launch families of the production step tied to the oracle at production shape:
+    `out` + `out_temporal` (GroupNorm + SiLU + conv3x3 320 -> 4 at 64x96, SiLU + Conv1d over T, fp32 output), the ControlNet's hint
+    stem at 512x768 (small_conv3x3 at 3 / 16 / 32 channels, the stride-2 convs, 2 frames), and one ControlNet block with its zero
+    conv (2-D ResBlock + SpatialTransformer with text attention at 64x96, 17 frames; the zero conv rides on the Linear dispatch)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from ccedit_amd import network, ops
+    from ccedit_amd.sgm_compat import build_network, build_network_spec
+    from ccedit_amd.utils.synth import fill_module_, synth_state_dict
+    from oracle import ccedit_oracle as O
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    g = torch.Generator().manual_seed(77)
+    bf = lambda v: v.to(torch.bfloat16).float()
+    cfg = O.NetConfig()
+    sd = synth_state_dict(build_network_spec({}))
+    w = build_network("cpu")
+    fill_module_(w, prefix="model.")
+    net = w.diffusion_model
+    net.pack("cuda")
+    P = "model.diffusion_model"
+    t = 17
+    if piece == "out_head":
+        x5 = bf(torch.randn(1, 320, t, 64, 96, generator=g))
+        with torch.no_grad(), O.bf16_emulation():
+            want = O.stf(x5, lambda x: O._conv2d(sd, P + ".out.2", O._gn(sd, P + ".out.0", x, O.GN_EPS_RES, silu=True), padding=1),
+                         lambda x, add: O._conv1d(sd, P + ".out_temporal.1", O._R(F.silu(x)), padding=1, add=add, rnd=False))
+        x_hip = x5.permute(0, 2, 3, 4, 1).reshape(t, 64, 96, 320).contiguous().to(torch.bfloat16).cuda()
+        got = net.head(x_hip, network.Geometry(1, t))
+        got5 = got.float().cpu().view(1, t, 64, 96, -1)[..., :4].permute(0, 4, 1, 2, 3)
+        tol = 9e-3
+    elif piece == "hint_stem":
+        hint = bf(torch.rand(2, 3, 512, 768, generator=g))                                # two frames at full resolution
+        with torch.no_grad(), O.bf16_emulation():
+            want = O.hint_stem(sd, P + ".controlnet.input_hint_block", hint)
+        h8 = torch.zeros(2, 512, 768, 8)
+        h8[..., :3] = hint.permute(0, 2, 3, 1)
+        got = net.controlnet.hint_stem(h8.to(torch.bfloat16).cuda())
+        got5 = got.float().cpu().permute(0, 3, 1, 2)
+        tol = 9e-3
+    else:
+        cn = net.controlnet
+        x4 = bf(torch.randn(t, 320, 64, 96, generator=g))
+        ctx = bf(torch.randn(1, 77, 768, generator=g))
+        tt = torch.tensor([601], dtype=torch.int64)
+        bp = P + ".controlnet.input_blocks.1"
+        with torch.no_grad(), O.bf16_emulation():
+            emb = O.time_embed(sd, P + ".controlnet.time_embed", tt, cfg.model_channels).repeat_interleave(t, dim=0)
+            h = O.resblock2d(sd, bp + ".0", x4, emb)
+            h = O.spatial_transformer2d(sd, bp + ".1", h, ctx.repeat_interleave(t, dim=0), cfg.num_heads)
+            want = torch.cat([h, O._conv2d(sd, P + ".controlnet.zero_convs.1.0", h) * cfg.control_scales], dim=1)
+        x_hip = x4.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+        ctx2d = ctx.to(torch.bfloat16).reshape(-1, 768).contiguous().cuda()
+        hh_ = cn.input_blocks[1].run(x_hip, cn._emb_silu(tt.cuda()), network.Geometry(1, t), ctx2d, 77)
+        zc = ops.conv2d(hh_, cn.zero_convs[1][0].pw)
+        got5 = torch.cat([hh_.float().cpu(), zc.float().cpu()], dim=-1).permute(0, 3, 1, 2)
+        tol = 9e-3
+    torch.cuda.synchronize()
+    assert tuple(got5.shape) == tuple(want.shape), (got5.shape, want.shape)
+    r = _rel(got5.numpy(), want.numpy())
+    print(f"full-size {piece}: HIP vs bf16-emulating oracle: {r:.4f}")
+    assert np.isfinite(r) and r < tol, f"{piece}: {r}"
