@@ -297,6 +297,23 @@ __global__ __launch_bounds__(256) void copy_row_blocks_kernel(const char* __rest
     }
 }
 
+// n_blocks strided 2-D copies of ONE geometry (rows x row_gran 16-byte granules, a row pitch on each side) that differ in their byte
+// offsets: the column-slice <-> contiguous-buffer halves of the head-parallel attention exchange of a row-sharded clip
+// (parallel.RowShard.to_heads / from_heads): block (peer rank, q | k | v) gathers that peer's head columns out of the [rows][3C]
+// projection into its contiguous send buffer, and the way back scatters [rows][C / N] buffers into the columns of [rows][C].
+__global__ __launch_bounds__(256) void copy_2d_blocks_kernel(const char* __restrict__ src, char* __restrict__ dst,
+                                                             const int64_t* __restrict__ blocks, int64_t rows, int row_gran,
+                                                             int64_t src_pitch, int64_t dst_pitch) {
+    const char* s = src + blocks[2 * blockIdx.y];
+    char* o = dst + blocks[2 * blockIdx.y + 1];
+    const int64_t total = rows * row_gran;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / row_gran;
+        const int g = (int)(i - r * row_gran);
+        *(u32x4*)(o + r * dst_pitch + g * 16) = *(const u32x4*)(s + r * src_pitch + g * 16);
+    }
+}
+
 inline unsigned grid_for(int64_t n, int threads) {
     int64_t g = (n + threads - 1) / threads;
     return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -337,6 +354,21 @@ extern "C" int ccedit_copy_row_blocks(const void* src, void* dst, const void* ad
     hipLaunchKernelGGL(copy_row_blocks_kernel, dim3((unsigned)gx, (unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const char*)src, (char*)dst, (const bf16*)add, blocks, row_gran);
     return cc_launch_status("copy_row_blocks");
+}
+
+extern "C" int ccedit_copy_2d_blocks(const void* src, void* dst, const int64_t* blocks, int32_t n_blocks, int64_t rows,
+                                     int32_t row_bytes, int64_t src_pitch, int64_t dst_pitch, void* stream) {
+    CC_CHECK_ARG(src && dst && blocks && n_blocks > 0 && rows > 0 && row_bytes > 0, "ccedit_copy_2d_blocks: bad args");
+    CC_UNSUPPORTED(row_bytes % 16 || src_pitch % 16 || dst_pitch % 16 || src_pitch < row_bytes || dst_pitch < row_bytes,
+                   "ccedit_copy_2d_blocks: row_bytes=%d, pitches %lld / %lld (multiples of 16, pitches >= row_bytes)", row_bytes,
+                   (long long)src_pitch, (long long)dst_pitch);
+    CC_UNSUPPORTED(n_blocks > 65535, "ccedit_copy_2d_blocks: more than 65535 blocks");
+    const int row_gran = row_bytes / 16;
+    int64_t gx = (rows * row_gran + 256 * 8 - 1) / (256 * 8);           // ~8 granules per thread
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(copy_2d_blocks_kernel, dim3((unsigned)gx, (unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const char*)src, (char*)dst, blocks, rows, row_gran, src_pitch, dst_pitch);
+    return cc_launch_status("copy_2d_blocks");
 }
 
 extern "C" int ccedit_cat_add(const void* a, const void* b, const void* c, void* out, int64_t rows, int32_t C1, int32_t C2,

@@ -60,7 +60,9 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int TI, int TJ, int STAGES, int BKE, int MODE>
+// HALO3 (M_CONV, CcGemmDesc.vpad == 2): the frames' rows are sharded over ranks — taps that fall one row above / below the local rows read
+// the neighbour ranks' boundary rows from d.halo_top / d.halo_bot ([frames][Win][lda]; null = the frame ends there: zeros).
+template <int WM, int WN, int TI, int TJ, int STAGES, int BKE, int MODE, bool HALO3 = false>
 __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc d) {
     static_assert(BKE == 64 || BKE == 32, "K tile");
     constexpr int kRowBytes = BKE * 2;       // one K tile row of one tile row in LDS (128 or 64 bytes)
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
 
     // per staged pixel row: source row index of tap (0,0) and the coordinates the bounds checks need
     int rrow[B_ISSUES], ra[B_ISSUES], rb[B_ISSUES];
+    int rn[HALO3 ? B_ISSUES : 1];              // HALO3: frame of the staged pixel row x Win (the halo rows' base)
 #pragma unroll
     for (int i = 0; i < B_ISSUES; ++i) {
         const int64_t m = pix0 + i * RPI + rsub;
@@ -163,10 +166,12 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
             const int oy = rem / d.Wout, ox = rem - oy * d.Wout;
             // subpix: parity (py, px) of an upsample + 3x3 conv on the low-resolution source — a 2 x 2 window starting at (oy - 1 + py, ox - 1 + px)
             // vpad: the source frames carry their own halo rows (RowShard) — one row less of vertical padding
-            const int pad_y = (d.subpix ? 1 - ((d.subpix - 1) >> 1) : d.pad) - (d.vpad ? 1 : 0), pad_x = d.subpix ? 1 - ((d.subpix - 1) & 1) : d.pad;
+            // (vpad 2: the halo rows are separate tensors — the padding geometry of the whole frame)
+            const int pad_y = (d.subpix ? 1 - ((d.subpix - 1) >> 1) : d.pad) - (d.vpad == 1 ? 1 : 0), pad_x = d.subpix ? 1 - ((d.subpix - 1) & 1) : d.pad;
             ra[i] = ok ? oy * d.stride - pad_y : -100000;
             rb[i] = ox * d.stride - pad_x;
             rrow[i] = (MODE == M_CONV) ? n * d.Hin * d.Win + ra[i] * d.Win + rb[i] : n * d.Hin * d.Win;
+            if constexpr (HALO3) rn[i] = n * d.Win;
         } else if constexpr (MODE == M_TEMPORAL) {
             const int frame = (int)(m / d.HW);
             const int b = frame / d.T, tl = frame - b * d.T;
@@ -246,6 +251,12 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
             }
             const bf16* src = sp + ((int64_t)row * ld + cc);
             src = (v & kvalid) ? src : zp;
+            if constexpr (HALO3) {
+                const int iy = ra[i] + dy, ix = rb[i] + dx;
+                const bool edge = ((iy == -1) | (iy == d.Hin)) & ((unsigned)ix < (unsigned)d.Win) & kvalid;
+                const bf16* hb = (const bf16*)(iy < 0 ? d.halo_top : d.halo_bot);
+                if (edge && hb) src = hb + ((int64_t)(rn[i] + ix) * ld + cc);
+            }
             glds16(src, sB + buf * B_BYTES + i * (RPI * kRowBytes) + wave * 1024);
         }
         // advance to the next K tile (+GPR granules)
@@ -355,12 +366,12 @@ __global__ __launch_bounds__(WM* WN * 64) void tap_gemm_kernel(const CcGemmDesc 
         d.gn_stats ? pix0 / d.gn_rows : 0);
 }
 
-template <int WM, int WN, int TI, int TJ, int STAGES, int BKE, int MODE>
+template <int WM, int WN, int TI, int TJ, int STAGES, int BKE, int MODE, bool HALO3 = false>
 int launch(const CcGemmDesc& d, hipStream_t s) {
     constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
     constexpr int lds = epi_lds_total(BMC, BNP, TJ, STAGES * (BMC + BNP) * BKE * 2);
     static unsigned long long attr_done = 0;
-    if (int rc = cc_max_dynamic_lds((const void*)tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>, lds, &attr_done, "tap_gemm"))
+    if (int rc = cc_max_dynamic_lds((const void*)tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE, HALO3>, lds, &attr_done, "tap_gemm"))
         return rc;
     const int64_t pt_n = (d.M + BNP - 1) / BNP, ct_n = (d.N + BMC - 1) / BMC;
     int64_t nblk = 8 * ((pt_n + 7) / 8) * ct_n;
@@ -392,13 +403,20 @@ int launch(const CcGemmDesc& d, hipStream_t s) {
         nblk = 8 * ((pt_n * ct_n + 7) / 8);
     }
     dim3 grid((unsigned)nblk);
-    cc_note_kernel("tap_gemm_kernel %dch x %dpix, %d stages of K=%d", BMC, BNP, STAGES, BKE);
-    hipLaunchKernelGGL((tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE>), grid, dim3(WM * WN * 64), lds, s, dd);
+    cc_note_kernel("tap_gemm_kernel %dch x %dpix, %d stages of K=%d%s", BMC, BNP, STAGES, BKE, HALO3 ? ", neighbour halo rows" : "");
+    hipLaunchKernelGGL((tap_gemm_kernel<WM, WN, TI, TJ, STAGES, BKE, MODE, HALO3>), grid, dim3(WM * WN * 64), lds, s, dd);
     return cc_launch_status("tap_gemm_kernel");
 }
 
 template <int MODE>
 int launch_tile(const CcGemmDesc& d, int tile, hipStream_t s) {
+    if constexpr (MODE == M_CONV) {
+        if (d.vpad == 2) {          // rows sharded over ranks, halo rows as separate tensors: the generic block shapes
+            if (tile == 3) return launch<2, 4, 2, 2, 3, 64, MODE, true>(d, s);
+            if (tile == 2) return launch<1, 4, 2, 2, 2, 64, MODE, true>(d, s);
+            return launch<2, 2, 2, 2, 2, 64, MODE, true>(d, s);
+        }
+    }
     if constexpr (MODE == M_LINEAR) {
         if (tile == 7) return launch<2, 2, 4, 4, 4, 32, MODE>(d, s);   // 256ch x 256pix, 4 waves of 128ch x 128pix, 4 stages of K=32
         if (tile == 10) return launch<2, 2, 5, 4, 4, 32, MODE>(d, s);  // 320ch x 256pix, 4 waves of 160ch x 128pix, 4 stages of K=32
@@ -443,13 +461,14 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
                      "ccedit_gemm: bad conv2d geometry");
         CC_CHECK_ARG(d.M % ((int64_t)d.Hout * d.Wout) == 0, "ccedit_gemm: M not a whole number of frames");
         CC_CHECK_ARG(d.subpix >= 0 && d.subpix <= 4, "ccedit_gemm: subpix must be 0..4");
-        CC_CHECK_ARG(d.vpad == 0 || d.vpad == 1, "ccedit_gemm: vpad must be 0 or 1");
-        CC_UNSUPPORTED(d.vpad && (d.upsample || d.tile > 3), "ccedit_gemm: vpad runs on the generic tap-gather block shapes only, without the fused upsample");
-        CC_UNSUPPORTED(d.subpix && (d.ksize != 2 || d.stride != 1 || d.upsample || d.Hin != d.Hout + (d.vpad ? 2 : 0) || d.Win != d.Wout || d.gn_stats || d.A2 ||
+        CC_CHECK_ARG(d.vpad >= 0 && d.vpad <= 2, "ccedit_gemm: vpad must be 0, 1 or 2");
+        CC_CHECK_ARG(d.vpad == 2 || (!d.halo_top && !d.halo_bot), "ccedit_gemm: halo_top / halo_bot go with vpad 2");
+        CC_UNSUPPORTED(d.vpad && (d.upsample || d.tile > 3 || d.A2), "ccedit_gemm: vpad runs on the generic tap-gather block shapes only, without the fused upsample / a second source");
+        CC_UNSUPPORTED(d.subpix && (d.ksize != 2 || d.stride != 1 || d.upsample || d.Hin != d.Hout + (d.vpad == 1 ? 2 : 0) || d.Win != d.Wout || d.gn_stats || d.A2 ||
                                     4 * d.M >= (1LL << 31)),
                        "ccedit_gemm: subpix needs ksize 2, stride 1, a same-size low-resolution frame, no gn_stats / second source");
-    } else if (d.subpix || d.vpad) {
-        CC_CHECK_ARG(false, "ccedit_gemm: subpix / vpad are CONV2D modes");
+    } else if (d.subpix || d.vpad || d.halo_top || d.halo_bot) {
+        CC_CHECK_ARG(false, "ccedit_gemm: subpix / vpad / halo rows are CONV2D modes");
     } else if (d.mode == CCEDIT_GEMM_TEMPORAL) {
         CC_CHECK_ARG(d.T > 0 && d.HW > 0 && d.M % ((int64_t)d.T * d.HW) == 0, "ccedit_gemm: bad temporal geometry");
         CC_CHECK_ARG(d.taps % 2 == 1, "ccedit_gemm: temporal taps must be odd");

@@ -37,6 +37,7 @@ class CcGemmDesc(C.Structure):
         ("gn_stats", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("split_k", C.c_int32), ("subpix", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_stats", C.c_void_p),
         ("ln_sums", C.c_void_p), ("row_sums", C.c_void_p), ("ln_sums_eps", C.c_float), ("vpad", C.c_int32),
+        ("halo_top", C.c_void_p), ("halo_bot", C.c_void_p),
     ]
 
 
@@ -100,6 +101,7 @@ _SIGS = {
     "ccedit_nhwc_to_ncthw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_void_p]),
     "ccedit_copy_row_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "ccedit_copy_2d_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "ccedit_cat_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                  C.c_void_p]),
     "ccedit_cat_add_gn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

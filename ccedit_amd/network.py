@@ -55,15 +55,15 @@ class Geometry:
 
 
 def sconv3(x, pw, geo: Geometry, stride: int = 1, **kw):
-    """Conv2d 3x3, pad 1 (stride 1 or 2).  Rows sharded (geo.rows): the neighbour ranks' boundary rows are received first and the
-    kernel runs on the extended frames without vertical padding (CcGemmDesc.vpad)."""
+    """Conv2d 3x3, pad 1 (stride 1 or 2).  Rows sharded (geo.rows): the neighbour ranks' boundary rows are received into two small
+    tensors and the kernel reads them in place where a tap leaves the local rows (CcGemmDesc.vpad = 2) — the slab is not copied."""
     rs = geo.rows
     if rs is None:
         return ops.conv2d(x, pw, stride=stride, **kw)
     if stride == 2 and x.shape[1] % 2:
         raise ValueError(f"row-sharded stride-2 convolution on {x.shape[1]} local rows: the local height must be even at every level "
                          f"(RowShard.check_latent)")
-    return ops.conv2d(rs.halo_rows(x, below=stride == 1), pw, stride=stride, vpad=True, **kw)
+    return ops.conv2d(x, pw, stride=stride, halo=rs.halo_exchange(x, below=stride == 1), **kw)
 
 
 def sgn(x, norm: "Norm", geo: Geometry, silu: bool):
@@ -323,7 +323,15 @@ class BasicTransformerBlock(nn.Module):
         a1, a2 = self.attn1, self.attn2
         c = a1.inner
         qkv = ln_linear(tok, self.norm1, a1.qkv, self.qkv_ln)      # (dim 320, 3 slices: folding the norm into lin320 does not pay)
-        if geo is not None and geo.rows is not None:               # rows sharded: local queries against the whole frame's keys
+        if geo is not None and geo.rows is not None and geo.rows.heads_ok(a1.heads):
+            # rows sharded, head-parallel: all-to-all q, k, v by head -> whole frames of 8 / N heads here -> all-to-all o back
+            rs = geo.rows
+            cw = c // rs.world
+            q_, k_, v_ = rs.to_heads([(qkv, 0), (qkv, c), (qkv, 2 * c)], frames, hw, cw)
+            oh = ops.attention(q_, k_, v_, a1.heads // rs.world, a1.dim_head, batches=frames, lq=hw * rs.world, lk=hw * rs.world,
+                               q_log2=a1.q_log2)
+            o = rs.from_heads(oh, frames, hw, cw)
+        elif geo is not None and geo.rows is not None:             # rows sharded: local queries against the gathered frame's keys
             kv = gathered_kv(qkv[:, c:], frames, geo)
             o = ops.attention(qkv[:, :c], kv[:, :c], kv[:, c:], a1.heads, a1.dim_head, batches=frames, lq=hw, lk=hw * geo.rows.world,
                               q_log2=a1.q_log2)
@@ -379,7 +387,18 @@ class BasicTransformerSingleLayerBlock(nn.Module):
         c = a.inner
         q = ln_linear(tok, self.norm1, a.to_q.pw, self.q_ln)
         kv = ops.linear(tok, a.kv)
-        if geo is not None and geo.rows is not None:               # rows sharded: the keys are the whole frame(s), gathered
+        if geo is not None and geo.rows is not None and geo.rows.heads_ok(a.heads):
+            # rows sharded, head-parallel: whole frames of this rank's heads, so the anchor keyframe is addressed as in the unsharded call
+            rs = geo.rows
+            cw, hwf = c // rs.world, hw * rs.world
+            q_, k_, v_ = rs.to_heads([(q, 0), (kv, 0), (kv, c)], frames, hw, cw)
+            if anchor_t is None:
+                oh = ops.attention(q_, k_, v_, a.heads // rs.world, a.dim_head, batches=frames, lq=hwf, lk=hwf)
+            else:
+                oh = ops.attention(q_, k_, v_, a.heads // rs.world, a.dim_head, batches=frames, lq=hwf, lk=2 * hwf, kv_outer_rows=hwf,
+                                   seg1_len=hwf, seg1_div=frames_per_clip, seg1_mul=frames_per_clip, seg1_add=anchor_t)
+            o = rs.from_heads(oh, frames, hw, cw)
+        elif geo is not None and geo.rows is not None:             # rows sharded: the keys are the whole frame(s), gathered
             kv = gathered_kv(kv, frames, geo)
             hwk = hw * geo.rows.world
             if anchor_t is None:
@@ -645,7 +664,7 @@ class Upsample3D(nn.Module):
         if geo.rows is not None:                # rows sharded: one low-resolution halo row from each neighbour
             if self.conv_parity is None:
                 raise NotImplementedError("row-sharded Upsample3D needs the parity form (channels % 64 == 0, CCEDIT_SUBPIX on)")
-            s = ops.conv2d_upsampled(geo.rows.halo_rows(x), self.conv_parity, vpad=True)
+            s = ops.conv2d_upsampled(x, self.conv_parity, halo=geo.rows.halo_exchange(x))
         elif self.conv_parity is not None:      # four 2 x 2 convolutions on the low-resolution tensor: 4/9 of the multiply-adds
             s = ops.conv2d_upsampled(x, self.conv_parity)
         else:
@@ -1207,15 +1226,18 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
     _graph_failed = False
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, c: Dict[str, torch.Tensor], **kwargs) -> torch.Tensor:
+        # row-sharded evaluations are captured too when their exchanges are stream operations (RCCL; the host-staged gloo transport of the
+        # CPU / one-GPU tests is not): the launch count per rank is the single-GPU one while every kernel is N times shorter
         if (self.use_graph and not OpenAIWrapperControlLDM3DTV2V._graph_failed and not kwargs and x.is_cuda
-                and self.frame_shard is None and self.row_shard is None and ops.PROFILE is None and TRACE is None
-                and not torch.cuda.is_current_stream_capturing()):
+                and self.frame_shard is None and (self.row_shard is None or self.row_shard.can_capture())
+                and ops.PROFILE is None and TRACE is None and not torch.cuda.is_current_stream_capturing()):
             return self._forward_graphed(x, t, c)
         return self._forward_eager(x, t, c, **kwargs)
 
     def _forward_graphed(self, x, t, c):
         # PACK_GENERATION: a captured graph holds the addresses of the packed weights it was recorded with
         key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, self.cache_hint_stem, self.overlap_controlnet, PACK_GENERATION[0],
+               None if self.row_shard is None else (id(self.row_shard), self.row_shard.attn),
                tuple(sorted((k, self._tensor_key(v)) if torch.is_tensor(v) else (k, repr(v)) for k, v in c.items())))
         if self._graphs is None:
             self._graphs = {}
@@ -1324,7 +1346,9 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
         x8 = ops.ncthw_to_nhwc(x.float().contiguous(), 8)
         control_ready = None
-        if self.overlap_controlnet and sh is None and rs is None and ops.PROFILE is None and TRACE is None:
+        # (row-sharded: the side stream only when the two networks' exchanges may interleave freely — one communicator issues its
+        #  collectives in ONE order on every rank, which two host-ordered streams keep: both are launched by this thread in program order)
+        if self.overlap_controlnet and sh is None and (rs is None or rs.can_capture()) and ops.PROFILE is None and TRACE is None:
             main = torch.cuda.current_stream()
             if OpenAIWrapperControlLDM3DTV2V._side_stream is None:
                 OpenAIWrapperControlLDM3DTV2V._side_stream = {}
@@ -1333,7 +1357,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                 side = OpenAIWrapperControlLDM3DTV2V._side_stream[main.cuda_stream] = torch.cuda.Stream()
             side.wait_stream(main)                      # x8 / ctx2d / t are ready
             with torch.cuda.stream(side):
-                guided = self._guided_hint(hint5)
+                guided = self._guided_hint(hint5, rows=rs)
                 control = net.controlnet.run(x8, guided, t, self._text_kv(net.controlnet, context, ctx2d), context.shape[1], geo)
                 control_ready = torch.cuda.Event()
                 control_ready.record(side)

@@ -106,7 +106,7 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
          res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, out_f32: bool = False, use_bias: bool = True, tile: int = 0,
          gn_rows: int = 0, ln_eps: float = 0.0, ln_stats: Optional[torch.Tensor] = None, ln_sums=None,
-         row_sums: bool = False, subpix: int = 0, vpad: bool = False) -> torch.Tensor:
+         row_sums: bool = False, subpix: int = 0, vpad: bool = False, halo=None) -> torch.Tensor:
     """out[m, :] = epilogue(sum_taps W . A[src(m, tap)]).  a2d: [rows, lda] bf16 (last dim contiguous).
 
     gn_rows > 0 (= H*W of the output frames) asks the epilogue to also accumulate the GroupNorm(32) statistics of
@@ -126,6 +126,14 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
     assert out.stride(-1) == 1 and out.shape[0] == (4 * m if subpix else m)
     d = CcGemmDesc()
     d.subpix, d.vpad = subpix, int(vpad)
+    if halo is not None:            # (top, bottom) boundary rows of the neighbour ranks, each (frames, Win, C) with A's row stride, or None
+        assert not vpad and mode == GEMM_CONV2D
+        d.vpad = 2
+        for h_ in halo:
+            if h_ is not None and not (h_.dtype == BF16 and h_.is_cuda and h_.is_contiguous() and h_.dim() == 3 and h_.shape[1] == win
+                                       and h_.shape[2] == lda):
+                raise ValueError("gemm: halo rows must be contiguous cuda bf16 (frames, Win, lda) tensors")
+        d.halo_top, d.halo_bot = _ptr(halo[0]), _ptr(halo[1])
     d.M, d.N, d.Cin, d.Cin1, d.taps, d.mode = m, pw.n, pw.cin, cin1, pw.taps, mode
     d.Hin, d.Win, d.Hout, d.Wout = hin, win, hout, wout
     d.stride, d.pad, d.ksize, d.upsample = stride, pad, pw.ksize, int(upsample)
@@ -264,7 +272,8 @@ def ff320(x2d: Optional[torch.Tensor], pk: PackedFF320, eps: float = 1e-5, ln: b
 
 
 def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, upsample: bool = False,
-           x2: Optional[torch.Tensor] = None, gn: bool = False, out_hw: Optional[tuple] = None, vpad: bool = False, **kw) -> torch.Tensor:
+           x2: Optional[torch.Tensor] = None, gn: bool = False, out_hw: Optional[tuple] = None, vpad: bool = False, halo=None,
+           **kw) -> torch.Tensor:
     """x: (N, H, W, C) -> (N, Hout, Wout, Cout); 3x3 (pad 1) or 1x1 (pad 0) by the packed kernel size.
     gn=True: the output feeds a spatial GroupNorm — accumulate its statistics in the epilogue."""
     n, h, w, c = x.shape
@@ -277,10 +286,13 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, stride: int = 1, pad: int = 1, ups
         assert pw.ksize == 3 and pad == 1 and not upsample and x2 is None
         hout = (hv - pw.ksize) // stride + 1
         kw["vpad"] = True
+    if halo is not None:            # rows sharded over ranks, the neighbours' boundary rows as separate tensors (CcGemmDesc.vpad = 2)
+        assert pw.ksize == 3 and pad == 1 and not upsample and x2 is None and not vpad
+        kw["halo"] = halo
     if out_hw is not None:          # asymmetric padding (VAE Downsample, model.py:74-93: pad right/bottom only, conv pad 0):
         hout, wout = out_hw         # taps that fall outside the source read zeros, so only the output size changes
     a2 = None if x2 is None else x2.reshape(-1, x2.shape[-1])
-    if pw.ksize == 1 and pw.taps == 1 and stride == 1 and not upsample and out_hw is None and not vpad and CONV1X1_LINEAR:
+    if pw.ksize == 1 and pw.taps == 1 and stride == 1 and not upsample and out_hw is None and not vpad and halo is None and CONV1X1_LINEAR:
         # a 1 x 1 convolution is a Linear over the pixels (zero convs, skip connections): the Linear dispatch reaches the streaming
         # K = 320 / 640 kernels and the persistent GEMM, the convolution modes do not
         out = gemm(x.reshape(-1, c), pw, mode=GEMM_LINEAR, a2=a2, gn_rows=hout * wout if gn else 0, **kw)
@@ -294,17 +306,17 @@ CONV1X1_LINEAR = policy.on("conv1x1_linear")      # 0: 1 x 1 convs through the c
 SUBPIX = policy.on("subpix")      # 0: upsample + 3x3 conv through the nine-tap gather (A/B)
 
 
-def conv2d_upsampled(x: torch.Tensor, pws, vpad: bool = False) -> torch.Tensor:
+def conv2d_upsampled(x: torch.Tensor, pws, vpad: bool = False, halo=None) -> torch.Tensor:
     """conv3x3(nearest_upsample_2x(x)) as four 2 x 2 convolutions on x, one per output parity (packing.pack_upsample_parities):
     x (N, H, W, C) -> (N, 2H, 2W, Cout); every launch writes its quarter of the output pixels in place.  vpad: x carries one halo
-    row above and below its H rows (RowShard)."""
+    row above and below its H rows (RowShard, extended copy); halo = (top, bottom): the same rows as separate tensors."""
     _chk_act(x, "conv2d_upsampled")
     n, hx, w, c = x.shape
     h = hx - 2 if vpad else hx
     out = torch.empty((n * 4 * h * w, pws[0].n), dtype=BF16, device=x.device)
     for p, pw in enumerate(pws):
         gemm(x.reshape(-1, c), pw, mode=GEMM_CONV2D, m=n * h * w, hin=hx, win=w, hout=h, wout=w, stride=1, pad=0, out=out, subpix=p + 1,
-             vpad=vpad)
+             vpad=vpad, halo=halo)
     return out.view(n, 2 * h, 2 * w, pws[0].n)
 
 
@@ -616,6 +628,18 @@ def copy_row_blocks(src: torch.Tensor, dst: torch.Tensor, blocks: torch.Tensor, 
         assert add.dtype == BF16 and dst.dtype == BF16 and add.is_contiguous() and add.shape == dst.shape
     hip.check(hip.lib().ccedit_copy_row_blocks(src.data_ptr(), dst.data_ptr(), _ptr(add), blocks.data_ptr(), blocks.shape[0], max_rows,
                                                src.shape[1] * src.element_size(), _stream()), "ccedit_copy_row_blocks")
+    return dst
+
+
+def copy_2d_blocks(src: torch.Tensor, dst: torch.Tensor, blocks: torch.Tensor, rows: int, row_bytes: int):
+    """For every block s: dst_bytes[blocks[s,1] + r * dst_pitch : + row_bytes] = src_bytes[blocks[s,0] + r * src_pitch : + row_bytes],
+    r < rows.  src / dst: 2-D tensors with contiguous rows (the pitches are their row strides in bytes); blocks: int64 (n, 2) on the
+    device, byte offsets from the tensors' first element."""
+    assert src.is_cuda and dst.is_cuda and src.dim() == 2 and dst.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1
+    assert blocks.dtype == torch.int64 and blocks.is_cuda and blocks.is_contiguous() and blocks.shape[1] == 2
+    hip.check(hip.lib().ccedit_copy_2d_blocks(src.data_ptr(), dst.data_ptr(), blocks.data_ptr(), blocks.shape[0], rows, row_bytes,
+                                              src.stride(0) * src.element_size(), dst.stride(0) * dst.element_size(), _stream()),
+              "ccedit_copy_2d_blocks")
     return dst
 
 

@@ -177,18 +177,31 @@ class RowShard(_ShardComm):
     the work of EVERY kernel, whatever T is (whole keyframes of T = 17 over 8 ranks cap at 0.71 / 0.85, `sharding_efficiency`).
       * temporal operators (Conv1d over T, GroupNorm over C/32 x T, temporal attention) see all T frames of their pixels: LOCAL, no
         exchange — the 272 transpositions per step of FrameShard's pair mode do not exist here;
-      * 3x3 convolutions need the neighbour ranks' boundary rows: `halo_rows` (one row up, one down, point-to-point) builds the
-        (h / N + 2)-row source the conv kernels take with CcGemmDesc.vpad (zero rows where the frame ends);
+      * 3x3 convolutions need the neighbour ranks' boundary rows: `halo_exchange` receives one row from above and one from below
+        (point-to-point) into two small tensors the conv kernel reads IN PLACE (CcGemmDesc.vpad = 2, halo_top / halo_bot: no
+        extended copy of the slab; a stride-2 convolution only needs — and only exchanges — the row above);
       * spatial GroupNorm: local (sum, sum of squares) per (frame, group), `gn_stats` all-reduces the 32 doubles per frame;
-      * spatial self-attention: queries are local, `gather_rows` all-gathers the K / V rows of the frame (the RCCL all-gather
-        BASELINE.json names, at the spatial attention where this decomposition needs it); text cross-attention is local;
-      * the TVI2V anchor frame is a frame like any other: its K / V rows are part of the gathered tensor — no broadcast.
-    Collectives go through torch.distributed as in FrameShard (nccl = RCCL, gloo staged through the host)."""
+      * spatial self-attention, attn = "heads" (default): the 8 heads are split over the ranks instead of the rows — one
+        all-to-all brings every rank the WHOLE frame of q, k and v for its 8 / N heads (`to_heads`), it runs the full-frame attention
+        for them, and one all-to-all returns the outputs to the ranks that own the rows (`from_heads`): q, k, v, o each cross the
+        links once, (N - 1) / N of them — a quarter of what all-gathering K and V costs.  attn = "gather": the RCCL all-gather of
+        the K / V rows BASELINE.json names (`gather_rows`), local queries against the gathered frame; also the fallback when the
+        heads do not divide by N.  Text cross-attention is local in both;
+      * the TVI2V anchor frame is a frame like any other — its K / V rows arrive with everything else, no broadcast.
+    Collectives go through torch.distributed as in FrameShard (nccl = RCCL, gloo staged through the host).  Pack / unpack around the
+    exchanges are HIP copy kernels with index plans cached per shape (ccedit_copy_2d_blocks / ccedit_copy_row_blocks) writing into
+    recycled slabs: no torch.cat, no allocation per exchange; with RCCL the whole evaluation is captured into a HIP graph like the
+    single-GPU one."""
 
     mode = "rows"
 
-    def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, group=None):
+    def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, group=None, attn: str = "heads"):
+        if attn not in ("heads", "gather"):
+            raise ValueError(f"RowShard attn {attn!r}: 'heads' or 'gather'")
+        self.attn = attn
         self._init_comm(rank, world, group)
+        self._plans = {}
+        self._slabs = {}
 
     def rows(self, h: int) -> Tuple[int, int]:
         """[r0, r1) of this rank at a level with h rows."""
@@ -206,17 +219,42 @@ class RowShard(_ShardComm):
                              f"(the frame height must be a multiple of {64 * self.world} pixels)")
         return row_sharding_efficiency(h, self.world)
 
-    def halo_rows(self, x: torch.Tensor, below: bool = True) -> torch.Tensor:
-        """x (n, h_local, w, C) -> (n, 1 + h_local + below, w, C): the last row of rank - 1 on top, the first row of rank + 1 at the
-        bottom (`below`; a stride-2 convolution reads only upwards), zero rows at the ends of the frame."""
+    def can_capture(self) -> bool:
+        """May an evaluation that uses this shard be captured into a HIP graph?  RCCL collectives are stream operations and capture;
+        the host-staged transport (gloo) copies through host memory and cannot."""
+        return not self.staged
+
+    # -- slabs: wire-side scratch, two alternating buffers per role (see FrameShard._slab for why recycling is safe) -----------------
+    def _slab(self, tag: str, shape, like: torch.Tensor) -> torch.Tensor:
+        key = (tag, tuple(shape), like.dtype, str(like.device))
+        ent = self._slabs.get(key)
+        if ent is None:
+            ent = [[torch.empty(shape, dtype=like.dtype, device=like.device) for _ in range(2)], 0]
+            self._slabs[key] = ent
+        ent[1] ^= 1
+        return ent[0][ent[1]]
+
+    # -- 3x3 convolutions ---------------------------------------------------------------------------------------------------------
+    def halo_exchange(self, x: torch.Tensor, below: bool = True):
+        """x (n, h_local, w, C) -> (top, bottom): the last row of rank - 1 and (with `below`) the first row of rank + 1, each
+        (n, w, C) contiguous, None where the frame ends (the conv kernel reads zeros there).  The slab itself is not touched."""
         n, h, w, c = x.shape
         up, down = self._neighbours(x[:, 0].contiguous() if below else None, x[:, h - 1].contiguous(), "halo_rows", from_next=below)
-        top = up if up is not None else x.new_zeros((n, w, c))
-        pieces = [top.view(n, 1, w, c), x]
-        if below:
-            bot = down if down is not None else x.new_zeros((n, w, c))
-            pieces.append(bot.view(n, 1, w, c))
-        return torch.cat(pieces, dim=1)
+        return up, (down if below else None)
+
+    def halo_rows(self, x: torch.Tensor, below: bool = True) -> torch.Tensor:
+        """The same exchange as ONE extended tensor (n, 1 + h_local + below, w, C) with zero rows at the ends of the frame — what the
+        conv kernels take with CcGemmDesc.vpad = 1.  Costs a copy of the slab; the network uses `halo_exchange` (vpad = 2), this form
+        remains for the tests that pin the two against each other."""
+        n, h, w, c = x.shape
+        up, down = self.halo_exchange(x, below)
+        out = x.new_zeros((n, h + 1 + int(below), w, c))
+        out[:, 1:h + 1] = x
+        if up is not None:
+            out[:, 0] = up
+        if below and down is not None:
+            out[:, h + 1] = down
+        return out
 
     def gn_stats(self, stats: torch.Tensor) -> torch.Tensor:
         """Local (sum, sum of squares) per (frame, group) -> the frame's, scaled by 1 / world: ccedit_groupnorm_spatial_apply divides
@@ -225,15 +263,107 @@ class RowShard(_ShardComm):
         stats.mul_(1.0 / self.world)
         return stats
 
+    # -- equal-split all-to-all / all-gather ------------------------------------------------------------------------------------
+    def _a2a_equal(self, send: torch.Tensor, out: torch.Tensor, kind: str) -> torch.Tensor:
+        ev = self._tick(send, kind)
+        if self.staged and send.is_cuda:
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_to_all_single(h_out, send.detach().cpu(), group=self.group)
+            out.copy_(h_out)
+        else:
+            self.dist.all_to_all_single(out, send, group=self.group)
+        self._tock(ev)
+        self.bytes_sent += send.numel() * send.element_size() * (self.world - 1) // self.world
+        return out
+
+    def _row_perm(self, src: torch.Tensor, dst: torch.Tensor, blocks_cpu, key, max_rows: int) -> torch.Tensor:
+        """dst rows = a block permutation of src rows (2-D tensors of one row width): HIP copy kernel on the device, index copy on
+        the CPU (gloo tests of the plans)."""
+        if src.is_cuda:
+            from . import ops
+            pl = self._plans.get(key)
+            if pl is None:
+                pl = self._plans[key] = torch.tensor(blocks_cpu, dtype=torch.int64, device=src.device)
+            return ops.copy_row_blocks(src, dst, pl, max_rows)
+        for s0, d0, nr in blocks_cpu:
+            dst[d0:d0 + nr] = src[s0:s0 + nr]
+        return dst
+
+    def _col_blocks(self, src: torch.Tensor, dst: torch.Tensor, blocks_cpu, key, rows: int, row_elems: int) -> torch.Tensor:
+        """For every block (src element offset, dst element offset): `rows` rows of `row_elems` elements, row pitches = the tensors'
+        row strides — column slices <-> contiguous buffers."""
+        if src.is_cuda:
+            from . import ops
+            pl = self._plans.get(key)
+            if pl is None:
+                es = src.element_size()
+                pl = self._plans[key] = torch.tensor([(a * es, b * es) for a, b in blocks_cpu], dtype=torch.int64, device=src.device)
+            return ops.copy_2d_blocks(src, dst, pl, rows, row_elems * src.element_size())
+        sf, df = src.reshape(-1), dst.reshape(-1)
+        ps, pd = src.stride(0), dst.stride(0)
+        for a, b in blocks_cpu:
+            sv = torch.as_strided(sf, (rows, row_elems), (ps, 1), a)
+            torch.as_strided(df, (rows, row_elems), (pd, 1), b).copy_(sv)
+        return dst
+
+    # -- spatial self-attention, head-parallel ------------------------------------------------------------------------------------
+    def heads_ok(self, heads: int) -> bool:
+        return self.attn == "heads" and heads % self.world == 0
+
+    def to_heads(self, parts, frames: int, p_local: int, cw: int):
+        """parts: [(2-D tensor (frames * p_local, >= cols), first column)] — e.g. q, k, v as column blocks of one projection, each C
+        wide.  Every rank's rows of the SAME cw columns (its heads: columns [r cw, (r + 1) cw) of each part) are brought together:
+        returns [len(parts)] tensors (frames * world * p_local, cw), frame-major, the ranks' row blocks in rank order = whole frames
+        of this rank's heads."""
+        w_, np_ = self.world, len(parts)
+        rows = frames * p_local
+        like = parts[0][0]
+        send = self._slab("hs", (w_ * np_ * rows, cw), like)
+        for j, (t2d, c0) in enumerate(parts):        # block (dest r, part j): columns c0 + r cw .. of every local row
+            assert t2d.shape[0] == rows and t2d.stride(1) == 1
+            blocks = [(c0 + r * cw, ((r * np_ + j) * rows) * cw) for r in range(w_)]
+            self._col_blocks(t2d, send, blocks, ("hpack", j, c0, rows, cw, t2d.stride(0), str(like.device)), rows, cw)
+        recv = self._a2a_equal(send, self._slab("hr", (w_ * np_ * rows, cw), like), "to_heads")       # [src s][part][frame][p]
+        full = self._slab("hf", (np_ * frames * w_ * p_local, cw), like)                               # [part][frame][s][p]
+        blocks = [(((s * np_ + j) * frames + f) * p_local, ((j * frames + f) * w_ + s) * p_local, p_local)
+                  for s in range(w_) for j in range(np_) for f in range(frames)]
+        self._row_perm(recv, full, blocks, ("hunpack", np_, frames, p_local, cw, str(like.device)), p_local)
+        n_ = frames * w_ * p_local
+        return [full[j * n_:(j + 1) * n_] for j in range(np_)]
+
+    def from_heads(self, o: torch.Tensor, frames: int, p_local: int, cw: int) -> torch.Tensor:
+        """o (frames * world * p_local, cw): whole frames of this rank's heads -> (frames * p_local, world * cw): this rank's rows of
+        all heads."""
+        w_ = self.world
+        rows = frames * p_local
+        send = self._slab("os", (w_ * rows, cw), o)                                                     # [dest s][frame][p]
+        blocks = [((f * w_ + s) * p_local, (s * frames + f) * p_local, p_local) for s in range(w_) for f in range(frames)]
+        self._row_perm(o, send, blocks, ("opack", frames, p_local, cw, str(o.device)), p_local)
+        recv = self._a2a_equal(send, self._slab("or", (w_ * rows, cw), o), "from_heads")              # [src r][rows]
+        out = torch.empty((rows, w_ * cw), dtype=o.dtype, device=o.device)
+        self._col_blocks(recv, out, [(r * rows * cw, r * cw) for r in range(w_)], ("ounpack", rows, cw, str(o.device)), rows, cw)
+        return out
+
+    # -- spatial self-attention, gathered K / V ----------------------------------------------------------------------------------
     def gather_rows(self, x: torch.Tensor) -> torch.Tensor:
-        """x (frames, p_local, C): this rank's pixel rows of every frame -> (frames, world * p_local, C), every rank's in order."""
+        """x (frames, p_local, C): this rank's pixel rows of every frame -> (frames, world * p_local, C), every rank's in order.  One
+        all_gather_into_tensor ([rank][frame][p]) and one row-block copy kernel into frame order."""
+        frames, p_local, c = x.shape
         ev = self._tick(x, "gather_rows")
-        send = self._out(x)
-        bufs = [torch.empty_like(send) for _ in range(self.world)]
-        self.dist.all_gather(bufs, send, group=self.group)
+        send = x.contiguous()
+        if self.staged and x.is_cuda:
+            host = torch.empty((self.world * frames * p_local, c), dtype=x.dtype)
+            self.dist.all_gather_into_tensor(host, send.detach().cpu().view(-1, c), group=self.group)
+            recv = host.to(x.device)
+        else:
+            recv = self._slab("gr", (self.world * frames * p_local, c), x)
+            self.dist.all_gather_into_tensor(recv, send.view(-1, c), group=self.group)
         self._tock(ev)
         self.bytes_sent += send.numel() * send.element_size()
-        return torch.cat(bufs, dim=1).to(x.device)
+        out = torch.empty((frames * self.world * p_local, c), dtype=x.dtype, device=x.device)
+        blocks = [((s * frames + f) * p_local, (f * self.world + s) * p_local, p_local) for s in range(self.world) for f in range(frames)]
+        self._row_perm(recv, out, blocks, ("gunpack", frames, p_local, c, str(x.device)), p_local)
+        return out.view(frames, self.world * p_local, c)
 
 
 class FrameShard(_ShardComm):

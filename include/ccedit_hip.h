@@ -165,8 +165,13 @@ typedef struct CcGemmDesc {
      * (one row above and, for stride 1, one below the rows that produce output; zeros where the frame ends), Hout = output rows — so
      * the vertical padding is one less than `pad` (resp. than the parity's, with subpix; then Hin == Hout + 2).  How a frame whose ROWS
      * are sharded over ranks is convolved after the neighbours' boundary rows were received (ccedit_amd/parallel.py: RowShard;
-     * BASELINE.json config 4).  Generic tap-gather kernel only. */
+     * BASELINE.json config 4).  Generic tap-gather kernel only.
+     * 2 (ABI 10): the same sharded frame WITHOUT an extended copy — A holds the local rows only (Hin = local rows, padding geometry of
+     * the whole frame), and taps one row above / below them read halo_top / halo_bot, bf16 [frames][Win][lda-strided rows] as received
+     * from the neighbour ranks; a null pointer means the frame ends there (zeros). */
     int32_t vpad;
+    const void* halo_top;
+    const void* halo_bot;
 } CcGemmDesc;
 
 int ccedit_gemm(const CcGemmDesc* desc, void* stream);
@@ -315,6 +320,12 @@ int ccedit_cat_add_gn(const void* a, const void* b, const void* c, void* out, do
  * blocks: int64 [n_blocks][3] in DEVICE memory; max_rows = the largest block (grid sizing); row_bytes % 16 == 0. */
 int ccedit_copy_row_blocks(const void* src, void* dst, const void* add, const int64_t* blocks, int32_t n_blocks,
                            int64_t max_rows, int32_t row_bytes, void* stream);
+/* n_blocks strided 2-D copies sharing one geometry (rows x row_bytes, byte pitches) and differing in their byte offsets:
+ * blocks = int64 [n_blocks][2] (src offset, dst offset) in DEVICE memory.  The column-slice halves of the head-parallel attention
+ * exchange of a row-sharded clip (ccedit_amd/parallel.py: RowShard.to_heads / from_heads; BASELINE.json config 4).
+ * row_bytes, pitches and offsets are multiples of 16. */
+int ccedit_copy_2d_blocks(const void* src, void* dst, const int64_t* blocks, int32_t n_blocks, int64_t rows, int32_t row_bytes,
+                          int64_t src_pitch, int64_t dst_pitch, void* stream);
 /* y = a + b (bf16), n elements — `h = h + control.pop()` (controlmodel.py:537), `h += guided_hint` (:300) */
 int ccedit_add(const void* a, const void* b, void* y, int64_t n, void* stream);
 /* y = silu(x), bf16 elementwise (out_temporal's leading nn.SiLU, openaimodel.py:1627-1632) */

@@ -10,6 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 G = dict(model_channels=64, num_heads=2, context_dim=64)          # head dims 32 / 64 / 128 / 128
+G4 = dict(model_channels=64, num_heads=4, context_dim=64)         # head dims 16 / 32 / 64 / 64: four heads for the 4-rank head split
 T, H, W = 5, 16, 16
 
 
@@ -21,7 +22,7 @@ def _free_port():
     return p
 
 
-def _inputs(crossframe=False):
+def _inputs(crossframe=False, H=H):
     g = torch.Generator().manual_seed(21)
     x = torch.randn(1, 4, T, H, W, generator=g)
     x2 = torch.cat([x, x])
@@ -51,25 +52,40 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     from ccedit_amd.parallel import FrameShard, RowShard
     from ccedit_amd.sgm_compat import build_network
     from ccedit_amd.utils.synth import fill_module_
-    cfg = dict(G, crossframe=True) if crossframe else G
+    base = G4 if world == 4 else G
+    hh = 8 * world if mode.startswith("rows") and world > 2 else H          # rows: the latent height must be a multiple of 8 * world
+    cfg = dict(base, crossframe=True) if crossframe else base
     w = build_network("cpu", **cfg)
     fill_module_(w, prefix="model.")
     w.diffusion_model.pack("cuda")
-    x2, t, c = _inputs(crossframe)
+    x2, t, c = _inputs(crossframe, hh)
     cc = {k: v.cuda() for k, v in c.items()}
     ref = w(x2.cuda(), t.cuda(), cc).cpu() if rank == 0 else None      # unsharded evaluation
     groups = (None, dist.new_group(list(range(world)))) if rccl else (None, None)      # bench.py's two-communicator arrangement
-    cls = RowShard if mode == "rows" else FrameShard
-    if mode == "rows":        # the balanced decomposition: 1 / world of the latent ROWS of every frame per rank
-        shards = (RowShard(),)
+    cls = RowShard if mode.startswith("rows") else FrameShard
+    if mode.startswith("rows"):        # the balanced decomposition: 1 / world of the latent ROWS of every frame per rank
+        shards = (RowShard(attn="gather" if mode == "rows-gather" else "heads"),)
         w.row_shard = shards[0]
     else:
         shards = FrameShard.cfg_pair(T, groups=groups) if mode == "pair" else (FrameShard(T, mode=mode),)
         w.frame_shard = shards if mode == "pair" else shards[0]
     assert all(s.staged != rccl for s in shards)
     cls.issue_log = []
-    out = w(x2.cuda(), t.cuda(), cc).cpu()
+    xg, tg = x2.cuda(), t.cuda()
+    out = w(xg, tg, cc).cpu()
     torch.cuda.synchronize()
+    n_first = len(cls.issue_log)
+    if mode.startswith("rows") and rccl:
+        # RCCL exchanges are stream operations: the sharded evaluation is captured into a HIP graph on its second call with the same
+        # conditioning tensors and replayed afterwards — capture and replay must reproduce the eager bits
+        assert shards[0].can_capture()
+        again = [w(xg, tg, cc).cpu() for _ in range(3)]          # capture + replay, replay, replay
+        graphed = bool(getattr(w, "_graphs", None)) and any("graph" in e for e in w._graphs.values())
+        assert graphed == (w.use_graph and not type(w)._graph_failed), "the sharded evaluation was not captured"
+        assert all(torch.equal(out, a_) for a_ in again), "HIP-graph replay of the row-sharded evaluation differs from the eager one"
+        del cls.issue_log[n_first:]                              # (the capture pass issued the sequence once more)
+        for s_ in shards:
+            s_.n_collectives = n_first
     # Every rank must have issued the SAME sequence of collectives (kind, size class, communicator) from its host thread — with
     # two communicators on two streams ("pair") a rank-dependent order is the classic RCCL deadlock.  Element counts differ
     # between ranks only through the shard sizes, so the comparable part is (partition, kind).
@@ -96,13 +112,16 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("world,crossframe,mode", [(1, False, "a2a"), (1, True, "pair-rccl"), (1, False, "halo-rccl"), (2, False, "a2a"), (2, True, "a2a"), (2, False, "pair"),
                                                    (2, True, "pair"), (2, False, "halo"), (2, True, "halo"),
-                                                   (1, True, "rows-rccl"), (2, False, "rows"), (2, True, "rows")])
+                                                   (1, True, "rows-rccl"), (1, False, "rows-gather-rccl"), (2, False, "rows"), (2, True, "rows"),
+                                                   (2, False, "rows-gather"), (2, True, "rows-gather"), (4, False, "rows")])
 # uneven 3- and 4-way splits: primitives in test_parallel_gloo.py (several processes time-slicing one GPU through
 # host-staged gloo take minutes).  crossframe=True: TVI2V — the centre keyframe (rank 1 of 2 at T=5) adds img_control and
 # broadcasts its K/V.  "-rccl": one rank on the nccl (= RCCL) backend — every exchange degenerates to a self-exchange, but the
 # calls, tensor placement and communicator set-up are the ones the multi-GPU run makes.  "rows" = parallel.RowShard: every rank holds
 # all keyframes of 1 / world of the latent rows (8 of 16 here; 4 / 2 / 1 at the deeper levels) — halo rows for the 3x3 convs, all-reduced
-# GroupNorm sums, all-gathered K / V for the spatial attention, temporal operators local.  mode: "a2a" = all-to-all layout transposition around the temporal ops; "pair" = the same with the two
+# GroupNorm sums, head-parallel spatial attention through two all-to-alls ("rows") or all-gathered K / V ("rows-gather"), temporal operators
+# local; with RCCL ("-rccl") the sharded evaluation is also captured into a HIP graph and replayed; (4, "rows"): four ranks, four heads,
+# 32 latent rows.  mode: "a2a" = all-to-all layout transposition around the temporal ops; "pair" = the same with the two
 # CFG halves on mirrored partitions and two streams; "halo" = round-1 halo / all-reduce / all-gather exchanges
 def test_sharded_network_matches_unsharded(world, crossframe, mode):
     if not torch.cuda.is_available():
@@ -127,7 +146,7 @@ def test_sharded_network_matches_unsharded(world, crossframe, mode):
 
     e_un = rel(ref, orc)
     for rank, out, _, sent, _ in res:
-        assert out.shape == ref.shape == (2, 4, T, H, W)
+        assert out.shape == ref.shape and out.shape[:3] == (2, 4, T)
         e_sh, d = rel(out, orc), rel(out, ref)
         print(f"world {world} rank {rank}: err vs fp32 oracle: unsharded {e_un:.4f}, sharded {e_sh:.4f}; "
               f"sharded vs unsharded {d:.4f}; (bytes sent, exchanges) {sent}")

@@ -1229,6 +1229,21 @@ def test_convs_on_row_slabs_with_halo_rows_equal_the_whole_frame():
     slabsu = torch.cat([ops.conv2d_upsampled(ext(r), par, vpad=True) for r in range(parts)], dim=1)
     assert slabsu.shape == fullu.shape
     assert torch.equal(slabsu, fullu), "parity convs on row slabs differ from the whole frame"
+    # CcGemmDesc.vpad = 2: the same slabs WITHOUT the extended copy — the neighbours' boundary rows as two separate (n, w, C) tensors the
+    # kernel reads in place, None at the frame's ends (what RowShard.halo_exchange hands to network.sconv3): same gathers, same bits
+    def halo(r, below=True):
+        top = xd[:, r * hl - 1].contiguous() if r > 0 else None
+        bot = xd[:, (r + 1) * hl].contiguous() if (below and r < parts - 1) else None
+        return top, bot
+
+    def local(r):
+        return xd[:, r * hl:(r + 1) * hl].contiguous()
+    slabs3 = torch.cat([ops.conv2d(local(r), pw, halo=halo(r)) for r in range(parts)], dim=1)
+    assert torch.equal(slabs3, slabs), "halo rows read in place differ from the extended copy (conv3x3)"
+    slabs32 = torch.cat([ops.conv2d(local(r), pw, stride=2, halo=halo(r, below=False)) for r in range(parts)], dim=1)
+    assert torch.equal(slabs32, slabs2), "halo rows read in place differ from the extended copy (stride 2)"
+    slabs3u = torch.cat([ops.conv2d_upsampled(local(r), par, halo=halo(r)) for r in range(parts)], dim=1)
+    assert torch.equal(slabs3u, fullu), "halo rows read in place differ from the whole frame (parity convs)"
     # the statistics half of the spatial GroupNorm: slab sums add up to the frame's
     st = sum(ops.groupnorm_spatial_stats(xd[:, r * hl:(r + 1) * hl].contiguous()).clone() for r in range(parts))
     xf = xd.float().view(n, h * w, 32, cin // 32)

@@ -222,6 +222,28 @@ def _row_worker(rank, world, port, q):
     ok &= torch.allclose(rs.gn_stats(st), want, rtol=1e-12)
     # K / V rows: every rank ends with all pixel rows of every frame, in row order
     ok &= torch.equal(rs.gather_rows(mine.view(n, -1, c)), full.view(n, -1, c))
+    # halo rows as two separate tensors (what the conv kernel reads in place): the rows above / below, None at the frame's ends
+    up, down = rs.halo_exchange(mine)
+    ok &= (up is None) == (rank == 0) and (down is None) == (rank == world - 1)
+    ok &= up is None or torch.equal(up, full[:, r0 - 1])
+    ok &= down is None or torch.equal(down, full[:, r1])
+    up2, down2 = rs.halo_exchange(mine, below=False)          # a stride-2 convolution: only the row above travels
+    ok &= down2 is None and (up2 is None or torch.equal(up2, full[:, r0 - 1]))
+    # head-parallel attention exchange: q | k | v as column blocks of one projection -> whole frames of this rank's heads, and back
+    heads, d = 8, 4
+    C = heads * d
+    cw = C // world
+    qkv_full = torch.randn(n, h * w, 3 * C, generator=g)
+    p_local = (r1 - r0) * w
+    qkv = qkv_full[:, r0 * w:r1 * w].reshape(n * p_local, 3 * C).contiguous()
+    parts = rs.to_heads([(qkv, 0), (qkv, C), (qkv, 2 * C)], n, p_local, cw)
+    for j, got in enumerate(parts):
+        want = qkv_full[:, :, j * C + rank * cw: j * C + (rank + 1) * cw].reshape(n * h * w, cw)
+        ok &= torch.equal(got, want)
+    o_full = torch.randn(n, h * w, C, generator=g)             # every rank computes its heads' columns of the whole frames
+    mine_o = o_full[:, :, rank * cw:(rank + 1) * cw].reshape(n * h * w, cw).contiguous()
+    back = rs.from_heads(mine_o, n, p_local, cw)
+    ok &= torch.equal(back, o_full[:, r0 * w:r1 * w].reshape(n * p_local, C))
     q.put((rank, bool(ok), rs.n_collectives, rs.bytes_sent, [k for _, k, _ in RowShard.issue_log]))
     dist.barrier()
     dist.destroy_process_group()
@@ -241,8 +263,8 @@ def test_row_shard_primitives_gloo(world):
         p.join(30)
         assert p.exitcode == 0
     assert all(r[1] for r in res), [r[:2] for r in res]
-    assert all(r[2] == 4 and r[4] == res[0][4] for r in res)              # same collectives, same order, on every rank
-    assert res[0][4] == ["halo_rows", "halo_rows", "allreduce", "gather_rows"]
+    assert all(r[2] == 8 and r[4] == res[0][4] for r in res)              # same collectives, same order, on every rank
+    assert res[0][4] == ["halo_rows", "halo_rows", "allreduce", "gather_rows", "halo_rows", "halo_rows", "to_heads", "from_heads"]
     # an interior rank sends two boundary rows per halo exchange, the end ranks one
     assert res[0][3] < res[world // 2][3] or world == 2
 
