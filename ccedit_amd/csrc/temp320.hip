@@ -2,7 +2,7 @@
 // openaimodel.py:617-629, 674-687) as a STREAMING kernel with the weights held in registers — gfx950.
 //
 // Every block shape of the tiled GEMMs lands at 230-290 us for this layer (208896 rows, 128 GFLOP, 0.4-0.5 GB of operands:
-// tools/exp/temp320_tiles.py): with 320 output channels a pixel tile meets 3-5 channel tiles, and each of them pulls the rows of
+// a tile sweep, round 4): with 320 output channels a pixel tile meets 3-5 channel tiles, and each of them pulls the rows of
 // three frames through the L2 -> LDS path again.  Here (the scheme of lin320s / lin640s, lin640.hip) a workgroup keeps the
 // weights of ALL THREE TAPS for a 128-channel slice in registers — wave w: 16 channels x 3 taps x 320 k = 30 A fragments, 120 VGPRs —
 // and walks pixel COLUMNS (clip, 16 pixels) frame by frame: the 16 x 320 activation tile of frame t arrives once by DMA and every

@@ -53,6 +53,15 @@ class Geometry:
         self.b, self.t, self.shard = b, t, shard
         self.rows = rows            # parallel.RowShard: every rank holds 1 / N of the ROWS of all frames (sconv3 / sgn / gathered K / V)
 
+    def half(self) -> "Geometry":
+        """The geometry of ONE CFG half of the batch (the shared prefix of the two halves is evaluated once, see `twin`)."""
+        return Geometry(self.b // 2, self.t, self.shard, self.rows)
+
+
+def twin(x: torch.Tensor) -> torch.Tensor:
+    """A tensor computed for one CFG half, materialised for both (uc first, then c: the same rows twice)."""
+    return torch.cat([x, x])
+
 
 def sconv3(x, pw, geo: Geometry, stride: int = 1, **kw):
     """Conv2d 3x3, pad 1 (stride 1 or 2).  Rows sharded (geo.rows): the neighbour ranks' boundary rows are received into two small
@@ -318,10 +327,16 @@ class BasicTransformerBlock(nn.Module):
         self.attn2 = CrossAttention(dim, context_dim, n_heads, d_head)
         self.norm1, self.norm2, self.norm3 = Norm(dim, 1e-5), Norm(dim, 1e-5), Norm(dim, 1e-5)
 
-    def run(self, tok, frames: int, hw: int, ctx_kv_src, ctx_len: int, frames_per_clip: int, geo: Optional[Geometry] = None, tail=None):
-        """tail = (proj_out Conv, x2d, gn_rows): also apply the owning transformer's proj_out + residual (transformer_tail)."""
+    def run(self, tok, frames: int, hw: int, ctx_kv_src, ctx_len: int, frames_per_clip: int, geo: Optional[Geometry] = None, tail=None,
+            shared: bool = False):
+        """tail = (proj_out Conv, x2d, gn_rows): also apply the owning transformer's proj_out + residual (transformer_tail).
+        shared: `tok` holds ONE CFG half (frames / 2 frames) whose twin is identical — the self-attention, which does not see the
+        text, is evaluated once; its result is repeated for the text cross-attention, where the halves part."""
         a1, a2 = self.attn1, self.attn2
         c = a1.inner
+        full_frames = frames
+        if shared:
+            frames //= 2
         qkv = ln_linear(tok, self.norm1, a1.qkv, self.qkv_ln)      # (dim 320, 3 slices: folding the norm into lin320 does not pay)
         if geo is not None and geo.rows is not None and geo.rows.heads_ok(a1.heads):
             # rows sharded, head-parallel: all-to-all q, k, v by head -> whole frames of 8 / N heads here -> all-to-all o back
@@ -339,6 +354,8 @@ class BasicTransformerBlock(nn.Module):
             o = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], a1.heads, a1.dim_head, batches=frames, lq=hw, lk=hw,
                               q_log2=a1.q_log2)
         tok = linear_ln_producer(o, a1.to_out[0].pw, res1=tok)
+        if shared:
+            tok, frames = twin(tok), full_frames
         q = ln_linear(tok, self.norm2, a2.to_q.pw, self.q2_ln)
         # [B*L, 2C]: once per clip, shared by its T frames; normally a column slice of the network's batched projection (TextKV)
         kv = ctx_kv_src.of(self) if isinstance(ctx_kv_src, TextKV) else ops.linear(ctx_kv_src, a2.kv)
@@ -468,15 +485,20 @@ class SpatialTransformer(nn.Module):
             self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, n_heads, d_head, context_dim)])
         self.proj_out = Conv(inner, in_channels, 1)
 
-    def run_spatial(self, x, ctx2d, ctx_len, frames_per_clip, gn: bool = False, geo: Optional[Geometry] = None):
+    def run_spatial(self, x, ctx2d, ctx_len, frames_per_clip, gn: bool = False, geo: Optional[Geometry] = None, shared: bool = False):
+        """shared: x holds ONE of two identical CFG halves; the result is the full batch (the halves part at the text attention)."""
         n, h, w, c = x.shape
         a = sgn(x, self.norm, geo, False) if geo is not None else ops.groupnorm_spatial(x, self.norm.g, self.norm.b, self.norm.eps, False)
         tok = linear_ln_producer(a.view(-1, c), self.proj_in.pw)
+        if shared:
+            if self.disable_text_ca:
+                raise ValueError("a transformer without text attention has no point where the CFG halves part")
+            x, n = twin(x), 2 * n
         tail = (self.proj_out, x.view(-1, c), h * w if (gn and self.gn_out) else 0)
         if self.disable_text_ca:
             y = self.transformer_blocks[0].run_frames(tok, n, h * w, geo=geo, tail=tail)
         else:
-            y = self.transformer_blocks[0].run(tok, n, h * w, ctx2d, ctx_len, frames_per_clip, geo=geo, tail=tail)
+            y = self.transformer_blocks[0].run(tok, n, h * w, ctx2d, ctx_len, frames_per_clip, geo=geo, tail=tail, shared=shared)
         return ops.carry_gn_stats(y, y.view(n, h, w, c))
 
     # Does the consumer of this transformer's output read GroupNorm statistics from the producer's epilogue?  True unless the owning
@@ -484,8 +506,8 @@ class SpatialTransformer(nn.Module):
     # are not accumulated, and at dim 320 proj_out can ride in the block-tail launch.
     gn_out = True
 
-    def run(self, x, geo, ctx2d, ctx_len):
-        return self.run_spatial(x, ctx2d, ctx_len, geo.t, gn=True, geo=geo)      # the next block opens with a GroupNorm
+    def run(self, x, geo, ctx2d, ctx_len, shared: bool = False):
+        return self.run_spatial(x, ctx2d, ctx_len, geo.t, gn=True, geo=geo, shared=shared)      # the next block opens with a GroupNorm
 
 
 class SpatialTransformer3D(SpatialTransformer):
@@ -502,8 +524,8 @@ class SpatialTransformer3D(SpatialTransformer):
         self.transformer_blocks_temporal = nn.ModuleList([BasicTransformerSingleLayerBlock(inner, n_heads, d_head)])
         self.proj_out_temporal = Conv(inner, in_channels, 1, dims=1)
 
-    def run(self, x, geo, ctx2d, ctx_len):
-        y = self.run_spatial(x, ctx2d, ctx_len, geo.t, geo=geo)
+    def run(self, x, geo, ctx2d, ctx_len, shared: bool = False):
+        y = self.run_spatial(x, ctx2d, ctx_len, geo.t, geo=geo, shared=shared)
         n, h, w, c = y.shape
         if _a2a(geo):       # the whole temporal branch (GroupNorm_T, projections, attention over T, FF) is per pixel:
             sh = geo.shard  # it runs on all T frames of this rank's pixel block, between two all-to-alls
@@ -545,8 +567,8 @@ class SpatialTransformer3DCA(SpatialTransformer3D):
     def gn_out_3d(self) -> bool:
         return True            # the 3-D transformer's output feeds this class's own GroupNorm (norm_temporal_ca): statistics wanted
 
-    def run(self, x, geo, ctx2d, ctx_len):
-        y = super().run(x, geo, ctx2d, ctx_len)
+    def run(self, x, geo, ctx2d, ctx_len, shared: bool = False):
+        y = super().run(x, geo, ctx2d, ctx_len, shared=shared)
         n, h, w, c = y.shape
         nc = self.norm_temporal_ca
         a = sgn(y, nc, geo, False)
@@ -672,17 +694,30 @@ class Upsample3D(nn.Module):
         return temporal_conv3(s, self.conv_temporal.pw, geo, res_self=True)
 
 
+def _splits_at_text(block) -> bool:
+    """Does this block end in a transformer whose text cross-attention is where two otherwise identical CFG halves part?"""
+    return (len(block) >= 2 and isinstance(block[0], (ResBlock, ResBlock3D)) and isinstance(block[-1], SpatialTransformer)
+            and not block[-1].disable_text_ca)
+
+
 class TimestepEmbedSequential(nn.Sequential):
     """Container with the reference's name (openaimodel.py:85-126); dispatch happens in the nets."""
 
-    def run(self, x, emb_silu, geo, ctx2d, ctx_len):
+    def run(self, x, emb_silu, geo, ctx2d, ctx_len, shared: bool = False):
+        """shared: x holds ONE of two identical CFG halves (geo is the FULL batch's geometry); the block's transformer returns the
+        full batch — the halves part at its text cross-attention.  Only a block that ends in such a transformer can be entered shared."""
         for layer in self:
             if isinstance(layer, (ResBlock, ResBlock3D)):
-                x = layer.run(x, emb_silu, geo)
+                x = layer.run(x, emb_silu, geo.half() if shared else geo)
             elif isinstance(layer, SpatialTransformer):
-                x = layer.run(x, geo, ctx2d, ctx_len)
+                x = layer.run(x, geo, ctx2d, ctx_len, shared=shared)
+                shared = False
             else:
+                if shared:
+                    raise ValueError("shared evaluation must end at a transformer with text attention")
                 x = layer.run(x, geo)
+        if shared:
+            raise ValueError("shared evaluation must end at a transformer with text attention")
         return x
 
 
@@ -955,26 +990,32 @@ class ControlNet2D(UNetModel):
             h = sconv3(h, cv.pw, geo, stride=cv.stride, act=0 if last else ACT_SILU)
         return h
 
-    def run(self, x_nhwc, guided, timesteps, ctx2d, ctx_len, geo: Geometry) -> List[torch.Tensor]:
+    def run(self, x_nhwc, guided, timesteps, ctx2d, ctx_len, geo: Geometry, shared: bool = False) -> List[torch.Tensor]:
         """x_nhwc (B*T, h, w, 8) bf16, guided = hint_stem(remapped hint) (B*T, h, w, C) -> 13 residuals.
         controlnet_img (no_add_x + identity hint block): x_nhwc is ignored and `guided` is the 8-channel-padded
-        reference latent; the first block's output is input_blocks[0](guided) (controlmodel.py:283-299)."""
+        reference latent; the first block's output is input_blocks[0](guided) (controlmodel.py:283-299).
+        shared (see OpenAIWrapperControlLDM3DTV2V._cfg_twins): the two CFG halves of the batch are identical up to the text — x_nhwc
+        and guided hold ONE half, and everything up to the first text cross-attention (input_blocks.0, the ResBlock and the
+        self-attention of input_blocks.1) is evaluated once; the results are the full batch's."""
         emb_silu = self._emb_silu(timesteps)
         ctx2d = self.text_kv(ctx2d)
+        if shared and not _splits_at_text(self.input_blocks[1]):
+            raise ValueError("shared CFG prefix: input_blocks.1 must end in a transformer with text attention")
         outs = []
         h = x_nhwc
         for i, (block, zc) in enumerate(zip(self.input_blocks, self.zero_convs)):
             if i == 0 and self.no_add_x:
                 h = sconv3(guided, block[0].pw, geo)
             elif i == 0:
-                h = sconv3(h, block[0].pw, geo, res1=guided.view(-1, guided.shape[-1]))     # h = conv(x); h += guided_hint
+                h = sconv3(h, block[0].pw, geo.half() if shared else geo, res1=guided.view(-1, guided.shape[-1]))     # h = conv(x); h += guided_hint
             else:
-                h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
+                h = block.run(h, emb_silu, geo, ctx2d, ctx_len, shared=shared and i == 1)
             if TRACE is not None:
                 _trace(f"controlnet.input_blocks.{i}", h)
                 if i == 0 and not self.no_add_x:
                     _trace("controlnet.guided_hint", guided)
-            outs.append(ops.conv2d(h, zc[0].pw))
+            zo = ops.conv2d(h, zc[0].pw)
+            outs.append(twin(zo) if (shared and i == 0) else zo)
         h = self.middle_block.run(h, emb_silu, geo, ctx2d, ctx_len)
         _trace("controlnet.middle_block", h)
         outs.append(ops.conv2d(h, self.middle_block_out[0].pw))
@@ -1011,12 +1052,14 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
             self.controlnet_img = instantiate_from_config(controlnet_img_config)
 
     def run(self, x_nhwc, timesteps, ctx2d, ctx_len, control: List[torch.Tensor], geo: Geometry,
-            img_control: Optional[List[torch.Tensor]] = None, control_ready=None):
+            img_control: Optional[List[torch.Tensor]] = None, control_ready=None, shared: bool = False):
         """x_nhwc (B*T, h, w, 8) bf16; control = 13 NHWC residuals (consumed); img_control = 13 (B, h, w, C)
         residuals added in place to the centre frame T//2 of every clip (controlmodel.py:529-535)
         -> eps (B*T, h, w, out) fp32."""
         emb_silu = self._emb_silu(timesteps)
         ctx2d = self.text_kv(ctx2d)
+        if shared and not _splits_at_text(self.input_blocks[1]):
+            raise ValueError("shared CFG prefix: input_blocks.1 must end in a transformer with text attention")
 
         def add_center(hh):
             if img_control is not None:
@@ -1026,9 +1069,9 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
                     centre = geo.shard.t_glob // 2 - geo.shard.t0
                     if not 0 <= centre < geo.t:
                         return hh
-                for b in range(geo.b):
+                for b in range(hh.shape[0] // geo.t):            # (a shared-prefix tensor holds one CFG half; ic then holds one too)
                     fr = hh[b * geo.t + centre]
-                    ops.add(fr, ic[b], out=fr)
+                    ops.add(fr, ic[b % ic.shape[0]], out=fr)
                 if hasattr(hh, "_gn_stats"):
                     del hh._gn_stats                             # modified in place: the producer's statistics are stale
                 if hasattr(hh, "_gn_global"):
@@ -1039,12 +1082,14 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
         h = x_nhwc
         for i, block in enumerate(self.input_blocks):
             if i == 0:
-                s = sconv3(h, block[0].pw, geo)
-                h = temporal_conv3(s, self.input_blocks_temporal[0].pw, geo, res_self=True)
+                g0 = geo.half() if shared else geo
+                s = sconv3(h, block[0].pw, g0)
+                h = temporal_conv3(s, self.input_blocks_temporal[0].pw, g0, res_self=True)
             else:
-                h = block.run(h, emb_silu, geo, ctx2d, ctx_len)
+                h = block.run(h, emb_silu, geo, ctx2d, ctx_len, shared=shared and i == 1)
             _trace(f"input_blocks.{i}", h)
-            hs.append(add_center(h))
+            h = add_center(h)
+            hs.append(twin(h) if (shared and i == 0) else h)     # (the skip connection serves the full batch)
         h = add_center(self.middle_block.run(h, emb_silu, geo, ctx2d, ctx_len))
         if control_ready is not None:      # ControlNet ran on a side stream while the encoder above was running
             torch.cuda.current_stream().wait_event(control_ready)
@@ -1157,16 +1202,17 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         self._hint_val = None
         self._hint_slices = None
         self._hint_dup = None
+        self._twin_val = None
         self._tkv_val = None
         self._graphs = None
 
-    def _guided_hint(self, hint5d: torch.Tensor, rows=None):
+    def _guided_hint(self, hint5d: torch.Tensor, rows=None, half: bool = False):
         """hint_stem(1 - (hint+1)/2), cached per source tensor.  An entry is keyed by (address, shape, strides, in-place
         version) AND keeps a reference to the source tensor: while the entry lives its storage cannot be freed, so no
         later tensor (the next clip's hint) can be handed that address by the caching allocator — a key match always
         means the same bytes."""
         net = self.diffusion_model.controlnet
-        key = self._tensor_key(hint5d) + (PACK_GENERATION[0],)        # (a re-pack replaces the stem's weights)
+        key = self._tensor_key(hint5d) + (PACK_GENERATION[0], half)        # (a re-pack replaces the stem's weights)
         if self.cache_hint_stem and isinstance(self._hint_val, dict) and key in self._hint_val:
             return self._hint_val[key][1]
         # The two CFG halves carry the SAME hint (the sampling scripts give `uc` a clone of c's control_hint, sampling_tv2v.py:339-344,
@@ -1177,22 +1223,49 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         if self.dedup_hint and hint5d.shape[0] % 2 == 0:
             if not isinstance(self._hint_dup, dict) or len(self._hint_dup) >= 8:
                 self._hint_dup = {}
-            ent = self._hint_dup.get(key)
+            ent = self._hint_dup.get(key[:-1])
             if ent is None and not torch.cuda.is_current_stream_capturing():
                 k = hint5d.shape[0] // 2
-                ent = self._hint_dup[key] = (hint5d, bool(torch.equal(hint5d[:k], hint5d[k:])))
+                ent = self._hint_dup[key[:-1]] = (hint5d, bool(torch.equal(hint5d[:k], hint5d[k:])))
             dup = ent is not None and ent[1]
+        dup = dup or half           # (half: the caller — _cfg_twins — has compared the halves itself)
         src = hint5d[: hint5d.shape[0] // 2] if dup else hint5d
         # control_hint in [-1,1] -> 1 - (h+1)/2 (wrappers.py:160-162), fused into the layout change
         hint8 = ops.ncthw_to_nhwc(src.float().contiguous(), 8, scale=-0.5, shift=0.5)
         g = net.hint_stem(hint8, rows=rows)
-        if dup:
+        if dup and not half:
             g = torch.cat([g, g])
         if self.cache_hint_stem:
             if not isinstance(self._hint_val, dict) or len(self._hint_val) >= 4:     # one entry per CFG half (+ shards)
                 self._hint_val = {}
             self._hint_val[key] = (hint5d, g)
         return g
+
+    # The two CFG halves of an evaluation (guiders.py:57-67: x, sigma, control_hint and cond_feat are the SAME tensor twice, only the
+    # text differs) are identical up to the first text cross-attention: input_blocks.0, the ResBlock and the 6144-key self-attention
+    # of input_blocks.1 — in the UNet and in the ControlNet — and all of controlnet_img.  With `share_cfg_prefix` that prefix is
+    # evaluated ONCE (half the rows in every launch) and repeated where the halves part: same results (the halves' shared prefix is
+    # then bit-identical, which the batched launches only deliver to summation-order noise), -2...3 ms per step at 17 x 512 x 768.
+    # Whether the halves ARE equal is checked on the device (one compare + host sync per new (x, t) tensor pair, remembered like the
+    # hint's); anything else — different latents in the two halves, odd batches, sharded evaluation — takes the general path.  bench.py
+    # reports the FLOPs executed (`executed_flops_per_step`) next to the algorithmic count the metric is priced with.
+    share_cfg_prefix = policy.on("share_cfg_prefix")
+    _twin_val = None
+
+    def _cfg_twins(self, x: torch.Tensor, t: torch.Tensor, c: Dict[str, torch.Tensor]) -> bool:
+        if not self.share_cfg_prefix or x.shape[0] % 2 or x.shape[0] < 2 or torch.cuda.is_current_stream_capturing():
+            return False
+        k = x.shape[0] // 2
+        key = self._tensor_key(x) + self._tensor_key(t) + tuple(self._tensor_key(c[n]) for n in ("control_hint", "cond_feat") if c.get(n) is not None)
+        if not isinstance(self._twin_val, dict) or len(self._twin_val) >= 8:
+            self._twin_val = {}
+        ent = self._twin_val.get(key)
+        if ent is None:
+            same = (x[:k] == x[k:]).all() & (t[:k] == t[k:]).all() & (c["control_hint"][:k] == c["control_hint"][k:]).all()
+            if c.get("cond_feat") is not None:
+                same = same & (c["cond_feat"][:k] == c["cond_feat"][k:]).all()
+            ent = self._twin_val[key] = ([x, t] + [c[n] for n in ("control_hint", "cond_feat") if c.get(n) is not None], bool(same.item()))
+        return ent[1]
 
     _tkv_val = None
 
@@ -1235,8 +1308,11 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         return self._forward_eager(x, t, c, **kwargs)
 
     def _forward_graphed(self, x, t, c):
+        # the shared CFG prefix is a property of the VALUES of x and t: decided here, outside any capture, and part of the key — a
+        # graph recorded for identical halves is never replayed for different ones
+        twins = self._cfg_twins(x, t, c) if (self.frame_shard is None and self.row_shard is None) else False
         # PACK_GENERATION: a captured graph holds the addresses of the packed weights it was recorded with
-        key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, self.cache_hint_stem, self.overlap_controlnet, PACK_GENERATION[0],
+        key = (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, self.cache_hint_stem, self.overlap_controlnet, PACK_GENERATION[0], twins,
                None if self.row_shard is None else (id(self.row_shard), self.row_shard.attn),
                tuple(sorted((k, self._tensor_key(v)) if torch.is_tensor(v) else (k, repr(v)) for k, v in c.items())))
         if self._graphs is None:
@@ -1247,7 +1323,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                 self._graphs.pop(next(iter(self._graphs)))
             # the conditioning tensors are pinned while the entry lives: a key match always means the same bytes (see _guided_hint)
             self._graphs[key] = dict(pins=[v for v in c.values() if torch.is_tensor(v)])
-            return self._forward_eager(x, t, c)
+            return self._forward_eager(x, t, c, _twins=twins)
         if "graph" not in ent:
             try:
                 ent["x"], ent["t"] = x.clone(), t.clone()
@@ -1260,7 +1336,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                     # fallback would accumulate statistics onto uninitialised memory and wait on garbage split-K counters
                     ops.reset_stream_scratch()
                     try:
-                        ent["out"] = self._forward_eager(ent["x"], ent["t"], c)
+                        ent["out"] = self._forward_eager(ent["x"], ent["t"], c, _twins=twins)
                         if self._fail_capture_for_test:
                             raise RuntimeError("capture failure injected by a test")
                     finally:
@@ -1274,7 +1350,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                 self._graphs = None
                 ops.reset_stream_scratch()                      # (again: whatever the aborted capture left behind)
                 warnings.warn(f"HIP graph capture of the network evaluation failed ({type(e).__name__}: {e}); continuing without graphs")
-                return self._forward_eager(x, t, c)
+                return self._forward_eager(x, t, c, _twins=twins)
         else:
             ent["x"].copy_(x)
             ent["t"].copy_(t)
@@ -1345,10 +1421,21 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         context = c["crossattn"]
         ctx2d = context.to(torch.bfloat16).reshape(-1, context.shape[-1]).contiguous()
         x8 = ops.ncthw_to_nhwc(x.float().contiguous(), 8)
+        # identical CFG halves: their shared prefix is evaluated once (see _cfg_twins); never for sharded / traced / split evaluations
+        twins = kwargs.get("_twins")
+        if sh is not None or rs is not None or TRACE is not None or kwargs.get("_half"):
+            twins = False
+        elif twins is None:
+            twins = self._cfg_twins(x, t, c)
+        twins = bool(twins) and _splits_at_text(net.input_blocks[1]) and _splits_at_text(net.controlnet.input_blocks[1])
+        x8h = x8[: x8.shape[0] // 2] if twins else x8
         control_ready = None
-        # (row-sharded: the side stream only when the two networks' exchanges may interleave freely — one communicator issues its
-        #  collectives in ONE order on every rank, which two host-ordered streams keep: both are launched by this thread in program order)
-        if self.overlap_controlnet and sh is None and (rs is None or rs.can_capture()) and ops.PROFILE is None and TRACE is None:
+        # Row-sharded: a captured evaluation keeps everything on ONE stream — capturing RCCL collectives issued from two streams that
+        # fork and join inside the graph crashes the runtime (ROCm 7.2, one or two communicators alike: tools/exp/rows_rccl_debug.py),
+        # and with every kernel N times shorter it is the graph, not the overlap, that matters.  Eager RCCL evaluations (graphs off)
+        # do use the side stream, the ControlNet's exchanges on a communicator of their own (RowShard.sibling).
+        rows_side_ok = rs is None or (rs.can_capture() and not (self.use_graph and not OpenAIWrapperControlLDM3DTV2V._graph_failed))
+        if self.overlap_controlnet and sh is None and rows_side_ok and ops.PROFILE is None and TRACE is None:
             main = torch.cuda.current_stream()
             if OpenAIWrapperControlLDM3DTV2V._side_stream is None:
                 OpenAIWrapperControlLDM3DTV2V._side_stream = {}
@@ -1357,24 +1444,32 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                 side = OpenAIWrapperControlLDM3DTV2V._side_stream[main.cuda_stream] = torch.cuda.Stream()
             side.wait_stream(main)                      # x8 / ctx2d / t are ready
             with torch.cuda.stream(side):
-                guided = self._guided_hint(hint5, rows=rs)
-                control = net.controlnet.run(x8, guided, t, self._text_kv(net.controlnet, context, ctx2d), context.shape[1], geo)
+                # rows sharded: the ControlNet's exchanges go through a communicator of their own (RowShard.sibling)
+                rs_side = None if rs is None else rs.sibling()
+                geo_side = geo if rs is None else Geometry(b, x.shape[2], sh, rows=rs_side)
+                guided = self._guided_hint(hint5, rows=rs_side, half=twins)
+                control = net.controlnet.run(x8h, guided, t, self._text_kv(net.controlnet, context, ctx2d), context.shape[1], geo_side,
+                                             shared=twins)
                 control_ready = torch.cuda.Event()
                 control_ready.record(side)
             for tns in (x8, ctx2d):
-                tns.record_stream(side)                 # allocated on the main stream, read on the side stream
+                tns.record_stream(side)                 # allocated on the main stream, read on the side stream (x8h is a view of x8)
             for tns in control:
                 tns.record_stream(main)                 # and vice versa
         else:
-            guided = self._guided_hint(hint5, rows=rs)
-            control = net.controlnet.run(x8, guided, t, self._text_kv(net.controlnet, context, ctx2d), context.shape[1], geo)
+            guided = self._guided_hint(hint5, rows=rs, half=twins)
+            control = net.controlnet.run(x8h, guided, t, self._text_kv(net.controlnet, context, ctx2d), context.shape[1], geo, shared=twins)
         img_control = None
         if cond_feat is not None and (sh is None or sh.owner_of(nt // 2) == sh.rank):
             # TVI2V (wrappers.py:176-190): controlnet_img on the reference latent; its residuals only touch keyframe T//2,
             # so under frame sharding only the rank holding that keyframe evaluates it
-            cf8 = ops.ncthw_to_nhwc(cond_feat.float()[:, :, None].contiguous(), 8)
-            img_control = net.controlnet_img.run(None, cf8, t, None, 0, Geometry(b, 1, rows=rs))
-        eps = net.run(x8, t, self._text_kv(net, context, ctx2d), context.shape[1], control, geo, img_control, control_ready=control_ready)
+            # (identical CFG halves: controlnet_img has no text input — ALL of it is evaluated once, the UNet indexes its residuals modulo)
+            cf = cond_feat[: b // 2] if twins else cond_feat
+            tt_ = t[: b // 2] if twins else t
+            cf8 = ops.ncthw_to_nhwc(cf.float()[:, :, None].contiguous(), 8)
+            img_control = net.controlnet_img.run(None, cf8, tt_, None, 0, Geometry(cf.shape[0], 1, rows=rs))
+        eps = net.run(x8h, t, self._text_kv(net, context, ctx2d), context.shape[1], control, geo, img_control, control_ready=control_ready,
+                      shared=twins)
         if sh is not None:             # all ranks get the full (B, C, T, h, w) prediction (1.6 MB at 17x64x96)
             eps = sh.gather_pixels(eps.view(-1, eps.shape[-1]), b, lh * lw) if sh.mode == "a2a" else sh.gather_frames(eps, b)
             eps = eps.view(b * nt, lh, lw, -1)

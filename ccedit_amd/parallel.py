@@ -219,6 +219,29 @@ class RowShard(_ShardComm):
                              f"(the frame height must be a multiple of {64 * self.world} pixels)")
         return row_sharding_efficiency(h, self.world)
 
+    _sibling = None
+
+    def sibling(self) -> "RowShard":
+        """A second RowShard over the SAME ranks on its own communicator, for work issued on a side stream (the ControlNet beside the
+        UNet encoder): a communicator serialises its collectives on one internal stream, and two HIP streams that fork and join
+        inside one captured graph must not share it.  `dist.new_group` is collective — every rank reaches this on its first
+        sharded evaluation."""
+        if self._sibling is None:
+            ranks = list(range(self.dist.get_world_size())) if self.group is None else self.dist.get_process_group_ranks(self.group)
+            self._sibling = RowShard(group=self.dist.new_group(ranks), attn=self.attn)
+            self._sibling._log_part = 1
+        return self._sibling
+
+    _log_part = 0
+
+    def _log_partition(self) -> int:
+        return self._log_part
+
+    def reset_counters(self):
+        super().reset_counters()
+        if self._sibling is not None:
+            self._sibling.reset_counters()
+
     def can_capture(self) -> bool:
         """May an evaluation that uses this shard be captured into a HIP graph?  RCCL collectives are stream operations and capture;
         the host-staged transport (gloo) copies through host memory and cannot."""

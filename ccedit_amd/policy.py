@@ -24,6 +24,7 @@ TABLE = {
     "split_cfg": (0, "py", "1: the two CFG halves as B = 1 passes on two streams (round-2 execution)"),
     "hint_dedup": (1, "py", "0: hint stem evaluated for both CFG halves"),
     "text_kv_batched": (1, "py", "0: one text K/V projection launch per transformer block"),
+    "share_cfg_prefix": (1, "py", "0: identical CFG halves evaluated in full (no shared prefix up to the first text attention)"),
     "fuse_gn_stats": (1, "py", "0: two-pass GroupNorm everywhere (no statistics from the producers' epilogues)"),
     "ff320": (1, "py", "0: LayerNorm + two GEMMs instead of the fused dim-320 feed-forward"),
     "ln320": (1, "py", "0: separate LayerNorm pass in front of the K = 320 projections"),

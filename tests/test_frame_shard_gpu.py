@@ -35,7 +35,9 @@ def _inputs(crossframe=False, H=H):
 
 
 def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
+    import faulthandler
     import torch.distributed as dist
+    faulthandler.dump_traceback_later(420, exit=True)          # a rank stuck in an exchange: say where, before the parent's timeout
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     # one GPU per rank and RCCL whenever the box has enough devices; otherwise every rank shares cuda:0 and gloo stages
     # the exchanges through host memory ("-rccl": world 1 on the nccl backend — the un-staged code path on a one-GPU box)

@@ -68,7 +68,11 @@ def test_full_size_properties(tmp_path):
     split = _run(tmp_path, "split", dict(CCEDIT_POLICY="split_cfg=1"))
     assert np.array_equal(split["eps_same"][0], split["eps_same"][1])
     assert _rel(fast["eps_same"][0], fast["eps_same"][1]) < 3.5e-2
-    assert np.array_equal(fast["eps_other"][0], fast["eps"][0]) and np.array_equal(split["eps_other"][0], split["eps"][0])
+    #     Round 5: with identical halves the default evaluates their shared prefix ONCE (network._cfg_twins), with another clip in
+    #     half 1 it takes the general path — half 0 then agrees to the noise floor in the default and bit for bit wherever the
+    #     prefix is not shared (the generic arm, the two-stream halves).
+    assert _rel(fast["eps_other"][0], fast["eps"][0]) < 3.5e-2 and _rel(fast["eps_other"][1], fast["eps"][1]) > 1e-2
+    assert np.array_equal(gen["eps_other"][0], gen["eps"][0]) and np.array_equal(split["eps_other"][0], split["eps"][0])
     assert _rel(fast["eps"], split["eps"]) < 3.5e-2
     # (4) specialised kernels == generic kernels, up to the bf16 noise floor: both are bf16 realisations of the same fp32
     #     computation with different summation orders, and a single flipped bf16 rounding spreads to that floor within a

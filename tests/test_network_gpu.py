@@ -174,7 +174,7 @@ def _teacher_forced_block_errors(z, wrapper, cfg_kw, b, t):
     """Every ControlNet / UNet block of the HIP path on the input the ORACLE's bf16-emulation mode feeds that block
     (oracle/ccedit_oracle.py: the fp32 restatement pinned by the reference goldens, additionally rounding to bf16 wherever
     this path stores a tensor), compared with the oracle's output of the block over the full tensors.  Stage by stage the
-    two agree to ~1e-5 (tools/exp/emu_diag.py); what a block accumulates is (i) the attention probabilities, whose bf16
+    two agree to ~1e-5; what a block accumulates is (i) the attention probabilities, whose bf16
     rounding depends on the online-softmax tile order (1.5e-3 per attention) and (ii) the timestep-embedding row bias
     (sin / cos of arguments up to 999 rad: a last-bit difference in the frequency flips bf16 roundings, 3e-4).  A block
     with a wrong or missing low-energy branch (temporal layer, zero-initialised projection, text attention) lands far
@@ -283,6 +283,58 @@ def test_network_eval_vs_oracle_other_shape(g160_wrapper):
     r = _rel(eps, ref)
     print(f"network eval rel rms err vs oracle (T=4, 8x8): {r:.4f}")
     assert r < NET_TOL
+
+
+def test_shared_cfg_prefix_equals_full_evaluation(g160_wrapper):
+    """Identical CFG halves (same latent, timestep and hint, two prompts — what VanillaCFGTV2V.prepare_inputs builds, guiders.py:57-67):
+    the prefix up to the first text cross-attention is evaluated once (network._cfg_twins).  Against the full evaluation of both
+    halves and against the fp32 oracle; different latents in the halves must take the general path; the decision is remembered per
+    tensor pair and re-taken when a tensor changes in place."""
+    from ccedit_amd import network
+    w = g160_wrapper
+    g = torch.Generator().manual_seed(91)
+    x1 = torch.randn(1, 4, 4, 8, 8, generator=g)
+    hint = torch.rand(1, 3, 4, 64, 64, generator=g) * 2 - 1
+    c = dict(crossattn=torch.randn(2, 77, 128, generator=g), control_hint=hint.repeat(2, 1, 1, 1, 1))
+    t = torch.tensor([433, 433], dtype=torch.int64)
+    x2 = torch.cat([x1, x1])
+    cc = {k: v.cuda() for k, v in c.items()}
+    calls = []
+    real_twin = network.twin
+    network.twin = lambda v: (calls.append(tuple(v.shape)), real_twin(v))[1]
+    saved = (w.use_graph, w.share_cfg_prefix)
+    try:
+        w.use_graph = False
+        w.reset_caches()
+        w.share_cfg_prefix = True
+        xg, tg = x2.cuda(), t.cuda()
+        shared = w(xg, tg, cc).cpu()
+        n_shared = len(calls)
+        assert n_shared >= 6, "the shared prefix was not taken for identical halves"      # tok + x in two networks, two skip twins
+        assert torch.equal(shared, w(xg, tg, cc).cpu())
+        w.share_cfg_prefix = False
+        full = w(xg, tg, cc).cpu()
+        assert len(calls) == 2 * n_shared
+        w.share_cfg_prefix = True
+        other = torch.cat([x1, torch.randn(1, 4, 4, 8, 8, generator=g)]).cuda()
+        n0 = len(calls)
+        w(other, tg, cc)
+        assert len(calls) == n0, "different latents in the two halves must not share a prefix"
+        xg[1].add_(1.0)                                     # in place: the remembered decision for this tensor is stale
+        n0 = len(calls)
+        w(xg, tg, cc)
+        assert len(calls) == n0, "a latent modified in place was still treated as twin halves"
+    finally:
+        network.twin = real_twin
+        w.use_graph, w.share_cfg_prefix = saved
+        w.reset_caches()
+    from ccedit_amd.sgm_compat import build_network_spec
+    from ccedit_amd.utils.synth import synth_state_dict
+    from oracle import ccedit_oracle as O
+    ref = O.network_forward(synth_state_dict(build_network_spec(G160)), O.NetConfig(**G160), x2, t, c)
+    r_s, r_f, d = _rel(shared, ref), _rel(full, ref), _rel(shared, full)
+    print(f"shared CFG prefix: vs oracle {r_s:.4f} (full evaluation {r_f:.4f}); shared vs full {d:.4f}")
+    assert r_s < NET_TOL and r_f < NET_TOL and d < r_s + r_f
 
 
 def test_hip_graph_replay_reproduces_eager_evaluation(g160_wrapper):

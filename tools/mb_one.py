@@ -42,6 +42,18 @@ elif which == "lin640":          # fused q,k,v projection of the 32x48 level, La
     pw = fold_layernorm([torch.randn(1920, 640) * 0.04], [torch.randn(1920)], torch.ones(640), torch.zeros(640)).to("cuda")
     st = ops.row_stats(x, 1e-5)
     f = lambda: ops.linear(x, pw, ln_stats=st)
+elif which in ("ff320", "ff320tail"):   # the dim-320 feed-forward alone / the block tail (to_out + FF + proj_out) at 34 x 6144 tokens
+    from ccedit_amd.packing import pack_ff320, pack_ff320_tail
+    g = torch.Generator().manual_seed(0)
+    base = pack_ff320(torch.randn(2560, 320, generator=g) * 0.05, torch.randn(2560, generator=g) * 0.1, torch.randn(320, 1280, generator=g) * 0.03,
+                      torch.randn(320, generator=g) * 0.1, torch.ones(320), torch.zeros(320), device="cuda")
+    a, r, x2 = (torch.randn(N * 6144, 320, device="cuda").to(BF) for _ in range(3))
+    if which == "ff320":
+        f = lambda: ops.ff320(a, base)
+    else:
+        pk = pack_ff320_tail(base, torch.randn(320, 320, generator=g) * 0.05, torch.randn(320, generator=g) * 0.1,
+                             torch.randn(320, 320, generator=g) * 0.05, torch.randn(320, generator=g) * 0.1, device="cuda")
+        f = lambda: ops.ff320(None, pk, a=a, res=r, res2=x2)
 elif which == "attnq":           # the network's call: q pre-scaled into log2 units
     q = torch.randn(N * 6144, 960, device="cuda").to(BF)
     f = lambda: ops.attention(q[:, :320], q[:, 320:640], q[:, 640:], 8, 40, batches=N, lq=6144, lk=6144, q_log2=True)

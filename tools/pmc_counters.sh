@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): tools/pmc_r04.sh <kernel-name-regex> <mb_one case> [args]
+# usage (on the GPU box): tools/pmc_counters.sh <kernel-name-regex> <mb_one case> [args]
 # Two counter passes (SQ issue / matrix pipe, then VALU activity / LDS / clock) over tools/mb_one.py, --pmc with --kernel-trace only.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

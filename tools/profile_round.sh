@@ -12,7 +12,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py 2>/dev/null | tail -1 > $O/${tag}_bench_line_default.json
-python $R/bench.py --workload tvi2v 2>/dev/null | tail -1 > $O/${tag}_bench_line_tvi2v.json
+if [ "${PROFILE_TVI2V:-0}" = 1 ]; then python $R/bench.py --workload tvi2v 2>/dev/null | tail -1 > $O/${tag}_bench_line_tvi2v.json; fi   # (the default line carries a tvi2v object)
 for mode in single streams; do
   rm -rf /tmp/pf_$mode
   if [ $mode = single ]; then export CCEDIT_SPLIT_CFG=0 CCEDIT_OVERLAP_CONTROLNET=0; sfx=""; else unset CCEDIT_SPLIT_CFG CCEDIT_OVERLAP_CONTROLNET; sfx="_streams"; fi
@@ -21,14 +21,11 @@ for mode in single streams; do
 done
 unset CCEDIT_SPLIT_CFG CCEDIT_OVERLAP_CONTROLNET
 PMC_JSON=$O/${tag}_pmc_traffic.json bash $R/tools/pmc_traffic.sh > $O/${tag}_pmc_traffic.txt 2>&1
-PMC_BENCH_ARGS="--workload tvi2v" PMC_JSON=$O/${tag}_pmc_traffic_tvi2v.json bash $R/tools/pmc_traffic.sh > $O/${tag}_pmc_traffic_tvi2v.txt 2>&1
-# matrix-pipe / VALU counters of the dominant kernels (tools/pmc_r04.sh: two --pmc passes each, --kernel-trace only)
-for spec in "attn_spatial attnq" "g8_kernel g8geglu" "g8_kernel g8res" "g8_kernel g8conv" "conv_halo conv" "lin320 lin320" "lin640 lin640"; do
+if [ "${PROFILE_TVI2V:-0}" = 1 ]; then PMC_BENCH_ARGS="--workload tvi2v" PMC_JSON=$O/${tag}_pmc_traffic_tvi2v.json bash $R/tools/pmc_traffic.sh > $O/${tag}_pmc_traffic_tvi2v.txt 2>&1; fi
+# matrix-pipe / VALU counters of the dominant kernels (tools/pmc_counters.sh: two --pmc passes each, --kernel-trace only); round 5: the feed-forward alone and as the block tail
+for spec in "ff320 ff320" "ff320 ff320tail" "attn_spatial attnq" "conv_halo conv"; do
   set -- $spec
   echo "=== $2 ($1) ===" >> $O/${tag}_pmc_counters.txt
-  bash $R/tools/pmc_r04.sh $1 $2 >> $O/${tag}_pmc_counters.txt 2>&1
+  bash $R/tools/pmc_counters.sh $1 $2 >> $O/${tag}_pmc_counters.txt 2>&1
 done
-# the same attention launch on the general kernel it replaced (round 3's), same box
-echo "=== attnq, CCEDIT_ATTN_SPATIAL=0 (attn_kernel<40,8>) ===" >> $O/${tag}_pmc_counters.txt
-CCEDIT_ATTN_SPATIAL=0 bash $R/tools/pmc_r04.sh "attn_kernel" attnq >> $O/${tag}_pmc_counters.txt 2>&1
 ls -la $O/${tag}_*
