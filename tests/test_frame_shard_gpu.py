@@ -37,7 +37,7 @@ def _inputs(crossframe=False, H=H):
 def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     import faulthandler
     import torch.distributed as dist
-    faulthandler.dump_traceback_later(420, exit=True)          # a rank stuck in an exchange: say where, before the parent's timeout
+    faulthandler.dump_traceback_later(int(os.environ.get("SHARD_TEST_DUMP_S", "420")), exit=True)   # a rank stuck in an exchange: say where
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     # one GPU per rank and RCCL whenever the box has enough devices; otherwise every rank shares cuda:0 and gloo stages
     # the exchanges through host memory ("-rccl": world 1 on the nccl backend — the un-staged code path on a one-GPU box)
@@ -51,6 +51,8 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_grad_enabled(False)
+    if world > 1:
+        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))      # several ranks build their networks on the host at once
     from ccedit_amd.parallel import FrameShard, RowShard
     from ccedit_amd.sgm_compat import build_network
     from ccedit_amd.utils.synth import fill_module_
@@ -107,8 +109,15 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     q.put((rank, out.numpy(), None if ref is None else ref.numpy(),
            (sum(s.bytes_sent for s in shards), sum(s.n_collectives for s in shards)),
            None if orc is None else orc.numpy()))      # numpy: pickled by value (the child may exit before the parent reads)
+    # teardown: captured graphs hold the communicator's streams — drop them first; a watchdog ends the process if the backend's own
+    # shutdown does not return (seen once with RCCL after a captured TVI2V evaluation: the results above are already with the parent)
+    import threading
+    w.reset_caches()
+    torch.cuda.synchronize()
+    threading.Timer(40, lambda: os._exit(0)).start()
     dist.barrier()
     dist.destroy_process_group()
+    os._exit(0)
 
 
 @pytest.mark.timeout(600)
