@@ -40,7 +40,7 @@ FLOP_PER_STEP_TVI2V = 110.31e12   # BASELINE.json config 3 (controlnet_img + anc
 MFMA_PEAK_TFLOPS = 2500.0         # MI355X dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0             # HBM3E spec (ibid.; a float4 copy measures 6290)
 T, H, W, L, CTX = 17, 64, 96, 77, 768
-PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"      # committed rocprofv3 PMC capture (FETCH_SIZE / WRITE_SIZE passes)
+PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"      # committed rocprofv3 PMC capture (FETCH_SIZE / WRITE_SIZE passes)
 
 
 def synth_inputs(device, seed=42, b=1):

@@ -97,7 +97,9 @@ def test_full_size_tvi2v_properties(tmp_path):
     for k in ("eps", "eps_same", "eps_ref"):
         assert np.array_equal(fast[k], again[k]), f"{k}: two runs of the same evaluation differ"
     assert _rel(fast["eps_same"][0], fast["eps_same"][1]) < 3.5e-2          # (bit-equal with policy split_cfg=1, see above)
-    assert np.array_equal(fast["eps_ref"][0], fast["eps"][0])
+    # half 0 is untouched by half 1's reference frame: bit for bit where the CFG prefix is not shared (the generic arm); in the default
+    # `eps` shares the halves' prefix and `eps_ref` (different reference frames) cannot, so there they agree to the noise floor
+    assert np.array_equal(gen["eps_ref"][0], gen["eps"][0]) and _rel(fast["eps_ref"][0], fast["eps"][0]) < 3.5e-2
     assert _rel(fast["eps_ref"][1], fast["eps"][1]) > 1e-2          # the reference latent does condition the prediction
     e = _rel(fast["eps"], gen["eps"])
     print(f"full size TVI2V: fast vs generic kernels: eps {e:.4f}")

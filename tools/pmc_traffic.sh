@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 export CCEDIT_SPLIT_CFG=0 CCEDIT_OVERLAP_CONTROLNET=0
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/tr1 /tmp/tr2
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/tr1 -- python $R/bench.py $PMC_BENCH_ARGS --steps 1 --warmup 0 --no-cpu-baseline --no-clip --no-profile-step > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/tr2 -- python $R/bench.py $PMC_BENCH_ARGS --steps 1 --warmup 0 --no-cpu-baseline --no-clip --no-profile-step > /dev/null 2>&1
-python $R/bench.py $PMC_BENCH_ARGS --steps 1 --warmup 0 --no-cpu-baseline --no-clip --no-profile-step --dump-shapes /tmp/shapes.json > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/tr1 -- python $R/bench.py $PMC_BENCH_ARGS --steps 1 --warmup 0 --no-cpu-baseline --no-clip --no-tvi2v --no-profile-step > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/tr2 -- python $R/bench.py $PMC_BENCH_ARGS --steps 1 --warmup 0 --no-cpu-baseline --no-clip --no-tvi2v --no-profile-step > /dev/null 2>&1
+python $R/bench.py $PMC_BENCH_ARGS --steps 1 --warmup 0 --no-cpu-baseline --no-clip --no-tvi2v --no-profile-step --dump-shapes /tmp/shapes.json > /dev/null 2>&1
 python $R/tools/pmc_traffic.py /tmp/tr1 /tmp/tr2 /tmp/shapes.json

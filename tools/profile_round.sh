@@ -16,7 +16,7 @@ if [ "${PROFILE_TVI2V:-0}" = 1 ]; then python $R/bench.py --workload tvi2v 2>/de
 for mode in single streams; do
   rm -rf /tmp/pf_$mode
   if [ $mode = single ]; then export CCEDIT_SPLIT_CFG=0 CCEDIT_OVERLAP_CONTROLNET=0; sfx=""; else unset CCEDIT_SPLIT_CFG CCEDIT_OVERLAP_CONTROLNET; sfx="_streams"; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_$mode -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-clip 2>/dev/null | tail -1 > $O/${tag}_bench_line_under_rocprof$sfx.json
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_$mode -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-clip --no-tvi2v 2>/dev/null | tail -1 > $O/${tag}_bench_line_under_rocprof$sfx.json
   python $R/tools/prof_summary.py /tmp/pf_$mode $O/${tag}_bench_kernel_stats$sfx.txt > /dev/null 2>&1
 done
 unset CCEDIT_SPLIT_CFG CCEDIT_OVERLAP_CONTROLNET
