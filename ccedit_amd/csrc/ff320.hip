@@ -73,8 +73,16 @@ constexpr int kPEChunks = 4;            // 4 x 5 = the 20 k-steps of a 320 x 320
 constexpr int kAuxOff = 60 * 1024;      // 40 GEMM1 + 20 GEMM2 fragments of 1 KB, then b1'
 constexpr int kChunkBytes = 64 * 1024;  // every wave issues at most 16 DMA instructions per chunk
 constexpr int kWavePix = 32;
-constexpr int kD = KD_VALUE;            // fragment reads in flight ahead of their use (divides 60 and 50: the ring runs across chunks)
+constexpr int kD = KD_VALUE;            // slots of the fragment read ring (divides 60 and 50: the ring runs across chunks)
 static_assert(60 % kD == 0 && kPE % kD == 0, "ring depth");
+// Which slot a step refills.  FF_RING_LAG 0: the slot its own MFMA has just been issued with (kD fragments ahead) — the ds_read then
+// writes registers that MFMA is still reading as its A operand, and the hardware holds the read's issue until the MFMA has fetched
+// them.  1: the slot of the PREVIOUS step's MFMA (kD - 1 fragments ahead), which was issued a whole step earlier.  Measured neutral
+// (block tail 760.2 / 762.1 us, feed-forward alone 640.8 / 632.8 us for 0 / 1): the stall is not what bounds the chunks; 0 stays.
+#ifndef FF_RING_LAG
+#define FF_RING_LAG 0
+#endif
+constexpr int kLA = kD - FF_RING_LAG;   // fragments in flight ahead of their use
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
@@ -145,7 +153,7 @@ struct GeluPipe {
 //            GEMM2 of chunk c-2 (twenty different accumulators)
 //     VALU   GEGLU of chunk c-1, one accumulator register (one hidden row of the lane's token) per k-step
 // Chunks -2, -1, 40, 41 do not exist: the packer supplies zero fragments / biases, so those MFMAs add zeros.
-// The fragment ring runs across iterations: barrier B (step NF - 2 - kD, after the wait for the next chunk's DMA) lets the last
+// The fragment ring runs across iterations: barrier B (step NF - 2 - kLA, after the wait for the next chunk's DMA) lets the last
 // steps prefetch the next chunk; barrier A (iteration top) lets the DMA overwrite the buffer every wave has left.
 //
 // One chunk of the round, as a compile-time description: KIND (0 prologue GEMM, 1 feed-forward, 2 epilogue GEMM), Q (index of a
@@ -192,10 +200,10 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
     for (int k = 0; k < 16; ++k) issue_frag(0, 0, k);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // the read stream starts: the first kD fragments of chunk 0 (and its b1' when it is a feed-forward chunk)
+    // the read stream starts: the first kLA fragments of chunk 0 (and its b1' when it is a feed-forward chunk)
     f32x4 bq[2][4];                      // b1' (value, gate) of the chunk GEMM1 starts next, in accumulator order
     bf16x8 ring[kD];
-    FF_DS_READ(ring[0], la0, 0);          // same order as in the steady state: fragment 0, b1', fragments 1 .. kD - 1
+    FF_DS_READ(ring[0], la0, 0);          // same order as in the steady state: fragment 0, b1', fragments 1 .. kLA - 1
     if constexpr (FIRST_HAS_BQ) {
 #pragma unroll
         for (int k = 0; k < 2; ++k)
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
             for (int q4 = 0; q4 < 4; ++q4) FF_DS_READ(bq[k][q4], lx0, k * 128 + q4 * 16);
     }
 #pragma unroll
-    for (int j = 1; j < kD; ++j) FF_DS_READ(ring[j], la0, j * 1024);
+    for (int j = 1; j < kLA; ++j) FF_DS_READ(ring[j], la0, j * 1024);
 
     f32x16 acc1[2][2];                   // [chunk parity][value, gate]
     bf16x8 hf[2][2];                     // [chunk parity][kappa]: GEGLU outputs = GEMM2 B operands
@@ -307,15 +315,15 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
             GeluPipe gp;
             auto step = [&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                // younger reads that may stay in flight: the kD - 1 fragments behind this one, + the 8 b1' reads slipped in
-                // behind fragment NF (= fragment 0 of the next chunk, read at step NF - kD) while that one is among them
-                constexpr int young8 = kD - 1 + 8 > 15 ? 15 : kD - 1 + 8;                              // (lgkmcnt is a 4-bit counter)
-                FF_WAIT(ring[j % kD], (CH::NEXT_BQ && j >= NF + 1 - kD ? young8 : kD - 1));
+                // younger reads that may stay in flight: the kLA - 1 fragments behind this one, + the 8 b1' reads slipped in
+                // behind fragment NF (= fragment 0 of the next chunk, read at step NF - kLA) while that one is among them
+                constexpr int young8 = kLA - 1 + 8 > 15 ? 15 : kLA - 1 + 8;                            // (lgkmcnt is a 4-bit counter)
+                FF_WAIT(ring[j % kD], (CH::NEXT_BQ && j >= NF + 1 - kLA ? young8 : kLA - 1));
                 if constexpr (j == 0 && CH::HAS_BQ) {
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) FF_WAIT(bq[k][q4], kD - 1);      // older than fragment 1: retired with fragment 0
+                        for (int q4 = 0; q4 < 4; ++q4) FF_WAIT(bq[k][q4], kLA - 1);     // older than fragment 1: retired with fragment 0
                 }
                 if constexpr (KIND == 1) {
                     constexpr int s = j / 3, role = j % 3;                        // k-step, (value, gate, GEMM2) fragment
@@ -335,9 +343,9 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
                     acc2[j % kOT] = mfma32(ring[j % kD], xf[CH::Q * (kPE / kOT) + j / kOT], acc2[j % kOT]);
                 }
                 // the ring continues into the next chunk's buffer behind barrier B
-                if constexpr (j + kD < NF) FF_DS_READ(ring[j % kD], la, (j + kD) * 1024);
-                else FF_DS_READ(ring[j % kD], lan, (j + kD - NF) * 1024);
-                if constexpr (CH::NEXT_BQ && j == NF - kD) {
+                if constexpr (j + kLA < NF) FF_DS_READ(ring[(j + kLA) % kD], la, (j + kLA) * 1024);
+                else FF_DS_READ(ring[(j + kLA) % kD], lan, (j + kLA - NF) * 1024);
+                if constexpr (CH::NEXT_BQ && j == NF - kLA) {
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const CcFf320Desc d, int 
                 if constexpr (dma_k < CH::NISS && j < 32) {
                     if (issue_next) issue_frag(cn, 1 - PAR, dma_k);
                 }
-                if constexpr (j == NF - 2 - kD) {    // barrier B: chunk c + 1 has landed for every wave
+                if constexpr (j == NF - 2 - kLA) {   // barrier B: chunk c + 1 has landed for every wave
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
