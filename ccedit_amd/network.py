@@ -1256,6 +1256,12 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         if not self.share_cfg_prefix or x.shape[0] % 2 or x.shape[0] < 2 or torch.cuda.is_current_stream_capturing():
             return False
         k = x.shape[0] // 2
+        # marked by this build's guider / denoiser (sampling.py): no device compare, no host sync
+        marks = [getattr(x, "_cfg_twin_halves", None), getattr(t, "_cfg_twin_halves", None), getattr(c["control_hint"], "_halves_equal", None)]
+        if c.get("cond_feat") is not None:
+            marks.append(getattr(c["cond_feat"], "_halves_equal", None))
+        if marks[0] is True and marks[1] is True and all(m is not None for m in marks[2:]):
+            return all(marks)
         key = self._tensor_key(x) + self._tensor_key(t) + tuple(self._tensor_key(c[n]) for n in ("control_hint", "cond_feat") if c.get(n) is not None)
         if not isinstance(self._twin_val, dict) or len(self._twin_val) >= 8:
             self._twin_val = {}

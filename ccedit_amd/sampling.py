@@ -164,6 +164,15 @@ class Denoiser(nn.Module):
         xs = torch.empty_like(x)
         for i in range(b):                                    # input * c_in
             ops.axpby(x[i], x[i], float(c_in[i]), 0.0, out=xs[i])
+        # The guider marks a batch whose two halves are the SAME latent (VanillaCFG.prepare_inputs); with equal sigmas the scaled
+        # input and the timestep indices are twins too.  The mark travels as a Python attribute on the tensors handed to the
+        # network, which then shares the halves' common prefix without comparing them on the device (a host sync per evaluation
+        # would expose the launch of every replayed graph: measured +4 ms per evaluation of a clip).
+        k = b // 2
+        if (getattr(input, "_cfg_twin_halves", False) and b % 2 == 0 and all(float(c_in[i]) == float(c_in[i + k]) for i in range(k))
+                and bool(torch.equal(c_noise[:k], c_noise[k:]))):
+            xs._cfg_twin_halves = True
+            c_noise_dev._cfg_twin_halves = True
         net = network(xs, c_noise_dev, cond).float().contiguous()
         out = torch.empty_like(x)
         for i in range(b):                                    # net * c_out + input * c_skip
@@ -236,12 +245,17 @@ class VanillaCFG:
                 hit = self._cat_cache.get(k)
                 if hit is None or hit[0] is not uc[k] or hit[1] is not c[k] or hit[2] != (uc[k]._version, c[k]._version):
                     hit = (uc[k], c[k], (uc[k]._version, c[k]._version), torch.cat((uc[k], c[k]), 0))
+                    # are the two halves the same values (control_hint, cond_feat: the scripts give uc a clone of c's)?  Compared once per
+                    # (uc[k], c[k]) pair, remembered on the concatenation for the network's shared CFG prefix
+                    hit[3]._halves_equal = bool(uc[k].shape == c[k].shape and torch.equal(uc[k], c[k]))
                     self._cat_cache[k] = hit
                 c_out[k] = hit[3]
             else:
                 assert c[k] == uc[k]
                 c_out[k] = c[k]
-        return torch.cat([x] * 2), torch.cat([s] * 2), c_out
+        x2, s2 = torch.cat([x] * 2), torch.cat([s] * 2)
+        x2._cfg_twin_halves = True          # the same latent twice (see Denoiser.__call__)
+        return x2, s2, c_out
 
 
 class VanillaCFGTV2V(VanillaCFG):

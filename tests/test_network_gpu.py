@@ -328,6 +328,24 @@ def test_shared_cfg_prefix_equals_full_evaluation(g160_wrapper):
         network.twin = real_twin
         w.use_graph, w.share_cfg_prefix = saved
         w.reset_caches()
+    # the sampler path: this build's guider and denoiser MARK the doubled batch, the wrapper then decides without a device compare
+    from ccedit_amd.sampling import DiscreteDenoiser, VanillaCFGTV2V
+    dd = "sgm.modules.diffusionmodules."
+    den = DiscreteDenoiser(dict(target=dd + "denoiser_weighting.EpsWeighting"), dict(target=dd + "denoiser_scaling.EpsScaling"), 1000,
+                           dict(target=dd + "discretizer.LegacyDDPMDiscretization"))
+    guider = VanillaCFGTV2V(7.5)
+    cond = dict(crossattn=c["crossattn"][1:].cuda(), control_hint=hint.cuda())
+    ucond = dict(crossattn=c["crossattn"][:1].cuda(), control_hint=hint.clone().cuda())
+    seen = {}
+
+    def fake_network(xs, tt, cc_):
+        seen.update(x=xs, t=tt, c=cc_)
+        return torch.zeros_like(xs)
+    den(fake_network, *guider.prepare_inputs(x1.cuda(), torch.tensor([3.0]), cond, ucond))
+    assert getattr(seen["x"], "_cfg_twin_halves", False) and getattr(seen["t"], "_cfg_twin_halves", False)
+    assert seen["c"]["control_hint"]._halves_equal is True and seen["c"]["crossattn"]._halves_equal is False
+    w._twin_val = None
+    assert w._cfg_twins(seen["x"], seen["t"], seen["c"]) is True and not w._twin_val, "marked halves must not need the device compare"
     from ccedit_amd.sgm_compat import build_network_spec
     from ccedit_amd.utils.synth import synth_state_dict
     from oracle import ccedit_oracle as O
