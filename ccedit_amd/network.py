@@ -282,15 +282,21 @@ class FeedForward(nn.Module):
 
     def tail_pack(self, to_out: "Linear", proj: Optional["Conv"], device):
         """Weight stream of the block-tail launch (to_out prologue GEMM [+ proj_out epilogue GEMM] around the fused feed-forward),
-        built on first use and kept until the next pack (a captured graph holds its address: PACK_GENERATION keys the cache)."""
-        key = (id(to_out), None if proj is None else id(proj), PACK_GENERATION[0])
-        if self._tails is None or next(iter(self._tails))[2] != PACK_GENERATION[0]:
+        built on first use and kept while the packs it was built from live: the entry holds (and is matched by the identity of) this
+        feed-forward's plain pack and the two layers' packed weights, all of which a re-pack of THIS network replaces — packing
+        another module (a VAE beside the network: bench.py's clip) leaves it alone.  A captured graph holds its address; graphs are
+        keyed on PACK_GENERATION and re-captured after any pack, by which time a stale entry has been replaced here."""
+        src = (self.fused, to_out.pw, None if proj is None else proj.pw)
+        key = (id(to_out), None if proj is None else id(proj))
+        if self._tails is None:
             self._tails = {}
-        if key not in self._tails:
+        ent = self._tails.get(key)
+        if ent is None or any(a is not b for a, b in zip(ent[0], src)):
             from .packing import pack_ff320_tail
-            self._tails[key] = pack_ff320_tail(self.fused, to_out.weight, to_out.bias, None if proj is None else proj.weight,
-                                               None if proj is None else proj.bias, device=device)
-        return self._tails[key]
+            ent = (src, pack_ff320_tail(self.fused, to_out.weight, to_out.bias, None if proj is None else proj.weight,
+                                        None if proj is None else proj.bias, device=device))
+            self._tails[key] = ent
+        return ent[1]
 
     def run(self, tok, norm: "Norm"):
         """tok + FF(LayerNorm(tok)) (attention.py:695-716 `x = self.ff(self.norm3(x)) + x`)."""

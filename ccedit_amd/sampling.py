@@ -158,7 +158,11 @@ class Denoiser(nn.Module):
     def __call__(self, network, input, sigma, cond):
         sigma = self.possibly_quantize_sigma(sigma.detach().to("cpu", torch.float32))
         c_skip, c_out, c_in, c_noise = self.scaling(sigma)
-        c_noise_dev = self.possibly_quantize_c_noise(c_noise).to(input.device)     # int64 table indices (discrete) or sigmas
+        # int64 table indices (discrete) or sigmas.  Through pinned memory and without blocking: a plain `.to(device)` of a pageable host
+        # tensor waits for everything queued on the stream — one full host sync per evaluation, the host could never enqueue the next
+        # evaluation's replay under the running one
+        c_noise_q = self.possibly_quantize_c_noise(c_noise)
+        c_noise_dev = c_noise_q.pin_memory().to(input.device, non_blocking=True) if input.is_cuda else c_noise_q.to(input.device)
         b = input.shape[0]
         x = input.float().contiguous()
         xs = torch.empty_like(x)
