@@ -231,6 +231,7 @@ def main():
     ap.add_argument("--no-profile-step", action="store_true", help="skip the extra HIP-event profiled step (PMC runs)")
     ap.add_argument("--no-tvi2v", action="store_true", help="skip the config-3 (TVI2V) step timing added to the default single-GPU line")
     ap.add_argument("--no-c4", action="store_true", help="N>1: skip the config-4 (one clip, rows sharded) object of the replica line")
+    ap.add_argument("--c4-deadline", type=float, default=240.0, help="N>1: seconds the config-4 section may take before the line is emitted without it")
     ap.add_argument("--attn", choices=["heads", "gather"], default="heads",
                     help="row-sharded spatial attention: all-to-all by head (heads) or all-gather of K/V (gather)")
     ap.add_argument("--dump-shapes", type=str, default="", help="write the GEMM launch shape sequence of one step (json)")
@@ -336,19 +337,6 @@ def main():
         single_ms = timed(args.steps)[0] / args.steps * 1e3
         wrapper.frame_shard, wrapper.row_shard = keep, keep_rows
         extra["shard"] = extra["c4"] = c4_object(args, world, ms_per_step, single_ms, info)
-    elif world > 1 and not args.no_c4:
-        xs = synth_inputs(device, seed=42)
-        saved = dict(inp)
-        set_inputs(*xs, 7)
-        shards = install_shards(wrapper, args)
-        step(); step()
-        c4_dt, o4 = timed(args.steps)
-        assert torch.isfinite(o4).all()
-        info = shard_counters(shards, step, world, dist)
-        wrapper.frame_shard = wrapper.row_shard = None
-        shards = ()
-        inp.update(saved)
-        extra["c4"] = c4_object(args, world, c4_dt / args.steps * 1e3, ms_per_step, info)
     if rank == 0 and args.dump_shapes and not shard:
         ops.PROFILE = ops.LaunchProfile()
         step()
@@ -466,7 +454,10 @@ def main():
     if rank == 0 and world == 1 and not tvi2v and not args.no_tvi2v:
         extra["tvi2v"] = time_tvi2v_step(device, args.steps)       # (a second full network beside the first: 288 GB of HBM)
 
-    if rank == 0:
+    def emit():
+        """Rank 0 prints the ONE JSON line (with whatever `extra` holds by now)."""
+        if rank != 0:
+            return
         line = {
             "metric": f"UNet denoising steps/s ({'TVI2V' if tvi2v else 'TV2V'} 17x512x768, bf16, CFG-doubled batch)", "value": round(value, 4),
             "unit": "UNet steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -494,6 +485,38 @@ def main():
         if clip:
             line["clip"] = clip
         print(json.dumps(line))
+
+
+    # ---- config 4 next to the replica value (default N > 1): ONE clip row-sharded over the ranks, timed LAST and under a watchdog — this
+    # path has never met a multi-GPU node, and a stuck collective must not cost the replica line the driver's scaling
+    # curve is computed from: if the sharded section does not finish in time every rank emits / exits without it.
+    if world > 1 and not shard and not args.no_c4:
+        import threading
+
+        def bail():
+            extra["c4"] = dict(error=f"the row-sharded section did not finish within {args.c4_deadline} s; replica value unaffected")
+            emit()
+            sys.stdout.flush()
+            os._exit(0)
+        dog = threading.Timer(args.c4_deadline, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            xs = synth_inputs(device, seed=42)
+            saved = dict(inp)
+            set_inputs(*xs, 7)
+            shards = install_shards(wrapper, args)
+            step(); step()
+            c4_dt, o4 = timed(args.steps)
+            assert torch.isfinite(o4).all()
+            info = shard_counters(shards, step, world, dist)
+            wrapper.frame_shard = wrapper.row_shard = None
+            inp.update(saved)
+            extra["c4"] = c4_object(args, world, c4_dt / args.steps * 1e3, ms_per_step, info)
+        except Exception as e:            # an error on this rank: say so on the line instead of losing it
+            extra["c4"] = dict(error=f"{type(e).__name__}: {e}")
+        dog.cancel()
+    emit()
     if dist is not None:
         dist.barrier()                              # rank 0 may still have been profiling: leave together
         dist.destroy_process_group()
