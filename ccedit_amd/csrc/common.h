@@ -74,6 +74,7 @@ struct CcPolicy {
     int attn_spatial = 1;   // d = 40 long self-attention kernel
     int attn_pv16 = 1;      // ... its PV product in 16x16x32 tiles (0: 32x32x16)
     int gn_flat = 1;        // flat thread mapping of the temporal GroupNorm at the two large levels
+    int gn_apply_flat = 1;  // column-per-thread, four-rows-in-flight mapping of the spatial GroupNorm apply pass (0: a wave per pixel row)
 };
 const CcPolicy& cc_policy();
 

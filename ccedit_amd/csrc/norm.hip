@@ -736,8 +736,76 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__
     }
 }
 
+// The apply pass with every lane busy and several rows in flight per lane (the cat_add_gn recipe).  A THREAD owns one 16-byte granule
+// column (its 8 channels' coefficients in 16 registers, set up once) and walks the pixel rows RS apart, FOUR rows requested before the
+// first is used; gt * RS threads = C / 8 columns x RS row lanes (320 threads at C = 320 / 640 / 1280 / 2560).  The wave-per-row kernel
+// above runs 40 of 64 lanes at C = 320 with one row in flight per wave: 20 KB outstanding per CU where the HBM latency x bandwidth
+// product asks for ~60 KB (3.9 - 4.0 TB/s; LayerNorm, which keeps two rows in flight, reaches 5 - 5.9).
+__global__ __launch_bounds__(320) void gn_spatial_apply_flat_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                                    const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, int hw, int C, float eps, int silu,
+                                                                    int rows_per_block, int RS) {
+    const int frame = blockIdx.y;
+    const int gt = C >> 3, cpg = C >> 5;
+    const int rs = threadIdx.x / gt, gc = threadIdx.x - rs * gt;
+    if (rs >= RS) return;
+    const float inv_n = 1.0f / ((float)cpg * (float)hw);
+    float a[8], b[8];
+    {
+        const int c0 = gc * 8;
+        const int g0 = c0 / cpg, g1 = min(g0 + 1, 31);
+        const int split = (g0 + 1) * cpg - c0;               // channels of this granule that belong to group g0 (cpg >= 8: at most two groups)
+        const double* sp0 = stats + (frame * 32 + g0) * 2;
+        const double* sp1 = stats + (frame * 32 + g1) * 2;
+        const float s00 = (float)sp0[0], s01 = (float)sp0[1], s10 = (float)sp1[0], s11 = (float)sp1[1];
+        const f32x4 ga0 = *(const f32x4*)(gamma + c0), ga1 = *(const f32x4*)(gamma + c0 + 4);
+        const f32x4 be0 = *(const f32x4*)(beta + c0), be1 = *(const f32x4*)(beta + c0 + 4);
+        const float m0 = s00 * inv_n, m1 = s10 * inv_n;
+        const float r0 = rsqrtf(fmaxf(s01 * inv_n - m0 * m0, 0.f) + eps), r1 = rsqrtf(fmaxf(s11 * inv_n - m1 * m1, 0.f) + eps);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ga = e < 4 ? ga0[e & 3] : ga1[e & 3], be = e < 4 ? be0[e & 3] : be1[e & 3];
+            const bool first = e < split;
+            a[e] = (first ? r0 : r1) * ga;
+            b[e] = be - (first ? m0 : m1) * a[e];
+        }
+    }
+    const int p0 = blockIdx.x * rows_per_block, p1 = min(p0 + rows_per_block, hw);
+    const bf16* xf = x + (size_t)frame * hw * C + gc * 8;
+    bf16* yf = y + (size_t)frame * hw * C + gc * 8;
+    auto emit = [&](int pix, bf16x8 v) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = fmaf(bf2f(v[e]), a[e], b[e]);
+            if (silu) f = silu_f(f);
+            o[e] = f2bf(f);
+        }
+        *(bf16x8*)(yf + (size_t)pix * C) = o;
+    };
+    int pix = p0 + rs;
+    for (; pix + 3 * RS < p1; pix += 4 * RS) {
+        bf16x8 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *(const bf16x8*)(xf + (size_t)(pix + k * RS) * C);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) emit(pix + k * RS, v[k]);
+    }
+    for (; pix < p1; pix += RS) emit(pix, *(const bf16x8*)(xf + (size_t)pix * C));
+}
+
 void launch_gn_apply(dim3 grid, hipStream_t s, const bf16* x, bf16* y, const double* stats, const float* gamma,
                      const float* beta, int hw, int C, float eps, int silu, int apb) {
+    const int gt = C >> 3;
+    if (cc_policy().gn_apply_flat && (C >> 5) >= 8 && gt <= 320 && (int64_t)hw * grid.y >= 4096) {
+        int RS = 320 / gt;
+        RS = RS < 1 ? 1 : (RS > 8 ? 8 : RS);
+        int rpb = 256;                                       // rows per workgroup: as many as still leave ~2000 workgroups
+        while (rpb > 8 * RS && (int64_t)((hw + rpb - 1) / rpb) * grid.y < 2048) rpb >>= 1;
+        hipLaunchKernelGGL(gn_spatial_apply_flat_kernel, dim3((hw + rpb - 1) / rpb, grid.y), dim3(gt * RS), 0, s, x, y, stats, gamma, beta,
+                           hw, C, eps, silu, rpb, RS);
+        return;
+    }
     const int cols = (C / 8 + 63) / 64;
 #define CC_GA(N) hipLaunchKernelGGL(gn_spatial_apply_kernel<N>, grid, dim3(256), 0, s, x, y, stats, gamma, beta, hw, C, eps, silu, apb)
     if (cols == 1) CC_GA(1); else if (cols == 2) CC_GA(2); else if (cols == 3) CC_GA(3); else if (cols == 4) CC_GA(4); else CC_GA(kMaxCols);

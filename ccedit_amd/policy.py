@@ -49,6 +49,7 @@ TABLE = {
     "attn_spatial": (1, "lib", "0: the 6144-key self-attention through the general flash kernel"),
     "attn_pv16": (1, "lib", "0: PV product of the spatial attention in 32x32x16 tiles"),
     "gn_flat": (1, "lib", "0: temporal GroupNorm through the per-pixel kernels at the two large levels"),
+    "gn_apply_flat": (1, "lib", "0: spatial GroupNorm apply with a wave per pixel row instead of a granule column per thread"),
 }
 
 _values: Dict[str, int] = {}

@@ -46,7 +46,7 @@ int ccedit_device_info(char* name, int name_len);
 /* Dispatch policy: ONE table of named integer switches that choose between kernels computing the same fp32 sums in a different order
  * (A/B arms and the "specialised kernels reproduce the generic ones" tests).  All default to the fast path.  The library never reads
  * the environment; the host sets entries before launching (process-wide, not thread-safe against concurrent launches).  Names:
- *   conv_halo g8 g8_conv g8_temporal g8_split lin320 lin320s lin640 temp320 attn_short attn_text attn_spatial attn_pv16 gn_flat
+ *   conv_halo g8 g8_conv g8_temporal g8_split lin320 lin320s lin640 temp320 attn_short attn_text attn_spatial attn_pv16 gn_flat gn_apply_flat
  *   (ccedit_policy_names() returns them comma-separated; semantics in csrc/common.h: CcPolicy)
  * Unknown name: CCEDIT_EINVAL. */
 int ccedit_policy_set(const char* name, int32_t value);

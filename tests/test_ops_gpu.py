@@ -721,6 +721,31 @@ def test_groupnorm_spatial(c, h, w, eps, silu):
     _close(_nchw(y), ref, rel=2.0 ** -6, what=f"GN spatial C={c}")
 
 
+@pytest.mark.parametrize("c,n,h,w,silu", [(320, 12, 16, 24, True), (640, 6, 32, 24, False), (960, 5, 32, 32, True), (1280, 11, 16, 24, True),
+                                         (2560, 12, 16, 24, True), (320, 2, 50, 43, True)])
+def test_groupnorm_spatial_apply_flat_mapping(c, n, h, w, silu):
+    """The column-per-thread apply kernel (>= 4096 pixel rows, C / 32 >= 8): statistics from a producer-style pass, every width of the
+    networks (row lanes 8 / 4 / 2 / 2 / 1), a row count that is not a multiple of the rows in flight, against fp32 torch and bit for
+    bit against the wave-per-row kernel it replaces (same arithmetic per element)."""
+    _dev()
+    from ccedit_amd import hip, ops
+    x = (_rnd(n, c, h, w, seed=1) * 1.7 + 0.3).to(BF).float()
+    g, b = _rnd(c, seed=2) * 0.1 + 1, _rnd(c, seed=3) * 0.1
+    xd = _nhwc(x)
+    ops.set_gn_stats(xd, ops.groupnorm_spatial_stats(xd))
+    y = ops.groupnorm_spatial(xd, g.cuda(), b.cuda(), 1e-5, silu)
+    ref = F.group_norm(x, 32, g, b, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    _close(_nchw(y), ref, rel=2.0 ** -6, what=f"GN apply (flat) C={c}")
+    assert hip.lib().ccedit_policy_set(b"gn_apply_flat", 0) == 0
+    try:
+        y0 = ops.groupnorm_spatial(xd, g.cuda(), b.cuda(), 1e-5, silu)
+    finally:
+        hip.lib().ccedit_policy_set(b"gn_apply_flat", 1)
+    assert torch.equal(y, y0), "flat apply differs from the wave-per-row apply"
+
+
 @pytest.mark.parametrize("h,w", [(8, 12), (16, 24)])
 def test_groupnorm_spatial_onepass_large_mean(h, w):
     """The one-pass kernel (C % 256 == 0, small frames: 8x12 and 16x24 at 1280 channels) with |mean| >> std: the variance is the sum
