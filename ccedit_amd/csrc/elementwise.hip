@@ -284,7 +284,18 @@ __global__ __launch_bounds__(256) void copy_row_blocks_kernel(const char* __rest
     const u32x4* s = (const u32x4*)(src + src_row * row_gran * 16);
     u32x4* o = (u32x4*)(dst + dst_row * row_gran * 16);
     const bf16x8* a = add ? (const bf16x8*)((const char*)add + dst_row * row_gran * 16) : nullptr;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (!a) {                                                     // plain copy: four granules requested before the first is stored
+        for (; i + 3 * stride < total; i += 4 * stride) {
+            const u32x4 v0 = s[i], v1 = s[i + stride], v2 = s[i + 2 * stride], v3 = s[i + 3 * stride];
+            o[i] = v0;
+            o[i + stride] = v1;
+            o[i + 2 * stride] = v2;
+            o[i + 3 * stride] = v3;
+        }
+    }
+    for (; i < total; i += stride) {
         u32x4 v = s[i];
         if (a) {
             bf16x8 x = *(bf16x8*)&v;

@@ -58,9 +58,25 @@ class Geometry:
         return Geometry(self.b // 2, self.t, self.shard, self.rows)
 
 
+_TWIN_PLANS: Dict[tuple, torch.Tensor] = {}
+
+
 def twin(x: torch.Tensor) -> torch.Tensor:
-    """A tensor computed for one CFG half, materialised for both (uc first, then c: the same rows twice)."""
-    return torch.cat([x, x])
+    """A tensor computed for one CFG half, materialised for both (uc first, then c: the same rows twice).  One HIP copy kernel that
+    reads the source once and writes it twice (ccedit_copy_row_blocks with two destination blocks; ATen's cat kernel moved these
+    200 MB at 2.3 TB/s: 87 us per level-0 tensor, four of them per step)."""
+    if not (x.is_cuda and x.is_contiguous() and x.dim() >= 2 and (x.shape[-1] * x.element_size()) % 16 == 0):
+        return torch.cat([x, x])
+    rows, width = x.numel() // x.shape[-1], x.shape[-1]
+    key = (rows, str(x.device))
+    plan = _TWIN_PLANS.get(key)
+    if plan is None:
+        if torch.cuda.is_current_stream_capturing():      # (plans are made by the eager evaluation that precedes every capture)
+            return torch.cat([x, x])
+        plan = _TWIN_PLANS[key] = torch.tensor([[0, 0, rows], [0, rows, rows]], dtype=torch.int64, device=x.device)
+    out = torch.empty((2 * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    ops.copy_row_blocks(x.view(rows, width), out.view(2 * rows, width), plan, rows)
+    return out
 
 
 def sconv3(x, pw, geo: Geometry, stride: int = 1, **kw):
