@@ -194,12 +194,19 @@ def hip_config1(wrapper, device, x, c, uc, noises, z_ref, frames_ref, vsd):
         return float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
 
     r_lat, r_fr = rel(z, z_ref), rel(frames, frames_ref)
-    ok = bool(torch.isfinite(frames).all()) and r_lat < C1_LATENT_TOL and r_fr < C1_FRAMES_TOL
+    # the decoder alone, in the reference's precision (policy vae_fp32): the ORACLE's final latent through the fp32 first stage
+    vae.precision = "fp32"
+    zr = z_ref.to(device=device, dtype=torch.float32).contiguous()
+    r_dec32 = rel(vae.decode(ops.axpby(zr, zr, 1.0 / 0.18215, 0.0)), frames_ref)
+    vae.precision = "bf16"
+    r_dec16 = rel(vae.decode(ops.axpby(zr, zr, 1.0 / 0.18215, 0.0)), frames_ref)
+    ok = bool(torch.isfinite(frames).all()) and r_lat < C1_LATENT_TOL and r_fr < C1_FRAMES_TOL and r_dec32 < C1_DECODE_FP32_TOL
     if not ok:
         sys.stderr.write(f"bench.py: config 1 on the HIP path is {r_lat:.4f} (latent) / {r_fr:.4f} (frames) from the oracle — outside the "
                          f"stated budget {C1_LATENT_TOL} / {C1_FRAMES_TOL}\n")
     return dict(final_latent_rel_rms=round(r_lat, 5), frames_rel_rms=round(r_fr, 5), within_budget=ok,
-                budget=dict(latent=C1_LATENT_TOL, frames=C1_FRAMES_TOL), hip_end_to_end_s=round(dt, 3),
+                budget=dict(latent=C1_LATENT_TOL, frames=C1_FRAMES_TOL, decode_fp32=C1_DECODE_FP32_TOL), hip_end_to_end_s=round(dt, 3),
+                decode_of_oracle_latent_rel_rms=dict(fp32_vae=float(f"{r_dec32:.3g}"), bf16_vae=float(f"{r_dec16:.3g}")),
                 note="same initial latent, conditioning and per-step ancestral noise as the oracle run; bf16 HIP path vs fp32 oracle over "
                      "9 evaluations + VAE decode at the shipped width")
 
@@ -208,6 +215,7 @@ def hip_config1(wrapper, device, x, c, uc, noises, z_ref, frames_ref, vsd):
 # (SURVEY 8d); ancestral noise re-injection keeps the per-step errors from compounding, tests/test_network_gpu.py holds the
 # reduced-width trajectory to 8e-2.
 C1_LATENT_TOL, C1_FRAMES_TOL = 8e-2, 8e-2
+C1_DECODE_FP32_TOL = 2e-5      # the fp32 first stage (policy vae_fp32) on the oracle's own final latent: fp32 rounding only
 
 
 def main():
@@ -442,7 +450,8 @@ def main():
         if dist is not None:
             dist.barrier()
         # config 3 (reference README.md:63-77): 50 steps = 99 evaluations at cfg 7 with the reference-frame latent as cond_feat
-        clip = time_clip(wrapper, device, seed=43 if shard else 43 + rank, **(dict(num_steps=50, scale=7.0, tvi2v=True) if tvi2v else {}))
+        clip = time_clip(wrapper, device, seed=43 if shard else 43 + rank, fp32_vae=world == 1,
+                         **(dict(num_steps=50, scale=7.0, tvi2v=True) if tvi2v else {}))
         if rank != 0:
             clip = None
 
@@ -614,7 +623,7 @@ def time_tvi2v_step(device, steps):
                 frac=round(FLOP_PER_STEP_TVI2V / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4), steps=steps)
 
 
-def time_clip(wrapper, device, num_steps=30, scale=7.5, seed=43, tvi2v=False):
+def time_clip(wrapper, device, num_steps=30, scale=7.5, seed=43, tvi2v=False, fp32_vae=False):
     """One full clip: DPMPP2SAncestral (30 steps = 59 evaluations; TVI2V: 50 steps = 99) + AutoencoderKL decode -> frames/s."""
     from ccedit_amd.config import instantiate_from_config
     from ccedit_amd.sgm_compat import build_vae
@@ -659,12 +668,27 @@ def time_clip(wrapper, device, num_steps=30, scale=7.5, seed=43, tvi2v=False):
     assert frames.shape == (1, 3, T, 8 * H, 8 * W)
     wrapper.cache_hint_stem = False
     finite = bool(torch.isfinite(frames).all())
+    f32 = {}
+    if fp32_vae:        # the same latent through the fp32 first stage (the reference's precision, policy vae_fp32): second decode time
+        vae.precision = "fp32"
+        vae.decode(zs[:, :, :2].contiguous())          # code objects + allocator growth, like the bf16 warm-up
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        frames32 = vae.decode(zs)
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        d = (frames - frames32).double()
+        f32 = dict(vae_decode_fp32_s=round(t4 - t3, 3), vae_fp32_tflops=round(64.56 / (t4 - t3), 1),
+                   frames_per_s_fp32_vae=round(T / (t1 - t0 + t4 - t3), 3) if finite else None,
+                   bf16_vs_fp32_frames_rel_rms=float(f"{float((d ** 2).mean().sqrt() / (frames32.double() ** 2).mean().sqrt()):.3g}"))
+        del frames32, d
     if not finite:                                 # a rate for garbage is not a measurement
         sys.stderr.write("bench.py: the sampled clip contains non-finite values — frames_per_s withheld\n")
     return dict(sampler_s=round(t1 - t0, 3), vae_decode_s=round(t2 - t1, 3), evaluations=evals[0], sampler_steps=num_steps, cfg_scale=scale,
                 hint_stem="once per clip", decoder_warmup="one untimed decode",
-                vae="bf16 storage / fp32 accumulation (the reference decodes in fp32, diffusion.py:151-156)",
-                frames_per_s=round(T / (t2 - t0), 3) if finite else None, finite=finite)
+                vae="bf16 storage / fp32 accumulation by default; the reference decodes in fp32 (diffusion.py:151-156) — policy vae_fp32=1 "
+                    "runs the first stage on v_mfma_f32_32x32x2_f32 (vae_decode_fp32_s, frames_per_s_fp32_vae)",
+                frames_per_s=round(T / (t2 - t0), 3) if finite else None, finite=finite, **f32)
 
 
 if __name__ == "__main__":

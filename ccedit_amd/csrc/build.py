@@ -13,7 +13,7 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.abspath(os.path.join(HERE, "..", "libccedit_hip.so"))
-SOURCES = ["gemm.hip", "gemm8p.hip", "convhalo.hip", "smallconv.hip", "lin320.hip", "lin640.hip", "temp320.hip", "ff320.hip", "norm.hip", "attention.hip", "attnspatial.hip", "attnshort.hip", "attntext.hip", "elementwise.hip", "core.cpp"]
+SOURCES = ["gemm.hip", "gemm8p.hip", "convhalo.hip", "smallconv.hip", "lin320.hip", "lin640.hip", "temp320.hip", "ff320.hip", "norm.hip", "attention.hip", "attnspatial.hip", "attnshort.hip", "attntext.hip", "elementwise.hip", "f32vae.hip", "core.cpp"]
 ARCH = "gfx950"
 # per-file flags: ff320's GEGLU must stay scalar fp32 (packed fp32 VALU is several times slower beside MFMAs, see the file).
 # norm.hip / attnshort.hip: without the SLP vectoriser nothing there becomes a packed-fp32 op whose LOW lane reads the HIGH half of

@@ -1,0 +1,404 @@
+// fp32 kernels of the first-stage model (KL-VAE) — the precision the reference decodes in: `decode_first_stage` runs the
+// decoder with autocast DISABLED (sgm/models/diffusion.py:151-156, `disable_first_stage_autocast`), i.e. fp32 operands, fp32
+// products, fp32 tensors.  The bf16 kernels of the rest of the path serve the VAE by default (a clip's decode is 1.4 % of its
+// FLOPs); these three entry points are the option that reproduces the reference's arithmetic class: fp32 in, fp32 MFMA
+// (`v_mfma_f32_32x32x2_f32`, true fp32 products and sums), fp32 out.
+//
+//   ccedit_gemm_f32           out[m][n] = bias[n] + sum_k W[n][k] * gather(A)[m][k] (+ res[m][n])
+//                             Linear / Conv 1x1 (mode 0) and Conv2d 3x3 with stride, padding, an explicit output size (the encoder's
+//                             asymmetric pad) and an optional fused nearest-2x upsample of the source (mode 1)
+//                             (model.py:56-71 Upsample, 74-93 Downsample, 94-151 ResnetBlock, 161-201 AttnBlock)
+//   ccedit_groupnorm_f32      GroupNorm(32, C, eps) [+ SiLU] over (H W) x C/32 of a frame (model.py:45-53), statistics in fp64
+//   ccedit_softmax_rows_f32   in-place softmax(scale * s) of the single-head attention scores (model.py:180-195)
+//
+// GEMM kernel: 128 channels x 128 pixels per workgroup, four waves of 64 x 64 (2 x 2 MFMA tiles, 64 accumulator registers),
+// K tiles of 16 through a two-buffer LDS ring filled from registers (the next tile's global loads are issued before the MFMAs of
+// the current one).  Weights are the A operand, pixels the B operand, as everywhere in this library: a lane owns one pixel and
+// runs of four consecutive channels, stored as 16-byte pieces.  The K index inside a tile is permuted (lanes 0-31 take k 0..7,
+// lanes 32-63 k 8..15: MFMA j multiplies k = {j, 8 + j}) so that a lane's eight operands are two ds_read_b128; rows are 80 bytes
+// apart in LDS (conflict-free for that pattern).  The matrix pipe runs fp32 at 256 FLOP / clk / CU (157 TFLOP/s): one MFMA is 64
+// cycles against two 16-byte LDS reads, so this simple loop is MFMA-bound.
+#include "common.h"
+
+namespace {
+
+constexpr int F_BM = 128, F_BN = 128, F_BK = 16, F_LD = 20;           // LDS row = 16 floats + 4 pad
+constexpr int F_TILE = (F_BM + F_BN) * F_LD;                           // floats per buffer
+
+struct F32Pix {            // geometry of one pixel row of the tile (conv mode)
+    int64_t base;          // element offset of its frame in A
+    int oy, ox;            // output coordinates times stride, minus pad (top-left tap position in the virtual source)
+};
+
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void f32_gemm_kernel(const CcGemmF32Desc d) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * F_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    // channel tiles fastest: the workgroups that run together share the pixel rows they gather
+    const int ct_n = (d.N + F_BN - 1) / F_BN;
+    const int64_t pt = blockIdx.x / ct_n;
+    const int ct = blockIdx.x - (int)pt * ct_n;
+    const int64_t m0 = pt * F_BM;
+    const int n0 = ct * F_BN;
+    const int nk = d.Kpad / F_BK;
+
+    // staging: thread -> rows (tid >> 2) and (tid >> 2) + 64 of both operands, floats 4 (tid & 3) .. + 3 of the K tile
+    const int srow = tid >> 2, sg = tid & 3;
+    const float* wsrc[2];
+    F32Pix px[2];
+    const float* asrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = min(n0 + srow + 64 * i, d.N - 1);
+        wsrc[i] = d.W + (size_t)n * d.ldw + sg * 4;
+        const int64_t m = min(m0 + srow + 64 * i, d.M - 1);
+        if constexpr (CONV) {
+            const int hw = d.Hout * d.Wout;
+            const int64_t f = m / hw;
+            const int r = (int)(m - f * hw);
+            const int y = r / d.Wout, x = r - y * d.Wout;
+            px[i].base = f * (int64_t)d.Hin * d.Win * d.lda;
+            px[i].oy = y * d.stride - d.pad;
+            px[i].ox = x * d.stride - d.pad;
+        } else {
+            asrc[i] = d.A + (size_t)m * d.lda + sg * 4;
+        }
+    }
+    const int Hv = d.upsample ? 2 * d.Hin : d.Hin, Wv = d.upsample ? 2 * d.Win : d.Win;      // the (virtual) source the taps walk over
+    const int us = d.upsample ? 1 : 0;
+
+    f32x4 ra[2], rb[2];
+    auto fetch = [&](int kt) {
+        const int k0 = kt * F_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = *(const f32x4*)(wsrc[i] + k0);
+        if constexpr (CONV) {
+            const int tap = k0 / d.Cpad, c = k0 - tap * d.Cpad + sg * 4;           // a K tile never straddles taps (Cpad % 16 == 0)
+            const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int iy = px[i].oy + ky, ix = px[i].ox + kx;
+                const bool ok = iy >= 0 && iy < Hv && ix >= 0 && ix < Wv && c < d.Cin;
+                const float* p = d.A + px[i].base + ((int64_t)(iy >> us) * d.Win + (ix >> us)) * d.lda + c;
+                rb[i] = ok ? *(const f32x4*)p : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            const bool ok = k0 + sg * 4 < d.Cin;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) rb[i] = ok ? *(const f32x4*)(asrc[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stash = [&](int buf) {
+        float* s = smem + buf * F_TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(f32x4*)(s + (srow + 64 * i) * F_LD + sg * 4) = ra[i];
+            *(f32x4*)(s + (F_BM + srow + 64 * i) * F_LD + sg * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) fetch(kt + 1);
+        const float* s = smem + (kt & 1) * F_TILE;
+        f32x4 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float* pa = s + (wr * 64 + t * 32 + l31) * F_LD + hi * 8;
+            const float* pb = s + (F_BM + wc * 64 + t * 32 + l31) * F_LD + hi * 8;
+            fa[t][0] = *(const f32x4*)pa;
+            fa[t][1] = *(const f32x4*)(pa + 4);
+            fb[t][0] = *(const f32x4*)pb;
+            fb[t][1] = *(const f32x4*)(pb + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ti][j >> 2][j & 3], fb[tj][j >> 2][j & 3], acc[ti][tj], 0, 0, 0);
+        if (kt + 1 < nk) stash((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane = pixel (column) l31 of tile tj; accumulator r = channel 8 (r / 4) + 4 hi + r % 4 of tile ti
+    const bool vec = (d.ldc & 3) == 0 && (!d.res || (d.ldr & 3) == 0);
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int64_t m = m0 + wc * 64 + tj * 32 + l31;
+        if (m >= d.M) continue;
+        float* orow = d.out + (size_t)m * d.ldc;
+        const float* rrow = d.res ? d.res + (size_t)m * d.ldr : nullptr;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wr * 64 + ti * 32 + 8 * q + 4 * hi;
+                if (n >= d.N) continue;
+                f32x4 v = {acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1], acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]};
+                if (vec && n + 3 < d.N) {
+                    if (d.bias) v += *(const f32x4*)(d.bias + n);
+                    if (rrow) v += *(const f32x4*)(rrow + n);
+                    *(f32x4*)(orow + n) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < d.N) {
+                            float o = v[e];
+                            if (d.bias) o += d.bias[n + e];
+                            if (rrow) o += rrow[n + e];
+                            orow[n + e] = o;
+                        }
+                }
+            }
+    }
+}
+
+// ---- GroupNorm(32) over fp32 frames ----
+// VEC = 4 (C a multiple of 128: a 16-byte granule never straddles groups) or 1 (C = 32 / 64: the reduced-width test models).
+template <int VEC>
+struct GnVec {
+    float v[VEC];
+    __device__ __forceinline__ void load(const float* p) {
+        if constexpr (VEC == 4) {
+            const f32x4 t = *(const f32x4*)p;
+            v[0] = t[0], v[1] = t[1], v[2] = t[2], v[3] = t[3];
+        } else {
+            v[0] = *p;
+        }
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        if constexpr (VEC == 4)
+            *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+        else
+            *p = v[0];
+    }
+};
+
+// statistics: a block takes a slice of a frame's rows; thread = (granule of VEC channels, row lane); fp64 partial sums, folded
+// per group and added to the frame's fp64 slots
+template <int VEC>
+__global__ __launch_bounds__(256) void gn32_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int hw, int C, int rows_per_block) {
+    __shared__ double red[256][2];
+    const int frame = blockIdx.y;
+    const int gpr = C / VEC;                                 // granules per row
+    const int g = threadIdx.x % gpr, rl = threadIdx.x / gpr, nrl = 256 / gpr;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, hw);
+    const float* base = x + ((size_t)frame * hw) * C + g * VEC;
+    double s = 0.0, q = 0.0;
+    int r = r0 + rl;
+    for (; r + 3 * nrl < r1; r += 4 * nrl) {                 // four rows in flight
+        GnVec<VEC> v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u].load(base + (size_t)(r + u * nrl) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const double t = (double)v[u].v[e];
+                s += t;
+                q += t * t;
+            }
+    }
+    for (; r < r1; r += nrl) {
+        GnVec<VEC> v;
+        v.load(base + (size_t)r * C);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const double t = (double)v.v[e];
+            s += t;
+            q += t * t;
+        }
+    }
+    red[threadIdx.x][0] = s;
+    red[threadIdx.x][1] = q;
+    __syncthreads();
+    if (threadIdx.x < 32) {                                   // one thread per group: fixed summation order inside the block
+        const int gpg = gpr / 32;                             // granules per group
+        double ts = 0.0, tq = 0.0;
+        for (int l = 0; l < nrl; ++l)
+            for (int k = 0; k < gpg; ++k) {
+                ts += red[l * gpr + threadIdx.x * gpg + k][0];
+                tq += red[l * gpr + threadIdx.x * gpg + k][1];
+            }
+        atomicAdd(stats + ((size_t)frame * 32 + threadIdx.x) * 2, ts);
+        atomicAdd(stats + ((size_t)frame * 32 + threadIdx.x) * 2 + 1, tq);
+    }
+}
+
+template <int VEC, bool SILU>
+__global__ __launch_bounds__(256) void gn32_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const double* __restrict__ stats,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int hw, int C, float eps,
+                                                         int rows_per_block) {
+    const int frame = blockIdx.y;
+    const int gpr = C / VEC;
+    const int g = threadIdx.x % gpr, rl = threadIdx.x / gpr, nrl = 256 / gpr;
+    const int grp = (g * VEC) / (C / 32);
+    const double cnt = (double)hw * (C / 32);
+    const double mean_d = stats[((size_t)frame * 32 + grp) * 2] / cnt;
+    double var = stats[((size_t)frame * 32 + grp) * 2 + 1] / cnt - mean_d * mean_d;
+    var = var > 0.0 ? var : 0.0;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    GnVec<VEC> ga, be;
+    ga.load(gamma + g * VEC);
+    be.load(beta + g * VEC);
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, hw);
+    const size_t off = ((size_t)frame * hw) * C + g * VEC;
+    auto norm = [&](const GnVec<VEC>& v) {
+        GnVec<VEC> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float t = (v.v[e] - mean) * rstd * ga.v[e] + be.v[e];
+            if (SILU) t = t / (1.0f + expf(-t));
+            o.v[e] = t;
+        }
+        return o;
+    };
+    int r = r0 + rl;
+    for (; r + 3 * nrl < r1; r += 4 * nrl) {
+        GnVec<VEC> v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u].load(x + off + (size_t)(r + u * nrl) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) norm(v[u]).store(y + off + (size_t)(r + u * nrl) * C);
+    }
+    for (; r < r1; r += nrl) {
+        GnVec<VEC> v;
+        v.load(x + off + (size_t)r * C);
+        norm(v).store(y + off + (size_t)r * C);
+    }
+}
+
+// ---- in-place row softmax of fp32 scores: one block per row, the row held in registers ----
+template <int PER>
+__global__ __launch_bounds__(256) void softmax_rows_f32_kernel(float* __restrict__ s, int cols, int64_t ld, float scale) {
+    __shared__ float red[4];
+    float* row = s + (size_t)blockIdx.x * ld;
+    float v[PER];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        v[i] = c < cols ? row[c] * scale : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        v[i] = expf(v[i] - mx);
+        sum += v[i];
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < cols) row[c] = v[i] * inv;
+    }
+}
+
+}  // namespace
+
+extern "C" int ccedit_gemm_f32(const CcGemmF32Desc* desc, void* stream) {
+    CC_CHECK_ARG(desc != nullptr, "ccedit_gemm_f32: null descriptor");
+    const CcGemmF32Desc& d = *desc;
+    CC_CHECK_ARG(d.A && d.W && d.out, "ccedit_gemm_f32: null operand");
+    CC_CHECK_ARG(d.M >= 0 && d.N > 0 && d.Cin > 0, "ccedit_gemm_f32: bad sizes (M=%lld N=%d Cin=%d)", (long long)d.M, d.N, d.Cin);
+    CC_CHECK_ARG(d.mode == 0 || d.mode == 1, "ccedit_gemm_f32: mode %d (0 = Linear / Conv 1x1, 1 = Conv2d 3x3)", d.mode);
+    CC_CHECK_ARG(d.Cin % 4 == 0 && d.lda % 4 == 0 && d.lda >= d.Cin, "ccedit_gemm_f32: Cin (%d) and lda (%d) must be multiples of 4, lda >= Cin", d.Cin, d.lda);
+    CC_CHECK_ARG(d.Cpad % 16 == 0 && d.Cpad >= d.Cin, "ccedit_gemm_f32: Cpad (%d) must be a multiple of 16 and >= Cin", d.Cpad);
+    CC_CHECK_ARG(d.Kpad == (d.mode == 1 ? 9 : 1) * d.Cpad && d.ldw >= d.Kpad && d.ldw % 4 == 0,
+                 "ccedit_gemm_f32: Kpad (%d) must be taps x Cpad, ldw (%d) >= Kpad and a multiple of 4", d.Kpad, d.ldw);
+    CC_CHECK_ARG(d.ldc >= d.N && (!d.res || d.ldr >= d.N), "ccedit_gemm_f32: ldc / ldr smaller than N");
+    CC_CHECK_ARG(((uintptr_t)d.A | (uintptr_t)d.W) % 16 == 0, "ccedit_gemm_f32: A and W must be 16-byte aligned");
+    CC_CHECK_ARG((d.ldc % 4 != 0 || (uintptr_t)d.out % 16 == 0) && (!d.bias || (uintptr_t)d.bias % 16 == 0) &&
+                     (!d.res || d.ldr % 4 != 0 || (uintptr_t)d.res % 16 == 0),
+                 "ccedit_gemm_f32: out / bias / res must be 16-byte aligned when their row stride is a multiple of 4");
+    if (d.mode == 1) {
+        CC_CHECK_ARG(d.Hin > 0 && d.Win > 0 && d.Hout > 0 && d.Wout > 0 && d.stride >= 1 && d.pad >= 0 && (d.upsample == 0 || d.upsample == 1),
+                     "ccedit_gemm_f32: bad convolution geometry");
+        CC_CHECK_ARG(d.M % ((int64_t)d.Hout * d.Wout) == 0, "ccedit_gemm_f32: M (%lld) is not a whole number of %d x %d output frames", (long long)d.M, d.Hout, d.Wout);
+    }
+    if (d.M == 0) return CCEDIT_OK;
+    const int64_t blocks = ((d.M + F_BM - 1) / F_BM) * ((d.N + F_BN - 1) / F_BN);
+    CC_CHECK_ARG(blocks < (1LL << 31), "ccedit_gemm_f32: too many tiles");
+    hipStream_t s = (hipStream_t)stream;
+    if (d.mode == 1) {
+        cc_note_kernel("f32_gemm_kernel 128ch x 128pix, 3x3 taps");
+        hipLaunchKernelGGL((f32_gemm_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, d);
+    } else {
+        cc_note_kernel("f32_gemm_kernel 128ch x 128pix");
+        hipLaunchKernelGGL((f32_gemm_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, d);
+    }
+    return cc_launch_status("f32_gemm_kernel");
+}
+
+extern "C" int ccedit_groupnorm_f32(const float* x, float* y, const float* gamma, const float* beta, double* stats, int32_t frames, int32_t hw,
+                                    int32_t C, float eps, int32_t silu, void* stream) {
+    CC_CHECK_ARG(x && y && gamma && beta && stats, "ccedit_groupnorm_f32: null pointer");
+    CC_CHECK_ARG(frames >= 0 && hw > 0, "ccedit_groupnorm_f32: bad sizes");
+    const int vec = C % 128 == 0 ? 4 : 1;
+    CC_CHECK_ARG(C % 32 == 0 && C / vec <= 256 && 256 % (C / vec) == 0,
+                 "ccedit_groupnorm_f32: C (%d) must be 32, 64 or 128, 256, 512, 1024 (32 groups, whole granules per thread column)", C);
+    CC_CHECK_ARG(((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) % 16 == 0, "ccedit_groupnorm_f32: 16-byte alignment");
+    if (frames == 0) return CCEDIT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(stats, 0, (size_t)frames * 64 * sizeof(double), s);
+    if (e != hipSuccess) {
+        cc_set_error("ccedit_groupnorm_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    // ~2048 blocks over the frames, at least 64 rows each
+    int per_frame = (2048 + frames - 1) / frames;
+    int rows = (hw + per_frame - 1) / per_frame;
+    rows = rows < 64 ? 64 : rows;
+    const int bx = (hw + rows - 1) / rows;
+#define GN32_GO(V)                                                                                                                  \
+    do {                                                                                                                            \
+        hipLaunchKernelGGL((gn32_stats_kernel<V>), dim3(bx, frames), dim3(256), 0, s, x, stats, hw, C, rows);                       \
+        if (silu)                                                                                                                   \
+            hipLaunchKernelGGL((gn32_apply_kernel<V, true>), dim3(bx, frames), dim3(256), 0, s, x, y, stats, gamma, beta, hw, C, eps, rows);  \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((gn32_apply_kernel<V, false>), dim3(bx, frames), dim3(256), 0, s, x, y, stats, gamma, beta, hw, C, eps, rows); \
+    } while (0)
+    if (vec == 4)
+        GN32_GO(4);
+    else
+        GN32_GO(1);
+#undef GN32_GO
+    return cc_launch_status("gn32 kernels");
+}
+
+extern "C" int ccedit_softmax_rows_f32(float* s, int64_t rows, int32_t cols, int64_t ld, float scale, void* stream) {
+    CC_CHECK_ARG(s != nullptr && rows >= 0 && cols > 0 && ld >= cols, "ccedit_softmax_rows_f32: bad arguments");
+    CC_CHECK_ARG(cols <= 256 * 32, "ccedit_softmax_rows_f32: at most 8192 columns (%d)", cols);
+    CC_CHECK_ARG(rows < (1LL << 31), "ccedit_softmax_rows_f32: too many rows");
+    if (rows == 0) return CCEDIT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (cols <= 256 * 8)
+        hipLaunchKernelGGL((softmax_rows_f32_kernel<8>), dim3((unsigned)rows), dim3(256), 0, st, s, cols, ld, scale);
+    else
+        hipLaunchKernelGGL((softmax_rows_f32_kernel<32>), dim3((unsigned)rows), dim3(256), 0, st, s, cols, ld, scale);
+    return cc_launch_status("softmax_rows_f32_kernel");
+}

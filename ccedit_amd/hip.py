@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the library is loaded: to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCEDIT_HIP_LIB") or os.path.join(_HERE, "libccedit_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 ATTN_Q_LOG2 = 1          # CcAttnDesc.flags: CCEDIT_ATTN_Q_LOG2
 
 GEMM_LINEAR, GEMM_CONV2D, GEMM_TEMPORAL = 0, 1, 2
@@ -61,6 +61,16 @@ class CcFf320Desc(C.Structure):
         ("x", C.c_void_p), ("out", C.c_void_p), ("wstream", C.c_void_p), ("b2p", C.c_void_p), ("dbg", C.c_void_p),
         ("a", C.c_void_p), ("res", C.c_void_p), ("res2", C.c_void_p), ("bop", C.c_void_p), ("bpp", C.c_void_p),
         ("lda", C.c_int32), ("ldr", C.c_int32), ("ldr2", C.c_int32), ("pad_", C.c_int32),
+    ]
+
+
+class CcGemmF32Desc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("out", C.c_void_p),
+        ("M", C.c_int64), ("N", C.c_int32), ("Cin", C.c_int32), ("Cpad", C.c_int32), ("Kpad", C.c_int32),
+        ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("mode", C.c_int32),
+        ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32), ("stride", C.c_int32),
+        ("pad", C.c_int32), ("upsample", C.c_int32),
     ]
 
 
@@ -111,6 +121,10 @@ _SIGS = {
     "ccedit_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ccedit_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                                       C.c_float, C.c_void_p]),
+    "ccedit_gemm_f32": (C.c_int, [C.POINTER(CcGemmF32Desc), C.c_void_p]),
+    "ccedit_groupnorm_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_float, C.c_int32, C.c_void_p]),
+    "ccedit_softmax_rows_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_void_p]),
     "ccedit_embedding_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_void_p]),
     "ccedit_gaussian_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,

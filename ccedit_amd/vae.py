@@ -3,8 +3,9 @@
 Reference: sgm/models/autoencoder.py:283-343 (AutoencoderKL, AutoencoderKLInferenceWrapper),
 sgm/modules/diffusionmodules/model.py:94-151 (ResnetBlock), 161-201 (AttnBlock), 56-71 (Upsample),
 617-761 (Decoder).  State-dict keys are the reference's (`decoder.up.3.block.0.norm1.weight`, ...).
-The reference runs the VAE in fp32 (autocast disabled); here it runs in bf16 storage with fp32
-accumulation / statistics like the rest of the path — the tolerance is stated in the tests.
+The reference runs the VAE in fp32 (autocast disabled); by default it runs here in bf16 storage with fp32
+accumulation / statistics like the rest of the path — the tolerance is stated in the tests.  `precision = "fp32"`
+(policy `vae_fp32=1`) evaluates the same modules on the fp32 kernels of `vae_f32.py` / `csrc/f32vae.hip` instead.
 
 `decode` is on the hot path (once per clip).  `encode` (Encoder model.py:498-614, asymmetric
 Downsample :74-93, DiagonalGaussianDistribution.sample distributions.py:24-41) serves the `--prior_coefficient_x`
@@ -19,7 +20,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, policy, vae_f32
 from .layers import Conv, Norm, Slot, pack_tree
 from .packing import PackedWeight
 
@@ -221,6 +222,7 @@ class AutoencoderKL(nn.Module):
         self.post_quant_conv = Conv(embed_dim, dd["z_channels"], 1)
         self.embed_dim = embed_dim
         self._packed = False
+        self.precision = "fp32" if policy.on("vae_fp32") else "bf16"      # "fp32": the reference's arithmetic class (vae_f32.py)
 
     def pack(self, device=None):
         device = torch.device("cuda") if device is None else device
@@ -264,7 +266,14 @@ class AutoencoderKLInferenceWrapper(AutoencoderKL):
         b, c, t, h, w = x5.shape
         if h % 8 or w % 8:
             raise ValueError(f"frame size {h}x{w} must be a multiple of 8")
-        z = self._encode_frames(ops.ncthw_to_nhwc(x5.float().contiguous(), 8), noise)     # (b*t, zc, h/8, w/8)
+        if self.precision == "fp32":
+            mom = vae_f32.encode_moments(self, x5.float())
+            zc = self.quant_conv.cout // 2
+            if noise is None:
+                noise = torch.randn(b * t, zc, h // 8, w // 8)           # CPU global generator, like distributions.py:37-41
+            z = ops.gaussian_sample(mom.view(-1, mom.shape[-1]), noise.to(device=mom.device, dtype=torch.float32).contiguous(), zc)
+        else:
+            z = self._encode_frames(ops.ncthw_to_nhwc(x5.float().contiguous(), 8), noise)     # (b*t, zc, h/8, w/8)
         if is_video:
             return z.view(b, t, *z.shape[1:]).permute(0, 2, 1, 3, 4).contiguous()
         return z
@@ -275,7 +284,9 @@ class AutoencoderKLInferenceWrapper(AutoencoderKL):
         is_video = z.dim() == 5
         z5 = z if is_video else z[:, :, None]
         b, c, t, h, w = z5.shape
-        z8 = ops.ncthw_to_nhwc(z5.float().contiguous(), 8)
-        dec = self._decode_frames(z8)                                   # (b*t, H, W, 4) fp32
+        if self.precision == "fp32":
+            dec = vae_f32.decode_frames(self, z5.float())
+        else:
+            dec = self._decode_frames(ops.ncthw_to_nhwc(z5.float().contiguous(), 8))    # (b*t, H, W, 4) fp32
         out = ops.nhwc_to_ncthw(dec, b, t, self.decoder.out_ch)
         return out if is_video else out[:, :, 0]

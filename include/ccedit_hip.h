@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCEDIT_ABI_VERSION 10
+#define CCEDIT_ABI_VERSION 11
 
 #define CCEDIT_OK 0
 #define CCEDIT_EINVAL (-1)       /* null pointer / bad size */
@@ -352,6 +352,41 @@ int ccedit_embedding_lookup(const int64_t* ids, const float* tok, const float* p
  * draws it with torch.randn on the CPU global generator). */
 int ccedit_gaussian_sample(const float* moments, const float* noise, float* out, int64_t frames, int32_t zc,
                            int32_t hw, int32_t ldm, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fp32 first-stage model (ABI 11).  The reference decodes with autocast disabled (sgm/models/diffusion.py:151-156): fp32 operands,
+ * products and tensors.  These three entry points evaluate the KL-VAE in that arithmetic class on the fp32 matrix instruction
+ * (v_mfma_f32_32x32x2_f32); the bf16 kernels above remain the default (ccedit_amd/vae.py, policy `vae_fp32`).
+ *
+ * ccedit_gemm_f32: out[m][n] = bias[n] + sum_k W[n][k] * src(A)[m][k] (+ res[m][n]); everything fp32, channels-last rows.
+ *   mode 0  Linear / Conv 1x1: A [M][lda], k = channel < Cin (Cin % 4 == 0); W [N][ldw] with Kpad = Cpad = Cin rounded up to 16,
+ *           columns [Cin, Kpad) ZERO (model.py:161-201 q/k/v/proj_out, nin_shortcut, quant / post_quant convs; the attention's
+ *           q k^T and p v products with the other tensor in the role of W)
+ *   mode 1  Conv2d 3x3: A [frames][Hin][Win][lda]; W [N][9][Cpad] (tap-major, tap = 3 ky + kx, columns [Cin, Cpad) zero);
+ *           output pixel (y, x) reads source (y stride - pad + ky, x stride - pad + kx), zeros outside; Hout / Wout are given (the
+ *           encoder's Downsample pads right / bottom only, model.py:74-93); upsample = 1: the taps walk over the nearest-2x
+ *           upsampled source (2 Hin x 2 Win) without materialising it (model.py:56-71).  M = frames * Hout * Wout.
+ * A and W 16-byte aligned, lda % 4 == 0, ldw % 4 == 0; out / res any row stride >= N (16-byte accesses when a multiple of 4).
+ * Fixed summation order: repeated calls are bit-identical. */
+typedef struct CcGemmF32Desc {
+    const float* A;
+    const float* W;
+    const float* bias; /* [N] or NULL */
+    const float* res;  /* [M][ldr] or NULL */
+    float* out;        /* [M][ldc] */
+    int64_t M;
+    int32_t N, Cin, Cpad, Kpad;
+    int32_t lda, ldw, ldc, ldr;
+    int32_t mode;
+    int32_t Hin, Win, Hout, Wout, stride, pad, upsample;
+} CcGemmF32Desc;
+int ccedit_gemm_f32(const CcGemmF32Desc* desc, void* stream);
+/* y = GroupNorm(32, C, eps)(x) [then SiLU when silu != 0] per frame over (hw x C / 32); x, y fp32 [frames][hw][C] (y may alias x),
+ * C in {32, 64, 128, 256, 512, 1024}; stats = fp64 scratch [frames][32][2] (sum, sum of squares; zeroed here).  model.py:45-53. */
+int ccedit_groupnorm_f32(const float* x, float* y, const float* gamma, const float* beta, double* stats, int32_t frames, int32_t hw,
+                         int32_t C, float eps, int32_t silu, void* stream);
+/* s[r][0..cols) = softmax(scale * s[r][0..cols)) in place, fp32 rows of stride ld; columns beyond cols are left alone; cols <= 8192 */
+int ccedit_softmax_rows_f32(float* s, int64_t rows, int32_t cols, int64_t ld, float scale, void* stream);
 
 /* Sampler / guider / denoiser elementwise math on the fp32 latent (417,792 elements at 17x64x96):
  *   ccedit_cfg_denoise : den = x + (-sigma) * (eps_u + scale*(eps_c - eps_u))        [denoiser.py:40 with

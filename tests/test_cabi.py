@@ -29,7 +29,7 @@ def test_header_symbols_exported(libpath):
         assert hasattr(lib, n), f"{n} declared in include/ccedit_hip.h but not exported"
     lib.ccedit_abi_version.restype = ctypes.c_int
     from ccedit_amd import hip
-    assert lib.ccedit_abi_version() == 10 == hip.ABI_VERSION
+    assert lib.ccedit_abi_version() == 11 == hip.ABI_VERSION
 
 
 def test_binding_matches_header(libpath):
@@ -39,6 +39,7 @@ def test_binding_matches_header(libpath):
     assert ctypes.sizeof(hip.CcGemmDesc) == 8 + 34 * 4 + 9 * 8 + (8 + 8 + 2 * 4) + 4 * 8 + 2 * 4 + 2 * 8      # ... + workspace, workspace_bytes, split_k, subpix; ln_colsum, ln_stats, ln_sums, row_sums, ln_sums_eps, vpad (ABI 9); halo_top, halo_bot (ABI 10)
     assert ctypes.sizeof(hip.CcFf320Desc) == 8 + 6 * 4 + 5 * 8 + 5 * 8 + 4 * 4                # ... + a, res, res2, bop, bpp, lda, ldr, ldr2, pad (ABI 10: block tail)
     assert ctypes.sizeof(hip.CcAttnDesc) % 8 == 0
+    assert ctypes.sizeof(hip.CcGemmF32Desc) == 5 * 8 + 8 + 16 * 4                               # ABI 11: fp32 first-stage model
 
 
 def test_invalid_arguments_are_reported_not_crashing(libpath):
@@ -55,6 +56,12 @@ def test_invalid_arguments_are_reported_not_crashing(libpath):
     assert rc == -2 and b"multiple of 4" in lib.ccedit_last_error()
     a = hip.CcAttnDesc()
     assert lib.ccedit_attention(ctypes.byref(a), None) == -1
+    f = hip.CcGemmF32Desc()
+    f.A = f.W = f.out = 16
+    f.M, f.N, f.Cin, f.Cpad, f.Kpad, f.lda, f.ldw, f.ldc = 64, 8, 6, 16, 16, 8, 16, 8
+    assert lib.ccedit_gemm_f32(ctypes.byref(f), None) == -1 and b"multiples of 4" in lib.ccedit_last_error()
+    assert lib.ccedit_groupnorm_f32(16, 16, 16, 16, 16, 1, 64, 96, 1e-6, 1, None) == -1 and b"128, 256, 512" in lib.ccedit_last_error()
+    assert lib.ccedit_softmax_rows_f32(16, 4, 9000, 9000, 1.0, None) == -1
 
 
 def test_ln_eps_is_refused_where_no_kernel_normalises(libpath):
