@@ -4,6 +4,7 @@
 #   <tag>_bench_line_tvi2v.json         python bench.py --workload tvi2v
 #   <tag>_bench_line_under_rocprof.json + <tag>_bench_kernel_stats.txt        rocprofv3 --kernel-trace --stats, batched single stream
 #   <tag>_bench_line_under_rocprof_streams.json + <tag>_bench_kernel_stats_streams.txt   the same, default multi-stream execution
+#   <tag>_vae_fp32_time.txt + <tag>_vae_fp32_kernel_stats.txt   full-size first-stage decode, bf16 default against the fp32 option (tools/vae32_time.py)
 #   <tag>_pmc_traffic.json / .txt       FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh), tagged with the kernel-source hash
 # Outputs land in gpurun_out/; copy what is to be judged into profiles/.
 tag=${1:-rXX}
@@ -20,6 +21,9 @@ for mode in single streams; do
   python $R/tools/prof_summary.py /tmp/pf_$mode $O/${tag}_bench_kernel_stats$sfx.txt > /dev/null 2>&1
 done
 unset CCEDIT_SPLIT_CFG CCEDIT_OVERLAP_CONTROLNET
+rm -rf /tmp/pf_vae32
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_vae32 -- python $R/tools/vae32_time.py > $O/${tag}_vae_fp32_time.txt 2>/dev/null
+python $R/tools/prof_summary.py /tmp/pf_vae32 $O/${tag}_vae_fp32_kernel_stats.txt > /dev/null 2>&1
 PMC_JSON=$O/${tag}_pmc_traffic.json bash $R/tools/pmc_traffic.sh > $O/${tag}_pmc_traffic.txt 2>&1
 if [ "${PROFILE_TVI2V:-0}" = 1 ]; then PMC_BENCH_ARGS="--workload tvi2v" PMC_JSON=$O/${tag}_pmc_traffic_tvi2v.json bash $R/tools/pmc_traffic.sh > $O/${tag}_pmc_traffic_tvi2v.txt 2>&1; fi
 # matrix-pipe / VALU counters of the dominant kernels (tools/pmc_counters.sh: two --pmc passes each, --kernel-trace only); round 5: the feed-forward alone and as the block tail
