@@ -21,6 +21,13 @@
 //     immediates of a loop unrolled by three — no address arithmetic in the loop;
 //   * the tile with masked keys (Lk % 64 != 0) is a separate instantiation: the main loop has no selects.
 // Same tile geometry, LDS image, K-row permutation and V transpose reads as attention.hip (see there).
+//
+// d = 80 (the 1536-token attention of the 32x48 level; round 5): the same body on 256-byte rows.  80 is a multiple of 16, so the
+// reference takes a k-step of its own whose K fragment is a register constant (column 80 = 1: no LDS read); three O^T row tiles
+// (80 value rows + the denominator row) in 32x32x16 tiles; ring of three 32 KB slots = one workgroup per CU, 157 registers, two
+// waves per SIMD.  Per wave and 64-key tile: 24 MFMAs (768 matrix-pipe cycles), ~24 KB of LDS fragment reads (768 cycles of the
+// CU's 128 B / clk shared by eight waves) and the same 84 VALU instructions as d = 40 — three co-critical resources; measured
+// 308 us against 387 us on the general kernel for 34 x 8 x 1536^2 (667 against 531 TFLOP/s).
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -50,11 +57,11 @@ __device__ __forceinline__ void as_barrier() {
 struct VFrag {
     u32x2 lo, hi;
 };
-template <int OFF>
+template <int OFF, int ROW4 = 512>          // ROW4: bytes between tile rows r and r + 4 (the second half of the fragment)
 __device__ __forceinline__ void as_tr_issue(VFrag& f, uint32_t addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
                  : "=&v"(f.lo), "=&v"(f.hi)
-                 : "v"(addr), "n"(OFF), "n"(OFF + 512));
+                 : "v"(addr), "n"(OFF), "n"(OFF + ROW4));
 }
 template <int N>
 __device__ __forceinline__ void as_tr_wait(VFrag& a, VFrag& b) {
@@ -80,9 +87,15 @@ __device__ __forceinline__ float bf16_ceil(float x) {
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 constexpr int kNW = 8, kNT = kNW * 64;
-constexpr int kKB = 64 * 64 * 2, kVB = 64 * 64 * 2, kSlot = kKB + kVB;      // 16 KB per ring slot
 constexpr int kSlots = 3;
-constexpr int kLds = kSlots * kSlot;
+// LDS image per head dimension: d = 40 in rows of 8 granules (128 B: 40 channels + the pad granule), d = 80 in rows of 16 (256 B)
+template <int D>
+struct AsGeo {
+    static constexpr bool WIDE = D > 56;
+    static constexpr int RB = WIDE ? 256 : 128;                  // bytes per tile row
+    static constexpr int KB = 64 * RB, SLOT = 2 * KB;            // K tile, ring slot (K + V): 16 KB / 32 KB
+    static constexpr int LDS = kSlots * SLOT;
+};
 
 // QLOG2: q arrives in log2 units (CCEDIT_ATTN_Q_LOG2) — scores leave the MFMA ready for v_exp_f32.  Otherwise q is used as it is
 // (scaling the bf16 fragments in here would round q a second time: at logits of +-70 that alone is several per cent of a
@@ -90,10 +103,22 @@ constexpr int kLds = kSlots * kSlot;
 // the exponential: 32 more VALU instructions per tile, the price of not packing the scale into the weights.
 template <int D, bool QLOG2, bool PV16>
 __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
-    static_assert(D % 16 == 8 && D < 64, "the reference rides in the pad column of the last k-step");
-    constexpr int KS = (D + 15) / 16;         // QK^T k-steps (last one: 8 channels + the reference column + 7 zeros)
+    static_assert(D % 8 == 0 && D % 32 != 0 && D <= 112, "the reference rides in a pad column of the last k-step; the denominator in a spare O^T row");
+    // d = 40: the last k-step holds 8 channels + the reference column (element 0 of the HI lanes' fragment) + 7 zeros.
+    // d = 80 (a multiple of 16): one more k-step that holds nothing but the reference column (element 0 of the LO lanes' fragment):
+    // 12 MFMAs instead of 10 for S^T, which still costs less than 32 subtractions on the VALU this kernel is bound by.
+    constexpr bool REF_HI = D % 16 == 8;
+    constexpr int KS = D / 16 + 1;            // QK^T k-steps
     constexpr int NT = (D + 1 + 31) / 32;     // O^T row tiles (D value rows + the denominator row D)
     constexpr int PADG = D / 8;               // granule of columns [D, D+8): K: {1, 0...}, V: {1, 0...}
+    using G = AsGeo<D>;
+    constexpr bool WIDE = G::WIDE;
+    constexpr int RB = G::RB, kKB = G::KB, kSlot = G::SLOT;
+    static_assert(!(WIDE && PV16), "the 16x16x32 PV image is laid out for 128-byte rows");
+    // ring slot s: narrow rows [K s | V s] back to back; wide rows [K 0 | K 1 | K 2 | V 0 | V 1 | V 2] — the transpose reads take their
+    // slot as a 16-bit instruction offset from ONE base register, and 2 x 32 KB + a k-step would not fit it
+    constexpr int VBASE = WIDE ? kSlots * kKB : kKB;              // first V tile
+    constexpr int SSTEP = WIDE ? kKB : kSlot;                     // bytes from a slot's K (V) tile to the next slot's
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -134,19 +159,26 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     // the reference column: element 0 of the last k-step's fragment on the hi lanes is column D
     auto set_ref = [&](float ref) {
         u32x4 w = __builtin_bit_cast(u32x4, qf[KS - 1]);
-        if (hi) w[0] = __float_as_uint(-ref) >> 16;
+        if ((hi != 0) == REF_HI) w[0] = __float_as_uint(-ref) >> 16;
         qf[KS - 1] = __builtin_bit_cast(bf16x8, w);
     };
 
-    // ---- DMA plan: thread -> (row, granule) of the 64 x 8-granule K and V tiles; wave w fills rows 8w..8w+7 ----
-    const int drow = tid >> 3;
-    const int gk = (tid & 7) ^ ((drow >> 1) & 7);              // LDS slot -> source granule (XOR swizzle, attention.hip)
+    // ---- DMA plan: thread -> (row, granule) of the 64-row K and V tiles (lane-linear LDS image: piece it * 512 + tid) ----
+    // narrow rows (8 granules): one piece per thread, wave w fills rows 8w..8w+7; wide rows (16 granules): two, rows 4w..4w+3 and 32 more
+    constexpr int IT = WIDE ? 2 : 1;
+    const int drow = WIDE ? tid >> 4 : tid >> 3;
+    const int dslot = WIDE ? tid & 15 : tid & 7;
+    const int gk = dslot ^ (WIDE ? (drow & 15) : ((drow >> 1) & 7));     // LDS slot -> source granule (XOR swizzle, attention.hip)
     // PV16: V rows are swizzled in 32-byte chunks (one 16-channel MFMA row tile each): chunk c of row r at c ^ vsw16(r)
     auto vsw16 = [](int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); };
-    const int gv = PV16 ? (((((tid & 7) >> 1) ^ vsw16(drow)) << 1) | (tid & 1)) : ((tid & 7) ^ (((drow >> 1) & 1) << 2));
+    const int gv = PV16 ? (((((tid & 7) >> 1) ^ vsw16(drow)) << 1) | (tid & 1)) : (dslot ^ (((drow >> 1) & 1) << 2));
     const bool use_k = gk * 8 < D, use_v = gv * 8 < D;         // pad granules are never written by the DMA
-    const uint32_t koff = (uint32_t)((int64_t)drow * a.kv_seq_rows * a.ldk + gk * 8) * 2u;
-    const uint32_t voff = (uint32_t)((int64_t)drow * a.kv_seq_rows * a.ldv + gv * 8) * 2u;
+    uint32_t koff[IT], voff[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {                            // (row + 32 has the same swizzle bits)
+        koff[it] = (uint32_t)((int64_t)(drow + 32 * it) * a.kv_seq_rows * a.ldk + gk * 8) * 2u;
+        voff[it] = (uint32_t)((int64_t)(drow + 32 * it) * a.kv_seq_rows * a.ldv + gv * 8) * 2u;
+    }
     const int64_t kstep = 64 * a.kv_seq_rows * (int64_t)a.ldk * 2, vstep = 64 * a.kv_seq_rows * (int64_t)a.ldv * 2;   // bytes per tile
     const char* const kreg = (const char*)((const bf16*)a.k + head * D + kvbase * a.ldk);
     const char* const vreg = (const char*)((const bf16*)a.v + head * D + kvbase * a.ldv);
@@ -175,12 +207,18 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
         kcur += kstep;
         vcur += vstep;
         if ((t + 1) * 64 <= a.Lk) {                             // wave-uniform
-            if (use_k) glds16(kb + koff, lds_wave + slot * kSlot);
-            if (use_v) glds16(vb + voff, lds_wave + slot * kSlot + kKB);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                if (use_k) glds16(kb + koff[it], lds_wave + slot * SSTEP + it * 8192);
+                if (use_v) glds16(vb + voff[it], lds_wave + VBASE + slot * SSTEP + it * 8192);
+            }
         } else {                                                // the tile that reaches past Lk: those rows come from the zero page
-            const bool valid = t * 64 + drow < a.Lk;
-            if (use_k) glds16(valid ? (const void*)(kb + koff) : (const void*)zp, lds_wave + slot * kSlot);
-            if (use_v) glds16(valid ? (const void*)(vb + voff) : (const void*)zp, lds_wave + slot * kSlot + kKB);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const bool valid = t * 64 + drow + 32 * it < a.Lk;
+                if (use_k) glds16(valid ? (const void*)(kb + koff[it]) : (const void*)zp, lds_wave + slot * SSTEP + it * 8192);
+                if (use_v) glds16(valid ? (const void*)(vb + voff[it]) : (const void*)zp, lds_wave + VBASE + slot * SSTEP + it * 8192);
+            }
         }
     };
 
@@ -189,16 +227,16 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     // (PV16: A-row i reads K row 16 (i>>2 & 1) + (i & 3) + 4 (i >> 3): register r of lane (q, hi) is key 32 t2 + 16 hi + r — sixteen
     //  consecutive keys per lane, which two v_permlane16_swap per register pair turn into the 16x16x32 B operand)
     const int krow_l = PV16 ? (((l31 >> 2) & 1) << 4) + (l31 & 3) + ((l31 >> 3) << 2) : ((l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1));
-    const int ksw = (krow_l >> 1) & 7;
+    const int ksw = WIDE ? (krow_l & 15) : ((krow_l >> 1) & 7);
     const char* kaddr[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kaddr[ks] = smem + krow_l * 128 + (((ks * 2 + hi) ^ ksw) << 4);
+    for (int ks = 0; ks < KS; ++ks) kaddr[ks] = smem + krow_l * RB + (((ks * 2 + hi) ^ ksw) << 4);
     const int i16 = lane & 15, dvhalf = (lane >> 4) & 1;
     const int vsw = ((i16 >> 3) & 1) << 6;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_AS char*)smem;
     uint32_t vaddr[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) vaddr[n] = lds0 + kKB + (8 * hi + (i16 >> 2)) * 128 + (dvhalf * 16 + (i16 & 3) * 4) * 2 + ((n * 64) ^ vsw);
+    for (int n = 0; n < NT; ++n) vaddr[n] = lds0 + VBASE + (8 * hi + (i16 >> 2)) * RB + (dvhalf * 16 + (i16 & 3) * 4) * 2 + ((n * 64) ^ vsw);
     // PV16: A operand of the 16x16x32 product = V^T[dv = 16 m + (lane & 15)][kv = 32 ks + 8 g + e]: lane group g transposes the 4-key x
     // 16-channel blocks at rows 8 g + (0..3) and 8 g + 4 + (0..3) of channel chunk m
     constexpr int NM = (D + 1 + 15) / 16;     // 16-channel row tiles of O^T (D value rows + the denominator row D)
@@ -211,11 +249,13 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     // ---- constant pad granules of all three slots: K[:, D] = 1 (the reference column), V[:, D] = 1 (the denominator row) ----
     for (int idx = tid; idx < kSlots * 64; idx += kNT) {
         const int sl = idx >> 6, row = idx & 63;
-        *(u32x4*)(smem + sl * kSlot + row * 128 + ((PADG ^ ((row >> 1) & 7)) << 4)) = u32x4{0x00003F80u, 0u, 0u, 0u};
+        const int rsw = WIDE ? (row & 15) : ((row >> 1) & 7);
+        if (REF_HI) *(u32x4*)(smem + sl * SSTEP + row * RB + ((PADG ^ rsw) << 4)) = u32x4{0x00003F80u, 0u, 0u, 0u};      // (d = 80: the reference k-step's K fragment is a register constant)
         const int vslot = PV16 ? ((((PADG >> 1) ^ vsw16(row)) << 1) | (PADG & 1)) : (PADG ^ (((row >> 1) & 1) << 2));
-        *(u32x4*)(smem + sl * kSlot + kKB + row * 128 + (vslot << 4)) = u32x4{0x00003F80u, 0u, 0u, 0u};
+        *(u32x4*)(smem + VBASE + sl * SSTEP + row * RB + (vslot << 4)) = u32x4{0x00003F80u, 0u, 0u, 0u};
     }
-    // K columns (D, 16 KS) beyond the reference column are zero in that same granule; granules above it are never read.
+    // K columns (D, 16 KS) beyond the reference column are zero in that same granule (and the one written above); granules above
+    // are never read.
 
     f32x16 o[PV16 ? 1 : NT];
     f32x4 o16[PV16 ? NM : 1][2];              // PV16: O^T[dv = 16 m + 4 g + reg][q = 16 t + (lane & 15)]
@@ -241,7 +281,7 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     const bool tail_masked = (a.Lk & 63) != 0;
     auto tile = [&](auto SLOTC, int j) {
         constexpr int SLOT = decltype(SLOTC)::value;
-        constexpr int SB = SLOT * kSlot;
+        constexpr int SB = SLOT * SSTEP;
 
         // ---- S^T = K Q^T - m~ for the 64 keys of this tile, log2 units ----
         f32x16 s[2];
@@ -251,7 +291,11 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
             for (int r = 0; r < 16; ++r) s[t2][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(kaddr[ks] + SB + t2 * 4096);
+                bf16x8 kf;
+                if (!REF_HI && ks == KS - 1)      // the k-step that holds only the reference column: K[:, D] = 1, a constant — no LDS read
+                    kf = __builtin_bit_cast(bf16x8, u32x4{hi ? 0u : 0x00003F80u, 0u, 0u, 0u});
+                else
+                    kf = *(const bf16x8*)(kaddr[ks] + SB + t2 * (32 * RB));
                 s[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t2], 0, 0, 0);
             }
         }
@@ -353,12 +397,18 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
             pv16(1, b0, b1);
             return;
         }
-        static_assert(NT == 2, "fragment bookkeeping below");
+        static_assert(NT == 2 || NT == 3, "fragment bookkeeping below");
         VFrag vf[4][NT];
         auto issue = [&](auto SPC) {
             constexpr int SP = decltype(SPC)::value;
-            as_tr_issue<SB + SP * 2048>(vf[SP][0], vaddr[0]);
-            as_tr_issue<SB + SP * 2048>(vf[SP][1], vaddr[1]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) as_tr_issue<SB + SP * (16 * RB), 4 * RB>(vf[SP][n], vaddr[n]);
+        };
+        auto wait = [&](auto SPC, auto PENDING) {          // the fragments of k-step SP are there when at most PENDING later reads are outstanding
+            constexpr int SP = decltype(SPC)::value;
+            constexpr int N = decltype(PENDING)::value * 2 * NT;
+            if constexpr (NT == 2) as_tr_wait<N>(vf[SP][0], vf[SP][1]);
+            else as_tr_wait3<N>(vf[SP][0], vf[SP][1], vf[SP][2]);
         };
         auto pexp = [&](int sp) {
             bf16x8 pf;
@@ -380,18 +430,18 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
         issue(I0{});
         issue(I1{});
         bf16x8 pf = pexp(0);
-        as_tr_wait<4>(vf[0][0], vf[0][1]);
+        wait(I0{}, I1{});
         pv(0, pf);
         issue(I2{});
         pf = pexp(1);
-        as_tr_wait<4>(vf[1][0], vf[1][1]);
+        wait(I1{}, I1{});
         pv(1, pf);
         issue(I3{});
         pf = pexp(2);
-        as_tr_wait<4>(vf[2][0], vf[2][1]);
+        wait(I2{}, I1{});
         pv(2, pf);
         pf = pexp(3);
-        as_tr_wait<0>(vf[3][0], vf[3][1]);
+        wait(I3{}, I0{});
         pv(3, pf);
     };
     // tile j: request tile j+2 (its slot was read in tile j-1, before the last barrier), compute, wait for tile j+1 (counted: the
@@ -456,29 +506,44 @@ template <int D, bool QLOG2, bool PV16>
 __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_spatial_kernel(const CcAttnDesc a) {
     attn_spatial_body<D, QLOG2, PV16>(a);
 }
+// d = 80: 96 KB of ring (one workgroup per CU) and 48 more accumulator registers: two waves per SIMD
+template <int D, bool QLOG2>
+__global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_spatial_wide_kernel(const CcAttnDesc a) {
+    attn_spatial_body<D, QLOG2, false>(a);
+}
 
 template <int D, bool QLOG2, bool PV16>
 int launch_spatial(const CcAttnDesc& a, hipStream_t s) {
+    constexpr int LDS = AsGeo<D>::LDS;
+    const void* fn;
+    if constexpr (AsGeo<D>::WIDE) fn = (const void*)attn_spatial_wide_kernel<D, QLOG2>;
+    else fn = (const void*)attn_spatial_kernel<D, QLOG2, PV16>;
     static unsigned long long attr_done = 0;
-    if (int rc = cc_max_dynamic_lds((const void*)attn_spatial_kernel<D, QLOG2, PV16>, kLds, &attr_done, "attn_spatial")) return rc;
+    if (int rc = cc_max_dynamic_lds(fn, LDS, &attr_done, "attn_spatial")) return rc;
     const int64_t qtiles = (a.Lq + kNW * 32 - 1) / (kNW * 32);
     const int64_t groups = ((int64_t)a.batches * a.heads + 7) / 8 * 8;
     cc_note_kernel("attn_spatial_kernel d=%d", D);
-    hipLaunchKernelGGL((attn_spatial_kernel<D, QLOG2, PV16>), dim3((unsigned)(qtiles * groups)), dim3(kNT), kLds, s, a);
+    if constexpr (AsGeo<D>::WIDE)
+        hipLaunchKernelGGL((attn_spatial_wide_kernel<D, QLOG2>), dim3((unsigned)(qtiles * groups)), dim3(kNT), LDS, s, a);
+    else
+        hipLaunchKernelGGL((attn_spatial_kernel<D, QLOG2, PV16>), dim3((unsigned)(qtiles * groups)), dim3(kNT), LDS, s, a);
     return cc_launch_status("attn_spatial_kernel");
 }
 
 }  // namespace
 
+// policy attn_spatial: 1 = d 40 and d 80, 2 = d 40 only (the d = 80 A/B arm: 1536-key attention on the general flash kernel), 0 = off
 bool cc_attn_spatial_applicable(const CcAttnDesc& a) {
     // per-lane byte offsets of a 64-row tile must fit 32 bits
     const int64_t span = 64 * a.kv_seq_rows * (int64_t)(a.ldk > a.ldv ? a.ldk : a.ldv) * 2;
-    return a.d == 40 && a.Lq >= 1024 && a.Lk >= 192 && !a.causal && (a.seg1_len & 63) == 0 && span < (1ll << 31);
+    return (a.d == 40 || (a.d == 80 && cc_policy().attn_spatial == 1)) && a.Lq >= 1024 && a.Lk >= 192 && !a.causal && (a.seg1_len & 63) == 0 &&
+           span < (1ll << 31);
 }
 
 int cc_attn_spatial_launch(const CcAttnDesc& a, hipStream_t s) {
     // policy attn_pv16 = 0: the PV product in 32x32x16 tiles (A/B; same sums in a different order: results differ in the last bit)
     const int pv16 = cc_policy().attn_pv16;
+    if (a.d == 80) return (a.flags & CCEDIT_ATTN_Q_LOG2) ? launch_spatial<80, true, false>(a, s) : launch_spatial<80, false, false>(a, s);
     if (pv16) return (a.flags & CCEDIT_ATTN_Q_LOG2) ? launch_spatial<40, true, true>(a, s) : launch_spatial<40, false, true>(a, s);
     return (a.flags & CCEDIT_ATTN_Q_LOG2) ? launch_spatial<40, true, false>(a, s) : launch_spatial<40, false, false>(a, s);
 }

@@ -75,7 +75,7 @@ struct CcPolicy {
     int temp320 = 1;        // streaming Conv1d k3 at 320 channels (0: tap_gemm)
     int attn_short = 1;     // temporal attention kernel (0: the general flash kernel)
     int attn_text = 1;      // text cross-attention kernel
-    int attn_spatial = 1;   // d = 40 long self-attention kernel
+    int attn_spatial = 1;   // long self-attention kernel with the reference in the MFMA: 1 = d 40 and d 80, 2 = d 40 only, 0 = off
     int attn_pv16 = 1;      // ... its PV product in 16x16x32 tiles (0: 32x32x16)
     int gn_flat = 1;        // flat thread mapping of the temporal GroupNorm at the two large levels
     int gn_apply_flat = 1;  // column-per-thread, four-rows-in-flight mapping of the spatial GroupNorm apply pass (0: a wave per pixel row)

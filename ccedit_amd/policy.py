@@ -48,7 +48,7 @@ TABLE = {
     "temp320": (1, "lib", "0: 320-channel Conv1d k3 on tap_gemm"),
     "attn_short": (1, "lib", "0: temporal attention through the general flash kernel"),
     "attn_text": (1, "lib", "0: text cross-attention through the general flash kernel"),
-    "attn_spatial": (1, "lib", "0: the 6144-key self-attention through the general flash kernel"),
+    "attn_spatial": (1, "lib", "0: the 6144-key (d = 40) and 1536-key (d = 80) self-attention through the general flash kernel; 2: only d = 40 on the specialised kernel"),
     "attn_pv16": (1, "lib", "0: PV product of the spatial attention in 32x32x16 tiles"),
     "gn_flat": (1, "lib", "0: temporal GroupNorm through the per-pixel kernels at the two large levels"),
     "gn_apply_flat": (1, "lib", "0: spatial GroupNorm apply with a wave per pixel row instead of a granule column per thread"),

@@ -1322,6 +1322,57 @@ def test_attention_spatial_kernel_reference_column_and_prescaled_q():
            what="spatial kernel, anchor + self keys")
 
 
+def test_attention_spatial_kernel_d80():
+    """The d = 80 instantiation of attn_spatial_kernel (256-byte LDS rows, the reference in a k-step of its own with a constant K
+    fragment, three O^T row tiles): dispatch, spikes beyond the 2^16 threshold in a late tile, a ragged last key tile and ragged
+    query tiles, q in log2 units, two-segment keys (TVI2V level 1), bit-identical repeats, and policy attn_spatial=2 = the general
+    kernel on the same inputs."""
+    _dev()
+    from ccedit_amd import hip, ops
+    heads, d = 2, 80
+    c = heads * d
+    lib = hip.lib()
+    last = lambda: lib.ccedit_last_kernel().decode()
+    for (lq, lk), (spike, row, key) in zip(((1024, 640), (1100, 1100), (1536, 1536)), ((4.0, 700, 450), (16.0, 33, 1099), (12.0, 1023, 64))):
+        q, k, v = _rnd(1, lq, c, seed=1), _rnd(1, lk, c, seed=2), _rnd(1, lk, c, seed=3)
+        k[0, key] = q[0, row] * spike
+        k[0, :64] -= q[0, row] * 2.0
+        q, k = q.to(BF).float(), k.to(BF).float()
+        args = (q.reshape(-1, c).to(BF).cuda(), k.reshape(-1, c).to(BF).cuda(), v.reshape(-1, c).to(BF).cuda(), heads, d)
+        o = ops.attention(*args, batches=1, lq=lq, lk=lk)
+        assert last() == "attn_spatial_kernel d=80", last()
+        ref = _sdpa_ref(q, k, v, heads)
+        _close(o.reshape(1, lq, c), ref, rel=2.0 ** -6, abs_=4e-3, what=f"spatial attention d=80 {lq}x{lk}, spike x{spike}")
+        assert torch.equal(o, ops.attention(*args, batches=1, lq=lq, lk=lk))
+        try:
+            assert lib.ccedit_policy_set(b"attn_spatial", 2) == 0
+            og = ops.attention(*args, batches=1, lq=lq, lk=lk)
+            assert last() == "attn_kernel d=80", last()
+        finally:
+            lib.ccedit_policy_set(b"attn_spatial", 1)
+        _close(og.reshape(1, lq, c), ref, rel=2.0 ** -6, abs_=4e-3, what="general kernel on the same inputs")
+    q, k, v = _rnd(3, 1280, c, seed=4), _rnd(3, 1280, c, seed=5), _rnd(3, 1280, c, seed=6)
+    qs = (q * (d ** -0.5 * 1.4426950408889634)).to(BF)
+    o = ops.attention(qs.reshape(-1, c).cuda(), k.reshape(-1, c).to(BF).cuda(), v.reshape(-1, c).to(BF).cuda(), heads, d,
+                      batches=3, lq=1280, lk=1280, q_log2=True)
+    assert last() == "attn_spatial_kernel d=80", last()
+    _close(o.reshape(3, 1280, c), _sdpa_ref(qs.float() / (d ** -0.5 * 1.4426950408889634), k, v, heads), rel=2.0 ** -6, abs_=4e-3,
+           what="d=80 attention with q in log2 units")
+    heads, t, clips, hw = 4, 3, 2, 1088
+    c = heads * d
+    n = clips * t
+    q = _rnd(n, hw, c, seed=7)
+    kv = _rnd(n, hw, 2 * c, seed=8)
+    kvd = kv.reshape(-1, 2 * c).to(BF).cuda()
+    o = ops.attention(q.reshape(-1, c).to(BF).cuda(), kvd[:, :c], kvd[:, c:], heads, d, batches=n, lq=hw, lk=2 * hw,
+                      kv_outer_rows=hw, seg1_len=hw, seg1_div=t, seg1_mul=t, seg1_add=t // 2)
+    assert last() == "attn_spatial_kernel d=80", last()
+    anchor = kv.reshape(clips, t, hw, 2 * c)[:, t // 2].repeat_interleave(t, 0)
+    ctx = torch.cat([anchor, kv], dim=1)
+    _close(o.reshape(n, hw, c), _sdpa_ref(q, ctx[..., :c], ctx[..., c:], heads), rel=2.0 ** -6, abs_=4e-3,
+           what="d=80 spatial kernel, anchor + self keys")
+
+
 def test_copy_row_blocks_pack_unpack_add():
     """ccedit_copy_row_blocks: the pack / unpack(+skip add) halves of FrameShard's all-to-all against index_select + add_."""
     _dev()
