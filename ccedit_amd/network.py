@@ -227,11 +227,11 @@ class CrossAttention(nn.Module):
         self.q_log2 = False
 
     def wants_q_log2(self) -> bool:
-        return self.self_attn and self.dim_head == 40 and ops.ATTN_Q_LOG2
+        return self.self_attn and self.dim_head in (40, 80) and ops.ATTN_Q_LOG2       # the head sizes attn_spatial_kernel serves
 
     def post_pack(self, device):
         if self.self_attn:
-            # d = 40 (the 64x96 level, 6144 keys): softmax scale * log2(e) rides in the packed to_q rows — the attention kernel
+            # d = 40 / 80 (the 64x96 and 32x48 levels): softmax scale * log2(e) rides in the packed to_q rows — the attention kernel
             # then exponentiates q.k directly (CCEDIT_ATTN_Q_LOG2), and q is rounded to bf16 once, as in the reference's
             # `q = self.to_q(x)` (attention.py:404), instead of a second time after an in-kernel multiply
             self.q_log2 = self.wants_q_log2()
@@ -395,11 +395,10 @@ class BasicTransformerBlock(nn.Module):
         self.ff.pack_fused(self.norm3, device)
         self.q2_ln = _fold_ln([self.attn2.to_q.weight], self.norm2, device)
         a1 = self.attn1
-        if a1.wants_q_log2() and a1.to_q.weight.shape[1] in (640, 1280):      # (asked of the child directly: pack order does not matter)
-            # the folded-norm pack below carries no softmax scale: a d = 40 head at 640 / 1280 channels would be attended un-scaled
-            raise NotImplementedError("CrossAttention: q_log2 (d = 40) together with the folded LayerNorm of the 640 / 1280-channel "
-                                      "projections is not packed; extend _fold_ln with the q scale before enabling this width")
-        self.qkv_ln = _fold_ln([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], self.norm1, device, dims=(640, 1280))
+        # the folded-norm pack carries the same softmax scale as a1.qkv (asked of the child directly: pack order does not matter):
+        # W' = s W diag(gamma), b' = s W beta — the scale commutes with the fold
+        qw = a1.to_q.weight * (a1.dim_head ** -0.5 * LOG2E) if a1.wants_q_log2() else a1.to_q.weight
+        self.qkv_ln = _fold_ln([qw, a1.to_k.weight, a1.to_v.weight], self.norm1, device, dims=(640, 1280))
 
 
 class BasicTransformerSingleLayerBlock(nn.Module):
