@@ -135,6 +135,26 @@ def test_packing_layouts():
     assert pc.n == 16 and pc.w[5, 0].item() == 2 and pc.w[15, 7].item() == 3
 
 
+def test_fp32_first_stage_packing_and_policy():
+    """ccedit_amd/vae_f32.py host side (no GPU): the fp32 kernel layout — [Cout][tap][Cpad], tap = 3 ky + kx, zero columns beyond Cin,
+    Cin rounded up to 4 for the activation rows — and the policy entry that selects the fp32 first stage (default off: bf16)."""
+    from ccedit_amd import policy
+    from ccedit_amd.vae_f32 import pack_f32
+    w = torch.arange(5 * 6 * 9, dtype=torch.float32).reshape(5, 6, 3, 3)
+    pw = pack_f32(w, torch.arange(5.0), "cpu")
+    assert pw.w.shape == (5, 9 * 16) and pw.w.dtype == torch.float32 and (pw.n, pw.cin, pw.cpad, pw.taps) == (5, 8, 16, 9)
+    assert pw.w[3, 7 * 16 + 4].item() == w[3, 4, 2, 1].item()          # tap 7 = (ky 2, kx 1)
+    assert pw.w.view(5, 9, 16)[:, :, 6:].abs().sum().item() == 0        # pad columns
+    assert pw.bias.tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+    p1 = pack_f32(torch.randn(7, 512, 1, 1), None, "cpu")
+    assert p1.w.shape == (7, 512) and p1.taps == 1 and p1.bias is None and p1.cin == 512
+    p3 = pack_f32(torch.randn(128, 3, 3, 3), None, "cpu")             # the encoder's conv_in: RGB frames carry a fourth, zero channel
+    assert (p3.cin, p3.cpad) == (4, 16)
+    assert policy.TABLE["vae_fp32"][0] == 0 and "vae_fp32=0" in policy.generic()
+    from ccedit_amd.sgm_compat import build_vae
+    assert build_vae("cpu", ch=32).precision == ("fp32" if policy.on("vae_fp32") else "bf16")
+
+
 def test_synth_weights_are_name_keyed_and_stable():
     from ccedit_amd.utils.synth import synth_tensor
     a = synth_tensor("model.diffusion_model.out.2.weight", (4, 320, 3, 3))
