@@ -17,7 +17,7 @@
 // runs of four consecutive channels, stored as 16-byte pieces.  The K index inside a tile is permuted (lanes 0-31 take k 0..7,
 // lanes 32-63 k 8..15: MFMA j multiplies k = {j, 8 + j}) so that a lane's eight operands are two ds_read_b128; rows are 80 bytes
 // apart in LDS (conflict-free for that pattern).  The matrix pipe runs fp32 at 256 FLOP / clk / CU (157 TFLOP/s): one MFMA is 64
-// cycles against two 16-byte LDS reads, so this simple loop is MFMA-bound.
+// cycles against two 16-byte LDS reads, so this simple loop is MFMA-bound; held to 128 registers: four workgroups per CU (4 x 40 KB of LDS = the CU's 160 KB).
 #include "common.h"
 
 namespace {
@@ -31,7 +31,7 @@ struct F32Pix {            // geometry of one pixel row of the tile (conv mode)
 };
 
 template <bool CONV>
-__global__ __launch_bounds__(256, 2) void f32_gemm_kernel(const CcGemmF32Desc d) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void f32_gemm_kernel(const CcGemmF32Desc d) {
     __shared__ __attribute__((aligned(16))) float smem[2 * F_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
