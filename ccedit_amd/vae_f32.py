@@ -21,6 +21,7 @@ import torch
 from . import hip, ops
 
 F32 = torch.float32
+GN_EPS = 1e-6          # model.py:50-53 (Normalize), as in vae.py
 
 
 def _ceil(a: int, b: int) -> int:
@@ -138,7 +139,6 @@ def _pw(conv) -> PackedF32:
 
 
 def resnet_block(blk, x):
-    from .vae import GN_EPS
     a = groupnorm_f32(x, blk.norm1.g, blk.norm1.b, GN_EPS, True)
     h = conv2d_f32(a, _pw(blk.conv1))
     a = groupnorm_f32(h, blk.norm2.g, blk.norm2.b, GN_EPS, True)
@@ -150,7 +150,6 @@ def attn_block(blk, x):
     """model.py:161-201 per frame: q k^T (fp32 scores) -> softmax -> p v, all through ccedit_gemm_f32 with the second tensor in the
     role of the weight matrix.  V arrives transposed (V^T = W_v x^T: the GEMM with weight and activation swapped) so that it is the
     K-contiguous operand of p v; its bias is added after the product (rows of p sum to 1)."""
-    from .vae import GN_EPS
     n, h, w, c = x.shape
     L = h * w
     l4, l16 = _ceil(L, 4), _ceil(L, 16)
@@ -175,7 +174,6 @@ def attn_block(blk, x):
 
 def decoder(dec, z4: torch.Tensor) -> torch.Tensor:
     """z4 (N, h, w, 4) fp32 (post_quant_conv output) -> (N, 8h, 8w, 4) fp32, 3 real channels (model.py:728-761)."""
-    from .vae import GN_EPS
     h = conv2d_f32(z4, _pw(dec.conv_in))
     h = resnet_block(dec.mid.block_1, h)
     h = attn_block(dec.mid.attn_1, h)
@@ -197,7 +195,6 @@ def decoder(dec, z4: torch.Tensor) -> torch.Tensor:
 def encoder(enc, x4: torch.Tensor) -> torch.Tensor:
     """x4 (N, H, W, 4) fp32 frames (3 real channels, the fourth zero) -> (N, H/8, W/8, 2 z) fp32 pre-quant moments
     (model.py:498-614; Downsample :74-93 = pad right / bottom, conv stride 2 pad 0)."""
-    from .vae import GN_EPS
     h = conv2d_f32(x4, _pw(enc.conv_in))
     for lvl in range(len(enc.ch_mult)):
         for i in range(enc.num_res_blocks):
