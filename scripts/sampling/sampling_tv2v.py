@@ -60,6 +60,9 @@ def add_common_args(p: argparse.ArgumentParser) -> None:
     p.add_argument("--sdedit_denoise_strength", type=float, default=0.0)
     p.add_argument("--inpainting_mode", action="store_true", help="inpainting mode")
     p.add_argument("--num_samples", type=int, default=1)
+    p.add_argument("--noise_seed", type=int, default=None,
+                   help="(not in the reference script) draw the samplers' per-step noise from a CPU generator with this seed instead of "
+                        "torch.randn_like on the device: the same clip on any GPU / against the CPU oracle (tests)")
     p.add_argument("--disable_check_repeat", action="store_true")
 
 
@@ -145,6 +148,15 @@ def save_result(args, tag, x):
     save_frames(args.save_path, tag, x)
 
 
+def _cpu_noise(sampler, args) -> None:
+    """--noise_seed: the ancestral / churn noise (`noise_sampler`, torch.randn_like(x) in the reference: sampling.py:100, 184) from a seeded
+    CPU generator, one draw per call in the samplers' own order."""
+    seed = getattr(args, "noise_seed", None)
+    if seed is not None and hasattr(sampler, "noise_sampler"):
+        gen = torch.Generator().manual_seed(int(seed))
+        sampler.noise_sampler = lambda x: torch.randn(x.shape, generator=gen).to(x.device)
+
+
 def sample_one(args, model, dev, c, uc, randn, keyframes=None, ref=None, prior_type="video"):
     """sampling_tv2v.py:361-470 for one clip."""
     from scripts.sampling.util import init_sampling, prior_latent, sdedit_start
@@ -162,6 +174,7 @@ def sample_one(args, model, dev, c, uc, randn, keyframes=None, ref=None, prior_t
         sampler = init_sampling(sample_steps=args.sample_steps, sampler_name=args.sampler_name,
                                 discretization_name=args.discretization_name, guider_config_target=GUIDER,
                                 cfg_scale=args.cfg_scale)
+        _cpu_noise(sampler, args)
         samples = sampler(denoiser, randn, c, uc=uc)
     else:
         assert 0.0 < args.sdedit_denoise_strength <= 1.0, "sdedit_denoise_strength should be in (0, 1]"
@@ -169,6 +182,7 @@ def sample_one(args, model, dev, c, uc, randn, keyframes=None, ref=None, prior_t
         sampler = init_sampling(sample_steps=args.sample_steps, sampler_name=args.sampler_name,
                                 discretization_name=args.discretization_name, guider_config_target=GUIDER,
                                 cfg_scale=args.cfg_scale, img2img_strength=args.sdedit_denoise_strength)
+        _cpu_noise(sampler, args)
         samples = sampler(denoiser, sdedit_start(model, sampler, keyframes), cond=c, uc=uc)
     return model.decode_first_stage(samples)
 
