@@ -38,6 +38,12 @@ class VideoDiffusionEngineTV2V(nn.Module):
         self.first_stage_model = instantiate_from_config(first_stage_config).eval()
         self.scale_factor = scale_factor
         self.disable_first_stage_autocast = disable_first_stage_autocast
+        # In the reference this flag IS the first stage's precision (diffusion.py:151-156: autocast off = fp32 tensors and products; the
+        # shipped yamls set it).  Here the first stage runs on the bf16 kernels by default — the dtype BASELINE.json quotes the path in —
+        # and policy vae_fp32 selects the fp32 kernels: 1 = always, 2 = exactly when the yaml's flag says so.
+        from . import policy
+        if policy.get("vae_fp32") == 2 and hasattr(self.first_stage_model, "precision"):
+            self.first_stage_model.precision = "fp32" if disable_first_stage_autocast else "bf16"
         self.setup_vaeembedder()
         self.use_ema = False
         if ckpt_path is not None:

@@ -35,7 +35,8 @@ TABLE = {
     "attn_q_log2": (1, "py", "0: softmax scale applied inside the attention kernels instead of folded into to_q"),
     "block_tail": (1, "py", "0: to_out / proj_out of the dim-320 transformer tails as their own launches, not inside ff320"),
     # (a precision option, not an A/B arm of equal arithmetic: the reference runs its first-stage model with autocast disabled)
-    "vae_fp32": (0, "py", "1: the KL-VAE evaluated in fp32 on v_mfma_f32_32x32x2_f32 (ccedit_amd/vae_f32.py) instead of the bf16 kernels"),
+    "vae_fp32": (0, "py", "1: the KL-VAE evaluated in fp32 on v_mfma_f32_32x32x2_f32 (ccedit_amd/vae_f32.py) instead of the bf16 kernels; "
+                          "2: fp32 exactly when the yaml sets disable_first_stage_autocast (the flag's meaning in the reference)"),
     # ---- kernel library (csrc/common.h: CcPolicy) ----
     "conv_halo": (1, "lib", "0: 3x3 stride-1 convs on the tap-gather kernel"),
     "g8": (1, "lib", "0: long Linears on the tap_gemm block shapes"),

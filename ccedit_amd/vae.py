@@ -222,7 +222,7 @@ class AutoencoderKL(nn.Module):
         self.post_quant_conv = Conv(embed_dim, dd["z_channels"], 1)
         self.embed_dim = embed_dim
         self._packed = False
-        self.precision = "fp32" if policy.on("vae_fp32") else "bf16"      # "fp32": the reference's arithmetic class (vae_f32.py)
+        self.precision = "fp32" if policy.get("vae_fp32") == 1 else "bf16"      # "fp32": the reference's arithmetic class (vae_f32.py); 2: the engine decides from the yaml
 
     def pack(self, device=None):
         device = torch.device("cuda") if device is None else device

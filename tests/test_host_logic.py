@@ -152,7 +152,18 @@ def test_fp32_first_stage_packing_and_policy():
     assert (p3.cin, p3.cpad) == (4, 16)
     assert policy.TABLE["vae_fp32"][0] == 0 and "vae_fp32=0" in policy.generic()
     from ccedit_amd.sgm_compat import build_vae
-    assert build_vae("cpu", ch=32).precision == ("fp32" if policy.on("vae_fp32") else "bf16")
+    assert build_vae("cpu", ch=32).precision == ("fp32" if policy.get("vae_fp32") == 1 else "bf16")
+    # vae_fp32=2: the engine follows the yaml's disable_first_stage_autocast, as the reference does (diffusion.py:151-156)
+    import subprocess, sys, os
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = ("from ccedit_amd.config import instantiate_from_config; from ccedit_amd.sgm_compat import engine_config; "
+            "cfg = engine_config(vae_ch=32, model_channels=32, num_heads=1, context_dim=32); "
+            "a = instantiate_from_config(cfg).first_stage_model.precision; cfg['params']['disable_first_stage_autocast'] = False; "
+            "print(a, instantiate_from_config(cfg).first_stage_model.precision)")
+    for pol, want in (("vae_fp32=2", "fp32 bf16"), ("vae_fp32=1", "fp32 fp32"), ("", "bf16 bf16")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CCEDIT_POLICY=pol, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert r.stdout.strip().splitlines()[-1] == want, (pol, r.stdout)
 
 
 def test_synth_weights_are_name_keyed_and_stable():
