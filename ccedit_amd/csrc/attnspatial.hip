@@ -37,6 +37,15 @@ namespace {
 __device__ __attribute__((aligned(64))) char g_as_zero_page[64];
 
 constexpr float kThr = 16.0f;          // log2 units: the reference is raised when a score exceeds it by more than this
+// OPTIMISTIC (round 6, policy attn_opt): only the FIRST key tile looks at its scores.  The reference of a query row is set to that
+// tile's row maximum + kOptMargin and never moves; the 16 v_max3 + compare + ballot + branch of every later tile are gone (19 of 84
+// VALU instructions per tile on a kernel whose VALU port is the critical resource).  bf16 P and the fp32 accumulators have eight
+// exponent bits: a row whose later scores exceed the first tile's maximum by up to ~2^(127 - margin) keeps every relative precision
+// (numerator and denominator carry the same factor), and terms 2^-126 below the reference are 2^-94 of the row's largest term.  A
+// row outside that window produces inf / NaN in its accumulators: every workgroup checks its accumulators after the key loop and,
+// if any lane saw a non-finite value (or an empty denominator), REPEATS its key loop with the exact per-tile tracking above — the
+// result is then bit-identical to policy attn_opt = 0.  tests/test_ops_gpu.py drives both outcomes (spikes of 2^9 log2 units).
+constexpr float kOptMargin = 32.0f;
 
 template <int N>
 __device__ __forceinline__ void as_vmcnt() {
@@ -101,7 +110,7 @@ struct AsGeo {
 // (scaling the bf16 fragments in here would round q a second time: at logits of +-70 that alone is several per cent of a
 // probability), reference and threshold are kept in raw q.k units and every score is multiplied by scale * log2(e) on its way into
 // the exponential: 32 more VALU instructions per tile, the price of not packing the scale into the weights.
-template <int D, bool QLOG2, bool PV16>
+template <int D, bool QLOG2, bool PV16, bool OPTIMISTIC>
 __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     static_assert(D % 8 == 0 && D % 32 != 0 && D <= 112, "the reference rides in a pad column of the last k-step; the denominator in a spare O^T row");
     // d = 40: the last k-step holds 8 channels + the reference column (element 0 of the HI lanes' fragment) + 7 zeros.
@@ -156,6 +165,7 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     }
     const float sc = QLOG2 ? 1.0f : a.scale * 1.4426950408889634f;      // score units -> log2 units
     const float thr = QLOG2 ? kThr : kThr / sc;                          // the threshold in score units
+    const float margin = QLOG2 ? kOptMargin : kOptMargin / sc;          // OPTIMISTIC: head-room above the first tile's maximum, score units
     // the reference column: element 0 of the last k-step's fragment on the hi lanes is column D
     auto set_ref = [&](float ref) {
         u32x4 w = __builtin_bit_cast(u32x4, qf[KS - 1]);
@@ -259,28 +269,35 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
 
     f32x16 o[PV16 ? 1 : NT];
     f32x4 o16[PV16 ? NM : 1][2];              // PV16: O^T[dv = 16 m + 4 g + reg][q = 16 t + (lane & 15)]
-#pragma unroll
-    for (int n = 0; n < (PV16 ? 1 : NT); ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
-#pragma unroll
-    for (int m = 0; m < (PV16 ? NM : 1); ++m)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) o16[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float mref = 0.f;
-
-    stage(0, 0);
-    if (ntiles > 1) {
-        stage(1, 1);
-        as_vmcnt<2>();
-    } else {
-        as_vmcnt<0>();
-    }
-    as_barrier();
+    // (re)start of a key loop: zero accumulators, reference 0, the first two tiles requested
+    auto begin = [&]() {
+#pragma unroll
+        for (int n = 0; n < (PV16 ? 1 : NT); ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < (PV16 ? NM : 1); ++m)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) o16[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mref = 0.f;
+        set_ref(0.f);
+        kcur = seg_tiles > 0 ? kseg : kreg;
+        vcur = seg_tiles > 0 ? vseg : vreg;
+        stage(0, 0);
+        if (ntiles > 1) {
+            stage(1, 1);
+            as_vmcnt<2>();
+        } else {
+            as_vmcnt<0>();
+        }
+        as_barrier();
+    };
 
     const bool tail_masked = (a.Lk & 63) != 0;
-    auto tile = [&](auto SLOTC, int j) {
+    auto tile = [&](auto SLOTC, auto OPTC, int j) {
         constexpr int SLOT = decltype(SLOTC)::value;
+        constexpr bool OPT = decltype(OPTC)::value;
         constexpr int SB = SLOT * SSTEP;
 
         // ---- S^T = K Q^T - m~ for the 64 keys of this tile, log2 units ----
@@ -309,45 +326,53 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
                 }
         }
         // ---- does the reference have to move?  (this lane: query q0 + l31, keys 64 j + 32 t2 + 16 (r>>3) + 8 hi + (r&7)) ----
-        float m0 = max3f(s[0][0], s[0][1], s[0][2]), m1 = max3f(s[0][3], s[0][4], s[0][5]);
-        float m2 = max3f(s[1][0], s[1][1], s[1][2]), m3 = max3f(s[1][3], s[1][4], s[1][5]);
+        // OPT: asked on the first tile only (wave-uniform scalar branch); its answer stands for the whole row
+        auto track = [&]() {
+            float m0 = max3f(s[0][0], s[0][1], s[0][2]), m1 = max3f(s[0][3], s[0][4], s[0][5]);
+            float m2 = max3f(s[1][0], s[1][1], s[1][2]), m3 = max3f(s[1][3], s[1][4], s[1][5]);
 #pragma unroll
-        for (int r = 6; r < 16; r += 4) {
-            m0 = max3f(m0, s[0][r], s[0][r + 1]);
-            m2 = max3f(m2, s[1][r], s[1][r + 1]);
-            if (r + 2 < 16) {
-                m1 = max3f(m1, s[0][r + 2], s[0][r + 3]);
-                m3 = max3f(m3, s[1][r + 2], s[1][r + 3]);
-            }
-        }
-        float mt = fmaxf(max3f(m0, m1, m2), m3);
-        if (j == 0 || __builtin_amdgcn_ballot_w64(mt > thr) != 0) {          // wave-uniform
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));        // row maximum (both lane halves of a query)
-            float nref = bf16_ceil(mref + mt);
-            if (j != 0) nref = fmaxf(nref, mref);          // later tiles only raise it
-            const float delta = nref - mref;
-            if (j != 0) {
-                const float alpha = __builtin_amdgcn_exp2f(QLOG2 ? -delta : -delta * sc);
-                if constexpr (PV16) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const float at = __shfl(alpha, 16 * t + i16, 64);      // the factor of query 16 t + (lane & 15)
-#pragma unroll
-                        for (int m = 0; m < NM; ++m) o16[m][t] *= at;
-                    }
-                } else {
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+            for (int r = 6; r < 16; r += 4) {
+                m0 = max3f(m0, s[0][r], s[0][r + 1]);
+                m2 = max3f(m2, s[1][r], s[1][r + 1]);
+                if (r + 2 < 16) {
+                    m1 = max3f(m1, s[0][r + 2], s[0][r + 3]);
+                    m3 = max3f(m3, s[1][r + 2], s[1][r + 3]);
                 }
             }
+            float mt = fmaxf(max3f(m0, m1, m2), m3);
+            if (OPT || j == 0 || __builtin_amdgcn_ballot_w64(mt > thr) != 0) {          // wave-uniform
+                mt = fmaxf(mt, __shfl_xor(mt, 32, 64));        // row maximum (both lane halves of a query)
+                float nref = bf16_ceil(OPT ? mref + mt + margin : mref + mt);
+                if (j != 0) nref = fmaxf(nref, mref);          // later tiles only raise it
+                const float delta = nref - mref;
+                if (!OPT && j != 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(QLOG2 ? -delta : -delta * sc);
+                    if constexpr (PV16) {
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
+                        for (int t = 0; t < 2; ++t) {
+                            const float at = __shfl(alpha, 16 * t + i16, 64);      // the factor of query 16 t + (lane & 15)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[t2][r] -= delta;
-            mref = nref;
-            set_ref(mref);
+                            for (int m = 0; m < NM; ++m) o16[m][t] *= at;
+                        }
+                    } else {
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+                    }
+                }
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[t2][r] -= delta;
+                mref = nref;
+                set_ref(mref);
+            }
+        };
+        if constexpr (OPT) {
+            if (j == 0) track();
+        } else {
+            track();
         }
         // ---- p = 2^s;  O^T += V^T P^T (row D of O^T: the denominator, from the ones column of V) ----
         // k-step sp covers keys 16 sp .. 16 sp + 15; its V^T fragments are requested two k-steps ahead of their MFMAs
@@ -446,18 +471,46 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
     };
     // tile j: request tile j+2 (its slot was read in tile j-1, before the last barrier), compute, wait for tile j+1 (counted: the
     // requests just issued stay in flight across the barrier)
-    auto step = [&](auto SLOTC, int j) {
+    auto step = [&](auto SLOTC, auto OPTC, int j) {
         constexpr int SL = decltype(SLOTC)::value;
         if (j + 2 < ntiles) stage(j + 2, (SL + 2) % kSlots);
-        tile(SLOTC, j);
+        tile(SLOTC, OPTC, j);
         if (j + 2 < ntiles) as_vmcnt<2>();
         else as_vmcnt<0>();
         as_barrier();
     };
-    for (int j = 0; j < ntiles; j += 3) {
-        step(std::integral_constant<int, 0>{}, j);
-        if (j + 1 < ntiles) step(std::integral_constant<int, 1>{}, j + 1);
-        if (j + 2 < ntiles) step(std::integral_constant<int, 2>{}, j + 2);
+    auto keys = [&](auto OPTC) {
+        begin();
+        for (int j = 0; j < ntiles; j += 3) {
+            step(std::integral_constant<int, 0>{}, OPTC, j);
+            if (j + 1 < ntiles) step(std::integral_constant<int, 1>{}, OPTC, j + 1);
+            if (j + 2 < ntiles) step(std::integral_constant<int, 2>{}, OPTC, j + 2);
+        }
+    };
+    if constexpr (OPTIMISTIC) {
+        keys(std::true_type{});
+        // every accumulator finite, every denominator positive?  x * 0 is NaN for x = +-inf / NaN (no fast-math: not folded)
+        float chk = 0.f;
+        bool bad = false;
+        if constexpr (PV16) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) chk = fmaf(o16[m][t][e], 0.f, chk);
+            if (g4 == (D % 16) / 4) bad = !(o16[D / 16][0][0] > 0.f) || !(o16[D / 16][1][0] > 0.f);
+        } else {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) chk = fmaf(o[n][r], 0.f, chk);
+            if (hi == ((D % 32) / 4) % 2) bad = !(o[D / 32][((D % 32) / 8) * 4] > 0.f);
+        }
+        bad = bad || !(chk == 0.f);
+        if (__syncthreads_or(bad ? 1 : 0)) keys(std::false_type{});          // workgroup-uniform: the rings and barriers are shared
+    } else {
+        keys(std::false_type{});
     }
 
     if constexpr (PV16) {
@@ -502,31 +555,31 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
 }
 
 // four waves per SIMD (two workgroups per CU): 2.04 ms against 2.30 ms with three on the 34 x 8 x 6144^2 launch
-template <int D, bool QLOG2, bool PV16>
+template <int D, bool QLOG2, bool PV16, bool OPTIMISTIC>
 __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_spatial_kernel(const CcAttnDesc a) {
-    attn_spatial_body<D, QLOG2, PV16>(a);
+    attn_spatial_body<D, QLOG2, PV16, OPTIMISTIC>(a);
 }
 // d = 80: 96 KB of ring (one workgroup per CU) and 48 more accumulator registers: two waves per SIMD
-template <int D, bool QLOG2>
+template <int D, bool QLOG2, bool OPTIMISTIC>
 __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_spatial_wide_kernel(const CcAttnDesc a) {
-    attn_spatial_body<D, QLOG2, false>(a);
+    attn_spatial_body<D, QLOG2, false, OPTIMISTIC>(a);
 }
 
-template <int D, bool QLOG2, bool PV16>
+template <int D, bool QLOG2, bool PV16, bool OPT>
 int launch_spatial(const CcAttnDesc& a, hipStream_t s) {
     constexpr int LDS = AsGeo<D>::LDS;
     const void* fn;
-    if constexpr (AsGeo<D>::WIDE) fn = (const void*)attn_spatial_wide_kernel<D, QLOG2>;
-    else fn = (const void*)attn_spatial_kernel<D, QLOG2, PV16>;
+    if constexpr (AsGeo<D>::WIDE) fn = (const void*)attn_spatial_wide_kernel<D, QLOG2, OPT>;
+    else fn = (const void*)attn_spatial_kernel<D, QLOG2, PV16, OPT>;
     static unsigned long long attr_done = 0;
     if (int rc = cc_max_dynamic_lds(fn, LDS, &attr_done, "attn_spatial")) return rc;
     const int64_t qtiles = (a.Lq + kNW * 32 - 1) / (kNW * 32);
     const int64_t groups = ((int64_t)a.batches * a.heads + 7) / 8 * 8;
     cc_note_kernel("attn_spatial_kernel d=%d", D);
     if constexpr (AsGeo<D>::WIDE)
-        hipLaunchKernelGGL((attn_spatial_wide_kernel<D, QLOG2>), dim3((unsigned)(qtiles * groups)), dim3(kNT), LDS, s, a);
+        hipLaunchKernelGGL((attn_spatial_wide_kernel<D, QLOG2, OPT>), dim3((unsigned)(qtiles * groups)), dim3(kNT), LDS, s, a);
     else
-        hipLaunchKernelGGL((attn_spatial_kernel<D, QLOG2, PV16>), dim3((unsigned)(qtiles * groups)), dim3(kNT), LDS, s, a);
+        hipLaunchKernelGGL((attn_spatial_kernel<D, QLOG2, PV16, OPT>), dim3((unsigned)(qtiles * groups)), dim3(kNT), LDS, s, a);
     return cc_launch_status("attn_spatial_kernel");
 }
 
@@ -542,8 +595,15 @@ bool cc_attn_spatial_applicable(const CcAttnDesc& a) {
 
 int cc_attn_spatial_launch(const CcAttnDesc& a, hipStream_t s) {
     // policy attn_pv16 = 0: the PV product in 32x32x16 tiles (A/B; same sums in a different order: results differ in the last bit)
+    // policy attn_opt = 0: the reference of every row tracked on every key tile (no optimistic pass; the A/B and test arm)
     const int pv16 = cc_policy().attn_pv16;
-    if (a.d == 80) return (a.flags & CCEDIT_ATTN_Q_LOG2) ? launch_spatial<80, true, false>(a, s) : launch_spatial<80, false, false>(a, s);
-    if (pv16) return (a.flags & CCEDIT_ATTN_Q_LOG2) ? launch_spatial<40, true, true>(a, s) : launch_spatial<40, false, true>(a, s);
-    return (a.flags & CCEDIT_ATTN_Q_LOG2) ? launch_spatial<40, true, false>(a, s) : launch_spatial<40, false, false>(a, s);
+    const bool ql = (a.flags & CCEDIT_ATTN_Q_LOG2) != 0;
+    if (cc_policy().attn_opt) {
+        if (a.d == 80) return ql ? launch_spatial<80, true, false, true>(a, s) : launch_spatial<80, false, false, true>(a, s);
+        if (pv16) return ql ? launch_spatial<40, true, true, true>(a, s) : launch_spatial<40, false, true, true>(a, s);
+        return ql ? launch_spatial<40, true, false, true>(a, s) : launch_spatial<40, false, false, true>(a, s);
+    }
+    if (a.d == 80) return ql ? launch_spatial<80, true, false, false>(a, s) : launch_spatial<80, false, false, false>(a, s);
+    if (pv16) return ql ? launch_spatial<40, true, true, false>(a, s) : launch_spatial<40, false, true, false>(a, s);
+    return ql ? launch_spatial<40, true, false, false>(a, s) : launch_spatial<40, false, false, false>(a, s);
 }

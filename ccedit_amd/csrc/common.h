@@ -77,6 +77,7 @@ struct CcPolicy {
     int attn_text = 1;      // text cross-attention kernel
     int attn_spatial = 1;   // long self-attention kernel with the reference in the MFMA: 1 = d 40 and d 80, 2 = d 40 only, 0 = off
     int attn_pv16 = 1;      // ... its PV product in 16x16x32 tiles (0: 32x32x16)
+    int attn_opt = 1;       // ... softmax reference fixed by the first key tile, exact re-run of a workgroup that overflowed (0: tracked on every tile)
     int gn_flat = 1;        // flat thread mapping of the temporal GroupNorm at the two large levels
     int gn_apply_flat = 1;  // column-per-thread, four-rows-in-flight mapping of the spatial GroupNorm apply pass (0: a wave per pixel row)
 };

@@ -64,7 +64,7 @@ const PolicyEntry kPolicy[] = {
     {"g8_temporal", &CcPolicy::g8_temporal}, {"g8_split", &CcPolicy::g8_split}, {"lin320", &CcPolicy::lin320},
     {"lin320s", &CcPolicy::lin320s},         {"lin640", &CcPolicy::lin640},   {"temp320", &CcPolicy::temp320},
     {"attn_short", &CcPolicy::attn_short},   {"attn_text", &CcPolicy::attn_text}, {"attn_spatial", &CcPolicy::attn_spatial},
-    {"attn_pv16", &CcPolicy::attn_pv16},     {"gn_flat", &CcPolicy::gn_flat}, {"gn_apply_flat", &CcPolicy::gn_apply_flat},
+    {"attn_pv16", &CcPolicy::attn_pv16},     {"attn_opt", &CcPolicy::attn_opt},       {"gn_flat", &CcPolicy::gn_flat}, {"gn_apply_flat", &CcPolicy::gn_apply_flat},
 };
 }  // namespace
 

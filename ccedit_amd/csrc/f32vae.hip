@@ -318,6 +318,33 @@ __global__ __launch_bounds__(256) void softmax_rows_f32_kernel(float* __restrict
     }
 }
 
+// Rows longer than 8192 columns (latents beyond 96 x 85: e.g. 768 x 768 frames = 9216 tokens; the reference has no such limit,
+// model.py:180-195): the same three steps — maximum, sum of exponentials, normalise — with the row re-read from memory instead of
+// held in registers; same per-thread column assignment and reduction order as the register kernel.
+__global__ __launch_bounds__(256) void softmax_rows_f32_long_kernel(float* __restrict__ s, int cols, int64_t ld, float scale) {
+    __shared__ float red[4];
+    float* row = s + (size_t)blockIdx.x * ld;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, row[c] * scale);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float e = expf(row[c] * scale - mx);
+        row[c] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int c = threadIdx.x; c < cols; c += 256) row[c] *= inv;
+}
+
 }  // namespace
 
 extern "C" int ccedit_gemm_f32(const CcGemmF32Desc* desc, void* stream) {
@@ -392,13 +419,14 @@ extern "C" int ccedit_groupnorm_f32(const float* x, float* y, const float* gamma
 
 extern "C" int ccedit_softmax_rows_f32(float* s, int64_t rows, int32_t cols, int64_t ld, float scale, void* stream) {
     CC_CHECK_ARG(s != nullptr && rows >= 0 && cols > 0 && ld >= cols, "ccedit_softmax_rows_f32: bad arguments");
-    CC_CHECK_ARG(cols <= 256 * 32, "ccedit_softmax_rows_f32: at most 8192 columns (%d)", cols);
     CC_CHECK_ARG(rows < (1LL << 31), "ccedit_softmax_rows_f32: too many rows");
     if (rows == 0) return CCEDIT_OK;
     hipStream_t st = (hipStream_t)stream;
     if (cols <= 256 * 8)
         hipLaunchKernelGGL((softmax_rows_f32_kernel<8>), dim3((unsigned)rows), dim3(256), 0, st, s, cols, ld, scale);
-    else
+    else if (cols <= 256 * 32)
         hipLaunchKernelGGL((softmax_rows_f32_kernel<32>), dim3((unsigned)rows), dim3(256), 0, st, s, cols, ld, scale);
+    else          // (a thread reads back only columns it wrote itself: no barrier between the passes is needed for the data)
+        hipLaunchKernelGGL(softmax_rows_f32_long_kernel, dim3((unsigned)rows), dim3(256), 0, st, s, cols, ld, scale);
     return cc_launch_status("softmax_rows_f32_kernel");
 }

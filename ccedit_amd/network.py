@@ -1278,9 +1278,10 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             return False
         k = x.shape[0] // 2
         # marked by this build's guider / denoiser (sampling.py): no device compare, no host sync
-        marks = [getattr(x, "_cfg_twin_halves", None), getattr(t, "_cfg_twin_halves", None), getattr(c["control_hint"], "_halves_equal", None)]
+        # (ops.get_mark: a mark is void once its tensor was written in place after marking — then the values are compared below)
+        marks = [ops.get_mark(x, "_cfg_twin_halves"), ops.get_mark(t, "_cfg_twin_halves"), ops.get_mark(c["control_hint"], "_halves_equal")]
         if c.get("cond_feat") is not None:
-            marks.append(getattr(c["cond_feat"], "_halves_equal", None))
+            marks.append(ops.get_mark(c["cond_feat"], "_halves_equal"))
         if marks[0] is True and marks[1] is True and all(m is not None for m in marks[2:]):
             return all(marks)
         key = self._tensor_key(x) + self._tensor_key(t) + tuple(self._tensor_key(c[n]) for n in ("control_hint", "cond_feat") if c.get(n) is not None)
@@ -1352,6 +1353,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             self._graphs[key] = dict(pins=[v for v in c.values() if torch.is_tensor(v)])
             return self._forward_eager(x, t, c, _twins=twins)
         if "graph" not in ent:
+            ok = True
             try:
                 ent["x"], ent["t"] = x.clone(), t.clone()
                 g = torch.cuda.CUDAGraph()
@@ -1373,10 +1375,18 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                 ent["pins"].append(dict(self._tkv_val) if isinstance(self._tkv_val, dict) else None)     # ... and the cached text K / V
             except Exception as e:                              # capture is an optimisation: report once, keep evaluating eagerly
                 import warnings
+                ok = False
+                warnings.warn(f"HIP graph capture of the network evaluation failed ({type(e).__name__}: {e}); continuing without graphs")
+            # Row-sharded: the ranks must AGREE on graph-or-eager before anyone goes on.  A rank that fell back alone would run
+            # the ControlNet's exchanges on the sibling communicator / side stream while its peers replay a single-stream graph: collectives
+            # on different communicators in different orders, i.e. a deadlock.  One all-reduced flag, issued outside any capture; every
+            # rank reaches it (a rank whose capture succeeded has not replayed yet).
+            if self.row_shard is not None:
+                ok = self.row_shard.all_agree(ok)
+            if not ok:
                 OpenAIWrapperControlLDM3DTV2V._graph_failed = True
                 self._graphs = None
                 ops.reset_stream_scratch()                      # (again: whatever the aborted capture left behind)
-                warnings.warn(f"HIP graph capture of the network evaluation failed ({type(e).__name__}: {e}); continuing without graphs")
                 return self._forward_eager(x, t, c, _twins=twins)
         else:
             ent["x"].copy_(x)

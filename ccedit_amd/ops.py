@@ -207,6 +207,21 @@ def linear(x2d, pw, **kw):
     return gemm(x2d, pw, mode=GEMM_LINEAR, **kw)
 
 
+def set_mark(t: torch.Tensor, name: str, value) -> None:
+    """A host-side fact about the VALUES of a tensor (e.g. "its two CFG halves are equal"), carried as a Python attribute together with
+    the tensor's in-place version counter: get_mark returns it only while the tensor has not been written since (ADVICE r5 — an
+    inpainting blend or per-half noise added in place after marking must not leave a stale mark behind)."""
+    setattr(t, name, (value, t._version))
+
+
+def get_mark(t, name: str):
+    """The marked value, or None when the tensor carries no such mark or was modified in place after it was marked."""
+    m = getattr(t, name, None) if torch.is_tensor(t) else None
+    if not (isinstance(m, tuple) and len(m) == 2):
+        return None
+    return m[0] if m[1] == t._version else None
+
+
 LN320 = policy.on("ln320")      # 0: separate LayerNorm pass in front of the K = 320 projections
 
 

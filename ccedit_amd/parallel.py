@@ -117,6 +117,16 @@ class _ShardComm:
         if self.timing is not None:
             self.timing = []
 
+    def all_agree(self, ok: bool) -> bool:
+        """True iff `ok` holds on EVERY rank of the communicator (a MIN all-reduce of one flag through host memory, not counted as a
+        data-path exchange).  Used where ranks must take the same branch before issuing further collectives — e.g. whether the HIP-graph
+        capture of a sharded evaluation succeeded everywhere (network._forward_graphed)."""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if not self.staged:
+            flag = flag.cuda()
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()) == 1)
+
     def _out(self, t: torch.Tensor) -> torch.Tensor:
         return t.detach().cpu().contiguous() if (self.staged and t.is_cuda) else t.contiguous()
 

@@ -35,8 +35,9 @@ TABLE = {
     "attn_q_log2": (1, "py", "0: softmax scale applied inside the attention kernels instead of folded into to_q"),
     "block_tail": (1, "py", "0: to_out / proj_out of the dim-320 transformer tails as their own launches, not inside ff320"),
     # (a precision option, not an A/B arm of equal arithmetic: the reference runs its first-stage model with autocast disabled)
-    "vae_fp32": (0, "py", "1: the KL-VAE evaluated in fp32 on v_mfma_f32_32x32x2_f32 (ccedit_amd/vae_f32.py) instead of the bf16 kernels; "
-                          "2: fp32 exactly when the yaml sets disable_first_stage_autocast (the flag's meaning in the reference)"),
+    "vae_fp32": (2, "py", "the KL-VAE's precision.  2 (default): the engine follows the yaml's disable_first_stage_autocast, the flag's meaning in "
+                          "the reference (diffusion.py:151-156; the shipped yamls set it => fp32 on v_mfma_f32_32x32x2_f32, ccedit_amd/vae_f32.py); "
+                          "1: always fp32, also for a first stage built outside an engine; 0: always the bf16-storage kernels"),
     # ---- kernel library (csrc/common.h: CcPolicy) ----
     "conv_halo": (1, "lib", "0: 3x3 stride-1 convs on the tap-gather kernel"),
     "g8": (1, "lib", "0: long Linears on the tap_gemm block shapes"),
@@ -51,6 +52,7 @@ TABLE = {
     "attn_text": (1, "lib", "0: text cross-attention through the general flash kernel"),
     "attn_spatial": (1, "lib", "0: the 6144-key (d = 40) and 1536-key (d = 80) self-attention through the general flash kernel; 2: only d = 40 on the specialised kernel"),
     "attn_pv16": (1, "lib", "0: PV product of the spatial attention in 32x32x16 tiles"),
+    "attn_opt": (1, "lib", "0: softmax reference of the spatial attention tracked on every key tile (no optimistic first-tile reference)"),
     "gn_flat": (1, "lib", "0: temporal GroupNorm through the per-pixel kernels at the two large levels"),
     "gn_apply_flat": (1, "lib", "0: spatial GroupNorm apply with a wave per pixel row instead of a granule column per thread"),
 }
@@ -58,12 +60,25 @@ TABLE = {
 _values: Dict[str, int] = {}
 
 
+def _parse(what: str, text: str, legacy_switch: bool = False) -> int:
+    """Integer value of a switch.  The pre-round-5 one-variable-per-switch spelling treated any string other than "0" as on
+    (CCEDIT_GRAPH="", "off", "true" ...): those keep that meaning instead of failing the import; CCEDIT_POLICY entries must be
+    integers and a malformed one names itself."""
+    t = text.strip()
+    try:
+        return int(t)
+    except ValueError:
+        if legacy_switch:
+            return 0 if t.lower() in ("0", "off", "false", "no") else 1
+        raise ValueError(f"{what}: '{text}' is not an integer") from None
+
+
 def _load():
     vals = {k: v[0] for k, v in TABLE.items()}
     for name in TABLE:                                   # legacy spelling
         legacy = {"g8_split": "CCEDIT_G8_SPLIT"}.get(name, "CCEDIT_" + name.upper())
         if legacy in os.environ:
-            vals[name] = int(os.environ[legacy])
+            vals[name] = _parse(legacy, os.environ[legacy], legacy_switch=True)
     spec = os.environ.get("CCEDIT_POLICY", "")
     for item in filter(None, (x.strip() for x in spec.split(","))):
         if "=" not in item:
@@ -71,7 +86,7 @@ def _load():
         k, v = item.split("=", 1)
         if k.strip() not in TABLE:
             raise ValueError(f"CCEDIT_POLICY: unknown switch '{k.strip()}' (known: {', '.join(TABLE)})")
-        vals[k.strip()] = int(v)
+        vals[k.strip()] = _parse(f"CCEDIT_POLICY: {k.strip()}", v)
     return vals
 
 
@@ -94,7 +109,7 @@ def non_default() -> Dict[str, int]:
 def generic() -> str:
     """The CCEDIT_POLICY string that switches every specialised kernel / fusion / overlap off: the generic kernels the small-size
     tests pin against the oracle and the reference goldens (tests/test_fullsize_gpu.py)."""
-    off = {k: 0 for k in TABLE if k not in ("split_cfg",)}
+    off = {k: 0 for k in TABLE if k not in ("split_cfg", "vae_fp32")}      # (vae_fp32 is a precision choice, not a kernel arm: left at its default)
     return ",".join(f"{k}={v}" for k, v in off.items())
 
 

@@ -173,10 +173,10 @@ class Denoiser(nn.Module):
         # network, which then shares the halves' common prefix without comparing them on the device (a host sync per evaluation
         # would expose the launch of every replayed graph: measured +4 ms per evaluation of a clip).
         k = b // 2
-        if (getattr(input, "_cfg_twin_halves", False) and b % 2 == 0 and all(float(c_in[i]) == float(c_in[i + k]) for i in range(k))
+        if (ops.get_mark(input, "_cfg_twin_halves") is True and b % 2 == 0 and all(float(c_in[i]) == float(c_in[i + k]) for i in range(k))
                 and bool(torch.equal(c_noise[:k], c_noise[k:]))):
-            xs._cfg_twin_halves = True
-            c_noise_dev._cfg_twin_halves = True
+            ops.set_mark(xs, "_cfg_twin_halves", True)         # (mark + in-place version: a later in-place edit voids it, ops.get_mark)
+            ops.set_mark(c_noise_dev, "_cfg_twin_halves", True)
         net = network(xs, c_noise_dev, cond).float().contiguous()
         out = torch.empty_like(x)
         for i in range(b):                                    # net * c_out + input * c_skip
@@ -251,14 +251,14 @@ class VanillaCFG:
                     hit = (uc[k], c[k], (uc[k]._version, c[k]._version), torch.cat((uc[k], c[k]), 0))
                     # are the two halves the same values (control_hint, cond_feat: the scripts give uc a clone of c's)?  Compared once per
                     # (uc[k], c[k]) pair, remembered on the concatenation for the network's shared CFG prefix
-                    hit[3]._halves_equal = bool(uc[k].shape == c[k].shape and torch.equal(uc[k], c[k]))
+                    ops.set_mark(hit[3], "_halves_equal", bool(uc[k].shape == c[k].shape and torch.equal(uc[k], c[k])))
                     self._cat_cache[k] = hit
                 c_out[k] = hit[3]
             else:
                 assert c[k] == uc[k]
                 c_out[k] = c[k]
         x2, s2 = torch.cat([x] * 2), torch.cat([s] * 2)
-        x2._cfg_twin_halves = True          # the same latent twice (see Denoiser.__call__)
+        ops.set_mark(x2, "_cfg_twin_halves", True)          # the same latent twice (see Denoiser.__call__)
         return x2, s2, c_out
 
 

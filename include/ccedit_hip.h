@@ -385,7 +385,8 @@ int ccedit_gemm_f32(const CcGemmF32Desc* desc, void* stream);
  * C in {32, 64, 128, 256, 512, 1024}; stats = fp64 scratch [frames][32][2] (sum, sum of squares; zeroed here).  model.py:45-53. */
 int ccedit_groupnorm_f32(const float* x, float* y, const float* gamma, const float* beta, double* stats, int32_t frames, int32_t hw,
                          int32_t C, float eps, int32_t silu, void* stream);
-/* s[r][0..cols) = softmax(scale * s[r][0..cols)) in place, fp32 rows of stride ld; columns beyond cols are left alone; cols <= 8192 */
+/* s[r][0..cols) = softmax(scale * s[r][0..cols)) in place, fp32 rows of stride ld; columns beyond cols are left alone
+ * (rows of up to 8192 columns are held in registers, longer ones are re-read: three passes) */
 int ccedit_softmax_rows_f32(float* s, int64_t rows, int32_t cols, int64_t ld, float scale, void* stream);
 
 /* Sampler / guider / denoiser elementwise math on the fp32 latent (417,792 elements at 17x64x96):

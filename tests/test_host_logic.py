@@ -137,7 +137,7 @@ def test_packing_layouts():
 
 def test_fp32_first_stage_packing_and_policy():
     """ccedit_amd/vae_f32.py host side (no GPU): the fp32 kernel layout — [Cout][tap][Cpad], tap = 3 ky + kx, zero columns beyond Cin,
-    Cin rounded up to 4 for the activation rows — and the policy entry that selects the fp32 first stage (default off: bf16)."""
+    Cin rounded up to 4 for the activation rows — and the policy entry that selects the fp32 first stage (default 2: whatever the yaml's disable_first_stage_autocast says)."""
     from ccedit_amd import policy
     from ccedit_amd.vae_f32 import pack_f32
     w = torch.arange(5 * 6 * 9, dtype=torch.float32).reshape(5, 6, 3, 3)
@@ -150,7 +150,9 @@ def test_fp32_first_stage_packing_and_policy():
     assert p1.w.shape == (7, 512) and p1.taps == 1 and p1.bias is None and p1.cin == 512
     p3 = pack_f32(torch.randn(128, 3, 3, 3), None, "cpu")             # the encoder's conv_in: RGB frames carry a fourth, zero channel
     assert (p3.cin, p3.cpad) == (4, 16)
-    assert policy.TABLE["vae_fp32"][0] == 0 and "vae_fp32=0" in policy.generic()
+    # default 2 since round 6: the engine follows the yaml's flag (the shipped yamls set it => the reference's fp32 first stage); a
+    # precision choice, not a kernel arm: the generic-kernels policy string leaves it alone
+    assert policy.TABLE["vae_fp32"][0] == 2 and "vae_fp32" not in policy.generic()
     from ccedit_amd.sgm_compat import build_vae
     assert build_vae("cpu", ch=32).precision == ("fp32" if policy.get("vae_fp32") == 1 else "bf16")
     # vae_fp32=2: the engine follows the yaml's disable_first_stage_autocast, as the reference does (diffusion.py:151-156)
@@ -160,7 +162,7 @@ def test_fp32_first_stage_packing_and_policy():
             "cfg = engine_config(vae_ch=32, model_channels=32, num_heads=1, context_dim=32); "
             "a = instantiate_from_config(cfg).first_stage_model.precision; cfg['params']['disable_first_stage_autocast'] = False; "
             "print(a, instantiate_from_config(cfg).first_stage_model.precision)")
-    for pol, want in (("vae_fp32=2", "fp32 bf16"), ("vae_fp32=1", "fp32 fp32"), ("", "bf16 bf16")):
+    for pol, want in (("", "fp32 bf16"), ("vae_fp32=2", "fp32 bf16"), ("vae_fp32=1", "fp32 fp32"), ("vae_fp32=0", "bf16 bf16")):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CCEDIT_POLICY=pol, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-1500:]
         assert r.stdout.strip().splitlines()[-1] == want, (pol, r.stdout)
@@ -389,3 +391,21 @@ def test_clip_tokenizer_path_plumbing(tmp_path, monkeypatch):
     add_common_args(p)
     args = p.parse_args(["--prompt", "a cat", "--tokenizer_path", str(tmp_path)])
     assert text_inputs({}, "cpu", args) == (["masterpiece, high quality, a cat"], ["ugly, low quality"])
+
+
+def test_policy_legacy_environment_values_are_lenient_and_malformed_policy_names_itself():
+    """the pre-round-5 one-variable-per-switch spelling treated any string other than "0" as on; such values
+    (CCEDIT_GRAPH="", "off", "true") must not fail the import with int()'s ValueError.  A malformed CCEDIT_POLICY entry is an error
+    that names the switch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = "from ccedit_amd import policy; print(policy.get('graph'), policy.get('ff320'), policy.get('lnf'), policy.get('g8_split'))"
+    env = dict(os.environ, PYTHONPATH=root, CCEDIT_GRAPH="", CCEDIT_FF320="off", CCEDIT_LNF="true", CCEDIT_G8_SPLIT="3")
+    env.pop("CCEDIT_POLICY", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert r.stdout.split() == ["1", "0", "1", "3"]
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=root, CCEDIT_POLICY="graph=yes"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "graph" in r.stderr and "not an integer" in r.stderr

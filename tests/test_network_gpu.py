@@ -342,10 +342,20 @@ def test_shared_cfg_prefix_equals_full_evaluation(g160_wrapper):
         seen.update(x=xs, t=tt, c=cc_)
         return torch.zeros_like(xs)
     den(fake_network, *guider.prepare_inputs(x1.cuda(), torch.tensor([3.0]), cond, ucond))
-    assert getattr(seen["x"], "_cfg_twin_halves", False) and getattr(seen["t"], "_cfg_twin_halves", False)
-    assert seen["c"]["control_hint"]._halves_equal is True and seen["c"]["crossattn"]._halves_equal is False
+    from ccedit_amd import ops
+    assert ops.get_mark(seen["x"], "_cfg_twin_halves") is True and ops.get_mark(seen["t"], "_cfg_twin_halves") is True
+    assert ops.get_mark(seen["c"]["control_hint"], "_halves_equal") is True and ops.get_mark(seen["c"]["crossattn"], "_halves_equal") is False
     w._twin_val = None
     assert w._cfg_twins(seen["x"], seen["t"], seen["c"]) is True and not w._twin_val, "marked halves must not need the device compare"
+    # a mark is void once its tensor is written IN PLACE after marking (an inpainting blend, per-half noise): the wrapper must
+    # fall back to comparing values — and find the halves different
+    seen["x"][1].add_(1.0)
+    assert ops.get_mark(seen["x"], "_cfg_twin_halves") is None
+    assert w._cfg_twins(seen["x"], seen["t"], seen["c"]) is False and w._twin_val, "a stale mark was taken at its word"
+    hint_cat = seen["c"]["control_hint"]
+    hint_cat[:1].mul_(0.5)
+    assert ops.get_mark(hint_cat, "_halves_equal") is None
+    w._twin_val = None
     from ccedit_amd.sgm_compat import build_network_spec
     from ccedit_amd.utils.synth import synth_state_dict
     from oracle import ccedit_oracle as O

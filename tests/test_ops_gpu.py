@@ -1373,6 +1373,54 @@ def test_attention_spatial_kernel_d80():
            what="d=80 spatial kernel, anchor + self keys")
 
 
+@pytest.mark.parametrize("d", [40, 80])
+def test_attention_spatial_optimistic_reference_and_exact_rerun(d):
+    """Round 6, policy attn_opt (attnspatial.hip): the softmax reference of a query row is fixed by its FIRST key tile (+ 2^32 of
+    head-room) and later tiles no longer look at their scores; a workgroup whose accumulators overflowed repeats its key loop with
+    the reference tracked on every tile.  Checked: ordinary logits and a late spike of 2^36 stay inside the window (same result as
+    the tracked arm up to the bf16 rounding of P, and as fp32 SDPA); a late spike of 2^146 over a first tile far below it overflows
+    the optimistic pass — the re-run must give EXACTLY the bits of policy attn_opt = 0; rows next to the spiked row (same
+    workgroup) are re-run with it and agree too; no NaN / inf anywhere."""
+    _dev()
+    from ccedit_amd import hip, ops
+    lib = hip.lib()
+    heads, lq, lk = 2, 1280, 1216
+    c = heads * d
+
+    def both(args, **kw):
+        out = []
+        for opt in (1, 0):
+            try:
+                assert lib.ccedit_policy_set(b"attn_opt", opt) == 0
+                out.append(ops.attention(*args, **kw))
+                assert "attn_spatial_kernel" in lib.ccedit_last_kernel().decode()
+            finally:
+                lib.ccedit_policy_set(b"attn_opt", 1)
+        return out
+    for spike, exact in ((0.0, False), (4.0, False), (16.0, False), (40.0, True)):      # x16: some of its rows overflow, some stay inside the window
+        q, k, v = _rnd(2, lq, c, seed=11), _rnd(2, lk, c, seed=12), _rnd(2, lk, c, seed=13)
+        if spike:
+            for row, key in ((700, 450), (33, lk - 1), (1279, 64)):
+                k[1, key] = q[1, row] * spike
+            k[1, :64] -= q[1, 700] * 2.0
+        q, k = q.to(BF).float(), k.to(BF).float()
+        args = (q.reshape(-1, c).to(BF).cuda(), k.reshape(-1, c).to(BF).cuda(), v.reshape(-1, c).to(BF).cuda(), heads, d)
+        o_opt, o_trk = both(args, batches=2, lq=lq, lk=lk)
+        assert bool(torch.isfinite(o_opt.float()).all()) and bool(torch.isfinite(o_trk.float()).all())
+        ref = _sdpa_ref(q, k, v, heads)
+        _close(o_opt.reshape(2, lq, c), ref, rel=2.0 ** -6, abs_=4e-3, what=f"optimistic reference, d={d}, spike x{spike}")
+        _close(o_trk.reshape(2, lq, c), ref, rel=2.0 ** -6, abs_=4e-3, what=f"tracked reference, d={d}, spike x{spike}")
+        on, tn = o_opt.reshape(2, lq, c), o_trk.reshape(2, lq, c)
+        _close(on, tn, rel=2.0 ** -6, abs_=4e-3, what="optimistic vs tracked")
+        if exact:
+            # the spiked rows live in batch 1, head 0 / 1 (the spike is along the whole 2 x d channel vector: both heads); their
+            # workgroups (256 query rows each) overflowed and were re-run: bit-identical to the tracked arm
+            for row in (700, 33, 1279):
+                blk = slice(row // 256 * 256, min(row // 256 * 256 + 256, lq))
+                assert torch.equal(on[1, blk], tn[1, blk]), f"re-run rows of the workgroup of row {row} differ from the tracked arm"
+        assert torch.equal(o_opt, both(args, batches=2, lq=lq, lk=lk)[0])
+
+
 def test_copy_row_blocks_pack_unpack_add():
     """ccedit_copy_row_blocks: the pack / unpack(+skip add) halves of FrameShard's all-to-all against index_select + add_."""
     _dev()

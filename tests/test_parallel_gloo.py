@@ -244,6 +244,11 @@ def _row_worker(rank, world, port, q):
     mine_o = o_full[:, :, rank * cw:(rank + 1) * cw].reshape(n * h * w, cw).contiguous()
     back = rs.from_heads(mine_o, n, p_local, cw)
     ok &= torch.equal(back, o_full[:, r0 * w:r1 * w].reshape(n * p_local, C))
+    # all_agree: the ranks take the same branch (graph or eager after a capture attempt, network._forward_graphed) — true only when
+    # every rank says so; not a data-path exchange (neither counted nor logged)
+    nc = rs.n_collectives
+    ok &= rs.all_agree(True) is True and rs.all_agree(rank != world - 1) is False and rs.all_agree(rank == 0) is (world == 1)
+    ok &= rs.n_collectives == nc
     q.put((rank, bool(ok), rs.n_collectives, rs.bytes_sent, [k for _, k, _ in RowShard.issue_log]))
     dist.barrier()
     dist.destroy_process_group()

@@ -20,7 +20,7 @@ def loop(name, n, make_x, mark=False):
     for _ in range(n):
         xi = make_x()
         if mark:
-            xi._cfg_twin_halves = True
+            ops.set_mark(xi, '_cfg_twin_halves', True)
         w(xi, t, cond)
     torch.cuda.synchronize()
     print(f"{name:70s} {(time.perf_counter() - t0) / n * 1e3:8.2f} ms / evaluation", flush=True)
@@ -31,8 +31,8 @@ for cache in (False, True):
     w.reset_caches()
     loop(f"cache={cache}: same x tensor every call", 20, lambda: x2)
     loop(f"cache={cache}: a NEW x tensor every call (device compare + host sync)", 20, lambda: x2.clone())
-    t._cfg_twin_halves = True
-    cond["control_hint"]._halves_equal = True
+    ops.set_mark(t, '_cfg_twin_halves', True)
+    ops.set_mark(cond["control_hint"], '_halves_equal', True)
     loop(f"cache={cache}: a NEW x tensor every call, marked (no compare)", 20, lambda: x2.clone(), mark=True)
     del t._cfg_twin_halves, cond["control_hint"]._halves_equal
     w.share_cfg_prefix = False
