@@ -76,7 +76,7 @@ def cpu_model() -> str:
     return platform.processor() or "unknown"
 
 
-def cpu_baseline(wrapper, tvi2v=False, device=None):
+def cpu_baseline(wrapper, tvi2v=False, device=None, full_step=False):
     """Oracle (CPU fp32 restatement, `kind: port`) on a bounded sample of the same workload: the same
     full-width network and weights on a crop — B=2 (CFG), T=6 keyframes, latent 32x48 — timed on the host
     cores; converted to steps/s through the FLOPs ATen actually executed (FlopCounterMode).  The full-size step is NOT run on
@@ -106,9 +106,40 @@ def cpu_baseline(wrapper, tvi2v=False, device=None):
                sample=f"oracle network_forward ({'TVI2V' if tvi2v else 'TV2V'}), full-width weights, B=2 T={tt} latent {hh}x{ww}: "
                       f"{flops/1e12:.2f} TFLOP in {dt:.1f}s; steps/s = CPU FLOP/s / {per_step / 1e12:.2f} TFLOP (a conversion of the "
                       f"crop's rate — the full-size step itself is not run on the CPU)")
+    if full_step:
+        out["full_size_step"] = cpu_full_size_step(sd, tvi2v)
     if not tvi2v:
         out.update(cpu_config1_end_to_end(sd, threads, wrapper, device))
     return out
+
+
+def cpu_full_size_step(sd, tvi2v=False):
+    """BASELINE.md section 3, second half (`--cpu-full-step`): ONE measured network evaluation of the oracle at the full 17 x 512 x 768
+    size — the same CFG-doubled batch the GPU step evaluates (B = 2 x T = 17, latent 64 x 96; 77.68 / 110.31 TFLOP in fp32) — and the
+    x (2 N - 1) extrapolation to a clip.  Not part of the default run (about two minutes of host time on 64 threads)."""
+    from oracle import ccedit_oracle as O
+    threads = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(1, 4, T, H, W, generator=g)
+    cc, cu = torch.randn(1, L, CTX, generator=g), torch.randn(1, L, CTX, generator=g)
+    hint = (torch.rand(1, 1, T, 8 * H, 8 * W, generator=g) * 2 - 1).repeat(1, 3, 1, 1, 1)
+    c = dict(crossattn=torch.cat([cu, cc]), control_hint=torch.cat([hint, hint]))
+    if tvi2v:
+        cf = torch.randn(1, 4, H, W, generator=g) * 0.18215
+        c["cond_feat"] = torch.cat([cf, cf])
+    t = torch.tensor([601, 601], dtype=torch.int64)
+    with torch.no_grad():
+        t0 = time.time()
+        eps = O.network_forward(sd, O.NetConfig(crossframe=tvi2v), torch.cat([x, x]), t, c)
+        dt = time.time() - t0
+    assert eps.shape == (2, 4, T, H, W) and bool(torch.isfinite(eps).all())
+    per_step = FLOP_PER_STEP_TVI2V if tvi2v else FLOP_PER_STEP
+    n_eval = 99 if tvi2v else 59
+    return dict(seconds=round(dt, 1), steps_per_s=round(1.0 / dt, 5), cpu_tflops=round(per_step / dt / 1e12, 3), cores=threads,
+                clip_extrapolated_s=round(n_eval * dt, 0), clip_evaluations=n_eval,
+                workload=f"oracle network_forward ({'TVI2V' if tvi2v else 'TV2V'}) at the full size: B=2 x T={T}, latent {H}x{W}, "
+                         f"{per_step / 1e12:.2f} TFLOP, fp32, {threads} threads — one measured evaluation; x{n_eval} = the sampler's evaluations of a clip")
 
 
 def cpu_config1_end_to_end(sd, threads, wrapper=None, device=None):
@@ -183,6 +214,8 @@ def hip_config1(wrapper, device, x, c, uc, noises, z_ref, frames_ref, vsd):
     t0 = time.perf_counter()
     z = sampler(lambda inp, sig, cc: denoiser(wrapper, inp, sig, cc), x.to(device).clone(), cd, uc=ud)
     zs = ops.axpby(z.contiguous(), z.contiguous(), 1.0 / 0.18215, 0.0)
+    from ccedit_amd import policy
+    vae.precision = "bf16" if policy.get("vae_fp32") == 0 else "fp32"       # the engine's default for the shipped yamls (time_clip)
     frames = vae.decode(zs)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -207,8 +240,8 @@ def hip_config1(wrapper, device, x, c, uc, noises, z_ref, frames_ref, vsd):
     return dict(final_latent_rel_rms=round(r_lat, 5), frames_rel_rms=round(r_fr, 5), within_budget=ok,
                 budget=dict(latent=C1_LATENT_TOL, frames=C1_FRAMES_TOL, decode_fp32=C1_DECODE_FP32_TOL), hip_end_to_end_s=round(dt, 3),
                 decode_of_oracle_latent_rel_rms=dict(fp32_vae=float(f"{r_dec32:.3g}"), bf16_vae=float(f"{r_dec16:.3g}")),
-                note="same initial latent, conditioning and per-step ancestral noise as the oracle run; bf16 HIP path vs fp32 oracle over "
-                     "9 evaluations + VAE decode at the shipped width")
+                note="same initial latent, conditioning and per-step ancestral noise as the oracle run; bf16 HIP network vs fp32 oracle over "
+                     "9 evaluations at the shipped width, then the VAE decode in the product's default precision (fp32 unless policy vae_fp32=0)")
 
 
 # Drift budget of the 5-step config-1 trajectory (bf16 path against the fp32 oracle): one evaluation is held to 5e-2 relative RMS
@@ -226,6 +259,8 @@ def main():
     ap.add_argument("--clip", action="store_true", help="(default on) time one full 30-step clip + VAE decode (frames/s)")
     ap.add_argument("--no-clip", action="store_true", help="skip the whole-clip timing (30-step sampler + VAE decode, ~7 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full-step", action="store_true",
+                    help="cpu_baseline: also time ONE full-size (17x512x768, CFG-doubled) evaluation of the oracle on the host (BASELINE.md section 3; ~2 min)")
     ap.add_argument("--shard-frames", action="store_true",
                     help="N>1: BASELINE.json config 4 — ONE clip, its T=17 keyframes sharded over the ranks; default N>1 mode "
                          "is config 5 (one clip per GPU, no collective)")
@@ -363,7 +398,7 @@ def main():
                 for shape, n, ms, tf in ops.PROFILE.by_shape(fam)[:int(os.environ.get('CCEDIT_BREAKDOWN_ROWS', '40'))]:
                     print(f"{fam:9s} {str(shape):60s} x{n:3d} {ms:8.3f} ms {tf:7.1f} TF/s", file=sys.stderr)
             mem = {}
-            for a_, b_, _, nb, shape, _k in ops.PROFILE.records.get("memory", []):
+            for a_, b_, _, nb, shape, _k, _ex in ops.PROFILE.records.get("memory", []):
                 e = mem.setdefault(shape, [0, 0.0, 0.0])
                 e[0] += 1; e[1] += a_.elapsed_time(b_); e[2] += nb
             for shape, (n, ms, nb) in sorted(mem.items(), key=lambda kv: -kv[1][1]):
@@ -382,23 +417,47 @@ def main():
                 if r["family"] != "memory":
                     row.update(tflops=round(r["tflops"], 1), flop_per_byte=round(flops / max(r["bytes"], 1.0), 1))
             else:
-                row.update(bound="mfma", tflops=round(r["tflops"], 1), frac=round(r["tflops"] / MFMA_PEAK_TFLOPS, 4))
+                # frac: the FLOPs the matrix pipe retired in this template's launches (executed) over the peak; the algorithmic
+                # count of the reference's operations (upsample + conv as nine taps) beside it where the two differ
+                row.update(bound="mfma", tflops=round(r["exec_tflops"], 1), frac=round(r["exec_tflops"] / MFMA_PEAK_TFLOPS, 4))
+                if abs(r["tflops"] - r["exec_tflops"]) > 1e-6 * r["tflops"]:
+                    row.update(algorithmic_tflops=round(r["tflops"], 1), algorithmic_frac=round(r["tflops"] / MFMA_PEAK_TFLOPS, 4))
+            row["_ms"], row["_flops"], row["_bytes"] = r["ms"], r["exec_tflops"] * 1e12 * r["ms"] * 1e-3, r["bytes"]
             by_kernel.append(row)
         executed_flops = ops.PROFILE.executed
         ops.PROFILE = None
         g = prof["tap_gemm"]
         ach = g["flops"] / (g["total_ms"] * 1e-3) / 1e12
-        # The DOMINANT kernel = the single template with the most time in it over ALL rows (GEMM, attention and memory passes):
-        # `kernel*`, `achieved`, `frac` are ITS algorithmic FLOPs / its HIP-event time in this profiled step (reproducible from
-        # the rocprofv3 summary under profiles/: calls x average duration of that kernel's row).  The whole GEMM family
-        # (every ccedit_gemm + ccedit_ff320 launch of the step), which earlier rounds reported as `achieved`, stays as `family_*`.
-        dom = max(by_kernel, key=lambda r: r["ms"])
-        dom_mfma = dom["bound"] == "mfma"
-        roof = dict(bound=dom["bound"], kernel=dom["kernel"], kernel_launches=dom["launches"], kernel_ms_per_step=dom["ms"],
-                    avg_launch_us=round(1e3 * dom["ms"] / dom["launches"], 2),
-                    achieved=dom["tflops"] if dom_mfma else dom["gbytes_per_s"],
+        # The DOMINANT kernel = the kernel TEMPLATE (by name: all instantiations and block shapes of `g8_kernel`, of `conv_halo_kernel`,
+        # ... summed) with the most time in it over ALL rows — GEMM, attention and memory passes (split by
+        # instantiation, the persistent GEMM's 34 ms hid behind the 13 ms of the single conv_halo symbol).  `achieved` / `frac` are
+        # its EXECUTED FLOPs over its HIP-event time in this profiled step (reproducible from the rocprofv3 summary under profiles/:
+        # sum over the template's rows of calls x average duration); `symbol_leader` is the single by_kernel row with the most time
+        # (what earlier rounds reported as the dominant kernel).  The whole GEMM family stays as `family_*`.
+        tmpl = {}
+        for r in by_kernel:
+            t = tmpl.setdefault(r["kernel"].split(" ")[0], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, rows=0))
+            t["ms"] += r["_ms"]; t["flops"] += r["_flops"]; t["bytes"] += r["_bytes"]; t["launches"] += r["launches"]; t["rows"] += 1
+        for r in by_kernel:
+            for k_ in ("_ms", "_flops", "_bytes"):
+                r.pop(k_)
+        dname, dt_ = max(tmpl.items(), key=lambda kv: kv[1]["ms"])
+        d_tf, d_gb = dt_["flops"] / (dt_["ms"] * 1e-3) / 1e12, dt_["bytes"] / (dt_["ms"] * 1e-3) / 1e9
+        dom_mfma = dt_["flops"] / max(dt_["bytes"], 1.0) >= balance
+        lead = max(by_kernel, key=lambda r: r["ms"])
+        dom = dict(kernel=dname, launches=dt_["launches"], ms=round(dt_["ms"], 3), alg_bytes_per_launch=round(dt_["bytes"] / dt_["launches"]))
+        roof = dict(bound="mfma" if dom_mfma else "hbm", kernel=dname, kernel_instantiations=dt_["rows"], kernel_launches=dt_["launches"],
+                    kernel_ms_per_step=dom["ms"], avg_launch_us=round(1e3 * dt_["ms"] / dt_["launches"], 2),
+                    achieved=round(d_tf if dom_mfma else d_gb, 1),
                     peak=MFMA_PEAK_TFLOPS if dom_mfma else HBM_PEAK_GBS, unit="TFLOP/s" if dom_mfma else "GB/s",
-                    frac=dom["frac"], traffic=None, algorithmic_bytes_per_launch=dom["alg_bytes_per_launch"],
+                    frac=round((d_tf / MFMA_PEAK_TFLOPS) if dom_mfma else (d_gb / HBM_PEAK_GBS), 4),
+                    frac_basis="executed FLOPs (what the matrix pipe retired) / HIP-event time of the template's launches / dense bf16 peak",
+                    traffic=None, algorithmic_bytes_per_launch=dom["alg_bytes_per_launch"],
+                    symbol_leader=dict(kernel=lead["kernel"], launches=lead["launches"], ms_per_step=lead["ms"], frac=lead["frac"],
+                                       bound=lead["bound"]),
+                    by_template=[dict(kernel=k_, ms=round(v_["ms"], 3), launches=v_["launches"],
+                                      tflops=round(v_["flops"] / (v_["ms"] * 1e-3) / 1e12, 1), gbytes_per_s=round(v_["bytes"] / (v_["ms"] * 1e-3) / 1e9, 1))
+                                 for k_, v_ in sorted(tmpl.items(), key=lambda kv: -kv[1]["ms"])][:12],
                     family="ccedit_gemm + ccedit_ff320 (g8_kernel, conv_halo_kernel, tap_gemm_kernel, lin320s_kernel / lin320_kernel, lin640s_kernel, temp320s_kernel, ff320_kernel, small_conv3x3_kernel)",
                     family_achieved=round(ach, 1), family_frac=round(ach / MFMA_PEAK_TFLOPS, 4), family_launches=g["launches"],
                     family_avg_launch_us=round(g["avg_us"], 2), algorithmic_flops_per_step=g["flops"], by_kernel=by_kernel)
@@ -434,13 +493,16 @@ def main():
             extra["attention"] = dict(tflops=round(a["flops"] / (a["total_ms"] * 1e-3) / 1e12, 1), launches=a["launches"],
                                       total_ms=round(a["total_ms"], 2), algorithmic_flops_per_step=a["flops"])
         extra["gemm_total_ms"] = round(g["total_ms"], 2)
-        extra["step_tflops"] = round(flop_per_step / (ms_per_step * 1e-3) / 1e12, 1)
-        extra["step_frac_of_mfma_peak"] = round(flop_per_step / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
         # what the matrix pipe really retires per step: the parity form of upsample + conv executes 4/9 of those convolutions'
-        # multiply-adds and the hint stem runs on ONE of the two identical CFG halves; `value` and the fractions above are priced
-        # with the ALGORITHMIC count of the reference's operations, this is the honest utilisation figure beside it
+        # multiply-adds, the hint stem runs on ONE of the two identical CFG halves and their shared prefix is evaluated once.  The
+        # step's fraction of the MFMA peak is priced with THOSE FLOPs; `value` (steps/s) needs no FLOP count, and
+        # the figure with the algorithmic count of the reference's operations (77.68 TFLOP) is kept beside it
         extra["executed_flops_per_step"] = executed_flops
-        extra["executed_frac_of_mfma_peak"] = round(executed_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+        extra["step_tflops"] = round(executed_flops / (ms_per_step * 1e-3) / 1e12, 1)
+        extra["step_frac_of_mfma_peak"] = round(executed_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+        extra["executed_frac_of_mfma_peak"] = extra["step_frac_of_mfma_peak"]          # (the name of rounds 4-5)
+        extra["algorithmic_step_tflops"] = round(flop_per_step / (ms_per_step * 1e-3) / 1e12, 1)
+        extra["algorithmic_step_frac_of_mfma_peak"] = round(flop_per_step / (ms_per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
 
     # BASELINE.json's metric names frames/s next to UNet steps/s: one whole clip (59 evaluations + sampler math + VAE decode)
     # outside the timed region above.  N > 1 replicas: every rank runs its own clip at the same time (rank 0's is reported);
@@ -457,7 +519,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(wrapper, tvi2v, device)
+        cpu = cpu_baseline(wrapper, tvi2v, device, full_step=args.cpu_full_step)
 
     # BASELINE.json config 3 on the default line: the TVI2V network's step, timed like the headline
     if rank == 0 and world == 1 and not tvi2v and not args.no_tvi2v:

@@ -20,6 +20,19 @@ namespace {
 
 __device__ __attribute__((aligned(64))) char g_zero_page_h[64];     // source of out-of-image halo rows
 
+#ifdef CONV_PROBE          // probe builds only (tools/exp/conv_probe.py): per-workgroup time stamps, never in the product library
+constexpr int kProbeWgs = 8192, kProbeStamps = 8;
+__device__ unsigned long long g_conv_probe[kProbeWgs * kProbeStamps];
+#define CONV_STAMP(i)                                                                                                     \
+    do {                                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x < kProbeWgs) g_conv_probe[blockIdx.x * kProbeStamps + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define CONV_STAMP(i) \
+    do {              \
+    } while (0)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_h() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -179,10 +192,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc
     };
 
     // ---- main loop: weights 2-deep ring per k-tile, halo 2-deep ring per chunk ----
+    CONV_STAMP(0);
     stageW(0, 0);
     stageH(0, 0);
     wait_vmcnt_h<0>();
     __syncthreads();
+    CONV_STAMP(1);
     int kt = 0;
     for (int c = 0; c < nc; ++c) {
         for (int t = 0; t < 9; ++t, ++kt) {
@@ -198,6 +213,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc
     }
 
     // ---- epilogue ----
+    CONV_STAMP(2);
     const int64_t row_base = ((int64_t)frame * d.Hout + y0) * d.Wout + x0;
     gemm_epilogue<WM, WN, TI, TJ, LDS_MAIN>(
         d, acc, smem, ch0,
@@ -206,9 +222,26 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc
             return x0 + tx < d.Wout ? row_base + (int64_t)(px >> tw_log2) * d.Wout + tx : -1;
         },
         (int64_t)frame, narrow);
+    CONV_STAMP(3);
+#ifdef CONV_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < kProbeWgs) {
+        unsigned hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_conv_probe[blockIdx.x * kProbeStamps + 4] = ((unsigned long long)xcc << 32) | hw_id;
+        g_conv_probe[blockIdx.x * kProbeStamps + 5] = (unsigned long long)ch0;
+    }
+#endif
 }
 
 }  // namespace
+
+#ifdef CONV_PROBE
+extern "C" int ccedit_conv_probe_read(unsigned long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_conv_probe), sizeof(unsigned long long) * (size_t)n, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 bool cc_conv_halo_applicable(const CcGemmDesc& d) {
     if (!(d.mode == CCEDIT_GEMM_CONV2D && d.taps == 9 && d.ksize == 3 && d.stride == 1 && d.pad == 1 && !d.upsample &&

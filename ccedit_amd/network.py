@@ -1031,14 +1031,14 @@ class ControlNet2D(UNetModel):
                 h = sconv3(h, block[0].pw, geo.half() if shared else geo, res1=guided.view(-1, guided.shape[-1]))     # h = conv(x); h += guided_hint
             else:
                 h = block.run(h, emb_silu, geo, ctx2d, ctx_len, shared=shared and i == 1)
-            if TRACE is not None:
-                _trace(f"controlnet.input_blocks.{i}", h)
+            if TRACE is not None:          # (controlnet_img — the no_add_x variant — traces under its own module path)
+                _trace(f"{'controlnet_img' if self.no_add_x else 'controlnet'}.input_blocks.{i}", h)
                 if i == 0 and not self.no_add_x:
                     _trace("controlnet.guided_hint", guided)
             zo = ops.conv2d(h, zc[0].pw)
             outs.append(twin(zo) if (shared and i == 0) else zo)
         h = self.middle_block.run(h, emb_silu, geo, ctx2d, ctx_len)
-        _trace("controlnet.middle_block", h)
+        _trace(f"{'controlnet_img' if self.no_add_x else 'controlnet'}.middle_block", h)
         outs.append(ops.conv2d(h, self.middle_block_out[0].pw))
         return outs
 

@@ -33,10 +33,11 @@ class LaunchProfile:
         if kernel is None:
             k = hip.lib().ccedit_last_kernel()           # the kernel template the entry point just dispatched to
             kernel = k.decode() if k else "?"
-        self.records.setdefault(family, []).append((e0, e1, flops, nbytes, shape, kernel))
         # FLOPs the matrix pipe really retires for this launch where that differs from the algorithmic count (the parity form of
         # upsample + conv executes 4/9 of the reference convolution's multiply-adds)
-        self.executed += flops if exec_flops is None else exec_flops
+        ex = flops if exec_flops is None else exec_flops
+        self.records.setdefault(family, []).append((e0, e1, flops, nbytes, shape, kernel, ex))
+        self.executed += ex
 
     def by_kernel(self, families=("tap_gemm", "attention", "memory")):
         """[{kernel, launches, ms, tflops, gbytes_per_s}] over the given families, sorted by time (gbytes_per_s: algorithmic bytes
@@ -44,18 +45,18 @@ class LaunchProfile:
         torch.cuda.synchronize()
         acc = {}
         for fam in families:
-            for a, b, fl, nb, _, k in self.records.get(fam, []):
-                n, ms, f, by, _ = acc.get(k, (0, 0.0, 0.0, 0.0, fam))
-                acc[k] = (n + 1, ms + a.elapsed_time(b), f + fl, by + nb, fam)
+            for a, b, fl, nb, _, k, ex in self.records.get(fam, []):
+                n, ms, f, by, _, fe = acc.get(k, (0, 0.0, 0.0, 0.0, fam, 0.0))
+                acc[k] = (n + 1, ms + a.elapsed_time(b), f + fl, by + nb, fam, fe + ex)
         return sorted(({"kernel": k, "family": fam, "launches": n, "ms": ms, "tflops": f / (ms * 1e-3) / 1e12,
-                        "gbytes_per_s": by / (ms * 1e-3) / 1e9, "bytes": by} for k, (n, ms, f, by, fam) in acc.items()),
-                      key=lambda r: -r["ms"])
+                        "exec_tflops": fe / (ms * 1e-3) / 1e12, "gbytes_per_s": by / (ms * 1e-3) / 1e9, "bytes": by}
+                       for k, (n, ms, f, by, fam, fe) in acc.items()), key=lambda r: -r["ms"])
 
     def by_shape(self, family):
         """{shape: (launches, total_ms, tflops)} sorted by time."""
         torch.cuda.synchronize()
         acc = {}
-        for a, b, fl, _, shape, _k in self.records.get(family, []):
+        for a, b, fl, _, shape, _k, _ex in self.records.get(family, []):
             n, ms, f = acc.get(shape, (0, 0.0, 0.0))
             acc[shape] = (n + 1, ms + a.elapsed_time(b), f + fl)
         return sorted(((k, n, ms, f / (ms * 1e-3) / 1e12) for k, (n, ms, f) in acc.items()), key=lambda r: -r[2])

@@ -397,10 +397,14 @@ def controlnet2d_img_forward(sd: SD, p: str, cfg: NetConfig, hint4, t, trace=Non
         else:
             h = _conv2d(sd, bp + ".0.op", h, stride=2, padding=1)
         outs.append(_conv2d(sd, f"{p}.zero_convs.{i}.0", h) * cfg.control_scales)
+        if trace is not None:
+            trace[bp] = h
     mp = p + ".middle_block"
     h = resblock2d(sd, mp + ".0", h, emb)
     h = spatial_transformer2d_selfonly(sd, mp + ".1", h, heads)
     h = resblock2d(sd, mp + ".2", h, emb)
+    if trace is not None:
+        trace[mp] = h
     outs.append(_conv2d(sd, p + ".middle_block_out.0", h) * cfg.control_scales)
     return outs
 

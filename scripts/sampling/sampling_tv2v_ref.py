@@ -4,7 +4,8 @@ scripts/sampling/sampling_tv2v_ref.py: everything of sampling_tv2v.py plus the e
 ((1,3,H,W) in [-1,1]; VAE-encoded to `cond_feat` by the conditioner's VAEEmbedder and, on the network side, fed to
 controlnet_img and the anchor cross-frame attention) and `--prior_type {video, ref, video_ref}` for the noise prior
 (sampling_tv2v_ref.py:415-437).  Config: configs/inference_ccedit/keyframe_ref_cp_no2ndca_add_cfca_depthzoe.yaml.
-`--cond_path` additionally holds `cond_img`.
+`--cond_path` additionally holds `cond_img`.  Job mode (lists, `--videos_directory`, `--json_path` + `--videos_root` + `--reference_root` with
+one `output-<Target Prompt>.png` per job, `--batch_size`, `--auto_ref_editing`, which raises as in the reference): see sampling_tv2v.py.
 """
 from __future__ import annotations
 
@@ -19,7 +20,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from scripts.sampling.sampling_tv2v import add_common_args, build_model, conditioning_tensors, sample_one, save_result, text_inputs  # noqa: E402
+from scripts.sampling.sampling_tv2v import (add_common_args, build_model, conditioning_tensors, job_mode, run_jobs, sample_one,  # noqa: E402
+                                            save_result, text_inputs)
 
 
 def main():
@@ -27,9 +29,16 @@ def main():
     add_common_args(p)
     p.add_argument("--prior_type", type=str, default="ref", choices=["video", "ref", "video_ref"])
     p.add_argument("--reference_path", type=str, default="", help="edited centre frame (image file) -> cond_img")
+    p.add_argument("--reference_root", type=str, default="", help="path to the root of reference videos")
+    p.add_argument("--auto_ref_editing", action="store_true", help="auto center editing")
     args = p.parse_args()
     torch.manual_seed(args.seed)
     torch.set_grad_enabled(False)
+    if job_mode(args):        # the reference script's list / directory / BalanceCC-json surface (sampling_tv2v_ref.py:124-194, 340-400)
+        return run_jobs(args, with_ref=True)
+    if args.auto_ref_editing:
+        print("Conduct auto ref editing, args.reference_path is ignored.")
+        raise NotImplementedError          # as the reference (sampling_tv2v_ref.py:366-369)
     from scripts.sampling.util import ResumeLog
     model, dev = build_model(args)
     T, h, w = args.num_keyframes, args.H // 8, args.W // 8

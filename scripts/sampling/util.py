@@ -101,6 +101,13 @@ def sdedit_start(model, sampler, keyframes: torch.Tensor) -> torch.Tensor:
     return ops.axpby(z.contiguous(), noise.contiguous(), inv, s0 * inv)
 
 
+def chunk(it, size):
+    """util.py:355-357."""
+    from itertools import islice
+    it = iter(it)
+    return iter(lambda: tuple(islice(it, size)), ())
+
+
 def load_conditioning(path: str) -> Dict[str, torch.Tensor]:
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
@@ -340,9 +347,19 @@ def perform_save_locally_video(save_path: str, samples: torch.Tensor, fps: int, 
     the T frames side by side).  savetype='mp4' needs a codec library and raises."""
     from PIL import Image
     assert samples.dim() == 5, "Expected samples to have shape (B, C, T, H, W)"
-    assert savetype in ["gif", "mp4"]
+    assert savetype in ["gif", "mp4", "npy"]
     if savetype == "mp4":
         raise NotImplementedError("mp4 encoding needs imageio-ffmpeg / cv2, not installed here: use savetype='gif'")
+    if savetype == "npy":          # (not in the reference) the frames themselves: <save_path>/npy/frames-XXXX.npy, (T, H, W, C) float32 in [0, 1]
+        os.makedirs(os.path.join(save_path, "npy"), exist_ok=True)
+        count = len(os.listdir(os.path.join(save_path, "npy")))
+        savepaths = []
+        for sample in samples:
+            savepath = os.path.join(save_path, "npy", f"frames-{count:04}.npy")
+            np.save(savepath, sample.detach().float().cpu().permute(1, 2, 3, 0).numpy())
+            count += 1
+            savepaths.append(savepath)
+        return savepaths if return_savepaths else None
     os.makedirs(os.path.join(save_path, savetype), exist_ok=True)
     count = len(os.listdir(os.path.join(save_path, savetype)))
     if save_grid:

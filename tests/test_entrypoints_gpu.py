@@ -135,3 +135,84 @@ def test_sampling_tv2v_values_vs_oracle(tmp_path, crossframe):
     rel = float(((frames.double() - want.double()) ** 2).mean().sqrt() / (want.double() ** 2).mean().sqrt())
     print(f"entry point vs oracle, 3 DPMPP2SAncestral steps + decode at reduced width: frames rel rms {rel:.4f}")
     assert rel < 1e-1        # five bf16 evaluations of the width-64 model (one evaluation is held to 5e-2) + bf16 decode
+
+
+@pytest.mark.timeout(1200)
+def test_sampling_tv2v_job_mode_lists_batches_and_balancecc_layout(tmp_path):
+    """Round 6: the reference script's own surface.  (a) --prompt_listpath / --video_listpath with three
+    (prompt, video) pairs, --batch_size 2: chunks of 2 + 1 clips, each one CFG-doubled batch; original / result / control_hint under
+    <save_path>/default/, log_info.json with the processed videos; a second invocation skips them.  A clip sampled inside a batch of
+    two equals the same clip sampled alone (clips do not interact).  (b) the BalanceCC json layout: one directory per
+    (video, target prompt).  (c) the TVI2V script with --reference_path on a list."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from PIL import Image
+    cfg = _write_config(str(tmp_path), False)
+    rs = np.random.RandomState(1)
+    vids = []
+    for name in ("a", "b", "c"):
+        d = tmp_path / "clips" / name
+        d.mkdir(parents=True)
+        for i in range(9):
+            Image.fromarray(rs.randint(0, 256, (48, 80, 3)).astype(np.uint8)).save(str(d / f"{i:03d}.png"))
+        vids.append(str(d))
+    (tmp_path / "prompts.txt").write_text("a red fox\na blue bird\na green frog\n")
+    (tmp_path / "videos.txt").write_text("\n".join(vids) + "\n")
+    base = ["--config_path", cfg, "--synthetic", "--H", "64", "--W", "128", "--num_keyframes", "3", "--sample_steps", "2",
+            "--sampler_name", "DPMPP2SAncestralSampler", "--original_fps", "9", "--target_fps", "3", "--noise_seed", "5"]
+
+    def run(script, out, *extra):
+        cmd = [sys.executable, os.path.join(ROOT, "scripts", "sampling", script), *base, "--save_path", out, *extra]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return r.stdout
+    out = str(tmp_path / "lists")
+    so = run("sampling_tv2v.py", out, "--prompt_listpath", str(tmp_path / "prompts.txt"), "--video_listpath", str(tmp_path / "videos.txt"),
+             "--batch_size", "2")
+    assert "Number of prompts: 3" in so and "chunk 0: 2 clip(s)" in so and "chunk 1: 1 clip(s)" in so
+    log = json.load(open(os.path.join(out, "default", "log_info.json")))
+    assert log["video_paths"] == vids and len(log["keyframes_paths"]) == 3 and log["basemodel_path"] == "default"
+    res = [np.load(os.path.join(out, "default", "result", "npy", f"frames-{i:04d}.npy")) for i in range(3)]
+    for kind in ("original", "control_hint"):
+        assert len(os.listdir(os.path.join(out, "default", kind, "npy"))) == 3
+    for fr in res:
+        assert fr.shape == (3, 64, 128, 3) and np.isfinite(fr).all() and 0.0 <= fr.min() and fr.max() <= 1.0 and fr.std() > 1e-3
+    assert not np.allclose(res[0], res[1])
+    hint = np.load(os.path.join(out, "default", "control_hint", "npy", "frames-0000.npy"))
+    assert np.allclose(hint[..., 0], hint[..., 1]) and hint.min() == 0.0 and hint.max() == 1.0      # the MiDaS recipe's per-clip min-max, 3 equal channels
+    so2 = run("sampling_tv2v.py", out, "--prompt_listpath", str(tmp_path / "prompts.txt"), "--video_listpath", str(tmp_path / "videos.txt"),
+              "--batch_size", "2")
+    assert "has been processed, skip it." in so2 and "chunk 1" not in so2
+    # the third clip alone: same start latent? (the job stream draws latents in order, so the single run starts from another one) —
+    # what must hold is independence INSIDE a batch: clip `a` in a batch with `b` == clip `a` in a batch with `c`
+    (tmp_path / "p2.txt").write_text("a red fox\na green frog\n")
+    (tmp_path / "v2.txt").write_text(vids[0] + "\n" + vids[2] + "\n")
+    out2 = str(tmp_path / "lists2")
+    run("sampling_tv2v.py", out2, "--prompt_listpath", str(tmp_path / "p2.txt"), "--video_listpath", str(tmp_path / "v2.txt"), "--batch_size", "2")
+    a2 = np.load(os.path.join(out2, "default", "result", "npy", "frames-0000.npy"))
+    d = float(np.sqrt(((a2 - res[0]) ** 2).mean()) / np.sqrt((res[0] ** 2).mean()))
+    print(f"clip `a` beside `b` vs beside `c`: rel rms {d:.4f}")
+    assert d < 2e-2          # (the per-step noise of --noise_seed is drawn for the whole batch: row 0 is the same in both runs)
+    # (b) BalanceCC layout
+    items = [{"Video Type": "Animal", "Video Name": "a", "Editing": [{"Target Prompt": "a tiger"}, {"Target Prompt": "a lion"}]}]
+    os.makedirs(str(tmp_path / "vroot" / "Animal"))
+    os.symlink(vids[0], str(tmp_path / "vroot" / "Animal" / "a"))
+    (tmp_path / "bcc.json").write_text(json.dumps(items))
+    out3 = str(tmp_path / "bcc")
+    run("sampling_tv2v.py", out3, "--json_path", str(tmp_path / "bcc.json"), "--videos_root", str(tmp_path / "vroot"), "--batch_size", "1",
+        "--disable_check_repeat")
+    for prompt in ("a tiger", "a lion"):
+        d3 = os.path.join(out3, "Animal", "a", prompt)
+        assert os.path.exists(os.path.join(d3, "result", "npy", "frames-0000.npy")) and os.path.exists(os.path.join(d3, "log_info.json"))
+    # (c) the reference-frame script on a list, one --reference_path for all jobs
+    cfg_ref = _write_config(str(tmp_path), True)
+    Image.fromarray(rs.randint(0, 256, (64, 128, 3)).astype(np.uint8)).save(str(tmp_path / "ref.png"))
+    out4 = str(tmp_path / "ref_lists")
+    base[1] = cfg_ref
+    run("sampling_tv2v_ref.py", out4, "--prompt_listpath", str(tmp_path / "p2.txt"), "--video_listpath", str(tmp_path / "v2.txt"), "--batch_size", "2",
+        "--reference_path", str(tmp_path / "ref.png"))
+    assert len(os.listdir(os.path.join(out4, "default", "result", "npy"))) == 2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "sampling", "sampling_tv2v_ref.py"), *base, "--save_path", out4, "--prompt", "p",
+                        "--video_path", vids[0], "--reference_path", str(tmp_path / "ref.png"), "--auto_ref_editing", "--disable_check_repeat"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode != 0 and "NotImplementedError" in r.stderr and "Conduct auto ref editing" in r.stdout
