@@ -264,7 +264,7 @@ def main():
     ap.add_argument("--shard-frames", action="store_true",
                     help="N>1: BASELINE.json config 4 — ONE clip, its T=17 keyframes sharded over the ranks; default N>1 mode "
                          "is config 5 (one clip per GPU, no collective)")
-    ap.add_argument("--shard-mode", choices=["pair", "a2a", "halo", "rows"], default="rows",
+    ap.add_argument("--shard-mode", choices=["pair", "a2a", "halo", "rows", "rows-pair"], default="rows",
                     help="pair: all-to-all layout transposition around the temporal ops, the two CFG halves on mirrored "
                          "partitions, two communicators and two streams; a2a: the same transposition, one partition; halo: "
                          "round-1 halo p2p + statistics all-reduce + K/V all-gather; rows: every rank holds all keyframes of 1/N of the "
@@ -599,6 +599,9 @@ def install_shards(wrapper, args):
     if args.shard_mode == "rows":               # the balanced decomposition (ceiling 1.0): rows of every frame, not keyframes
         shards = (RowShard(attn=args.attn),)
         wrapper.row_shard = shards[0]
+    elif args.shard_mode == "rows-pair":        # ... with the CFG halves on two streams, a communicator each (exchanges of one half under
+        shards = RowShard.cfg_pair(attn=args.attn)      # the other half's kernels); eager: two-stream capture of RCCL crashes the runtime
+        wrapper.row_shard = shards
     elif args.shard_mode == "pair":             # a communicator per CFG half: their exchanges run independently
         shards = FrameShard.cfg_pair(T)
         wrapper.frame_shard = shards
@@ -635,14 +638,14 @@ def shard_counters(shards, step, world, dist, wrapper=None):
 
 def c4_object(args, world, sharded_ms, single_ms, allr):
     from ccedit_amd.parallel import cfg_pair_efficiency, row_sharding_efficiency, sharding_efficiency
-    ceiling = (row_sharding_efficiency(H, world) if args.shard_mode == "rows" else
+    ceiling = (row_sharding_efficiency(H, world) if args.shard_mode.startswith("rows") else
                cfg_pair_efficiency(T, world) if args.shard_mode == "pair" else sharding_efficiency(T, world))
     return dict(
         config="BASELINE config 4: ONE 17x512x768 clip sharded over the ranks", mode=args.shard_mode,
-        attention=(args.attn if args.shard_mode == "rows" else None), scaling="strong",
+        attention=(args.attn if args.shard_mode.startswith("rows") else None), scaling="strong",
         ms_per_step=round(sharded_ms, 3), steps_per_s=round(1e3 / sharded_ms, 4),
         frame_instances_per_rank=[int(a[3]) * (1 if args.shard_mode == "pair" else 2) for a in allr],
-        latent_rows_per_rank=(H // world if args.shard_mode == "rows" else H),
+        latent_rows_per_rank=(H // world if args.shard_mode.startswith("rows") else H),
         measured_on="NOT measured over xGMI unless n_gpus real devices ran it",
         ceiling=round(ceiling, 4), single_gpu_ms_per_step=round(single_ms, 3),
         efficiency_per_gpu=round(single_ms / (world * sharded_ms), 4),

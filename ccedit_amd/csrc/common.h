@@ -33,10 +33,15 @@ __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
 // made the GroupNorm + SiLU passes VALU-bound (temporal GroupNorm at 34 x 64 x 96 x 320: 70 us with SiLU, 56 us without, 45 us for a
 // copy of the same bytes).  The result is rounded to bf16 (8 bits) right after.
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-// Exact-form GELU, 0.5 v (1 + erf(v / sqrt 2)) (GEGLU, attention.py:115-126).  erf by Abramowitz & Stegun 7.1.28,
-// erf(x) = 1 - (1 + a1 x + ... + a6 x^6)^-16 for x >= 0, |error| <= 3e-7 — two orders below the bf16 rounding of the
-// result — in 6 FMAs, 4 squarings and one v_rcp_f32; libdevice's erff costs about twice as much in the GEGLU
-// epilogue (measured: 13-16 % of the whole GEGLU GEMM at the 64x96 and 32x48 levels).
+// GELU, 0.5 v (1 + erf(v / sqrt 2)) = v Phi(v) (GEGLU, attention.py:115-126: F.gelu, the exact-erf form), as v * sigmoid(u(v)) with
+// u = v (a + b v^2 + c v^4) fitted to Phi (minimax over |v| <= 9; the argument is clamped there — beyond, Phi is 0 or 1 to 1e-11 and
+// the quartic would turn around at |v| = 11).  |error| <= 2.6e-5 ABSOLUTE over all v (tools/exp/gelu_fit.py: fp32 evaluation against
+// fp64 erf) — 300 times below the bf16 rounding of the result at |v| ~ 3, where the maximum sits, and the result is rounded to bf16
+// right after.  Six plain VALU instructions + v_exp_f32 + v_rcp_f32; rounds 1-5 used Abramowitz & Stegun 7.1.28
+// (1 - (1 + a1 x + ... + a6 x^6)^-16: 3e-7, sixteen VALU instructions) — the GELU is the VALU share of ff320 and of the GEGLU
+// epilogues (13-16 % of a GEGLU GEMM at the 64x96 and 32x48 levels with the cheaper of the two before), libdevice's erff twice that.
+// The coefficients carry -log2(e): v_exp_f32 is 2^x.
+#ifdef CCEDIT_GELU_AS71_28          // probe builds only (tools/exp/build_gelu_variant.sh): the formula of rounds 1-5, for the same-box A/B
 __device__ __forceinline__ float gelu_erf_f(float v) {
     const float x = fabsf(v) * 0.70710678118654752440f;
     float p = fmaf(x, 0.0000430638f, 0.0002765672f);
@@ -52,6 +57,16 @@ __device__ __forceinline__ float gelu_erf_f(float v) {
     const float e = 1.0f - __builtin_amdgcn_rcpf(p);          // erf(|v| / sqrt 2)
     return 0.5f * v + 0.5f * fabsf(v) * e;                     // 0.5 v (1 + sign(v) e)
 }
+#else
+__device__ __forceinline__ float gelu_erf_f(float v) {
+    const float vc = __builtin_amdgcn_fmed3f(v, -9.0f, 9.0f);
+    const float t = vc * vc;
+    float p = fmaf(t, 0.00101426306f, -0.106775724f);       // -log2(e) * (c, b, a) = -log2(e) * (-7.03033577e-4, 7.40112921e-2, 1.59501577)
+    p = fmaf(t, p, -2.30112134f);
+    const float e = __builtin_amdgcn_exp2f(p * vc);          // exp(-u)
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+#endif
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -64,7 +79,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // pushes it).  Every switch selects between kernels that compute the same fp32 sums in a different order — A/B and test arms
 // ("specialised kernels reproduce the generic ones", tests/test_fullsize_gpu.py), never a change of arithmetic.
 struct CcPolicy {
-    int conv_halo = 1;      // 3x3 stride-1 convs on the LDS-halo kernel (0: tap-gather)
+    int conv_halo = 1;      // 3x3 stride-1 convs on the LDS-halo kernel with the four-slot weight ring (2: the two-slot kernel of rounds 2-5; 0: tap-gather)
     int g8 = 1;             // persistent eight-phase GEMM for long Linears (0: the tap_gemm block shapes)
     int g8_conv = 1;        // ... its tap-gather mode for 3x3 convs onto >= 1024 channels
     int g8_temporal = 1;    // ... and for Conv1d k3 over T at >= 640 channels

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -235,6 +236,226 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(const CcGemmDesc
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same tile with the WEIGHT operand in a four-slot ring of K = 32 half tiles and counted waits — the default (policy
+// conv_halo = 1); conv_halo = 2 keeps the two-slot kernel above as the A/B arm (bit-identical results: same k-step order).
+// Measured, same process, cold operands (tools/exp/conv_ring_ab.py): 34 x 64 x 96 320 -> 320 424.6 -> 412.4 us, 640 -> 320 787.9 -> 758.9,
+// 34 x 32 x 48 640 -> 640 377.2 -> 366.0, 960 -> 640 547.9 -> 523.9, 1920 -> 640 1033.9 -> 1024.1: -1 ... -4.4 %, 14.81 -> 14.39 ms over the
+// 29 launches of a step.
+//
+// What the per-workgroup time stamps of the kernel above say (tools/exp/conv_probe.py, 34 x 64 x 96, 320 -> 320): a full 128-channel
+// tile spends 40.1 us in its K loop = 0.89 us per k-tile, a NARROW tile — half the MFMAs, half the weight bytes — 35.5 us = 0.79 us:
+// 0.69 us of a k-tile do not depend on the matrix work at all.  That is the round trip of the weight tile: it is requested at the top
+// of tap t and `vmcnt(0)` + barrier at the bottom of the same tap wait for it (prefetch distance ONE: what the two workgroups of a CU
+// can hide is one tap of the partner's MFMAs, 0.24 us, against 0.6-0.8 us of L2 -> LDS latency under load).  Here the weight tile
+// of a tap is two half tiles of K = 32 (128 rows x 64 B = 8 KB), four slots = the same 32 KB, and half tile s + 3 is requested at
+// the top of phase s: three phases (1.5 taps of this workgroup, 3 of the CU) of latency cover; the wait at the bottom of a phase is
+// COUNTED — it retires half tile s + 1 and leaves s + 2, s + 3 (and, for the three phases after a chunk boundary, the next chunk's
+// halo rectangle, which comes from HBM) in flight.  Everything else is the kernel above: tile geometry, halo image and its
+// swizzle, narrow last channel tile, block order, epilogue.
+//   W half-tile rows are 64 bytes: granule g of row r sits at slot g ^ ((r >> 2) & 3) — the 16 lanes of a ds_read_b128 group hold
+//   rows {0-3, 12-15, 20-27} (+ k): every residue r % 4 four times with four different (r >> 2) & 3, i.e. 16 distinct 16-byte bank
+//   groups (MI355X_MICROARCH.md, LDS); the DMA writes a wave's 1 KB = rows 16 w .. 16 w + 15 lane-linearly.
+constexpr int kHaloBytes4 = 192 * 128;         // whole 32-row DMA issues: every wave issues exactly kHaloIssues loads (exact counted waits)
+
+template <int WM, int WN, int TI, int TJ>
+__global__ __launch_bounds__(WM* WN * 64) void conv_halo4_kernel(const CcGemmDesc d, int tw_log2_flags) {
+    const int tw_log2 = tw_log2_flags & 0xFF;
+    constexpr int NT = WM * WN * 64;
+    constexpr int BMC = WM * TI * 32, BNP = WN * TJ * 32;
+    static_assert(NT == 256 && BNP == 128 && BMC == 128 && TI == 2, "tile geometry");
+    constexpr int NS = 4;                          // weight ring slots
+    constexpr int W_SUB = BMC * 64;                // 8 KB: 128 rows x 32 k
+    constexpr int LDS_MAIN = NS * W_SUB + 2 * kHaloBytes4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sW = smem;                         // [NS][W_SUB]
+    char* const sH = smem + NS * W_SUB;            // [2][kHaloBytes4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int TW = 1 << tw_log2, TH = BNP >> tw_log2, HW_ = TW + 2;
+    const int tiles_x = (d.Wout + TW - 1) >> tw_log2, tiles_y = d.Hout / TH;
+    const int tpf = tiles_x * tiles_y;
+
+    const int ct_n = (d.N + BMC - 1) / BMC;
+    const int64_t pt_n = (int64_t)(d.M / (d.Hout * d.Wout)) * tpf;
+    const int64_t pt_per_xcd = (pt_n + 7) / 8;
+    const int64_t bid = blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const int64_t local = bid >> 3;
+    const int Q = d.cgroup > 0 ? d.cgroup : ct_n;
+    const int64_t gsz = pt_per_xcd * Q;
+    const int cg = (int)(local / gsz);
+    const int64_t rr = local - cg * gsz;
+    const int qn = min(Q, ct_n - cg * Q);
+    const int64_t pl = rr / qn;
+    const int64_t pt = xcd * pt_per_xcd + pl;
+    if (pt >= pt_n) return;
+    const int ch0 = (cg * Q + (int)(rr - pl * qn)) * BMC;
+    const int frame = (int)(pt / tpf);
+    const int tr = (int)(pt - (int64_t)frame * tpf);
+    const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) << tw_log2;
+
+    const bf16* __restrict__ Ap = (const bf16*)d.A;
+    const bf16* __restrict__ Wp = (const bf16*)d.W;
+    const bf16* zp = (const bf16*)g_zero_page_h;
+    const int nc = d.Cin >> 6, nsub = nc * 18;
+    const bool narrow = ((tw_log2_flags >> 8) & 1) && (d.N - ch0 <= WM * 32);
+
+    // ---- staging coordinates ----
+    const int f_hy = (tw_log2 == 3) ? 1 : 0;
+    const int p = tid & 7, rsub = tid >> 3;        // halo: 8 granules per 128-byte row
+    int64_t hoff[kHaloIssues];                     // halo issue i stages rows i * 32 + rsub: element offset without the chunk, or -1 (zero page)
+#pragma unroll
+    for (int i = 0; i < kHaloIssues; ++i) {
+        const int hrow = i * 32 + rsub;
+        const int hy = hrow / HW_, hx = hrow - hy * HW_;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const bool v = hrow < kHaloRows && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+        const int gsrc = p ^ (((hx >> 1) + ((hy & 1) << 2) * f_hy) & 7);
+        hoff[i] = v ? (((int64_t)frame * d.Hin + iy) * d.Win + ix) * d.lda + gsrc * 8 : -1;      // rows 180 .. 191: zero page (never read)
+    }
+    const int p4 = tid & 3, r4 = tid >> 2;         // weights: 4 granules per 64-byte row, rows r4 and r4 + 64
+    const int gsrc_w = p4 ^ ((r4 >> 2) & 3);
+    const bf16* const wsrc = Wp + (size_t)(ch0 + r4) * d.Kpad + gsrc_w * 8;
+    const size_t wsrc64 = (size_t)64 * d.Kpad;
+
+    auto stageH = [&](int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < kHaloIssues; ++i) {
+            const bf16* src = hoff[i] >= 0 ? Ap + hoff[i] + c * 64 : zp;
+            glds16(src, sH + buf * kHaloBytes4 + i * (32 * 128) + wave * 1024);
+        }
+    };
+
+    // ---- fragment coordinates ----
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int sw_w = (l31 >> 2) & 3;
+    int hb[TJ], pty[TJ], ptx[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int px = (wn * TJ + j) * 32 + l31;
+        pty[j] = px >> tw_log2;
+        ptx[j] = px & (TW - 1);
+        hb[j] = pty[j] * HW_ + ptx[j];
+    }
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    CONV_STAMP(0);
+    // The K loop, compiled once per tile kind (NARROW: one MFMA row tile per wave and one weight issue per half tile — no selects
+    // or branches around the MFMAs).
+    auto kloop = [&](auto NARROWC) {
+        constexpr bool NARROW = decltype(NARROWC)::value;
+        constexpr int WI = NARROW ? 1 : 2;         // DMA instructions per thread and weight half tile
+        constexpr int NTI = NARROW ? 1 : TI;
+        const char* const fa = sW + ((NARROW ? wm * 32 : wm * TI * 32) + l31) * 64;
+        auto stageW = [&](int sidx) {
+            const bf16* src = wsrc + sidx * 32;
+            char* dst = sW + (sidx & (NS - 1)) * W_SUB + wave * 1024;
+#pragma unroll
+            for (int i = 0; i < WI; ++i) glds16(src + i * wsrc64, dst + i * 4096);
+        };
+        auto wait_for = [&](int w_tiles, bool halo) {          // at most (w_tiles weight half tiles [+ the halo rectangle]) still in flight
+            if (halo) {
+                if (w_tiles >= 2) wait_vmcnt_h<2 * WI + kHaloIssues>();
+                else if (w_tiles == 1) wait_vmcnt_h<WI + kHaloIssues>();
+                else wait_vmcnt_h<kHaloIssues>();
+            } else {
+                if (w_tiles >= 2) wait_vmcnt_h<2 * WI>();
+                else if (w_tiles == 1) wait_vmcnt_h<WI>();
+                else wait_vmcnt_h<0>();
+            }
+        };
+        // one phase = one weight half tile (two k-steps of 16) against the halo rows of tap (dy, dx)
+        auto phase = [&](int sidx, int hbuf, int half, const int (&hr)[TJ], const int (&hsw)[TJ]) {
+            const char* pa = fa + (sidx & (NS - 1)) * W_SUB;
+            const char* ph = sH + hbuf * kHaloBytes4;
+            bf16x8 af[2][NTI], bfr[2][TJ];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+                for (int i = 0; i < NTI; ++i) af[k2][i] = *(const bf16x8*)(pa + i * 32 * 64 + (((k2 * 2 + hi) ^ sw_w) << 4));
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) bfr[k2][j] = *(const bf16x8*)(ph + hr[j] * 128 + ((((half * 2 + k2) * 2 + hi) ^ hsw[j]) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int i = 0; i < NTI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k2][i], bfr[k2][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        // prologue: half tiles 0, 1, 2 and the first halo rectangle; 0 and the halo must have landed
+        stageW(0);
+        stageH(0, 0);
+        stageW(1);
+        stageW(2);
+        wait_vmcnt_h<2 * WI>();
+        __syncthreads();
+        CONV_STAMP(1);
+        int sidx = 0;
+        for (int c = 0; c < nc; ++c) {
+            const bool more_chunks = c + 1 < nc;
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3, dx = t - dy * 3;
+                const int shift = dy * HW_ + dx;
+                int hr[TJ], hsw[TJ];
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    hr[j] = hb[j] + shift;
+                    hsw[j] = (((ptx[j] + dx) >> 1) + (((pty[j] + dy) & 1) << 2) * f_hy) & 7;
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half, ++sidx) {
+                    if (sidx + 3 < nsub) stageW(sidx + 3);
+                    const bool first = (t == 0 && half == 0);
+                    if (first && more_chunks) stageH(c + 1, (c + 1) & 1);       // AFTER the weight request: the youngest loads of the queue
+                    phase(sidx, c & 1, half, hr, hsw);
+                    // half tile sidx + 1 must have landed; sidx + 2, sidx + 3 may stay in flight, and so may the next chunk's halo while
+                    // it is younger than the half tile waited for (the three phases after it was requested)
+                    const int left = nsub - 2 - sidx;                               // half tiles beyond sidx + 1
+                    wait_for(left < 0 ? 0 : left, more_chunks && t == 0 || (more_chunks && t == 1 && half == 0));
+                    __syncthreads();
+                }
+            }
+        }
+    };
+    if (narrow) kloop(std::true_type{});
+    else kloop(std::false_type{});
+
+    // ---- epilogue ----
+    CONV_STAMP(2);
+    const int64_t row_base = ((int64_t)frame * d.Hout + y0) * d.Wout + x0;
+    gemm_epilogue<WM, WN, TI, TJ, LDS_MAIN>(
+        d, acc, smem, ch0,
+        [&](int px) -> int64_t {
+            const int tx = px & (TW - 1);
+            return x0 + tx < d.Wout ? row_base + (int64_t)(px >> tw_log2) * d.Wout + tx : -1;
+        },
+        (int64_t)frame, narrow);
+    CONV_STAMP(3);
+#ifdef CONV_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < kProbeWgs) {
+        g_conv_probe[blockIdx.x * kProbeStamps + 4] = 0;
+        g_conv_probe[blockIdx.x * kProbeStamps + 5] = (unsigned long long)ch0;
+    }
+#endif
+}
+
 }  // namespace
 
 #ifdef CONV_PROBE
@@ -278,6 +499,14 @@ int cc_conv_halo_launch(const CcGemmDesc& d, hipStream_t s) {
         const int q = 3;
         const int ng = (int)((ct_n + q - 1) / q);
         dd.cgroup = (int)((ct_n + ng - 1) / ng);
+    }
+    if (cc_policy().conv_halo != 2) {            // the four-slot weight ring (round 6; policy conv_halo = 2: the two-slot kernel of rounds 2-5, the A/B arm)
+        constexpr int lds4 = epi_lds_total(BMC, BNP, TJ, 4 * BMC * 64 + 2 * kHaloBytes4);
+        static unsigned long long attr_done4 = 0;
+        if (int rc = cc_max_dynamic_lds((const void*)conv_halo4_kernel<WM, WN, TI, TJ>, lds4, &attr_done4, "conv_halo4")) return rc;
+        cc_note_kernel("conv_halo_kernel");
+        hipLaunchKernelGGL((conv_halo4_kernel<WM, WN, TI, TJ>), dim3((unsigned)nblk), dim3(WM * WN * 64), lds4, s, dd, tw_log2 | (1 << 8));
+        return cc_launch_status("conv_halo4_kernel");
     }
     cc_note_kernel("conv_halo_kernel");
     hipLaunchKernelGGL((conv_halo_kernel<WM, WN, TI, TJ>), dim3((unsigned)nblk), dim3(WM * WN * 64), lds, s, dd,

@@ -106,6 +106,40 @@ def sgn(x, norm: "Norm", geo: Geometry, silu: bool):
     return ops.groupnorm_spatial(x, norm.g, norm.b, norm.eps, silu)
 
 
+FUSE_HALO_STATS = policy.on("fuse_halo_stats")      # rows sharded: GroupNorm statistics ride on the following 3x3 conv's halo exchange
+
+
+def sgn_conv3(x, norm: "Norm", pw, geo: Geometry, silu: bool = True, **kw):
+    """conv3x3(SiLU?(GroupNorm(x))) — the in_layers / out_layers pair of every ResBlock (openaimodel.py:441-449, 483-492) and the `out`
+    head.  Unsharded: the two launches as before.  Rows sharded (round 6): ONE exchange carries the raw boundary rows to the
+    neighbours and the statistics partials to everybody (RowShard.halo_stats_exchange); the slab and the two received rows are then
+    normalised locally with the same totals and the conv reads the normalised rows in place — 64 of the 88 statistics all-reduces of a
+    step disappear into halo exchanges that were there anyway."""
+    rs = geo.rows
+    if rs is None or not FUSE_HALO_STATS:
+        return sconv3(sgn(x, norm, geo, silu), pw, geo, **kw)
+    n, h, w, c = x.shape
+    st = ops.gn_stats_of(x, h * w)
+    if st is None:
+        st = ops.groupnorm_spatial_stats(x)
+    if getattr(x, "_gn_global", None) is st:              # (already the frame's: nothing to add — only the halo rows travel)
+        a = ops.groupnorm_spatial(x, norm.g, norm.b, norm.eps, silu)
+        return sconv3(a, pw, geo, **kw)
+    top, bot, total = rs.halo_stats_exchange(x, st)
+    ops.set_gn_stats(x, total.mul_(1.0 / rs.world))       # apply divides by the LOCAL element count: (sum / N) / (count / N)
+    x._gn_global = ops.gn_stats_of(x, h * w)
+    a = ops.groupnorm_spatial(x, norm.g, norm.b, norm.eps, silu)
+    halo = []
+    for row in (top, bot):
+        if row is None:
+            halo.append(None)
+            continue
+        r4 = row.view(n, 1, w, c)
+        ops.set_gn_stats(r4, total * (1.0 / h))            # one row of the slab's h: the same mean / variance through the same kernel
+        halo.append(ops.groupnorm_spatial(r4, norm.g, norm.b, norm.eps, silu).view(n, w, c))
+    return ops.conv2d(a, pw, halo=tuple(halo), **kw)
+
+
 def gathered_kv(kv2d, frames: int, geo: Geometry):
     """K | V rows of `frames` frames, (frames * pixels, 2C): with sharded rows the other ranks' rows of every frame are all-gathered
     (the spatial self-attention's keys are the whole frame; queries stay local)."""
@@ -616,12 +650,10 @@ class ResBlock(nn.Module):
 
     def run(self, x, emb_silu, geo: Geometry):
         n, h, w, _ = x.shape
-        a = sgn(x, self.in_layers[0], geo, True)
         e = emb_silu.of(self)                                                      # (B, Cout) fp32 = emb_layers(emb)
-        hid = sconv3(a, self.in_layers[2].pw, geo, group_bias=e, group_rows=geo.t * h * w, gn=True)
-        a = sgn(hid, self.out_layers[0], geo, True)
+        hid = sgn_conv3(x, self.in_layers[0], self.in_layers[2].pw, geo, group_bias=e, group_rows=geo.t * h * w, gn=True)
         skip = x if isinstance(self.skip_connection, Slot) else ops.conv2d(x, self.skip_connection.pw)
-        return sconv3(a, self.out_layers[3].pw, geo, res1=skip.view(-1, skip.shape[-1]), gn=True)
+        return sgn_conv3(hid, self.out_layers[0], self.out_layers[3].pw, geo, res1=skip.view(-1, skip.shape[-1]), gn=True)
 
 
 class ResBlock3D(nn.Module):
@@ -645,15 +677,13 @@ class ResBlock3D(nn.Module):
 
     def run(self, x, emb_silu, geo: Geometry):
         n, h, w, _ = x.shape
-        a = sgn(x, self.in_layers[0], geo, True)
-        s = sconv3(a, self.in_layers[2].pw, geo)
+        s = sgn_conv3(x, self.in_layers[0], self.in_layers[2].pw, geo)
         co = s.shape[-1]
         e = emb_silu.of(self)
         # stf output (s + conv_t) and the `+ emb_out` of openaimodel.py:762 in one epilogue
         hid = temporal_gn_conv3(s, self.in_layers_temporal[0], self.in_layers_temporal[2].pw, geo, group_bias=e,
                                 group_rows=geo.t * h * w, gn=True)
-        a = sgn(hid, self.out_layers[0], geo, True)
-        s2 = sconv3(a, self.out_layers[3].pw, geo)
+        s2 = sgn_conv3(hid, self.out_layers[0], self.out_layers[3].pw, geo)
         if isinstance(self.skip_connection, Slot):
             skip = x
         else:
@@ -1330,7 +1360,8 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         # row-sharded evaluations are captured too when their exchanges are stream operations (RCCL; the host-staged gloo transport of the
         # CPU / one-GPU tests is not): the launch count per rank is the single-GPU one while every kernel is N times shorter
         if (self.use_graph and not OpenAIWrapperControlLDM3DTV2V._graph_failed and not kwargs and x.is_cuda
-                and self.frame_shard is None and (self.row_shard is None or self.row_shard.can_capture())
+                and self.frame_shard is None
+                and (self.row_shard is None or (not isinstance(self.row_shard, (tuple, list)) and self.row_shard.can_capture()))
                 and ops.PROFILE is None and TRACE is None and not torch.cuda.is_current_stream_capturing()):
             return self._forward_graphed(x, t, c)
         return self._forward_eager(x, t, c, **kwargs)
@@ -1396,13 +1427,19 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
 
     def _forward_eager(self, x: torch.Tensor, t: torch.Tensor, c: Dict[str, torch.Tensor], **kwargs) -> torch.Tensor:
         pair = isinstance(self.frame_shard, (tuple, list)) and not kwargs.get("_half")
+        # RowShard.cfg_pair (round 6): the two CFG halves are independent evaluations — each on its own stream and communicator, so
+        # one half's exchanges (head all-to-alls, halo rows with their statistics) wait under the other half's kernels
+        rpair = isinstance(self.row_shard, (tuple, list)) and not kwargs.get("_half")
+        if rpair and x.shape[0] != 2:
+            raise ValueError("a RowShard.cfg_pair shards the two CFG halves of a batch-2 step")
         if pair and x.shape[0] != 2:
             raise ValueError("a FrameShard.cfg_pair shards the two CFG halves of a batch-2 step")
-        if pair or (_SPLIT_CFG and x.shape[0] == 2 and self.frame_shard is None and ops.PROFILE is None and TRACE is None
-                    and not kwargs.get("_half")):
+        if pair or rpair or (_SPLIT_CFG and x.shape[0] == 2 and self.frame_shard is None and ops.PROFILE is None and TRACE is None
+                             and not kwargs.get("_half")):
             # the two CFG halves are independent: two streams (and, frame-sharded, two communicators with mirrored
             # partitions — one half's exchanges overlap the other half's kernels)
             shards = self.frame_shard if pair else (None, None)
+            rshards = self.row_shard if rpair else (None, None)
             main = torch.cuda.current_stream()
             if OpenAIWrapperControlLDM3DTV2V._half_stream is None:
                 OpenAIWrapperControlLDM3DTV2V._half_stream = torch.cuda.Stream()
@@ -1410,8 +1447,8 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
             hs.wait_stream(main)
             halves = [{k: (v[i:i + 1].contiguous() if torch.is_tensor(v) else v) for k, v in c.items()} for i in range(2)]
             with torch.cuda.stream(hs):
-                e1 = self._forward_eager(x[1:2].contiguous(), t[1:2].contiguous(), halves[1], _half=True, _shard=shards[1])
-            e0 = self._forward_eager(x[0:1].contiguous(), t[0:1].contiguous(), halves[0], _half=True, _shard=shards[0])
+                e1 = self._forward_eager(x[1:2].contiguous(), t[1:2].contiguous(), halves[1], _half=True, _shard=shards[1], _rshard=rshards[1])
+            e0 = self._forward_eager(x[0:1].contiguous(), t[0:1].contiguous(), halves[0], _half=True, _shard=shards[0], _rshard=rshards[0])
             main.wait_stream(hs)
             e1.record_stream(main)
             return torch.cat([e0, e1])
@@ -1438,7 +1475,7 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
                 # a stable tensor object so the hint-stem cache can hit; the entry pins the source (see _guided_hint)
                 self._hint_slices[hk] = (c["control_hint"], hint5.contiguous())
             hint5 = self._hint_slices[hk][1]
-        rs = self.row_shard
+        rs = kwargs.get("_rshard", None) if kwargs.get("_half") else self.row_shard
         cond_feat = c.get("cond_feat", None)
         if rs is not None:             # keep this rank's latent rows of every frame (and the 8x finer hint rows that feed them)
             if sh is not None:
@@ -1472,6 +1509,8 @@ class OpenAIWrapperControlLDM3DTV2V(IdentityWrapper):
         # and with every kernel N times shorter it is the graph, not the overlap, that matters.  Eager RCCL evaluations (graphs off)
         # do use the side stream, the ControlNet's exchanges on a communicator of their own (RowShard.sibling).
         rows_side_ok = rs is None or (rs.can_capture() and not (self.use_graph and not OpenAIWrapperControlLDM3DTV2V._graph_failed))
+        if kwargs.get("_half") and rs is not None:
+            rows_side_ok = False                        # a CFG half of a RowShard pair: the other half is what overlaps, one stream each
         if self.overlap_controlnet and sh is None and rows_side_ok and ops.PROFILE is None and TRACE is None:
             main = torch.cuda.current_stream()
             if OpenAIWrapperControlLDM3DTV2V._side_stream is None:

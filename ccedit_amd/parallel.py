@@ -231,6 +231,22 @@ class RowShard(_ShardComm):
 
     _sibling = None
 
+    @staticmethod
+    def cfg_pair(groups=(None, None), attn: str = "heads"):
+        """Two RowShards over the same ranks, one per CFG half of a step (uc, c): the wrapper evaluates the halves as two B = 1 passes
+        on two HIP streams (network._forward_eager), each with its own communicator, so the exchanges of one half are hidden behind
+        the kernels of the other.  `groups`: one process group per half; the second is created here over the same ranks when it is
+        not given (`dist.new_group` is collective: every rank calls cfg_pair at the same point)."""
+        g0, g1 = groups
+        if g1 is None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(g0) > 1:
+                ranks = list(range(dist.get_world_size())) if g0 is None else dist.get_process_group_ranks(g0)
+                g1 = dist.new_group(ranks)
+        a, b = RowShard(group=g0, attn=attn), RowShard(group=g1, attn=attn)
+        b._log_part = 2
+        return (a, b)
+
     def sibling(self) -> "RowShard":
         """A second RowShard over the SAME ranks on its own communicator, for work issued on a side stream (the ControlNet beside the
         UNet encoder): a communicator serialises its collectives on one internal stream, and two HIP streams that fork and join
@@ -274,6 +290,42 @@ class RowShard(_ShardComm):
         n, h, w, c = x.shape
         up, down = self._neighbours(x[:, 0].contiguous() if below else None, x[:, h - 1].contiguous(), "halo_rows", from_next=below)
         return up, (down if below else None)
+
+    def halo_stats_exchange(self, x: torch.Tensor, stats: torch.Tensor):
+        """GroupNorm(32) [+ SiLU] followed by a 3x3 convolution, ONE exchange instead of two (round 6): the RAW boundary rows of `x`
+        go to the two neighbours and this rank's partial (sum, sum of squares) per (frame, group) to every rank, all as point-to-point
+        messages of one batch (an all-gather of the 17 KB of partials riding with the halo rows: the all-reduce it replaces is pure
+        latency, ~15-20 us, 64 times per step).  Returns (top, bottom, total): the neighbours' raw rows ((n, w, C) or None at the ends
+        of the frame) and the frame's statistics as the SUM of the partials in rank order — the same bits on every rank.  The caller
+        normalises its slab and the two received rows with `total` (network.sgn_conv3)."""
+        dist = self.dist
+        n, h, w, c = x.shape
+        dev = x.device
+        ev = self._tick(x[:, 0], "halo_stats")
+        first, last, st = self._out(x[:, 0].contiguous()), self._out(x[:, h - 1].contiguous()), self._out(stats)
+        parts = [st if r == self.rank else torch.empty_like(st) for r in range(self.world)]
+        ops_, prev_buf, next_buf = [], None, None
+        for r in range(self.world):                       # same op order on every rank pair: (send to r, receive from r) by ascending r
+            if r == self.rank:
+                continue
+            peer = self._global_rank(r)
+            if r == self.rank - 1:
+                prev_buf = torch.empty_like(last)
+                ops_ += [dist.P2POp(dist.isend, first, peer, self.group), dist.P2POp(dist.irecv, prev_buf, peer, self.group)]
+            elif r == self.rank + 1:
+                next_buf = torch.empty_like(first)
+                ops_ += [dist.P2POp(dist.isend, last, peer, self.group), dist.P2POp(dist.irecv, next_buf, peer, self.group)]
+            ops_ += [dist.P2POp(dist.isend, st, peer, self.group), dist.P2POp(dist.irecv, parts[r], peer, self.group)]
+        if ops_:
+            for r_ in dist.batch_isend_irecv(ops_):
+                r_.wait()
+        self._tock(ev)
+        nb = int(self.rank > 0) + int(self.rank < self.world - 1)
+        self.bytes_sent += nb * first.numel() * first.element_size() + (self.world - 1) * st.numel() * st.element_size()
+        total = parts[0].to(dev).clone()
+        for r in range(1, self.world):
+            total += parts[r].to(dev)
+        return (None if prev_buf is None else prev_buf.to(dev)), (None if next_buf is None else next_buf.to(dev)), total
 
     def halo_rows(self, x: torch.Tensor, below: bool = True) -> torch.Tensor:
         """The same exchange as ONE extended tensor (n, 1 + h_local + below, w, C) with zero rows at the ends of the frame — what the

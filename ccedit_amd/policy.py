@@ -33,13 +33,14 @@ TABLE = {
     "subpix": (1, "py", "0: upsample + 3x3 conv through the nine-tap gather instead of four parity convs"),
     "conv1x1_linear": (1, "py", "0: 1 x 1 convs through the convolution mode instead of the Linear dispatch"),
     "attn_q_log2": (1, "py", "0: softmax scale applied inside the attention kernels instead of folded into to_q"),
+    "fuse_halo_stats": (1, "py", "0 (rows sharded): GroupNorm statistics all-reduced on their own instead of riding on the 3x3 conv's halo exchange"),
     "block_tail": (1, "py", "0: to_out / proj_out of the dim-320 transformer tails as their own launches, not inside ff320"),
     # (a precision option, not an A/B arm of equal arithmetic: the reference runs its first-stage model with autocast disabled)
     "vae_fp32": (2, "py", "the KL-VAE's precision.  2 (default): the engine follows the yaml's disable_first_stage_autocast, the flag's meaning in "
                           "the reference (diffusion.py:151-156; the shipped yamls set it => fp32 on v_mfma_f32_32x32x2_f32, ccedit_amd/vae_f32.py); "
                           "1: always fp32, also for a first stage built outside an engine; 0: always the bf16-storage kernels"),
     # ---- kernel library (csrc/common.h: CcPolicy) ----
-    "conv_halo": (1, "lib", "0: 3x3 stride-1 convs on the tap-gather kernel"),
+    "conv_halo": (1, "lib", "0: 3x3 stride-1 convs on the tap-gather kernel; 2: the LDS-halo kernel with the two-slot weight ring of rounds 2-5"),
     "g8": (1, "lib", "0: long Linears on the tap_gemm block shapes"),
     "g8_conv": (1, "lib", "0: 3x3 convs onto >= 1024 channels not on the persistent kernel"),
     "g8_temporal": (1, "lib", "0: Conv1d k3 at >= 640 channels not on the persistent kernel"),

@@ -374,6 +374,7 @@ def run_jobs(args, with_ref: bool = False) -> None:
     args_nobase = argparse.Namespace(**vars(args))
     args_nobase.basemodel_path = ""
     model, dev = build_model(args_nobase)
+    args.context_dim = args_nobase.context_dim
     T, H, W = args.num_keyframes, args.H, args.W
     g = torch.Generator().manual_seed(args.seed + 7919 * rank)
     for basemodel_idx, basemodel_path in enumerate(basemodels):

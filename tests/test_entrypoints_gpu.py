@@ -192,7 +192,10 @@ def test_sampling_tv2v_job_mode_lists_batches_and_balancecc_layout(tmp_path):
     a2 = np.load(os.path.join(out2, "default", "result", "npy", "frames-0000.npy"))
     d = float(np.sqrt(((a2 - res[0]) ** 2).mean()) / np.sqrt((res[0] ** 2).mean()))
     print(f"clip `a` beside `b` vs beside `c`: rel rms {d:.4f}")
-    assert d < 2e-2          # (the per-step noise of --noise_seed is drawn for the whole batch: row 0 is the same in both runs)
+    dd = float(np.sqrt(((res[1] - res[0]) ** 2).mean()) / np.sqrt((res[0] ** 2).mean()))
+    # (the per-step noise of --noise_seed is drawn for the whole batch: row 0 is the same in both runs; what differs is the tile
+    #  partition of the batched launches, i.e. the bf16 summation-order floor of tests/test_fullsize_gpu.py: 3.5e-2 per evaluation)
+    assert d < 5e-2 and dd > 4 * d, (d, dd)
     # (b) BalanceCC layout
     items = [{"Video Type": "Animal", "Video Name": "a", "Editing": [{"Target Prompt": "a tiger"}, {"Target Prompt": "a lion"}]}]
     os.makedirs(str(tmp_path / "vroot" / "Animal"))

@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 
 G = dict(model_channels=64, num_heads=2, context_dim=64)          # head dims 32 / 64 / 128 / 128
 G4 = dict(model_channels=64, num_heads=4, context_dim=64)         # head dims 16 / 32 / 64 / 64: four heads for the 4-rank head split
+G8 = dict(model_channels=128, num_heads=8, context_dim=64)        # head dims 16 / 32 / 64 / 64: eight heads for the 8-rank head split
 T, H, W = 5, 16, 16
 
 
@@ -56,7 +57,7 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     from ccedit_amd.parallel import FrameShard, RowShard
     from ccedit_amd.sgm_compat import build_network
     from ccedit_amd.utils.synth import fill_module_
-    base = G4 if world == 4 else G
+    base = G8 if world == 8 else (G4 if world == 4 else G)
     hh = 8 * world if mode.startswith("rows") and world > 2 else H          # rows: the latent height must be a multiple of 8 * world
     cfg = dict(base, crossframe=True) if crossframe else base
     w = build_network("cpu", **cfg)
@@ -68,8 +69,12 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     groups = (None, dist.new_group(list(range(world)))) if rccl else (None, None)      # bench.py's two-communicator arrangement
     cls = RowShard if mode.startswith("rows") else FrameShard
     if mode.startswith("rows"):        # the balanced decomposition: 1 / world of the latent ROWS of every frame per rank
-        shards = (RowShard(attn="gather" if mode == "rows-gather" else "heads"),)
-        w.row_shard = shards[0]
+        if mode == "rows-pair":        # the two CFG halves as two B = 1 evaluations on two streams, one communicator each (round 6)
+            shards = RowShard.cfg_pair(groups=groups)
+            w.row_shard = shards
+        else:
+            shards = (RowShard(attn="gather" if mode == "rows-gather" else "heads"),)
+            w.row_shard = shards[0]
     else:
         shards = FrameShard.cfg_pair(T, groups=groups) if mode == "pair" else (FrameShard(T, mode=mode),)
         w.frame_shard = shards if mode == "pair" else shards[0]
@@ -120,11 +125,12 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
     os._exit(0)
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(1500)
 @pytest.mark.parametrize("world,crossframe,mode", [(1, False, "a2a"), (1, True, "pair-rccl"), (1, False, "halo-rccl"), (2, False, "a2a"), (2, True, "a2a"), (2, False, "pair"),
                                                    (2, True, "pair"), (2, False, "halo"), (2, True, "halo"),
                                                    (1, True, "rows-rccl"), (1, False, "rows-gather-rccl"), (2, False, "rows"), (2, True, "rows"),
-                                                   (2, False, "rows-gather"), (2, True, "rows-gather"), (4, False, "rows")])
+                                                   (2, False, "rows-gather"), (2, True, "rows-gather"), (4, False, "rows"),
+                                                   (2, False, "rows-pair"), (2, True, "rows-pair"), (8, False, "rows")])
 # uneven 3- and 4-way splits: primitives in test_parallel_gloo.py (several processes time-slicing one GPU through
 # host-staged gloo take minutes).  crossframe=True: TVI2V — the centre keyframe (rank 1 of 2 at T=5) adds img_control and
 # broadcasts its K/V.  "-rccl": one rank on the nccl (= RCCL) backend — every exchange degenerates to a self-exchange, but the
@@ -132,7 +138,8 @@ def _worker(rank, world, port, q, crossframe=False, mode="a2a"):
 # all keyframes of 1 / world of the latent rows (8 of 16 here; 4 / 2 / 1 at the deeper levels) — halo rows for the 3x3 convs, all-reduced
 # GroupNorm sums, head-parallel spatial attention through two all-to-alls ("rows") or all-gathered K / V ("rows-gather"), temporal operators
 # local; with RCCL ("-rccl") the sharded evaluation is also captured into a HIP graph and replayed; (4, "rows"): four ranks, four heads,
-# 32 latent rows.  mode: "a2a" = all-to-all layout transposition around the temporal ops; "pair" = the same with the two
+# 32 latent rows; (8, "rows"): eight ranks, eight heads, 64 latent rows — ONE row per rank at the 8 x 12 level, the N = 8 geometry of
+# BASELINE.json config 4; "rows-pair": RowShard.cfg_pair — the CFG halves on two streams with a communicator each.  mode: "a2a" = all-to-all layout transposition around the temporal ops; "pair" = the same with the two
 # CFG halves on mirrored partitions and two streams; "halo" = round-1 halo / all-reduce / all-gather exchanges
 def test_sharded_network_matches_unsharded(world, crossframe, mode):
     if not torch.cuda.is_available():
@@ -144,7 +151,7 @@ def test_sharded_network_matches_unsharded(world, crossframe, mode):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, crossframe, mode)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=500) for _ in range(world)), key=lambda r: r[0])
+    res = sorted((q.get(timeout=500 if world < 8 else 1100) for _ in range(world)), key=lambda r: r[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

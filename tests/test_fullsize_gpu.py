@@ -338,7 +338,8 @@ def test_full_size_step_vs_oracle(workload):
     from ccedit_amd.utils.synth import fill_module_, synth_state_dict
     from oracle import ccedit_oracle as O
     torch.set_grad_enabled(False)
-    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("CCEDIT_ORACLE_THREADS", "64"))       # (64: 113 s for the TV2V step on the GPU box's host; 128 threads: 180 s)))
+    # (64 threads: 113 s for the TV2V step on the GPU box's host; 128 threads: 180 s)
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("CCEDIT_ORACLE_THREADS", "64"))))
     cross = workload == "tvi2v"
     T, H, W = 17, 64, 96
     g = torch.Generator().manual_seed(2024 + cross)

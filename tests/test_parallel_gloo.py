@@ -244,6 +244,19 @@ def _row_worker(rank, world, port, q):
     mine_o = o_full[:, :, rank * cw:(rank + 1) * cw].reshape(n * h * w, cw).contiguous()
     back = rs.from_heads(mine_o, n, p_local, cw)
     ok &= torch.equal(back, o_full[:, r0 * w:r1 * w].reshape(n * p_local, C))
+    # GroupNorm statistics riding on the halo exchange (round 6): raw boundary rows to the neighbours + every rank's partial sums to
+    # everybody in ONE batch; the total is the sum of the partials in rank order — identical bits on every rank
+    st_loc = torch.stack([mine.double().sum(dim=(1, 2, 3)), (mine.double() ** 2).sum(dim=(1, 2, 3))], dim=1)
+    up3, down3, total = rs.halo_stats_exchange(mine, st_loc.clone())
+    ok &= (up3 is None) == (rank == 0) and (down3 is None) == (rank == world - 1)
+    ok &= up3 is None or torch.equal(up3, full[:, r0 - 1])
+    ok &= down3 is None or torch.equal(down3, full[:, r1])
+    parts = [torch.stack([full[:, a:b].double().sum(dim=(1, 2, 3)), (full[:, a:b].double() ** 2).sum(dim=(1, 2, 3))], dim=1)
+             for a, b in ((r * h // world, (r + 1) * h // world) for r in range(world))]
+    want_total = parts[0].clone()
+    for p_ in parts[1:]:
+        want_total += p_
+    ok &= torch.equal(total, want_total)
     # all_agree: the ranks take the same branch (graph or eager after a capture attempt, network._forward_graphed) — true only when
     # every rank says so; not a data-path exchange (neither counted nor logged)
     nc = rs.n_collectives
@@ -268,8 +281,8 @@ def test_row_shard_primitives_gloo(world):
         p.join(30)
         assert p.exitcode == 0
     assert all(r[1] for r in res), [r[:2] for r in res]
-    assert all(r[2] == 8 and r[4] == res[0][4] for r in res)              # same collectives, same order, on every rank
-    assert res[0][4] == ["halo_rows", "halo_rows", "allreduce", "gather_rows", "halo_rows", "halo_rows", "to_heads", "from_heads"]
+    assert all(r[2] == 9 and r[4] == res[0][4] for r in res)              # same collectives, same order, on every rank
+    assert res[0][4] == ["halo_rows", "halo_rows", "allreduce", "gather_rows", "halo_rows", "halo_rows", "to_heads", "from_heads", "halo_stats"]
     # an interior rank sends two boundary rows per halo exchange, the end ranks one
     assert res[0][3] < res[world // 2][3] or world == 2
 
