@@ -498,13 +498,17 @@ __device__ __forceinline__ void attn_spatial_body(const CcAttnDesc& a) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) chk = fmaf(o16[m][t][e], 0.f, chk);
+                    for (int e = 0; e < 4; ++e)
+                        if (16 * m < D + 8) chk = fmaf(o16[m][t][e], 0.f, chk);          // (see below: rows fed by unwritten V columns are skipped)
             if (g4 == (D % 16) / 4) bad = !(o16[D / 16][0][0] > 0.f) || !(o16[D / 16][1][0] > 0.f);
         } else {
+            // (only rows the kernel owns: value rows, the denominator row and the zero rows of its pad granule — V columns beyond
+            //  D + 8 are never written in LDS, and what the last O^T tile accumulates from them is never stored either)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) chk = fmaf(o[n][r], 0.f, chk);
+                for (int r = 0; r < 16; ++r)
+                    if (32 * n + 8 * (r >> 2) < D + 8) chk = fmaf(o[n][r], 0.f, chk);
             if (hi == ((D % 32) / 4) % 2) bad = !(o[D / 32][((D % 32) / 8) * 4] > 0.f);
         }
         bad = bad || !(chk == 0.f);

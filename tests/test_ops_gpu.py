@@ -1418,7 +1418,8 @@ def test_attention_spatial_optimistic_reference_and_exact_rerun(d):
             for row in (700, 33, 1279):
                 blk = slice(row // 256 * 256, min(row // 256 * 256 + 256, lq))
                 assert torch.equal(on[1, blk], tn[1, blk]), f"re-run rows of the workgroup of row {row} differ from the tracked arm"
-        assert torch.equal(o_opt, both(args, batches=2, lq=lq, lk=lk)[0])
+        for _ in range(10):          # run-to-run identical: whether a workgroup re-runs must depend on its data alone (round 6: the check once read
+            assert torch.equal(o_opt, both(args, batches=2, lq=lq, lk=lk)[0])      # O^T rows fed by V columns nobody writes — LDS leftovers)
 
 
 def test_copy_row_blocks_pack_unpack_add():
