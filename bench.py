@@ -258,6 +258,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clip", action="store_true", help="(default on) time one full 30-step clip + VAE decode (frames/s)")
     ap.add_argument("--no-clip", action="store_true", help="skip the whole-clip timing (30-step sampler + VAE decode, ~7 s)")
+    ap.add_argument("--json-out", type=str, default="", help="also write the JSON line to this file (rank 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full-step", action="store_true",
                     help="cpu_baseline: also time ONE full-size (17x512x768, CFG-doubled) evaluation of the oracle on the host (BASELINE.md section 3; ~2 min)")
@@ -541,8 +542,11 @@ def main():
                                     "TV2V depth-midas, 17x512x768, one network evaluation = ControlNet2D + pseudo-3D UNet on "
                                     "B=2 (cfg 7.5 uncond+cond) x T=17 frames, latent 64x96, 77x768 text context; "
                                     "77.68 TFLOP/step; a 30-step DPMPP2SAncestral clip = 59 such steps + VAE decode"),
-                       "parallelism": ("one clip, the latent ROWS of every keyframe sharded over the ranks (halo rows for the 3x3 convs, all-reduced "
-                                       "GroupNorm sums, RCCL all-gather of K/V at the spatial attention, temporal ops local)" if shard and args.shard_mode == "rows" else
+                       "parallelism": ("one clip, the latent ROWS of every keyframe sharded over the ranks (halo rows for the 3x3 convs with the GroupNorm "
+                                       "partial sums riding on them, " + ("head-parallel spatial attention through two all-to-alls" if args.attn == "heads"
+                                                                          else "RCCL all-gather of K/V at the spatial attention") + ", temporal ops local"
+                                       + ("; the CFG halves on two streams with a communicator each)" if args.shard_mode == "rows-pair" else ")")
+                                       if shard and args.shard_mode.startswith("rows") else
                                        f"one clip, T=17 keyframes sharded over the ranks (mode {args.shard_mode}: " +
                                        ("halo p2p + stats all-reduce + K/V all-gather)" if args.shard_mode == "halo" else
                                         "all-to-all frame<->pixel transposition around every temporal op)") if shard else
@@ -551,11 +555,19 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         line.update(extra)
+        # how many DEVICES the ranks really ran on: development runs (CCEDIT_DIST_BACKEND=gloo) let N ranks time-slice fewer GPUs — such a
+        # line is a functional record, not a scaling measurement
+        line["gpus_physical"] = min(world, torch.cuda.device_count())
+        line["dist_backend"] = backend if world > 1 else None
         from ccedit_amd import policy
         line["policy_non_default"] = policy.non_default()
         if clip:
             line["clip"] = clip
         print(json.dumps(line))
+        if args.json_out:            # the same line as a file that holds nothing else (stdout of a multi-rank run also carries the backends' banners)
+            with open(args.json_out, "w") as f:
+                json.dump(line, f)
+                f.write("\n")
 
 
     # ---- config 4 next to the replica value (default N > 1): ONE clip row-sharded over the ranks, timed LAST and under a watchdog — this

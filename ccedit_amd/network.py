@@ -1154,12 +1154,11 @@ class ControlledUNetModel3DTV2V(UNetModel3D):
     def head(self, h, geo: Geometry):
         """`out` (GroupNorm + SiLU + conv3x3 -> 4 channels) and `out_temporal` (SiLU + Conv1d k3 over T, residual): the prediction,
         fp32 (controlmodel.py:545-550, openaimodel.py:1627-1632)."""
-        a = sgn(h, self.out[0], geo, True)
-        n, hh, ww, _ = a.shape
+        n, hh, ww, _ = h.shape
         oc = self.out_channels
         ocp = (oc + 7) // 8 * 8
-        s = torch.zeros((n * hh * ww, ocp), dtype=torch.bfloat16, device=a.device)
-        sconv3(a, self.out[2].pw, geo, out=s[:, : self.out[2].pw.n])
+        s = torch.zeros((n * hh * ww, ocp), dtype=torch.bfloat16, device=h.device)
+        sgn_conv3(h, self.out[0], self.out[2].pw, geo, out=s[:, : self.out[2].pw.n])
         if _a2a(geo):       # SiLU + Conv1d_T on this rank's pixel block; the caller all-gathers the pixel blocks
             sh = geo.shard
             sp = sh.to_pixels(s, geo.b, hh * ww)

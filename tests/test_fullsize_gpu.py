@@ -30,6 +30,12 @@ from ccedit_amd import policy
 GENERIC = dict(CCEDIT_POLICY=policy.generic())
 
 
+def _oracle_threads():
+    """Host threads for the fp32 oracle (ATen CPU kernels): 64 on the GPU box's 128-core host — the full-size TV2V step takes 113 s on 64
+    threads and 180 s on 128; CCEDIT_ORACLE_THREADS overrides."""
+    return min(os.cpu_count() or 1, int(os.environ.get("CCEDIT_ORACLE_THREADS", "64")))
+
+
 def _rel(a, b):
     a, b = a.astype(np.float64), b.astype(np.float64)
     return float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))
@@ -160,7 +166,7 @@ def test_full_size_block_teacher_forced_vs_bf16_emulating_oracle(name, cin, hh, 
     from ccedit_amd.sgm_compat import build_network, build_network_spec
     from ccedit_amd.utils.synth import fill_module_, synth_state_dict
     from oracle import ccedit_oracle as O
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(_oracle_threads())
     t = 17
     g = torch.Generator().manual_seed(100 + hh)
     bf = lambda v: v.to(torch.bfloat16).float()
@@ -209,7 +215,7 @@ def test_full_size_pieces_vs_oracle(piece):
     from ccedit_amd.sgm_compat import build_network, build_network_spec
     from ccedit_amd.utils.synth import fill_module_, synth_state_dict
     from oracle import ccedit_oracle as O
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(_oracle_threads())
     g = torch.Generator().manual_seed(77)
     bf = lambda v: v.to(torch.bfloat16).float()
     cfg = O.NetConfig()
@@ -273,7 +279,7 @@ def test_full_size_vae_decode_vs_oracle_bf16_and_fp32():
     from ccedit_amd.sgm_compat import build_vae
     from ccedit_amd.utils.synth import fill_module_
     from oracle import ccedit_oracle as O
-    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    torch.set_num_threads(_oracle_threads())
     vae = build_vae("cpu")
     fill_module_(vae, prefix="first_stage_model.")
     sd = {"first_stage_model." + k: v.detach().float() for k, v in vae.state_dict().items()}
@@ -338,8 +344,7 @@ def test_full_size_step_vs_oracle(workload):
     from ccedit_amd.utils.synth import fill_module_, synth_state_dict
     from oracle import ccedit_oracle as O
     torch.set_grad_enabled(False)
-    # (64 threads: 113 s for the TV2V step on the GPU box's host; 128 threads: 180 s)
-    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("CCEDIT_ORACLE_THREADS", "64"))))
+    torch.set_num_threads(_oracle_threads())
     cross = workload == "tvi2v"
     T, H, W = 17, 64, 96
     g = torch.Generator().manual_seed(2024 + cross)

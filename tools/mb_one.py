@@ -57,6 +57,9 @@ elif which in ("ff320", "ff320tail"):   # the dim-320 feed-forward alone / the b
 elif which == "attnq":           # the network's call: q pre-scaled into log2 units
     q = torch.randn(N * 6144, 960, device="cuda").to(BF)
     f = lambda: ops.attention(q[:, :320], q[:, 320:640], q[:, 640:], 8, 40, batches=N, lq=6144, lk=6144, q_log2=True)
+elif which == "attnq80":         # the 32x48 level: 1536 keys, d = 80, q in log2 units
+    q = torch.randn(N * 1536, 1920, device="cuda").to(BF)
+    f = lambda: ops.attention(q[:, :640], q[:, 640:1280], q[:, 1280:], 8, 80, batches=N, lq=1536, lk=1536, q_log2=True)
 elif which == "attn":
     q = torch.randn(N * 6144, 960, device="cuda").to(BF)
     f = lambda: ops.attention(q[:, :320], q[:, 320:640], q[:, 640:], 8, 40, batches=N, lq=6144, lk=6144)
