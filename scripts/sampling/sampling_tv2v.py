@@ -373,6 +373,8 @@ def run_jobs(args, with_ref: bool = False) -> None:
 
     args_nobase = argparse.Namespace(**vars(args))
     args_nobase.basemodel_path = ""
+    if world > 1:                                                         # one process per GPU (torch.distributed.run sets LOCAL_RANK)
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1))
     model, dev = build_model(args_nobase)
     args.context_dim = args_nobase.context_dim
     T, H, W = args.num_keyframes, args.H, args.W

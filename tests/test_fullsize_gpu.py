@@ -31,9 +31,9 @@ GENERIC = dict(CCEDIT_POLICY=policy.generic())
 
 
 def _oracle_threads():
-    """Host threads for the fp32 oracle (ATen CPU kernels): 64 on the GPU box's 128-core host — the full-size TV2V step takes 113 s on 64
-    threads and 180 s on 128; CCEDIT_ORACLE_THREADS overrides."""
-    return min(os.cpu_count() or 1, int(os.environ.get("CCEDIT_ORACLE_THREADS", "64")))
+    """Host threads for the fp32 oracle (ATen CPU kernels).  Measured on the GPU box's 128-core host (round 6): the thirteen full-size
+    block / piece cases take 335 s on 32 threads, 483 s on 64, 652 s on 96 — more threads are SLOWER; CCEDIT_ORACLE_THREADS overrides."""
+    return min(os.cpu_count() or 1, int(os.environ.get("CCEDIT_ORACLE_THREADS", "32")))
 
 
 def _rel(a, b):
@@ -154,8 +154,10 @@ def _oracle_block(O, sd, cfg, name, x5, emb, ctx):
 # Round 5: an Upsample3D block (`output_blocks.8`: the parity convs 32x48 -> 64x96 at 640 channels), a Downsample3D
 # (`input_blocks.3`: the stride-2 gather), and level 0 at B = 2 (`input_blocks.1` at M = 208896: the launches of the batched default
 # step — lin320s, the block-tail ff320 and the spatial attention kernel over 34 frames).
-@pytest.mark.parametrize("name,cin,hh,ww,b", [("input_blocks.1", 320, 64, 96, 1), ("input_blocks.4", 320, 32, 48, 1),
-                                              ("input_blocks.7", 640, 16, 24, 1), ("output_blocks.11", 640, 64, 96, 1),
+# Round 6: three cases retired — `input_blocks.1` at B = 1 (the B = 2 case below launches the same kernels on twice the rows),
+# `input_blocks.4` (32x48 at B = 1: `input_blocks.5` at B = 2 is that level) and `output_blocks.11` (a level-0 decoder block: pinned
+# free-running, with its concatenation, by test_full_size_step_vs_oracle) — 96 s of host time that the whole-network test now spends.
+@pytest.mark.parametrize("name,cin,hh,ww,b", [("input_blocks.7", 640, 16, 24, 1),
                                               ("middle_block", 1280, 8, 12, 2), ("output_blocks.1", 2560, 8, 12, 2),
                                               ("input_blocks.5", 640, 32, 48, 2), ("output_blocks.8", 960, 32, 48, 1),
                                               ("input_blocks.3", 320, 64, 96, 1), ("input_blocks.1", 320, 64, 96, 2)])
