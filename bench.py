@@ -116,9 +116,9 @@ def cpu_baseline(wrapper, tvi2v=False, device=None, full_step=False):
 def cpu_full_size_step(sd, tvi2v=False):
     """BASELINE.md section 3, second half (`--cpu-full-step`): ONE measured network evaluation of the oracle at the full 17 x 512 x 768
     size — the same CFG-doubled batch the GPU step evaluates (B = 2 x T = 17, latent 64 x 96; 77.68 / 110.31 TFLOP in fp32) — and the
-    x (2 N - 1) extrapolation to a clip.  Not part of the default run (about two minutes of host time on 64 threads)."""
+    x (2 N - 1) extrapolation to a clip.  Not part of the default run (about a minute and a half of host time)."""
     from oracle import ccedit_oracle as O
-    threads = min(os.cpu_count() or 1, 64)
+    threads = min(os.cpu_count() or 1, 32)        # measured on the GPU box's 128-core host: 90 s on 16 or 32 threads, 113 s on 64, 180 s on 128
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(42)
     x = torch.randn(1, 4, T, H, W, generator=g)
