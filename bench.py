@@ -396,8 +396,8 @@ def main():
         prof = ops.PROFILE.summary()
         if args.breakdown:
             for fam in ("tap_gemm", "attention"):
-                for shape, n, ms, tf in ops.PROFILE.by_shape(fam)[:int(os.environ.get('CCEDIT_BREAKDOWN_ROWS', '40'))]:
-                    print(f"{fam:9s} {str(shape):60s} x{n:3d} {ms:8.3f} ms {tf:7.1f} TF/s", file=sys.stderr)
+                for shape, n, ms, tf in ops.PROFILE.by_shape(fam, with_kernel=True)[:int(os.environ.get('CCEDIT_BREAKDOWN_ROWS', '40'))]:
+                    print(f"{fam:9s} {str(shape[0]):52s} x{n:3d} {ms:8.3f} ms {tf:7.1f} TF/s  {shape[1]}", file=sys.stderr)
             mem = {}
             for a_, b_, _, nb, shape, _k, _ex in ops.PROFILE.records.get("memory", []):
                 e = mem.setdefault(shape, [0, 0.0, 0.0])

@@ -398,16 +398,20 @@ __global__ __launch_bounds__(kNT, 1) void lin320s_kernel(const CcGemmDesc d, int
             const bf16* __restrict__ Wp = (const bf16*)d.W;
 #pragma unroll
             for (int ti = 0; ti < NTW; ++ti) {
-                const bf16* row = Wp + (size_t)(ch0 + 16 * (tile0 + ti) + c16) * d.Kpad + g4 * 8;
+                if (d.Wfrag) {      // fragment-ordered copy (CcGemmDesc.Wfrag): one contiguous kilobyte per fragment and wave
+                    const bf16* blk = (const bf16*)d.Wfrag + ((size_t)((ch0 >> 4) + tile0 + ti) * (kK / 32) * 64 + lane) * 8;
 #pragma unroll
-                for (int ks = 0; ks < kK / 32; ++ks) wf[ti][ks] = *(const bf16x8*)(row + ks * 32);
+                    for (int ks = 0; ks < kK / 32; ++ks) wf[ti][ks] = *(const bf16x8*)(blk + ks * 512);
+                } else {
+                    const bf16* row = Wp + (size_t)(ch0 + 16 * (tile0 + ti) + c16) * d.Kpad + g4 * 8;
+#pragma unroll
+                    for (int ks = 0; ks < kK / 32; ++ks) wf[ti][ks] = *(const bf16x8*)(row + ks * 32);
+                }
                 const int cb = ch0 + 16 * (tile0 + ti) + 4 * g4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bq[ti][e] = d.bias ? d.bias[cb + e] : 0.f;
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the weights are in: from here on the queue holds DMA and stores only
-
         const int xlane = c16 * kRS + g4 * 16;                  // B fragment of pixel tile p, k-step ks: + p * 16 rows + ks * 64
         const int olane = c16 * kRS + (16 * tile0 + 4 * g4) * 2;      // C cell (pixel, 4 channels): + p * 16 rows + ti * 32
 
@@ -419,7 +423,9 @@ __global__ __launch_bounds__(kNT, 1) void lin320s_kernel(const CcGemmDesc d, int
             xs = xs == RX - 1 ? 0 : xs + 1;
             os = os == RO - 1 ? 0 : os + 1;
         }
-        l3_vmcnt_n((staged - 1) * per_tile);                    // tile 0 has landed (this wave's part)
+        // (round 6) the first tiles were requested BEHIND the weight loads, in the same breath — one latency instead of two at the start
+        // of every launch; this wait covers both: from here on the queue holds DMA and stores only
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int xb = 0, ob = 0, obp = 0;                             // slots of tile i / of tile i - 1's output
         for (int i = 0; i < ntile; ++i) {
             lds_barrier();      // tile i is in LDS for every wave; output tile i-1 is complete; X slot of tile i-1 and O slot of tile i-2 are free

@@ -152,10 +152,16 @@ __global__ __launch_bounds__(kNT, 1) void lin640s_kernel(const CcGemmDesc d, int
     f32x4 bq[2], cq[2];
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
-        const int cr = min(ch0 + 32 * wave + 16 * ti + c16, d.N - 1);      // (dead waves: any valid row)
-        const bf16* __restrict__ row = (const bf16*)d.W + (size_t)cr * d.Kpad + g4 * 8;
+        if (d.Wfrag) {      // fragment-ordered copy (CcGemmDesc.Wfrag): a fragment is one contiguous kilobyte per wave (rows are padded to 256: dead waves read zeros)
+            const bf16* __restrict__ blk = (const bf16*)d.Wfrag + ((size_t)((ch0 + 32 * wave + 16 * ti) >> 4) * (kK / 32) * 64 + lane) * 8;
 #pragma unroll
-        for (int ks = 0; ks < kKS; ++ks) wf[ti][ks] = *(const bf16x8*)(row + ks * 32);
+            for (int ks = 0; ks < kKS; ++ks) wf[ti][ks] = *(const bf16x8*)(blk + ks * 512);
+        } else {
+            const int cr = min(ch0 + 32 * wave + 16 * ti + c16, d.N - 1);      // (dead waves: any valid row)
+            const bf16* __restrict__ row = (const bf16*)d.W + (size_t)cr * d.Kpad + g4 * 8;
+#pragma unroll
+            for (int ks = 0; ks < kKS; ++ks) wf[ti][ks] = *(const bf16x8*)(row + ks * 32);
+        }
         const int cb = min(ch0 + 32 * wave + 16 * ti + 4 * g4, d.N - 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -164,7 +170,11 @@ __global__ __launch_bounds__(kNT, 1) void lin640s_kernel(const CcGemmDesc d, int
         }
     }
     if (tid < 2 * kP * 2) sSum[tid] = 0.0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the weights are in: from here on a requesting wave's queue holds DMA only
+    // the first tiles are requested BEHIND the weight loads, in the same breath (round 6: one latency instead of two at the start of
+    // every launch); one wait below covers both — from then on a requesting wave's queue holds DMA only
+    int staged = 0;
+    for (; staged < kRX - 1 && staged < ntile; ++staged) stage_next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     int xlane[4];                                               // B fragment of k-step ks: xlane[ks & 3] + (ks >> 2) * 256
 #pragma unroll
@@ -188,9 +198,6 @@ __global__ __launch_bounds__(kNT, 1) void lin640s_kernel(const CcGemmDesc d, int
     int64_t so_off = (int64_t)pt0 * kP * d.ldc * 2;              // output cursor: the tile stored at step i is i - 1
     int64_t so_rows = (int64_t)pt0 * kP;                         // ... its first row (row sums)
 
-    int staged = 0;
-    for (; staged < kRX - 1 && staged < ntile; ++staged) stage_next();
-    if (dma_wave) wait_later(staged - 1);                        // tile 0 has landed (this wave's part)
     int xb = 0, ob = 0, obp = 0;                                 // slots of tile i / of tile i - 1's output
     const double inv_k = 1.0 / kK;
     for (int i = 0; i < ntile; ++i) {

@@ -110,20 +110,23 @@ __global__ __launch_bounds__(kNT, 1) void temp320s_kernel(const CcGemmDesc d, in
     {
         const int cr = min(ch0 + 16 * wave + c16, d.N - 1);
         const bf16* __restrict__ row = (const bf16*)d.W + (size_t)cr * d.Kpad;
+        // fragment-ordered copy (CcGemmDesc.Wfrag): one contiguous kilobyte per fragment and wave (rows are padded to 256: a wave
+        // beyond N reads zeros); the 32-element k block of (tap, ks) is the one its g4 = 0 lanes start
+        const bf16* __restrict__ blk = (const bf16*)d.Wfrag + ((size_t)((ch0 >> 4) + wave) * (d.Kpad / 32) * 64 + lane) * 8;
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
             for (int ks = 0; ks < kKS; ++ks) {
-                const int c = 32 * ks + 8 * g4;
-                const int off = d.korder ? (c >> 6) * 192 + tap * 64 + (c & 63) : tap * kC + c;
-                wf[tap][ks] = *(const bf16x8*)(row + off);
+                const int c0 = 32 * ks;
+                const int off0 = d.korder ? (c0 >> 6) * 192 + tap * 64 + (c0 & 63) : tap * kC + c0;
+                if (d.Wfrag) wf[tap][ks] = *(const bf16x8*)(blk + (off0 >> 5) * 512);
+                else wf[tap][ks] = *(const bf16x8*)(row + off0 + 8 * g4);
             }
         const int cb = min(ch0 + 16 * wave + 4 * g4, d.N - 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) bq[e] = d.bias ? d.bias[cb + e] : 0.f;
     }
     if (tid < 64) sSt[tid] = 0.0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     int xlane[4];
 #pragma unroll
@@ -190,7 +193,9 @@ __global__ __launch_bounds__(kNT, 1) void temp320s_kernel(const CcGemmDesc d, in
     static_assert(kRX - 2 == 4, "wait_later covers four tiles in flight behind the awaited one");
     int staged = 0;
     for (; staged < kRX - 1 && staged < nstep; ++staged) stage_next();
-    if (dma_wave) wait_later(staged - 1);
+    // (round 6) the first tiles are requested BEHIND the weight loads, in the same breath — one latency instead of two at the start of
+    // every launch; this wait covers both: from here on a requesting wave's queue holds DMA only
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int cx = 0, fr = kRR - 2, sr = kRR - 3;                      // slots: activations of tile s; cells of output s - 2; output s - 3
     // output cursor: the output stored at step s is s - 3
     int so_t = 0, so_col = 0, so_clip;

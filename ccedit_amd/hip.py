@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the library is loaded: to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCEDIT_HIP_LIB") or os.path.join(_HERE, "libccedit_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 ATTN_Q_LOG2 = 1          # CcAttnDesc.flags: CCEDIT_ATTN_Q_LOG2
 
 GEMM_LINEAR, GEMM_CONV2D, GEMM_TEMPORAL = 0, 1, 2
@@ -37,7 +37,7 @@ class CcGemmDesc(C.Structure):
         ("gn_stats", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("split_k", C.c_int32), ("subpix", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_stats", C.c_void_p),
         ("ln_sums", C.c_void_p), ("row_sums", C.c_void_p), ("ln_sums_eps", C.c_float), ("vpad", C.c_int32),
-        ("halo_top", C.c_void_p), ("halo_bot", C.c_void_p),
+        ("halo_top", C.c_void_p), ("halo_bot", C.c_void_p), ("Wfrag", C.c_void_p),
     ]
 
 

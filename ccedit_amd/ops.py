@@ -52,11 +52,13 @@ class LaunchProfile:
                         "exec_tflops": fe / (ms * 1e-3) / 1e12, "gbytes_per_s": by / (ms * 1e-3) / 1e9, "bytes": by}
                        for k, (n, ms, f, by, fam, fe) in acc.items()), key=lambda r: -r["ms"])
 
-    def by_shape(self, family):
-        """{shape: (launches, total_ms, tflops)} sorted by time."""
+    def by_shape(self, family, with_kernel=False):
+        """{shape: (launches, total_ms, tflops)} sorted by time (with_kernel: keyed on (shape, kernel label))."""
         torch.cuda.synchronize()
         acc = {}
         for a, b, fl, _, shape, _k, _ex in self.records.get(family, []):
+            if with_kernel:
+                shape = (shape, _k)
             n, ms, f = acc.get(shape, (0, 0.0, 0.0))
             acc[shape] = (n + 1, ms + a.elapsed_time(b), f + fl)
         return sorted(((k, n, ms, f / (ms * 1e-3) / 1e12) for k, (n, ms, f) in acc.items()), key=lambda r: -r[2])
@@ -97,6 +99,9 @@ def _ptr(t: Optional[torch.Tensor]):
 def _chk_act(t: torch.Tensor, name: str):
     if t.dtype != BF16 or not t.is_cuda or not t.is_contiguous():
         raise ValueError(f"{name}: expected a contiguous cuda bf16 tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+
+
+WFRAG = policy.on("wfrag")      # 0: CcGemmDesc.Wfrag stays null (A/B of the coalesced weight preload)
 
 
 def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Optional[int] = None,
@@ -171,6 +176,7 @@ def gemm(a2d: torch.Tensor, pw: PackedWeight, *, mode: int = GEMM_LINEAR, m: Opt
         del out._ln_sums
     d.korder = pw.korder
     d.A, d.A2, d.W = a2d.data_ptr(), _ptr(a2), pw.w.data_ptr()
+    d.Wfrag = _ptr(pw.wfrag) if WFRAG else None
     d.bias = _ptr(pw.bias) if use_bias else None
     d.group_bias = _ptr(group_bias)
     d.res1, d.res2, d.out = _ptr(res1), _ptr(res2), out.data_ptr()

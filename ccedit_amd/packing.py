@@ -36,6 +36,7 @@ class PackedWeight:
     flops_per_row: float = 0.0      # algorithmic 2*O*I*taps (unpadded) per output row
     korder: int = 0                 # 0: K = [tap][Cin];  1: K = [Cin/64][tap][64]
     colsum: Optional[torch.Tensor] = None   # fp32 [n]: row sums of the bf16 weights as packed (CcGemmDesc.ln_colsum), folded-LayerNorm weights only
+    wfrag: Optional[torch.Tensor] = None    # bf16 [Opad * Kpad]: `w` in MFMA A-fragment order (CcGemmDesc.Wfrag), K = 320 / 640 / 960 only
 
     def to(self, device):
         self.w = self.w.to(device)
@@ -43,7 +44,20 @@ class PackedWeight:
             self.bias = self.bias.to(device)
         if self.colsum is not None:
             self.colsum = self.colsum.to(device)
+        if self.wfrag is not None:
+            self.wfrag = self.wfrag.to(device)
         return self
+
+
+FRAG_KPADS = (320, 640, 960)      # weight widths the register-resident kernels serve (lin320.hip, lin640.hip, temp320.hip)
+
+
+def fragment_order(w: torch.Tensor) -> torch.Tensor:
+    """[rows][Kpad] -> the 16 x 32 blocks of CcGemmDesc.Wfrag: block (t, s) = rows 16 t .. + 15, k 32 s .. + 31 as 64 lanes x 8
+    elements, lane (g, c) = W[16 t + c][32 s + 8 g .. + 7] — what one v_mfma_f32_16x16x32_bf16 A operand holds, contiguous."""
+    rows, kpad = w.shape
+    assert rows % 16 == 0 and kpad % 32 == 0
+    return w.view(rows // 16, 16, kpad // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
 
 
 def _geglu_perm(two_inner: int) -> torch.Tensor:
@@ -94,7 +108,10 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, geglu
     if b is not None:
         bb = torch.zeros(n, dtype=torch.float32, device=dev)
         bb[:o] = b.to(dev)
-    return PackedWeight(buf, bb, n, (o // 2) if geglu else o, cin, taps, kpad, ksize, geglu, 2.0 * o * i * taps, korder)
+    pw = PackedWeight(buf, bb, n, (o // 2) if geglu else o, cin, taps, kpad, ksize, geglu, 2.0 * o * i * taps, korder)
+    if kpad in FRAG_KPADS and taps in (1, 3) and ksize in (1, 3) and w.ndim != 4:
+        pw.wfrag = fragment_order(buf)
+    return pw
 
 
 def pack_upsample_parities(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, device: Optional[torch.device] = None):

@@ -34,6 +34,7 @@ TABLE = {
     "conv1x1_linear": (1, "py", "0: 1 x 1 convs through the convolution mode instead of the Linear dispatch"),
     "attn_q_log2": (1, "py", "0: softmax scale applied inside the attention kernels instead of folded into to_q"),
     "fuse_halo_stats": (1, "py", "0 (rows sharded): GroupNorm statistics all-reduced on their own instead of riding on the 3x3 conv's halo exchange"),
+    "wfrag": (1, "py", "0: the register-resident-weight kernels (K = 320 / 640 Linears, 320-channel Conv1d k3) preload their weights from the row-major matrix instead of its fragment-ordered copy"),
     "block_tail": (1, "py", "0: to_out / proj_out of the dim-320 transformer tails as their own launches, not inside ff320"),
     # (a precision option, not an A/B arm of equal arithmetic: the reference runs its first-stage model with autocast disabled)
     "vae_fp32": (2, "py", "the KL-VAE's precision.  2 (default): the engine follows the yaml's disable_first_stage_autocast, the flag's meaning in "

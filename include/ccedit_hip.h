@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCEDIT_ABI_VERSION 11
+#define CCEDIT_ABI_VERSION 12
 
 #define CCEDIT_OK 0
 #define CCEDIT_EINVAL (-1)       /* null pointer / bad size */
@@ -172,6 +172,14 @@ typedef struct CcGemmDesc {
     int32_t vpad;
     const void* halo_top;
     const void* halo_bot;
+    /* optional (ABI 12): the same weights as W once more in MFMA A-FRAGMENT order, for the kernels that keep a weight slice in
+     * registers for their whole life (tile 9 / 10 / 14: K = 320 / 640 Linears, 320-channel Conv1d k3).  Block (t, s) — output rows
+     * 16 t .. 16 t + 15, k 32 s .. 32 s + 31 of the [rows][Kpad] matrix W — is 1 KB at element offset (t * (Kpad / 32) + s) * 512:
+     * 64 lanes x 8 bf16, lane (g = lane >> 4, c = lane & 15) holding W[16 t + c][32 s + 8 g .. + 7]; rows padded to a multiple of 16.
+     * A wave then loads a fragment as ONE contiguous kilobyte instead of sixteen 64-byte row pieces: the per-launch weight preload
+     * (200-400 KB per workgroup through the CU's L1-miss path) is 12 -> 4 us at 400 KB (tools/exp/lin640w.hip, round 6).
+     * null: the kernels read W (same values). */
+    const void* Wfrag;
 } CcGemmDesc;
 
 int ccedit_gemm(const CcGemmDesc* desc, void* stream);

@@ -29,14 +29,14 @@ def test_header_symbols_exported(libpath):
         assert hasattr(lib, n), f"{n} declared in include/ccedit_hip.h but not exported"
     lib.ccedit_abi_version.restype = ctypes.c_int
     from ccedit_amd import hip
-    assert lib.ccedit_abi_version() == 11 == hip.ABI_VERSION
+    assert lib.ccedit_abi_version() == 12 == hip.ABI_VERSION
 
 
 def test_binding_matches_header(libpath):
     from ccedit_amd import hip
     assert sorted(hip.EXPORTS) == _declared()
     # descriptor layouts: sizes the C side was compiled with (kept in sync by hand; a mismatch shows up here)
-    assert ctypes.sizeof(hip.CcGemmDesc) == 8 + 34 * 4 + 9 * 8 + (8 + 8 + 2 * 4) + 4 * 8 + 2 * 4 + 2 * 8      # ... + workspace, workspace_bytes, split_k, subpix; ln_colsum, ln_stats, ln_sums, row_sums, ln_sums_eps, vpad (ABI 9); halo_top, halo_bot (ABI 10)
+    assert ctypes.sizeof(hip.CcGemmDesc) == 8 + 34 * 4 + 9 * 8 + (8 + 8 + 2 * 4) + 4 * 8 + 2 * 4 + 2 * 8 + 8      # ... + workspace, workspace_bytes, split_k, subpix; ln_colsum, ln_stats, ln_sums, row_sums, ln_sums_eps, vpad (ABI 9); halo_top, halo_bot (ABI 10); Wfrag (ABI 12)
     assert ctypes.sizeof(hip.CcFf320Desc) == 8 + 6 * 4 + 5 * 8 + 5 * 8 + 4 * 4                # ... + a, res, res2, bop, bpp, lda, ldr, ldr2, pad (ABI 10: block tail)
     assert ctypes.sizeof(hip.CcAttnDesc) % 8 == 0
     assert ctypes.sizeof(hip.CcGemmF32Desc) == 5 * 8 + 8 + 16 * 4                               # ABI 11: fp32 first-stage model

@@ -135,6 +135,28 @@ def test_packing_layouts():
     assert pc.n == 16 and pc.w[5, 0].item() == 2 and pc.w[15, 7].item() == 3
 
 
+def test_fragment_ordered_weight_copy():
+    """PackedWeight.wfrag (CcGemmDesc.Wfrag, ABI 12): the K = 320 / 640 / 960 matrices once more as the 16 x 32 blocks one
+    v_mfma_f32_16x16x32_bf16 A operand holds — block (t, s) is 64 lanes x 8 elements, lane (g, c) = W[16 t + c][32 s + 8 g .. + 7] —
+    so that the register-resident-weight kernels preload a fragment as one contiguous kilobyte.  Same values as `w`; only the widths
+    those kernels serve carry it."""
+    from ccedit_amd.packing import fold_layernorm, fragment_order, pack_concat, pack_weight
+    g = torch.Generator().manual_seed(5)
+    for shape in ((640, 640), (320, 320), (1920, 640), (320, 320, 3), (64, 640)):
+        pw = pack_weight(torch.randn(*shape, generator=g))
+        assert pw.wfrag is not None and pw.wfrag.numel() == pw.w.numel(), shape
+        rows, kpad = pw.w.shape
+        f = pw.wfrag.view(rows // 16, kpad // 32, 64, 8)
+        for t, s_, lane in ((0, 0, 0), (1, 3, 17), (rows // 16 - 1, kpad // 32 - 1, 63), (2, 5, 40)):
+            gq, c = lane >> 4, lane & 15
+            assert torch.equal(f[t, s_, lane], pw.w[16 * t + c, 32 * s_ + 8 * gq: 32 * s_ + 8 * gq + 8]), (shape, t, s_, lane)
+        assert torch.equal(fragment_order(pw.w), pw.wfrag)
+    assert pack_concat([torch.randn(640, 640, generator=g)] * 3).wfrag is not None                   # fused q, k, v
+    assert fold_layernorm([torch.randn(640, 640, generator=g)], [None], torch.ones(640), torch.zeros(640)).wfrag is not None
+    for shape in ((1280, 1280), (320, 320, 3, 3), (640, 2560), (1280, 1280, 3)):                   # widths no such kernel serves
+        assert pack_weight(torch.randn(*shape, generator=g)).wfrag is None, shape
+
+
 def test_fp32_first_stage_packing_and_policy():
     """ccedit_amd/vae_f32.py host side (no GPU): the fp32 kernel layout — [Cout][tap][Cpad], tap = 3 ky + kx, zero columns beyond Cin,
     Cin rounded up to 4 for the activation rows — and the policy entry that selects the fp32 first stage (default 2: whatever the yaml's disable_first_stage_autocast says)."""

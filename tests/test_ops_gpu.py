@@ -556,6 +556,56 @@ def test_linear_k320_register_resident_weights(m, n):
             ops.linear(xc, pw, act=1, tile=9)
 
 
+def test_fragment_ordered_weights_give_identical_results():
+    """CcGemmDesc.Wfrag (ABI 12): lin320s / lin640s / temp320s preload their register-resident weight slice from the fragment-ordered
+    copy (one contiguous kilobyte per fragment and wave) or, with a null pointer (policy wfrag = 0), from the row-major matrix —
+    the same values in the same registers, so the outputs are bit-identical, for every slice / dead-wave case of the three kernels."""
+    _dev()
+    from ccedit_amd import hip, ops
+    from ccedit_amd.packing import fold_layernorm, pack_weight
+    last = lambda: hip.lib().ccedit_last_kernel().decode()
+
+    def both(fn, kernel):
+        old = ops.WFRAG
+        try:
+            ops.WFRAG = True
+            y1 = fn()
+            assert kernel in last(), last()
+            ops.WFRAG = False
+            y0 = fn()
+            assert kernel in last(), last()
+        finally:
+            ops.WFRAG = old
+        assert torch.equal(y0, y1), kernel
+        return y1
+
+    for n in (128, 384, 640, 1920):                       # K = 640: 256-channel slices, the last one half empty for 128 / 384 / 640
+        m = 16 * 260
+        x, w, b = _rnd(m, 640, seed=1), _rnd(n, 640, seed=2, scale=640 ** -0.5), _rnd(n, seed=3)
+        pw = pack_weight(w, b).to("cuda")
+        xc = x.to(BF).cuda()
+        y = both(lambda: ops.linear(xc, pw, tile=10), "lin640s")
+        _close(y, F.linear(xc.float().cpu(), w, b), what=f"lin640s wfrag N={n}")
+        g, be = _rnd(640, seed=4) * 0.2 + 1.0, _rnd(640, seed=5) * 0.2
+        pl = fold_layernorm([w], [b], g, be).to("cuda")
+        st = ops.row_stats(xc, 1e-5)
+        both(lambda: ops.linear(xc, pl, ln_stats=st, tile=10), "lin640s")
+    for n in (320, 960):                                  # K = 320
+        m = 32 * 1100
+        x, w, b = _rnd(m, 320, seed=6), _rnd(n, 320, seed=7, scale=320 ** -0.5), _rnd(n, seed=8)
+        pw = pack_weight(w, b).to("cuda")
+        xc = x.to(BF).cuda()
+        y = both(lambda: ops.linear(xc, pw, tile=9), "lin320")
+        _close(y, F.linear(xc.float().cpu(), w, b), what=f"lin320s wfrag N={n}")
+    # Conv1d k3 over T at 320 channels (both weight K orders travel through pack_weight's korder)
+    t, h, w_ = 5, 16, 32
+    x = _rnd(2 * t, h, w_, 320, seed=9)
+    wt, b = _rnd(320, 320, 3, seed=10, scale=960 ** -0.5), _rnd(320, seed=11)
+    pt = pack_weight(wt, b).to("cuda")
+    xc = x.to(BF).cuda()
+    both(lambda: ops.conv_temporal(xc, t, pt, tile=14), "temp320s")
+
+
 @pytest.mark.parametrize("m,n", [(16, 640), (2064, 1920), (8416, 128), (8208, 384), (52224, 640), (17408, 1280), (26112, 1920)])
 def test_linear_k640_register_resident_weights(m, n):
     """tile 10 = lin640s_kernel (lin640.hip): K = 640, a 256-channel weight slice lives in registers (wave w: 32 channels x
