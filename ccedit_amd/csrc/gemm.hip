@@ -547,8 +547,12 @@ extern "C" int ccedit_gemm(const CcGemmDesc* desc, void* stream) {
         return cc_g8_launch(d, s, 1);
     // Few tiles, long K (the 8x12 level: 3264 pixels x 1280 channels = 65 tiles of 256 x 256, K loops of 60-360 K tiles — a quarter of the
     // chip busy for the whole loop on any block shape): split-K in the persistent kernel when the caller lent a workspace.
-    if (d.tile == 0 && pol.g8 && !d.subpix && !d.vpad && d.workspace && cc_g8_split(d, 0) > 1 && d.workspace_bytes >= cc_g8_workspace_bytes(d, 0))
+    if (d.tile == 0 && pol.g8 && (!d.subpix || pol.g8_conv) && !d.vpad && d.workspace && cc_g8_split(d, 0) > 1 && d.workspace_bytes >= cc_g8_workspace_bytes(d, 0))
         return cc_g8_launch(d, s, 1);
+    // The four parity convs of an upsample + conv 3x3 (K = 4 Cin on the low-resolution source): the same persistent gather loop with a
+    // 2 x 2 window (round 6).  16x24 -> 32x48 (13056 source pixels x 1280 channels, K = 5120: 255 tiles, one round of the chip) is taken
+    // by the clause above, the 8x12 source by split-K; this one takes the 32x48 source (640 channels: 128ch x 512pix).
+    if (d.tile == 0 && pol.g8_conv && pol.g8 && d.subpix && d.M >= 12000 && d.N >= 640 && cc_g8_applicable(d, 0)) return cc_g8_launch(d, s, 0);
     if ((d.tile == 0 && pol.conv_halo && !d.vpad) || d.tile == 8) {
         if (!d.vpad && cc_conv_halo_applicable(d)) return cc_conv_halo_launch(d, s);
         CC_UNSUPPORTED(d.tile == 8, "ccedit_gemm: tile 8 (LDS-halo 3x3 conv) does not apply to this descriptor");

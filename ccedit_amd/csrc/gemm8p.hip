@@ -178,7 +178,16 @@ __device__ __forceinline__ void g8_flush_rows(float (&rs)[NR], float (&rq)[NR], 
 // zeros outside the clip) or Conv2d 3x3 stride 1 pad 1 (openaimodel.py:445-449, 483-492; rows dy * W + dx apart, zeros outside the
 // frame).  Only the activation request changes: a uniform row offset per tap and one select (row or zero page) per 16-byte piece;
 // which taps a thread's rows have is a 9-bit mask per row, computed once per output tile.
-enum { G8_LINEAR = 0, G8_TEMPORAL = 1, G8_CONV3 = 2 };
+// G8_SUBPIX (round 6): one output parity of `conv3x3(nearest_upsample_2x(x))` (CcGemmDesc.subpix, Upsample.forward,
+// openaimodel.py:204-217 / 254-263) — four taps of a 2 x 2 window on the LOW-resolution source starting at (oy - 1 + py, ox - 1 + px),
+// K = [Cin / 64][4][64]; the output row of source pixel m is (2 oy + py, 2 ox + px) of the up-sampled frame (cc_out_row).
+enum { G8_LINEAR = 0, G8_TEMPORAL = 1, G8_CONV3 = 2, G8_SUBPIX = 3 };
+__device__ __forceinline__ size_t g8_out_row(const CcGemmDesc& d, int64_t m) {       // (cc_out_row of gemm_epilogue.h)
+    const int hw = d.Hout * d.Wout;
+    const int n = (int)(m / hw), rem = (int)(m - (int64_t)n * hw);
+    const int oy = rem / d.Wout, ox = rem - oy * d.Wout;
+    return ((size_t)n * 2 * d.Hout + 2 * oy + ((d.subpix - 1) >> 1)) * (2 * d.Wout) + 2 * ox + ((d.subpix - 1) & 1);
+}
 
 // SPLIT = 1: split-K for outputs with far fewer tiles than CUs (the 8x12 level: 3264 pixels x 1280 channels = 65 tiles, K loops of
 // 60-360 K tiles).  A work item is (tile, split); the d.split_k items of a tile are consecutive in the walk (same XCD), each
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
     const char* at;
     int rmax;
     const uint32_t ldab = (uint32_t)d.lda * 2, gcol16 = gcol * 16;
-    constexpr int NTAP = GATHER == G8_CONV3 ? 9 : 3;
+    constexpr int NTAP = GATHER == G8_CONV3 ? 9 : (GATHER == G8_SUBPIX ? 4 : 3);
     uint32_t tap_ok[(2 * BI + 2) / 3] = {};      // GATHER: 9 bits per row j * 64 + rsub of the tile (3 rows per word): bit = that tap exists
     const int64_t row_bytes = (int64_t)d.lda * 2;
     auto set_tile = [&](int pt_, int ct_) {
@@ -282,6 +291,12 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                 if constexpr (GATHER == G8_TEMPORAL) {
                     const int fr = (int)(m / d.HW) % d.T;                                   // keyframe index inside the clip
                     ok = (uint32_t)(fr > 0) | 2u | ((uint32_t)(fr < d.T - 1) << 2);
+                } else if constexpr (GATHER == G8_SUBPIX) {
+                    const int rem = (int)(m % ((int64_t)d.Hin * d.Win));
+                    const int y = rem / d.Win, x = rem - y * d.Win;
+                    const int sy = y - 1 + ((d.subpix - 1) >> 1), sx = x - 1 + ((d.subpix - 1) & 1);   // window origin; tap = 2 dy + dx
+                    const uint32_t xm = (uint32_t)(sx >= 0) | ((uint32_t)(sx + 1 < d.Win) << 1);
+                    ok = (sy >= 0 ? xm : 0u) | (sy + 1 < d.Hin ? xm << 2 : 0u);
                 } else {
                     const int rem = (int)(m % ((int64_t)d.Hin * d.Win));
                     const int y = rem / d.Win, x = rem - y * d.Win;
@@ -305,7 +320,9 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
         const int kt = kt_ + kbase;
         if constexpr (GATHER != G8_LINEAR) {
             const int chunk = kt / NTAP, tap = kt - NTAP * chunk;                  // uniform
-            const int shift = GATHER == G8_TEMPORAL ? (tap - 1) * d.HW : (tap / 3 - 1) * d.Win + (tap % 3 - 1);       // rows
+            const int shift = GATHER == G8_TEMPORAL ? (tap - 1) * d.HW
+                              : (GATHER == G8_SUBPIX ? ((tap >> 1) - 1 + ((d.subpix - 1) >> 1)) * d.Win + ((tap & 1) - 1 + ((d.subpix - 1) & 1))
+                                                     : (tap / 3 - 1) * d.Win + (tap % 3 - 1));       // rows
             const char* const base = at + (int64_t)shift * row_bytes + chunk * 128;
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
@@ -775,7 +792,7 @@ __global__ __launch_bounds__(512) void g8_kernel(const CcGemmDesc d) {
                     const int row = j * (64 / G) + lane / G, c = lane % G;
                     const bf16x8 v = *(const bf16x8*)(stg + row * RB + ((c ^ (row & (G - 1))) << 4));
                     const int64_t m = pix0 + pixbase(tjf) + row;
-                    if (st && m < d.M && chw + 8 * c < d.N) *(bf16x8*)(outp + (size_t)m * d.ldc + chw + 8 * c) = v;
+                    if (st && m < d.M && chw + 8 * c < d.N) *(bf16x8*)(outp + (GATHER == G8_SUBPIX ? g8_out_row(d, m) : (size_t)m) * d.ldc + chw + 8 * c) = v;
                     if constexpr (GATHER == G8_LINEAR && !LNF) {
                         if (d.row_sums && chw + 8 * c < d.N) {
 #pragma unroll
@@ -859,9 +876,9 @@ int g8_launch_shape(const CcGemmDesc& d, hipStream_t s, int n_cu, int split_k = 
     if (LNF)
         cc_note_kernel("g8_kernel %dch x %dpix, LayerNorm folded", BM, BN);
     else if (SPLIT)
-        cc_note_kernel(GATHER == G8_TEMPORAL ? "g8_kernel %dch x %dpix, temporal taps, split-K" : (GATHER == G8_CONV3 ? "g8_kernel %dch x %dpix, 3x3 taps, split-K" : "g8_kernel %dch x %dpix, split-K"), BM, BN);
+        cc_note_kernel(GATHER == G8_TEMPORAL ? "g8_kernel %dch x %dpix, temporal taps, split-K" : (GATHER == G8_CONV3 ? "g8_kernel %dch x %dpix, 3x3 taps, split-K" : (GATHER == G8_SUBPIX ? "g8_kernel %dch x %dpix, upsample parity taps, split-K" : "g8_kernel %dch x %dpix, split-K")), BM, BN);
     else
-        cc_note_kernel(GATHER == G8_TEMPORAL ? "g8_kernel %dch x %dpix, temporal taps" : (GATHER == G8_CONV3 ? "g8_kernel %dch x %dpix, 3x3 taps" : "g8_kernel %dch x %dpix"), BM, BN);
+        cc_note_kernel(GATHER == G8_TEMPORAL ? "g8_kernel %dch x %dpix, temporal taps" : (GATHER == G8_CONV3 ? "g8_kernel %dch x %dpix, 3x3 taps" : (GATHER == G8_SUBPIX ? "g8_kernel %dch x %dpix, upsample parity taps" : "g8_kernel %dch x %dpix")), BM, BN);
     hipLaunchKernelGGL((g8_kernel<TIH, TJH, EPI, GATHER, SPLIT, LNF>), dim3((unsigned)wgs), dim3(512), LDS, s, dd);
     return cc_launch_status("g8_kernel");
 }
@@ -885,8 +902,12 @@ bool cc_g8_applicable(const CcGemmDesc& d, int shape) {
         geo = d.taps == 3 && d.korder == 1 && d.Kpad == 3 * d.Cin && d.T > 0 && d.HW > 0 &&
               (d.Tsrc == 0 || (d.Tsrc == d.T && d.tsrc_off == 0 && d.t0 == 0 && d.Tglob == d.T)) &&      // unsharded clips only
               d.act == CCEDIT_ACT_NONE;
+    else if (d.subpix)      // one parity of upsample + conv 3x3 on the low-resolution source: 2 x 2 window, plain epilogue only
+        geo = d.taps == 4 && d.ksize == 2 && d.korder == 1 && d.Kpad == 4 * d.Cin && d.stride == 1 && !d.upsample && !d.vpad &&
+              d.Hin == d.Hout && d.Win == d.Wout && d.Hin > 1 && d.Win > 1 && d.act == CCEDIT_ACT_NONE && !d.res1 && !d.res2 &&
+              !d.group_bias && !d.gn_stats && 4 * d.M < (1LL << 31);
     else          // Conv2d 3x3, stride 1, pad 1, same-size output, no fused upsample
-        geo = d.taps == 9 && d.ksize == 3 && d.korder == 1 && d.Kpad == 9 * d.Cin && d.stride == 1 && d.pad == 1 && !d.upsample &&
+        geo = !d.vpad && d.taps == 9 && d.ksize == 3 && d.korder == 1 && d.Kpad == 9 * d.Cin && d.stride == 1 && d.pad == 1 && !d.upsample &&
               d.Hin == d.Hout && d.Win == d.Wout && d.Hin > 1 && d.Win > 1 && d.act == CCEDIT_ACT_NONE;
     return geo && d.A2 == nullptr && d.Cin % 64 == 0 && d.Kpad >= 128 && d.N % 16 == 0 &&
            (d.act == CCEDIT_ACT_NONE || d.act == CCEDIT_ACT_GEGLU) && !d.out_f32 && d.ln_eps == 0.f &&
@@ -946,6 +967,7 @@ int cc_g8_launch(const CcGemmDesc& d, hipStream_t s, int shape) {
             const bool res = d.res1 || d.res2;
             if (d.mode == CCEDIT_GEMM_TEMPORAL)
                 return res ? g8_launch_shape<2, 1, G8_RES, G8_TEMPORAL, 1>(d, s, n_cu, sk) : g8_launch_shape<2, 1, G8_PLAIN, G8_TEMPORAL, 1>(d, s, n_cu, sk);
+            if (d.mode == CCEDIT_GEMM_CONV2D && d.subpix) return g8_launch_shape<2, 1, G8_PLAIN, G8_SUBPIX, 1>(d, s, n_cu, sk);
             if (d.mode == CCEDIT_GEMM_CONV2D)
                 return res ? g8_launch_shape<2, 1, G8_RES, G8_CONV3, 1>(d, s, n_cu, sk) : g8_launch_shape<2, 1, G8_PLAIN, G8_CONV3, 1>(d, s, n_cu, sk);
             return res ? g8_launch_shape<2, 1, G8_RES, G8_LINEAR, 1>(d, s, n_cu, sk) : g8_launch_shape<2, 1, G8_PLAIN, G8_LINEAR, 1>(d, s, n_cu, sk);
@@ -953,6 +975,8 @@ int cc_g8_launch(const CcGemmDesc& d, hipStream_t s, int shape) {
     }
     const int epi = d.act == CCEDIT_ACT_GEGLU ? G8_GEGLU : ((d.res1 || d.res2) ? G8_RES : G8_PLAIN);
     const int gm = d.mode == CCEDIT_GEMM_TEMPORAL ? G8_TEMPORAL : (d.mode == CCEDIT_GEMM_CONV2D ? G8_CONV3 : G8_LINEAR);
+    if (d.mode == CCEDIT_GEMM_CONV2D && d.subpix)
+        return shape == 2 ? g8_launch_shape<1, 2, G8_PLAIN, G8_SUBPIX>(d, s, n_cu) : g8_launch_shape<2, 1, G8_PLAIN, G8_SUBPIX>(d, s, n_cu);
 #define G8_GO(TI, TJ, EP)                                                                            \
     (gm == G8_TEMPORAL ? g8_launch_shape<TI, TJ, EP, G8_TEMPORAL>(d, s, n_cu)                        \
                        : (gm == G8_CONV3 ? g8_launch_shape<TI, TJ, EP, G8_CONV3>(d, s, n_cu) : g8_launch_shape<TI, TJ, EP, G8_LINEAR>(d, s, n_cu)))

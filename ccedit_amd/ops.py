@@ -328,7 +328,7 @@ CONV1X1_LINEAR = policy.on("conv1x1_linear")      # 0: 1 x 1 convs through the c
 SUBPIX = policy.on("subpix")      # 0: upsample + 3x3 conv through the nine-tap gather (A/B)
 
 
-def conv2d_upsampled(x: torch.Tensor, pws, vpad: bool = False, halo=None) -> torch.Tensor:
+def conv2d_upsampled(x: torch.Tensor, pws, vpad: bool = False, halo=None, tile: int = 0) -> torch.Tensor:
     """conv3x3(nearest_upsample_2x(x)) as four 2 x 2 convolutions on x, one per output parity (packing.pack_upsample_parities):
     x (N, H, W, C) -> (N, 2H, 2W, Cout); every launch writes its quarter of the output pixels in place.  vpad: x carries one halo
     row above and below its H rows (RowShard, extended copy); halo = (top, bottom): the same rows as separate tensors."""
@@ -338,7 +338,7 @@ def conv2d_upsampled(x: torch.Tensor, pws, vpad: bool = False, halo=None) -> tor
     out = torch.empty((n * 4 * h * w, pws[0].n), dtype=BF16, device=x.device)
     for p, pw in enumerate(pws):
         gemm(x.reshape(-1, c), pw, mode=GEMM_CONV2D, m=n * h * w, hin=hx, win=w, hout=h, wout=w, stride=1, pad=0, out=out, subpix=p + 1,
-             vpad=vpad, halo=halo)
+             vpad=vpad, halo=halo, tile=tile)
     return out.view(n, 2 * h, 2 * w, pws[0].n)
 
 

@@ -1249,6 +1249,35 @@ def test_attention_long_pingpong_rescale_and_anchor():
            what="long anchor + self attention")
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,tile,kernel", [
+    (3, 8, 12, 128, 192, 12, "256ch x 256pix, upsample parity taps"), (1, 5, 7, 64, 64, 12, "upsample parity taps"),
+    (2, 16, 24, 64, 320, 13, "128ch x 512pix, upsample parity taps"),
+    (34, 16, 24, 1280, 1280, 0, "256ch x 256pix, upsample parity taps"), (34, 8, 12, 1280, 1280, 0, "upsample parity taps, split-K"),
+    (8, 32, 48, 640, 640, 0, "128ch x 512pix, upsample parity taps")])
+def test_upsample_parity_convs_on_the_persistent_kernel(n, h, w, cin, cout, tile, kernel):
+    """The four parity convs of upsample + conv 3x3 (CcGemmDesc.subpix) through the persistent eight-phase kernel's gather mode with a
+    2 x 2 window (gemm8p.hip: G8_SUBPIX, round 6): forced block shapes on small / odd frames, and the automatic dispatch at the
+    network's three up-sampling shapes (16x24 -> 32x48: one round of 255 tiles; 8x12 -> 16x24: split-K; 32x48 -> 64x96: 128ch x
+    512pix).  Against fp32 torch, against the generic tap-gather kernel (same products, another summation order), run-to-run."""
+    _dev()
+    from ccedit_amd import hip, ops
+    from ccedit_amd.packing import pack_upsample_parities
+    x = _rnd(n, cin, h, w, seed=1)
+    wt, b = _rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), _rnd(cout, seed=3)
+    xd = _nhwc(x)
+    par = pack_upsample_parities(wt, b, device="cuda")
+    y = ops.conv2d_upsampled(xd, par, tile=tile)
+    assert kernel in hip.lib().ccedit_last_kernel().decode(), hip.lib().ccedit_last_kernel().decode()
+    assert y.shape == (n, 2 * h, 2 * w, cout)
+    gen = ops.conv2d_upsampled(xd, par, tile=1)
+    assert "tap_gemm" in hip.lib().ccedit_last_kernel().decode()
+    _close(y, gen, rel=2.0 ** -7, abs_=2e-3, what="persistent parity convs vs the tap-gather kernel")
+    if n * h * w * cin * cout < 1 << 31:
+        ref = F.conv2d(F.interpolate(x.to(BF).float(), scale_factor=2, mode="nearest"), wt, b, padding=1)
+        _close(_nchw(y), ref, what="upsample + conv3x3 as parity convs on the persistent kernel")
+    assert torch.equal(y, ops.conv2d_upsampled(xd, par, tile=tile)), "run-to-run difference"
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout", [(3, 8, 12, 128, 192), (2, 16, 24, 64, 320), (1, 5, 7, 64, 64)])
 def test_upsample_conv_as_four_parity_convs(n, h, w, cin, cout):
     """conv3x3(nearest 2x(x)) (openaimodel.py:254-263) evaluated as four 2 x 2 convolutions on x (CcGemmDesc.subpix): against fp32 torch
