@@ -40,7 +40,6 @@ FLOP_PER_STEP_TVI2V = 110.31e12   # BASELINE.json config 3 (controlnet_img + anc
 MFMA_PEAK_TFLOPS = 2500.0         # MI355X dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0             # HBM3E spec (ibid.; a float4 copy measures 6290)
 T, H, W, L, CTX = 17, 64, 96, 77, 768
-PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"      # committed rocprofv3 PMC capture (FETCH_SIZE / WRITE_SIZE passes)
 
 
 def synth_inputs(device, seed=42, b=1):
@@ -467,9 +466,9 @@ def main():
         # MI355X_MICROARCH.md), averaged per tap_gemm launch like `achieved`.
         # The capture records the hash of the kernel sources it was taken from (tools/pmc_traffic.sh); a capture of OTHER
         # kernels is not reported: traffic stays null and the line says why.
-        pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
         roof["family_algorithmic_bytes_per_launch"] = round(g["bytes"] / g["launches"])
-        pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE.replace(".json", "_tvi2v.json")) if tvi2v else pmc
+        PMC_TRAFFIC_FILE = pmc_traffic_file(tvi2v)
+        pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
         if os.path.exists(pmc):
             with open(pmc) as f:
                 cap = json.load(f)
@@ -671,6 +670,22 @@ def max_over_ranks_ms(ms, dist, device, backend):
     tt = torch.tensor([ms], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return float(tt.item())
+
+
+def pmc_traffic_file(tvi2v: bool = False) -> str:
+    """The committed rocprofv3 PMC capture (FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.sh) to read `traffic` from: the
+    newest profiles/rNN_pmc_traffic.json taken from THIS build's kernel sources, else the newest one (reported as stale)."""
+    import glob
+    suffix = "_pmc_traffic_tvi2v.json" if tvi2v else "_pmc_traffic.json"
+    names = sorted((os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]" + suffix))), reverse=True)
+    for name in names:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                if json.load(f).get("kernel_source_hash") == kernel_source_hash():
+                    return name
+        except (OSError, ValueError):
+            continue
+    return names[0] if names else "r06" + suffix
 
 
 def kernel_source_hash() -> str:
