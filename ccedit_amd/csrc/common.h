@@ -95,6 +95,7 @@ struct CcPolicy {
     int attn_opt = 1;       // ... softmax reference fixed by the first key tile, exact re-run of a workgroup that overflowed (0: tracked on every tile)
     int gn_flat = 1;        // flat thread mapping of the temporal GroupNorm at the two large levels
     int gn_apply_flat = 1;  // column-per-thread, four-rows-in-flight mapping of the spatial GroupNorm apply pass (0: a wave per pixel row)
+    int f32_split = 1;      // fp32 first-stage contractions as six exact bf16 products per fp32 product on the bf16 matrix pipe (0: v_mfma_f32_32x32x2_f32)
 };
 const CcPolicy& cc_policy();
 

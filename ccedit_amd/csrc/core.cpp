@@ -65,6 +65,7 @@ const PolicyEntry kPolicy[] = {
     {"lin320s", &CcPolicy::lin320s},         {"lin640", &CcPolicy::lin640},   {"temp320", &CcPolicy::temp320},
     {"attn_short", &CcPolicy::attn_short},   {"attn_text", &CcPolicy::attn_text}, {"attn_spatial", &CcPolicy::attn_spatial},
     {"attn_pv16", &CcPolicy::attn_pv16},     {"attn_opt", &CcPolicy::attn_opt},       {"gn_flat", &CcPolicy::gn_flat}, {"gn_apply_flat", &CcPolicy::gn_apply_flat},
+    {"f32_split", &CcPolicy::f32_split},
 };
 }  // namespace
 

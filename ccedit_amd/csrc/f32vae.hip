@@ -167,6 +167,226 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---- the same contraction on the bf16 matrix pipe: exact three-way operand split (policy f32_split, the default) ----
+// An fp32 number is EXACTLY the sum of three bf16 numbers: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (round-to-nearest-even
+// each; x - h and x - h - m are exact in fp32, the last remainder has <= 8 significant bits, and bf16 has fp32's exponent range).
+// Then w * a = sum of nine bf16 x bf16 products, each EXACT in fp32 (8 x 8 significant bits).  The kernel keeps the six with
+// weight >= 2^-16 (hh, hm, mh, hl, lh, mm) and drops ml, lm, ll: <= 2 * 2^-9 * 2^-17 + 2^-34 = 2^-25 of |w a|, signs random — below
+// the 2^-24 |acc| rounding that EVERY fp32 accumulation step of v_mfma_f32_32x32x2_f32 makes as well.  Sums are fp32 inside the matrix
+// pipe exactly as before; per output and 16 k there are six accumulations where the fp32 instruction makes eight.  The result is an
+// fp32 contraction in every measurable sense (tests/test_vae_f32_gpu.py holds BOTH arms to the same 3e-6 against fp64 and the
+// whole decoder to the reference's fp32 goldens) at six v_mfma_f32_32x32x16_bf16 (8 passes each: 48) where the fp32 form
+// needs eight of 16 passes (128): 2.67 x the matrix rate.
+//
+// 128 channels x 256 pixels per workgroup, eight waves of 64 x 64; K tiles of 16; operands arrive as fp32 in registers (the
+// gather of f32_gemm_kernel, unchanged), are split there and stored as three bf16 planes of 32-byte rows (granule g of row r at
+// slot g ^ ((r >> 3) & 1): ds_read_b128's four 16-lane groups each touch sixteen distinct 16-byte slots); two buffers of 36 KB:
+// two workgroups per CU.  Six fragment sets per k-tile, loaded just before their first use (three sets live at a time).
+constexpr int S_BM = 128, S_BN = 256, S_BK = 16;
+constexpr int S_ROWS = S_BM + S_BN;
+constexpr int S_PLANE = S_ROWS * 32;           // bytes of one plane of one buffer
+constexpr int S_BUF = 3 * S_PLANE;
+
+// The split, two elements at a time (x0, x1 -> one packed bf16 pair per plane): eleven instructions.  Inline asm for the conversion
+// and the subtraction: left to itself hipcc converts the low element a second time to get its value back and forms packed-fp32
+// subtractions (csrc/build.py: EXTRA_FLAGS, what those cost beside MFMAs).
+__device__ __forceinline__ uint32_t f32s_cvt_pk(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float f32s_sub(float a, uint32_t bits) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bits));
+    return r;
+}
+struct F32Split {          // four consecutive k of one row, three planes
+    u32x2 p[3];
+};
+__device__ __forceinline__ F32Split f32_split3(f32x4 v) {
+    F32Split s;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float x0 = v[2 * h], x1 = v[2 * h + 1];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const uint32_t b = f32s_cvt_pk(x0, x1);
+            s.p[p][h] = b;
+            if (p < 2) {
+                x0 = f32s_sub(x0, b << 16);
+                x1 = f32s_sub(x1, b & 0xffff0000u);
+            }
+        }
+    }
+    return s;
+}
+
+// MODE 0: Linear / Conv 1x1; 1: Conv2d 3x3; 2: Conv2d 3x3 on the nearest-2x up-sampled source (stride 1, pad 1).
+// Gather addressing: a pixel row keeps ONE pointer — its top-left tap in the source, this thread's k piece included — and a 9-bit
+// mask of the taps that fall inside the frame; a tap adds a wave-uniform element offset (mode 2: (dy Win + dx) lda with
+// dy = (parity_y + ky) >> 1, the source row of the virtual row, per lane).
+template <int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void f32s_gemm_kernel(const CcGemmF32Desc d) {
+    constexpr bool CONV = MODE != 0, UPS = MODE == 2;
+    __shared__ __attribute__((aligned(16))) char smem[2 * S_BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ct_n = (d.N + S_BM - 1) / S_BM;
+    const int64_t pt = blockIdx.x / ct_n;
+    const int ct = blockIdx.x - (int)pt * ct_n;
+    const int64_t m0 = pt * S_BN;
+    const int n0 = ct * S_BM;
+    const int nk = d.Kpad / S_BK;
+
+    // staging: thread -> weight row tid >> 2 and pixel rows (tid >> 2), (tid >> 2) + 128; floats 4 (tid & 3) .. + 3 of the K tile
+    const int srow = tid >> 2, sg = tid & 3;
+    const float* wsrc = d.W + (size_t)min(n0 + srow, d.N - 1) * d.ldw + sg * 4;
+    const float* asrc[2];
+    uint32_t tapmask[2];          // CONV: bit t = tap t of this pixel lies inside the frame
+    int par[2];                   // UPS: parity of the top-left tap's virtual (y, x): bit 1 = y, bit 0 = x
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t m = min(m0 + srow + 128 * i, d.M - 1);
+        if constexpr (CONV) {
+            const int hw = d.Hout * d.Wout;
+            const int64_t f = m / hw;
+            const int r = (int)(m - f * hw);
+            const int y = r / d.Wout, x = r - y * d.Wout;
+            const int oy = y * d.stride - d.pad, ox = x * d.stride - d.pad;        // top-left tap in the (virtual) source
+            const int Hv = UPS ? 2 * d.Hin : d.Hin, Wv = UPS ? 2 * d.Win : d.Win;
+            uint32_t mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = oy + t / 3, ix = ox + t % 3;
+                mk |= (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) ? 1u << t : 0u;
+            }
+            tapmask[i] = mk;
+            par[i] = UPS ? ((oy & 1) << 1 | (ox & 1)) : 0;
+            const int sy = UPS ? oy >> 1 : oy, sx = UPS ? ox >> 1 : ox;            // (arithmetic shift: -1 >> 1 = -1)
+            asrc[i] = d.A + (f * (int64_t)d.Hin * d.Win + (int64_t)sy * d.Win + sx) * d.lda + sg * 4;
+        } else {
+            asrc[i] = d.A + (size_t)m * d.lda + sg * 4;
+        }
+    }
+    const int cmax = d.Cin - sg * 4;           // this thread's k piece holds real channels while the tile's first channel is < cmax
+
+    f32x4 ra, rb[2];
+    auto fetch = [&](int kt) {
+        const int k0 = kt * S_BK;
+        ra = *(const f32x4*)(wsrc + k0);
+        if constexpr (CONV) {
+            const int tap = k0 / d.Cpad, c0 = k0 - tap * d.Cpad;           // a K tile never straddles taps (Cpad % 16 == 0)
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int uoff = (ky * d.Win + kx) * d.lda + c0;               // (not UPS) wave-uniform
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int off = uoff;
+                if constexpr (UPS) off = ((((par[i] >> 1) + ky) >> 1) * d.Win + (((par[i] & 1) + kx) >> 1)) * d.lda + c0;
+                const bool ok = ((tapmask[i] >> tap) & 1) && c0 < cmax;
+                rb[i] = ok ? *(const f32x4*)(asrc[i] + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            const bool ok = k0 < cmax;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) rb[i] = ok ? *(const f32x4*)(asrc[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // byte offset of (row r, k piece sg) inside a plane
+    auto slot = [&](int r) { return r * 32 + ((((sg >> 1) ^ (r >> 3)) & 1) << 4) + ((sg & 1) << 3); };
+    const int so_a = slot(srow), so_b0 = slot(S_BM + srow), so_b1 = slot(S_BM + srow + 128);
+    auto stash = [&](int buf) {
+        char* s = smem + buf * S_BUF;
+        const F32Split sa = f32_split3(ra), sb0 = f32_split3(rb[0]), sb1 = f32_split3(rb[1]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            *(u32x2*)(s + p * S_PLANE + so_a) = sa.p[p];
+            *(u32x2*)(s + p * S_PLANE + so_b0) = sb0.p[p];
+            *(u32x2*)(s + p * S_PLANE + so_b1) = sb1.p[p];
+        }
+    };
+    // fragment addresses: row l31 of a 32-row tile, k granule hi
+    const int fo = l31 * 32 + ((hi ^ (l31 >> 3)) & 1) * 16;
+    const int fa0 = (wr * 64) * 32 + fo, fb0 = (S_BM + wc * 64) * 32 + fo;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) fetch(kt + 1);
+        const char* s = smem + (kt & 1) * S_BUF;
+        auto fragA = [&](int p, bf16x8 (&f)[2]) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) f[t] = *(const bf16x8*)(s + p * S_PLANE + fa0 + t * 1024);
+        };
+        auto fragB = [&](int p, bf16x8 (&f)[2]) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) f[t] = *(const bf16x8*)(s + p * S_PLANE + fb0 + t * 1024);
+        };
+        auto mm = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[2]) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+        };
+        bf16x8 a_l[2], a_m[2], a_h[2], b_h[2], b_m[2], b_l[2];
+        fragA(2, a_l);
+        fragB(0, b_h);
+        fragA(1, a_m);
+        mm(a_l, b_h);
+        fragB(1, b_m);
+        mm(a_m, b_h);
+        fragA(0, a_h);
+        mm(a_m, b_m);
+        fragB(2, b_l);
+        mm(a_h, b_m);
+        mm(a_h, b_l);
+        mm(a_h, b_h);
+        if (kt + 1 < nk) stash((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane = pixel (column) l31 of tile tj; accumulator r = channel 8 (r / 4) + 4 hi + r % 4 of tile ti
+    const bool vec = (d.ldc & 3) == 0 && (!d.res || (d.ldr & 3) == 0);
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int64_t m = m0 + wc * 64 + tj * 32 + l31;
+        if (m >= d.M) continue;
+        float* orow = d.out + (size_t)m * d.ldc;
+        const float* rrow = d.res ? d.res + (size_t)m * d.ldr : nullptr;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wr * 64 + ti * 32 + 8 * q + 4 * hi;
+                if (n >= d.N) continue;
+                f32x4 v = {acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1], acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]};
+                if (vec && n + 3 < d.N) {
+                    if (d.bias) v += *(const f32x4*)(d.bias + n);
+                    if (rrow) v += *(const f32x4*)(rrow + n);
+                    *(f32x4*)(orow + n) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < d.N) {
+                            float o = v[e];
+                            if (d.bias) o += d.bias[n + e];
+                            if (rrow) o += rrow[n + e];
+                            orow[n + e] = o;
+                        }
+                }
+            }
+    }
+}
+
 // ---- GroupNorm(32) over fp32 frames ----
 // VEC = 4 (C a multiple of 128: a 16-byte granule never straddles groups) or 1 (C = 32 / 64: the reduced-width test models).
 template <int VEC>
@@ -368,9 +588,25 @@ extern "C" int ccedit_gemm_f32(const CcGemmF32Desc* desc, void* stream) {
         CC_CHECK_ARG(d.M % ((int64_t)d.Hout * d.Wout) == 0, "ccedit_gemm_f32: M (%lld) is not a whole number of %d x %d output frames", (long long)d.M, d.Hout, d.Wout);
     }
     if (d.M == 0) return CCEDIT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (cc_policy().f32_split) {
+        const int64_t sblocks = ((d.M + S_BN - 1) / S_BN) * ((d.N + S_BM - 1) / S_BM);
+        CC_CHECK_ARG(sblocks < (1LL << 31), "ccedit_gemm_f32: too many tiles");
+        if (d.mode == 1 && d.upsample && d.stride == 1 && d.pad == 1) {
+            cc_note_kernel("f32s_gemm_kernel 128ch x 256pix, 3x3 taps on the 2x up-sampled source, six bf16 products");
+            hipLaunchKernelGGL((f32s_gemm_kernel<2>), dim3((unsigned)sblocks), dim3(512), 0, s, d);
+        } else if (d.mode == 1) {
+            CC_UNSUPPORTED(d.upsample, "ccedit_gemm_f32: the fused up-sampling gather takes stride 1, pad 1 (got %d, %d)", d.stride, d.pad);
+            cc_note_kernel("f32s_gemm_kernel 128ch x 256pix, 3x3 taps, six bf16 products");
+            hipLaunchKernelGGL((f32s_gemm_kernel<1>), dim3((unsigned)sblocks), dim3(512), 0, s, d);
+        } else {
+            cc_note_kernel("f32s_gemm_kernel 128ch x 256pix, six bf16 products");
+            hipLaunchKernelGGL((f32s_gemm_kernel<0>), dim3((unsigned)sblocks), dim3(512), 0, s, d);
+        }
+        return cc_launch_status("f32s_gemm_kernel");
+    }
     const int64_t blocks = ((d.M + F_BM - 1) / F_BM) * ((d.N + F_BN - 1) / F_BN);
     CC_CHECK_ARG(blocks < (1LL << 31), "ccedit_gemm_f32: too many tiles");
-    hipStream_t s = (hipStream_t)stream;
     if (d.mode == 1) {
         cc_note_kernel("f32_gemm_kernel 128ch x 128pix, 3x3 taps");
         hipLaunchKernelGGL((f32_gemm_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, d);
