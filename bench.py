@@ -796,15 +796,18 @@ def time_clip(wrapper, device, num_steps=30, scale=7.5, seed=43, tvi2v=False, fp
         sys.stderr.write("bench.py: the sampled clip contains non-finite values — frames_per_s withheld\n")
     res = dict(sampler_s=round(t1 - t0, 3), vae_decode_s=round(t2 - t1, 3), vae_precision=primary, evaluations=evals[0], sampler_steps=num_steps,
                cfg_scale=scale, hint_stem="once per clip", decoder_warmup="one untimed decode",
-               vae="fp32 first stage on v_mfma_f32_32x32x2_f32 — the reference decodes with autocast off (diffusion.py:151-156; the shipped yamls set "
-                   "disable_first_stage_autocast and policy vae_fp32=2, the default, follows the flag); the bf16-storage first stage (policy vae_fp32=0) "
-                   "is the *_bf16_vae figure",
+               vae="fp32 first stage — the reference decodes with autocast off (diffusion.py:151-156; the shipped yamls set disable_first_stage_autocast "
+                   "and policy vae_fp32=2, the default, follows the flag) — its contractions as "
+                   + ("six exact bf16 x bf16 products per fp32 product on v_mfma_f32_32x32x16_bf16 (exact three-way operand split, fp32 sums; policy "
+                      "f32_split=1, the default: same error against fp64 and the reference's fp32 goldens as the fp32 matrix instruction)"
+                      if policy.get("f32_split") else "v_mfma_f32_32x32x2_f32 (policy f32_split=0)")
+                   + "; the bf16-storage first stage (policy vae_fp32=0) is the *_bf16_vae figure",
                frames_per_s=round(T / (t2 - t0), 3) if finite else None, finite=finite, **out2)
     for prec, sec in dec.items():
         res[f"vae_decode_{prec}_s"] = round(sec, 3)
         res[f"frames_per_s_{prec}_vae"] = round(T / (t1 - t0 + sec), 3) if finite else None
     if "fp32" in dec:
-        res["vae_fp32_tflops"] = round(64.56 / dec["fp32"], 1)
+        res["vae_fp32_tflops"] = round(64.56 / dec["fp32"], 1)          # fp32-equivalent FLOPs of the decoder / time (the fp32 matrix peak is 157)
     return res
 
 

@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                 for (int tj = 0; tj < 2; ++tj)
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ti][j >> 2][j & 3], fb[tj][j >> 2][j & 3], acc[ti][tj], 0, 0, 0);
+#if F32S_ABL != 3
         if (kt + 1 < nk) stash((kt + 1) & 1);
+#endif
         __syncthreads();
     }
 
@@ -182,6 +184,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // gather of f32_gemm_kernel, unchanged), are split there and stored as three bf16 planes of 32-byte rows (granule g of row r at
 // slot g ^ ((r >> 3) & 1): ds_read_b128's four 16-lane groups each touch sixteen distinct 16-byte slots); two buffers of 36 KB:
 // two workgroups per CU.  Six fragment sets per k-tile, loaded just before their first use (three sets live at a time).
+#ifndef F32S_ABL
+#define F32S_ABL 0          // probe builds only (tools/exp/f32s_abl.sh): 1 no split arithmetic, 2 no loads in the loop, 3 no LDS stores in the loop, 4 no MFMAs
+#endif
 constexpr int S_BM = 128, S_BN = 256, S_BK = 16;
 constexpr int S_ROWS = S_BM + S_BN;
 constexpr int S_PLANE = S_ROWS * 32;           // bytes of one plane of one buffer
@@ -205,6 +210,12 @@ struct F32Split {          // four consecutive k of one row, three planes
 };
 __device__ __forceinline__ F32Split f32_split3(f32x4 v) {
     F32Split s;
+#if F32S_ABL == 1          // (probe builds: no split arithmetic)
+    s.p[0] = u32x2{f32s_cvt_pk(v[0], v[1]), f32s_cvt_pk(v[2], v[3])};
+    s.p[1] = s.p[0];
+    s.p[2] = s.p[0];
+    return s;
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float x0 = v[2 * h], x1 = v[2 * h + 1];
@@ -321,7 +332,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     stash(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
+#if F32S_ABL != 2
         if (kt + 1 < nk) fetch(kt + 1);
+#endif
         const char* s = smem + (kt & 1) * S_BUF;
         auto fragA = [&](int p, bf16x8 (&f)[2]) {
 #pragma unroll
@@ -335,7 +348,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+                for (int tj = 0; tj < 2; ++tj) {
+#if F32S_ABL == 4
+                    acc[ti][tj][0] += (float)a[ti][0] * (float)b[tj][0];
+#else
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+#endif
+                }
         };
         bf16x8 a_l[2], a_m[2], a_h[2], b_h[2], b_m[2], b_l[2];
         fragA(2, a_l);
@@ -385,6 +404,193 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             }
     }
+}
+
+// ---- the pipelined form of the same kernel (large M, Cout > 128): ONE 16-wave workgroup per CU, tiles two K steps ahead ----
+// The ablation of f32s_gemm_kernel (tools/exp/f32s_abl.sh, 17 x 512 x 768, 128 -> 128: 10.35 ms; without the loop's global loads 8.3;
+// without its MFMAs 6.0; without the split arithmetic 10.1) says an iteration is a load round trip (~1.5 us) that two workgroups per
+// CU overlap badly — not VALU, not LDS.  Here a workgroup is 1024 threads on 256 ch x 256 pix (4 x 4 waves of 64 x 64: the same 64
+// accumulator registers and four waves per SIMD, half the staged bytes per FLOP, TWO 16-byte pieces per thread and K tile instead of
+// three): tile kt + 2 is REQUESTED while tile kt is multiplied and tile kt + 1 — requested one iteration earlier — is split and
+// stored behind the first product groups (two register sets, two LDS buffers of 48 KB).
+constexpr int P_BM = 256, P_BN = 256;
+constexpr int P_PLANE = (P_BM + P_BN) * 32, P_BUF = 3 * P_PLANE;
+
+template <int MODE>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void f32p_gemm_kernel(const CcGemmF32Desc d) {
+    constexpr bool CONV = MODE != 0, UPS = MODE == 2;
+    extern __shared__ __attribute__((aligned(16))) char psmem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ct_n = (d.N + P_BM - 1) / P_BM;
+    const int64_t pt = blockIdx.x / ct_n;
+    const int ct = blockIdx.x - (int)pt * ct_n;
+    const int64_t m0 = pt * P_BN;
+    const int n0 = ct * P_BM;
+    const int nk = d.Kpad / S_BK;
+
+    // staging: thread -> weight row tid >> 2 and pixel row tid >> 2; floats 4 (tid & 3) .. + 3 of the K tile
+    const int srow = tid >> 2, sg = tid & 3;
+    const float* wsrc = d.W + (size_t)min(n0 + srow, d.N - 1) * d.ldw + sg * 4;
+    const float* asrc;
+    uint32_t geo = 0;             // CONV: bits 0-8 = taps inside the frame; UPS: bit 9 / 10 = parity of the top-left tap's virtual x / y
+    {
+        const int64_t m = min(m0 + srow, d.M - 1);
+        if constexpr (CONV) {
+            const int hw = d.Hout * d.Wout;
+            const int64_t f = m / hw;
+            const int r = (int)(m - f * hw);
+            const int y = r / d.Wout, x = r - y * d.Wout;
+            const int oy = y * d.stride - d.pad, ox = x * d.stride - d.pad;
+            const int Hv = UPS ? 2 * d.Hin : d.Hin, Wv = UPS ? 2 * d.Win : d.Win;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = oy + t / 3, ix = ox + t % 3;
+                geo |= (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) ? 1u << t : 0u;
+            }
+            if constexpr (UPS) geo |= (uint32_t)(ox & 1) << 9 | (uint32_t)(oy & 1) << 10;
+            const int sy = UPS ? oy >> 1 : oy, sx = UPS ? ox >> 1 : ox;
+            asrc = d.A + (f * (int64_t)d.Hin * d.Win + (int64_t)sy * d.Win + sx) * d.lda + sg * 4;
+        } else {
+            asrc = d.A + (size_t)m * d.lda + sg * 4;
+        }
+    }
+    const int cmax = d.Cin - sg * 4;
+
+    // tile kt >= nk reads as zeros (an odd tile count is rounded up: the loop below is two steps per trip, no early exit — a second
+    // exit made hipcc carry the accumulators through scratch)
+    auto fetch = [&](int kt, f32x4& ra, f32x4& rb) {
+        const int k0 = kt * S_BK;
+        const bool live = kt < nk;
+        ra = live ? *(const f32x4*)(wsrc + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (CONV) {
+            const int tap = k0 / d.Cpad, c0 = k0 - tap * d.Cpad;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            int off = (ky * d.Win + kx) * d.lda + c0;
+            if constexpr (UPS) off = (((((geo >> 10) & 1) + ky) >> 1) * d.Win + ((((geo >> 9) & 1) + kx) >> 1)) * d.lda + c0;
+            const bool ok = live && ((geo >> tap) & 1) && c0 < cmax;
+            rb = ok ? *(const f32x4*)(asrc + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            rb = live && k0 < cmax ? *(const f32x4*)(asrc + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // byte offset of (row srow, k piece sg) inside the weight half of a plane; the pixel rows follow P_BM rows later
+    const int so = srow * 32 + ((((sg >> 1) ^ (srow >> 3)) & 1) << 4) + ((sg & 1) << 3);
+    auto stash = [&](char* s, f32x4 ra, f32x4 rb) {
+        const F32Split sa = f32_split3(ra), sb = f32_split3(rb);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            *(u32x2*)(s + p * P_PLANE + so) = sa.p[p];
+            *(u32x2*)(s + p * P_PLANE + P_BM * 32 + so) = sb.p[p];
+        }
+    };
+    const int fo = l31 * 32 + ((hi ^ (l31 >> 3)) & 1) * 16;
+    const int fa0 = (wr * 64) * 32 + fo, fb0 = (P_BM + wc * 64) * 32 + fo;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+    // one K tile: six product groups on buffer `buf`; the NEXT tile (already in ra / rb) is split and stored into the other buffer
+    // behind the second group (after the last tile: zeros into a buffer nobody reads)
+    auto step = [&](int buf, f32x4 ra, f32x4 rb) {
+        const char* s = psmem + buf * P_BUF;
+        auto fragA = [&](int p, bf16x8 (&f)[2]) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) f[t] = *(const bf16x8*)(s + p * P_PLANE + fa0 + t * 1024);
+        };
+        auto fragB = [&](int p, bf16x8 (&f)[2]) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) f[t] = *(const bf16x8*)(s + p * P_PLANE + fb0 + t * 1024);
+        };
+        auto mm = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[2]) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+        };
+        bf16x8 a_l[2], a_m[2], a_h[2], b_h[2], b_m[2], b_l[2];
+        __builtin_amdgcn_sched_barrier(0);          // (the scheduler otherwise carries MFMAs across the workgroup barrier and spills accumulators)
+        fragA(2, a_l);
+        fragB(0, b_h);
+        fragA(1, a_m);
+        mm(a_l, b_h);
+        fragB(1, b_m);
+        mm(a_m, b_h);
+        __builtin_amdgcn_sched_barrier(0);
+        stash(psmem + (buf ^ 1) * P_BUF, ra, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        fragA(0, a_h);
+        mm(a_m, b_m);
+        fragB(2, b_l);
+        mm(a_h, b_m);
+        mm(a_h, b_l);
+        mm(a_h, b_h);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    f32x4 ra0, rb0, ra1, rb1;
+    fetch(0, ra0, rb0);
+    fetch(1, ra1, rb1);
+    stash(psmem, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        // LDS buffer 0 holds tile kt, register set 1 tile kt + 1; set 0 is free
+        fetch(kt + 2, ra0, rb0);
+        step(0, ra1, rb1);
+        __syncthreads();
+        fetch(kt + 3, ra1, rb1);
+        step(1, ra0, rb0);
+        __syncthreads();
+    }
+
+    const bool vec = (d.ldc & 3) == 0 && (!d.res || (d.ldr & 3) == 0);
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int64_t m = m0 + wc * 64 + tj * 32 + l31;
+        if (m >= d.M) continue;
+        float* orow = d.out + (size_t)m * d.ldc;
+        const float* rrow = d.res ? d.res + (size_t)m * d.ldr : nullptr;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wr * 64 + ti * 32 + 8 * q + 4 * hi;
+                if (n >= d.N) continue;
+                f32x4 v = {acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1], acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]};
+                if (vec && n + 3 < d.N) {
+                    if (d.bias) v += *(const f32x4*)(d.bias + n);
+                    if (rrow) v += *(const f32x4*)(rrow + n);
+                    *(f32x4*)(orow + n) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < d.N) {
+                            float o = v[e];
+                            if (d.bias) o += d.bias[n + e];
+                            if (rrow) o += rrow[n + e];
+                            orow[n + e] = o;
+                        }
+                }
+            }
+    }
+}
+
+template <int MODE>
+static int f32p_launch(const CcGemmF32Desc& d, hipStream_t s) {
+    constexpr int LDS = 2 * P_BUF;
+    static unsigned long long done = 0;
+    const int rc = cc_max_dynamic_lds((const void*)f32p_gemm_kernel<MODE>, LDS, &done, "f32p_gemm_kernel");
+    if (rc != CCEDIT_OK) return rc;
+    const int64_t blocks = ((d.M + P_BN - 1) / P_BN) * ((d.N + P_BM - 1) / P_BM);
+    cc_note_kernel("f32p_gemm_kernel 256ch x 256pix%s, six bf16 products", MODE == 2 ? ", 3x3 taps on the 2x up-sampled source" : MODE == 1 ? ", 3x3 taps" : "");
+    hipLaunchKernelGGL((f32p_gemm_kernel<MODE>), dim3((unsigned)blocks), dim3(1024), LDS, s, d);
+    return cc_launch_status("f32p_gemm_kernel");
 }
 
 // ---- GroupNorm(32) over fp32 frames ----
@@ -592,11 +798,16 @@ extern "C" int ccedit_gemm_f32(const CcGemmF32Desc* desc, void* stream) {
     if (cc_policy().f32_split) {
         const int64_t sblocks = ((d.M + S_BN - 1) / S_BN) * ((d.N + S_BM - 1) / S_BM);
         CC_CHECK_ARG(sblocks < (1LL << 31), "ccedit_gemm_f32: too many tiles");
+        const int ups = d.mode == 1 && d.upsample;
+        CC_UNSUPPORTED(ups && !(d.stride == 1 && d.pad == 1), "ccedit_gemm_f32: the fused up-sampling gather takes stride 1, pad 1 (got %d, %d)", d.stride, d.pad);
+        if (cc_policy().f32_split == 1 && d.M >= 8192 && d.N > 128) {          // (2: always the two-workgroups-per-CU kernel)
+            const int mode = ups ? 2 : d.mode;
+            return mode == 2 ? f32p_launch<2>(d, s) : mode == 1 ? f32p_launch<1>(d, s) : f32p_launch<0>(d, s);
+        }
         if (d.mode == 1 && d.upsample && d.stride == 1 && d.pad == 1) {
             cc_note_kernel("f32s_gemm_kernel 128ch x 256pix, 3x3 taps on the 2x up-sampled source, six bf16 products");
             hipLaunchKernelGGL((f32s_gemm_kernel<2>), dim3((unsigned)sblocks), dim3(512), 0, s, d);
         } else if (d.mode == 1) {
-            CC_UNSUPPORTED(d.upsample, "ccedit_gemm_f32: the fused up-sampling gather takes stride 1, pad 1 (got %d, %d)", d.stride, d.pad);
             cc_note_kernel("f32s_gemm_kernel 128ch x 256pix, 3x3 taps, six bf16 products");
             hipLaunchKernelGGL((f32s_gemm_kernel<1>), dim3((unsigned)sblocks), dim3(512), 0, s, d);
         } else {
