@@ -130,9 +130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                 for (int tj = 0; tj < 2; ++tj)
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ti][j >> 2][j & 3], fb[tj][j >> 2][j & 3], acc[ti][tj], 0, 0, 0);
-#if F32S_ABL != 3
         if (kt + 1 < nk) stash((kt + 1) & 1);
-#endif
         __syncthreads();
     }
 
@@ -185,7 +183,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // slot g ^ ((r >> 3) & 1): ds_read_b128's four 16-lane groups each touch sixteen distinct 16-byte slots); two buffers of 36 KB:
 // two workgroups per CU.  Six fragment sets per k-tile, loaded just before their first use (three sets live at a time).
 #ifndef F32S_ABL
-#define F32S_ABL 0          // probe builds only (tools/exp/f32s_abl.sh): 1 no split arithmetic, 2 no loads in the loop, 3 no LDS stores in the loop, 4 no MFMAs
+#define F32S_ABL 0          // probe builds only (tools/exp/f32s_abl.sh): 1 no split arithmetic, 2 no loads in the loop, 3 no LDS stores in the loop, 4 no MFMAs, 5 (f32p) no workgroup barriers in the loop
 #endif
 constexpr int S_BM = 128, S_BN = 256, S_BK = 16;
 constexpr int S_ROWS = S_BM + S_BN;
@@ -369,7 +367,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         mm(a_h, b_m);
         mm(a_h, b_l);
         mm(a_h, b_h);
+#if F32S_ABL != 3
         if (kt + 1 < nk) stash((kt + 1) & 1);
+#endif
         __syncthreads();
     }
 
@@ -512,7 +512,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+                for (int tj = 0; tj < 2; ++tj) {
+#if F32S_ABL == 4
+                    acc[ti][tj][0] += (float)a[ti][0] * (float)b[tj][0];
+#else
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+#endif
+                }
         };
         bf16x8 a_l[2], a_m[2], a_h[2], b_h[2], b_m[2], b_l[2];
         __builtin_amdgcn_sched_barrier(0);          // (the scheduler otherwise carries MFMAs across the workgroup barrier and spills accumulators)
@@ -523,7 +529,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         fragB(1, b_m);
         mm(a_m, b_h);
         __builtin_amdgcn_sched_barrier(0);
+#if F32S_ABL != 3
         stash(psmem + (buf ^ 1) * P_BUF, ra, rb);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         fragA(0, a_h);
         mm(a_m, b_m);
@@ -541,12 +549,20 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
         // LDS buffer 0 holds tile kt, register set 1 tile kt + 1; set 0 is free
+#if F32S_ABL != 2
         fetch(kt + 2, ra0, rb0);
+#endif
         step(0, ra1, rb1);
+#if F32S_ABL != 5
         __syncthreads();
+#endif
+#if F32S_ABL != 2
         fetch(kt + 3, ra1, rb1);
+#endif
         step(1, ra0, rb0);
+#if F32S_ABL != 5
         __syncthreads();
+#endif
     }
 
     const bool vec = (d.ldc & 3) == 0 && (!d.res || (d.ldr & 3) == 0);
