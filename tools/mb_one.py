@@ -63,6 +63,13 @@ elif which == "attnq80":         # the 32x48 level: 1536 keys, d = 80, q in log2
 elif which == "attn":
     q = torch.randn(N * 6144, 960, device="cuda").to(BF)
     f = lambda: ops.attention(q[:, :320], q[:, 320:640], q[:, 640:], 8, 40, batches=N, lq=6144, lk=6144)
+elif which in ("f32conv", "f32conv128"):   # fp32 first stage: 3x3 conv 512 -> 512 at 128x192 (f32p_gemm_kernel) / 128 -> 128 at 512x768 (f32s_gemm_kernel), 17 frames;
+    from ccedit_amd import vae_f32 as V          # CCEDIT_POLICY=f32_split=0 puts both on v_mfma_f32_32x32x2_f32 (f32_gemm_kernel)
+    cin, hh, ww = (512, 128, 192) if which == "f32conv" else (128, 512, 768)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(17, hh, ww, cin, generator=g).to("cuda")
+    pw = V.pack_f32(torch.randn(cin, cin, 3, 3, generator=g) * (9 * cin) ** -0.5, torch.randn(cin, generator=g), "cuda")
+    f = lambda: V.conv2d_f32(x, pw)
 for _ in range(4):
     f()
 torch.cuda.synchronize()

@@ -27,9 +27,10 @@ python $R/tools/prof_summary.py /tmp/pf_vae32 $O/${tag}_vae_fp32_kernel_stats.tx
 PMC_JSON=$O/${tag}_pmc_traffic.json bash $R/tools/pmc_traffic.sh > $O/${tag}_pmc_traffic.txt 2>&1
 if [ "${PROFILE_TVI2V:-0}" = 1 ]; then PMC_BENCH_ARGS="--workload tvi2v" PMC_JSON=$O/${tag}_pmc_traffic_tvi2v.json bash $R/tools/pmc_traffic.sh > $O/${tag}_pmc_traffic_tvi2v.txt 2>&1; fi
 # matrix-pipe / VALU counters of the dominant kernels (tools/pmc_counters.sh: two --pmc passes each, --kernel-trace only); round 5: the feed-forward alone and as the block tail;
-# round 6: the spatial attention with the optimistic reference against the tracked one, the 3x3 conv with the four-slot weight ring against the two-slot one
+# round 6: the spatial attention with the optimistic reference against the tracked one, the 3x3 conv with the four-slot weight ring against the two-slot one,
+# the fp32 first stage's 3x3 conv as six bf16 products (f32p / f32s) against the fp32 matrix instruction
 rm -f $O/${tag}_pmc_counters.txt
-for spec in "ff320|ff320|" "ff320|ff320tail|" "attn_spatial|attnq|" "attn_spatial|attnq|attn_opt=0" "attn_spatial|attnq80|" "attn_spatial|attnq80|attn_opt=0" "conv_halo|conv|" "conv_halo|conv|conv_halo=2" "g8_kernel|g8geglu|"; do
+for spec in "f32p_gemm|f32conv|" "f32_gemm|f32conv|f32_split=0" "f32s_gemm|f32conv128|" "ff320|ff320|" "ff320|ff320tail|" "attn_spatial|attnq|" "attn_spatial|attnq|attn_opt=0" "attn_spatial|attnq80|" "attn_spatial|attnq80|attn_opt=0" "conv_halo|conv|" "conv_halo|conv|conv_halo=2" "g8_kernel|g8geglu|"; do
   IFS='|' read -r pat case pol <<< "$spec"
   echo "=== $case ($pat) CCEDIT_POLICY='$pol' ===" >> $O/${tag}_pmc_counters.txt
   CCEDIT_POLICY="$pol" bash $R/tools/pmc_counters.sh $pat $case >> $O/${tag}_pmc_counters.txt 2>&1
