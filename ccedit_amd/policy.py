@@ -58,7 +58,7 @@ TABLE = {
     "gn_flat": (1, "lib", "0: temporal GroupNorm through the per-pixel kernels at the two large levels"),
     "gn_apply_flat": (1, "lib", "0: spatial GroupNorm apply with a wave per pixel row instead of a granule column per thread"),
     "f32_split": (1, "lib", "0: the fp32 first stage's contractions on v_mfma_f32_32x32x2_f32 instead of six exact bf16 x bf16 products per fp32 product "
-                            "(three-way operand split, the dropped terms below fp32's own accumulation rounding) on the bf16 matrix pipe"),
+                            "(three-way operand split, the dropped terms below fp32's own accumulation rounding) on the bf16 matrix pipe; 2: the split form on the eight-wave kernel only"),
 }
 
 _values: Dict[str, int] = {}

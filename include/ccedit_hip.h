@@ -46,7 +46,8 @@ int ccedit_device_info(char* name, int name_len);
 /* Dispatch policy: ONE table of named integer switches that choose between kernels computing the same fp32 sums in a different order
  * (A/B arms and the "specialised kernels reproduce the generic ones" tests).  All default to the fast path.  The library never reads
  * the environment; the host sets entries before launching (process-wide, not thread-safe against concurrent launches).  Names:
- *   conv_halo g8 g8_conv g8_temporal g8_split lin320 lin320s lin640 temp320 attn_short attn_text attn_spatial attn_pv16 gn_flat gn_apply_flat
+ *   conv_halo g8 g8_conv g8_temporal g8_split lin320 lin320s lin640 temp320 attn_short attn_text attn_spatial attn_pv16 attn_opt gn_flat
+ *   gn_apply_flat f32_split
  *   (ccedit_policy_names() returns them comma-separated; semantics in csrc/common.h: CcPolicy)
  * Unknown name: CCEDIT_EINVAL. */
 int ccedit_policy_set(const char* name, int32_t value);
@@ -363,8 +364,12 @@ int ccedit_gaussian_sample(const float* moments, const float* noise, float* out,
 
 /* ------------------------------------------------------------------------------------------
  * fp32 first-stage model (ABI 11).  The reference decodes with autocast disabled (sgm/models/diffusion.py:151-156): fp32 operands,
- * products and tensors.  These three entry points evaluate the KL-VAE in that arithmetic class on the fp32 matrix instruction
- * (v_mfma_f32_32x32x2_f32); the bf16 kernels above remain the default (ccedit_amd/vae.py, policy `vae_fp32`).
+ * products and tensors.  These three entry points evaluate the KL-VAE in that arithmetic class: fp32 tensors in and out, fp32 sums.
+ * ccedit_gemm_f32 has two realisations of the same fp32 contraction (policy `f32_split`): 1 (default, round 6) — every fp32 operand is
+ * split EXACTLY into three bf16 numbers and an fp32 product is formed as six exact bf16 x bf16 products on v_mfma_f32_32x32x16_bf16 (the
+ * dropped terms are <= 2^-25 of the product, below the rounding of any fp32 accumulation step); 0 — v_mfma_f32_32x32x2_f32; 2 — as 1 but only
+ * the eight-wave kernel.  Same descriptor, same results to fp32 rounding (tests/test_vae_f32_gpu.py holds both to the same tolerances).
+ * The engine selects the fp32 first stage from the yaml (ccedit_amd/vae.py, policy `vae_fp32`).
  *
  * ccedit_gemm_f32: out[m][n] = bias[n] + sum_k W[n][k] * src(A)[m][k] (+ res[m][n]); everything fp32, channels-last rows.
  *   mode 0  Linear / Conv 1x1: A [M][lda], k = channel < Cin (Cin % 4 == 0); W [N][ldw] with Kpad = Cpad = Cin rounded up to 16,

@@ -25,9 +25,8 @@ for n in (320,):          # (the folded form serves single-slice layers only: op
 # VERDICT r5 item 9 (GroupNorm apply, no SiLU, inside lin320s' LDS row pass in front of proj_in): what an in-LDS row pass costs is the
 # difference "folded - lin320" above (the LayerNorm variant: statistics + normalise + write back + one more barrier per 32-pixel tile);
 # what it would replace is the spatial GroupNorm's APPLY pass (statistics come from the producer's epilogue):
-x4 = [t_.view(34, 64, 96, 320) for t_ in a]
 gn_g, gn_b = torch.ones(320, device="cuda"), torch.zeros(320, device="cuda")
 def gn_apply(x):
-    return ops.groupnorm_spatial(x, gn_g, gn_b, 1e-6, False)
+    return ops.groupnorm_spatial(x.view(34, 64, 96, 320), gn_g, gn_b, 1e-6, False)
 print(f"spatial GroupNorm (no SiLU) 34 x 64 x 96 x 320, statistics pass + apply pass: {t(gn_apply):.1f} us "
       f"(the apply pass alone is the `gn_spatial_apply (statistics from the producer)` row of bench.py --breakdown)")
