@@ -418,7 +418,10 @@ constexpr int P_PLANE = (P_BM + P_BN) * 32, P_BUF = 3 * P_PLANE;
 
 template <int MODE>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void f32p_gemm_kernel(const CcGemmF32Desc d) {
-    constexpr bool CONV = MODE != 0, UPS = MODE == 2;
+    // MODE 3: one output parity (py, px) = d.upsample - 2 of `conv3x3(nearest_upsample_2x(x))` as a 2 x 2 convolution on x itself
+    // (model.py:56-71; the merged taps are the packer's, vae_f32.pack_f32_parities): K = [4][Cpad], the window of low-resolution
+    // pixel (y, x) starts at (y - 1 + py, x - 1 + px), its output row is pixel (2 y + py, 2 x + px) of the up-sampled frame.
+    constexpr bool CONV = MODE != 0, UPS = MODE == 2, PAR = MODE == 3;
     extern __shared__ __attribute__((aligned(16))) char psmem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -442,11 +445,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const int64_t f = m / hw;
             const int r = (int)(m - f * hw);
             const int y = r / d.Wout, x = r - y * d.Wout;
-            const int oy = y * d.stride - d.pad, ox = x * d.stride - d.pad;
+            const int oy = PAR ? y - 1 + ((d.upsample - 2) >> 1) : y * d.stride - d.pad;
+            const int ox = PAR ? x - 1 + ((d.upsample - 2) & 1) : x * d.stride - d.pad;
             const int Hv = UPS ? 2 * d.Hin : d.Hin, Wv = UPS ? 2 * d.Win : d.Win;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int iy = oy + t / 3, ix = ox + t % 3;
+            for (int t = 0; t < (PAR ? 4 : 9); ++t) {
+                const int iy = oy + (PAR ? t >> 1 : t / 3), ix = ox + (PAR ? t & 1 : t % 3);
                 geo |= (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) ? 1u << t : 0u;
             }
             if constexpr (UPS) geo |= (uint32_t)(ox & 1) << 9 | (uint32_t)(oy & 1) << 10;
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         ra = live ? *(const f32x4*)(wsrc + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (CONV) {
             const int tap = k0 / d.Cpad, c0 = k0 - tap * d.Cpad;
-            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int ky = PAR ? tap >> 1 : tap / 3, kx = PAR ? tap & 1 : tap - 3 * ky;
             int off = (ky * d.Win + kx) * d.lda + c0;
             if constexpr (UPS) off = (((((geo >> 10) & 1) + ky) >> 1) * d.Win + ((((geo >> 9) & 1) + kx) >> 1)) * d.lda + c0;
             const bool ok = live && ((geo >> tap) & 1) && c0 < cmax;
@@ -570,7 +574,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     for (int tj = 0; tj < 2; ++tj) {
         const int64_t m = m0 + wc * 64 + tj * 32 + l31;
         if (m >= d.M) continue;
-        float* orow = d.out + (size_t)m * d.ldc;
+        size_t orow_i = (size_t)m;
+        if constexpr (PAR) {
+            const int hw = d.Hin * d.Win;
+            const int64_t f = m / hw;
+            const int r = (int)(m - f * hw);
+            const int y = r / d.Win, x = r - y * d.Win;
+            orow_i = ((size_t)f * 2 * d.Hin + 2 * y + ((d.upsample - 2) >> 1)) * (2 * d.Win) + 2 * x + ((d.upsample - 2) & 1);
+        }
+        float* orow = d.out + orow_i * d.ldc;
         const float* rrow = d.res ? d.res + (size_t)m * d.ldr : nullptr;
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
@@ -604,7 +616,8 @@ static int f32p_launch(const CcGemmF32Desc& d, hipStream_t s) {
     const int rc = cc_max_dynamic_lds((const void*)f32p_gemm_kernel<MODE>, LDS, &done, "f32p_gemm_kernel");
     if (rc != CCEDIT_OK) return rc;
     const int64_t blocks = ((d.M + P_BN - 1) / P_BN) * ((d.N + P_BM - 1) / P_BM);
-    cc_note_kernel("f32p_gemm_kernel 256ch x 256pix%s, six bf16 products", MODE == 2 ? ", 3x3 taps on the 2x up-sampled source" : MODE == 1 ? ", 3x3 taps" : "");
+    cc_note_kernel("f32p_gemm_kernel 256ch x 256pix%s, six bf16 products",
+                   MODE == 3 ? ", upsample parity taps" : MODE == 2 ? ", 3x3 taps on the 2x up-sampled source" : MODE == 1 ? ", 3x3 taps" : "");
     hipLaunchKernelGGL((f32p_gemm_kernel<MODE>), dim3((unsigned)blocks), dim3(1024), LDS, s, d);
     return cc_launch_status("f32p_gemm_kernel");
 }
@@ -797,7 +810,9 @@ extern "C" int ccedit_gemm_f32(const CcGemmF32Desc* desc, void* stream) {
     CC_CHECK_ARG(d.mode == 0 || d.mode == 1, "ccedit_gemm_f32: mode %d (0 = Linear / Conv 1x1, 1 = Conv2d 3x3)", d.mode);
     CC_CHECK_ARG(d.Cin % 4 == 0 && d.lda % 4 == 0 && d.lda >= d.Cin, "ccedit_gemm_f32: Cin (%d) and lda (%d) must be multiples of 4, lda >= Cin", d.Cin, d.lda);
     CC_CHECK_ARG(d.Cpad % 16 == 0 && d.Cpad >= d.Cin, "ccedit_gemm_f32: Cpad (%d) must be a multiple of 16 and >= Cin", d.Cpad);
-    CC_CHECK_ARG(d.Kpad == (d.mode == 1 ? 9 : 1) * d.Cpad && d.ldw >= d.Kpad && d.ldw % 4 == 0,
+    const bool parity = d.mode == 1 && d.upsample >= 2;          // one output parity of upsample + conv 3x3: four merged taps
+    CC_CHECK_ARG(d.upsample >= 0 && d.upsample <= 5, "ccedit_gemm_f32: upsample %d (0 none, 1 fused nearest-2x source, 2 + 2 py + px = one output parity)", d.upsample);
+    CC_CHECK_ARG(d.Kpad == (d.mode == 1 ? (parity ? 4 : 9) : 1) * d.Cpad && d.ldw >= d.Kpad && d.ldw % 4 == 0,
                  "ccedit_gemm_f32: Kpad (%d) must be taps x Cpad, ldw (%d) >= Kpad and a multiple of 4", d.Kpad, d.ldw);
     CC_CHECK_ARG(d.ldc >= d.N && (!d.res || d.ldr >= d.N), "ccedit_gemm_f32: ldc / ldr smaller than N");
     CC_CHECK_ARG(((uintptr_t)d.A | (uintptr_t)d.W) % 16 == 0, "ccedit_gemm_f32: A and W must be 16-byte aligned");
@@ -805,8 +820,10 @@ extern "C" int ccedit_gemm_f32(const CcGemmF32Desc* desc, void* stream) {
                      (!d.res || d.ldr % 4 != 0 || (uintptr_t)d.res % 16 == 0),
                  "ccedit_gemm_f32: out / bias / res must be 16-byte aligned when their row stride is a multiple of 4");
     if (d.mode == 1) {
-        CC_CHECK_ARG(d.Hin > 0 && d.Win > 0 && d.Hout > 0 && d.Wout > 0 && d.stride >= 1 && d.pad >= 0 && (d.upsample == 0 || d.upsample == 1),
-                     "ccedit_gemm_f32: bad convolution geometry");
+        CC_CHECK_ARG(d.Hin > 0 && d.Win > 0 && d.Hout > 0 && d.Wout > 0 && d.stride >= 1 && d.pad >= 0, "ccedit_gemm_f32: bad convolution geometry");
+        CC_CHECK_ARG(!parity || (d.Hout == d.Hin && d.Wout == d.Win && d.stride == 1 && d.pad == 1 && !d.res),
+                     "ccedit_gemm_f32: a parity conv runs over the SOURCE pixels (Hout x Wout = Hin x Win, stride 1, pad 1, no residual); out holds the 2 Hin x 2 Win frames");
+        CC_UNSUPPORTED(parity && cc_policy().f32_split == 0, "ccedit_gemm_f32: the parity form of upsample + conv exists on the six-product kernels only (policy f32_split)");
         CC_CHECK_ARG(d.M % ((int64_t)d.Hout * d.Wout) == 0, "ccedit_gemm_f32: M (%lld) is not a whole number of %d x %d output frames", (long long)d.M, d.Hout, d.Wout);
     }
     if (d.M == 0) return CCEDIT_OK;
@@ -816,6 +833,7 @@ extern "C" int ccedit_gemm_f32(const CcGemmF32Desc* desc, void* stream) {
         CC_CHECK_ARG(sblocks < (1LL << 31), "ccedit_gemm_f32: too many tiles");
         const int ups = d.mode == 1 && d.upsample;
         CC_UNSUPPORTED(ups && !(d.stride == 1 && d.pad == 1), "ccedit_gemm_f32: the fused up-sampling gather takes stride 1, pad 1 (got %d, %d)", d.stride, d.pad);
+        if (parity) return f32p_launch<3>(d, s);
         if (cc_policy().f32_split == 1 && d.M >= 8192 && d.N > 128) {          // (2: always the two-workgroups-per-CU kernel)
             const int mode = ups ? 2 : d.mode;
             return mode == 2 ? f32p_launch<2>(d, s) : mode == 1 ? f32p_launch<1>(d, s) : f32p_launch<0>(d, s);

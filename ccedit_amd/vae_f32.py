@@ -45,6 +45,9 @@ def pack_f32(weight: torch.Tensor, bias: Optional[torch.Tensor], device) -> Pack
     if w.dim() == 4 and w.shape[2] == 3:
         o, i = w.shape[:2]
         taps, w3 = 9, w.permute(0, 2, 3, 1).reshape(o, 9, i)          # tap = 3 ky + kx
+    elif w.dim() == 4 and w.shape[2] == 2:                            # a parity window of upsample + conv (pack_f32_parities)
+        o, i = w.shape[:2]
+        taps, w3 = 4, w.permute(0, 2, 3, 1).reshape(o, 4, i)          # tap = 2 dy + dx
     else:
         o, i = w.shape[:2]
         taps, w3 = 1, w.reshape(o, 1, i)
@@ -53,6 +56,28 @@ def pack_f32(weight: torch.Tensor, bias: Optional[torch.Tensor], device) -> Pack
     p[:, :, :i] = w3
     b = None if bias is None else bias.detach().to(device=device, dtype=F32).contiguous()
     return PackedF32(p.reshape(o, taps * cpad).contiguous().to(device), b, o, _ceil(i, 4), cpad, taps)
+
+
+def pack_f32_parities(weight: torch.Tensor, bias: Optional[torch.Tensor], device):
+    """conv3x3(nearest_upsample_2x(x)) (model.py:56-71) as four 2 x 2 convolutions on x itself, one per output parity (py, px): output
+    pixel (2y + py, 2x + px) reads up-sampled rows 2y + py - 1 + ky, i.e. source rows y - 1, y, y for py = 0 and y, y, y + 1 for py = 1;
+    taps that land on the same source pixel are added up (in fp64, one fp32 rounding per merged tap).  4/9 of the multiply-adds of the
+    nine-tap gather; the sum of two or four products w_i x becomes (sum w_i) x — equal to fp32 rounding, not bit for bit.  Returns the
+    four PackedF32 in CcGemmF32Desc.upsample order p = 2 py + px (the bf16 path's packing.pack_upsample_parities restated for fp32)."""
+    w = weight.detach().to(dtype=torch.float64, device="cpu")
+    assert w.ndim == 4 and w.shape[2] == 3 and w.shape[3] == 3
+    merge = (((0,), (1, 2)), ((0, 1), (2,)))               # parity -> for each of the two window positions, the 3 x 3 taps it collects
+    out = []
+    for py in range(2):
+        for px in range(2):
+            w2 = torch.zeros(w.shape[0], w.shape[1], 2, 2, dtype=torch.float64)
+            for dy in range(2):
+                for dx in range(2):
+                    for ky in merge[py][dy]:
+                        for kx in merge[px][dx]:
+                            w2[:, :, dy, dx] += w[:, :, ky, kx]
+            out.append(pack_f32(w2.to(F32), bias, device))
+    return out
 
 
 def _chk(t: torch.Tensor, name: str):
@@ -78,8 +103,8 @@ def gemm_f32(a2d: torch.Tensor, pw: PackedF32, *, m: Optional[int] = None, conv=
         _chk(res, "gemm_f32.res")
         d.res, d.ldr = res.data_ptr(), res.stride(0)
     if conv is not None:
-        if pw.taps != 9:
-            raise ValueError("gemm_f32: conv geometry given for a 1x1 weight")
+        if pw.taps != (4 if int(conv[6]) >= 2 else 9):
+            raise ValueError("gemm_f32: conv geometry given for a 1x1 weight (or a parity geometry for a nine-tap weight)")
         d.mode = 1
         d.Hin, d.Win, d.Hout, d.Wout, d.stride, d.pad, d.upsample = (int(v) for v in conv)
     elif pw.taps != 1:
@@ -100,6 +125,29 @@ def conv2d_f32(x: torch.Tensor, pw: PackedF32, stride: int = 1, pad: int = 1, up
     out = gemm_f32(x.reshape(-1, c), pw, m=n * hout * wout, conv=(h, w, hout, wout, stride, pad, int(upsample)),
                    res=None if res is None else res.reshape(-1, res.shape[-1]), ldc=ldc)
     return out.view(n, hout, wout, out.shape[-1])
+
+
+def parity_form_available() -> bool:
+    """upsample + conv 3x3 as four parity convs: host policy `subpix` (shared with the bf16 path) and the six-product kernels (library
+    policy `f32_split`, read from the library: tests flip it at run time)."""
+    import ctypes
+    from . import policy
+    v = ctypes.c_int32(0)
+    hip.check(hip.lib().ccedit_policy_get(b"f32_split", ctypes.byref(v)), "ccedit_policy_get")
+    return policy.on("subpix") and v.value != 0
+
+
+def upsample_conv2d_f32(x: torch.Tensor, conv) -> torch.Tensor:
+    """conv3x3(nearest_upsample_2x(x)), x (N, H, W, C) fp32 -> (N, 2H, 2W, Cout): four parity convs on x (4/9 of the FLOPs) where the
+    six-product kernels run, else the nine-tap gather over the virtual up-sampled source."""
+    if not parity_form_available():
+        return conv2d_f32(x, _pw(conv), upsample=True)
+    n, h, w, c = x.shape
+    packs = _pw_parities(conv)
+    out = torch.empty((n, 2 * h, 2 * w, packs[0].n), dtype=F32, device=x.device)
+    for p, pw in enumerate(packs):
+        gemm_f32(x.reshape(-1, c), pw, m=n * h * w, conv=(h, w, h, w, 1, 1, 2 + p), out=out.view(-1, pw.n))
+    return out
 
 
 _gn_ws = {}
@@ -135,6 +183,14 @@ def _pw(conv) -> PackedF32:
     ent = getattr(conv, "_pw32", None)
     if ent is None or ent[0] != PACK_GENERATION[0] or ent[1].w.device != conv.pw.w.device:
         ent = conv._pw32 = (PACK_GENERATION[0], pack_f32(conv.weight, conv.bias, conv.pw.w.device))
+    return ent[1]
+
+
+def _pw_parities(conv):
+    from .layers import PACK_GENERATION
+    ent = getattr(conv, "_pw32p", None)
+    if ent is None or ent[0] != PACK_GENERATION[0] or ent[1][0].w.device != conv.pw.w.device:
+        ent = conv._pw32p = (PACK_GENERATION[0], pack_f32_parities(conv.weight, conv.bias, conv.pw.w.device))
     return ent[1]
 
 
@@ -182,7 +238,7 @@ def decoder(dec, z4: torch.Tensor) -> torch.Tensor:
         for i in range(dec.num_res_blocks + 1):
             h = resnet_block(dec.up[lvl].block[i], h)
         if lvl != 0:
-            h = conv2d_f32(h, _pw(dec.up[lvl].upsample.conv), upsample=True)
+            h = upsample_conv2d_f32(h, dec.up[lvl].upsample.conv)
     a = groupnorm_f32(h, dec.norm_out.g, dec.norm_out.b, GN_EPS, True)
     del h
     n, hh, ww, _ = a.shape
