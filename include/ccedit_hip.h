@@ -379,6 +379,10 @@ int ccedit_gaussian_sample(const float* moments, const float* noise, float* out,
  *           output pixel (y, x) reads source (y stride - pad + ky, x stride - pad + kx), zeros outside; Hout / Wout are given (the
  *           encoder's Downsample pads right / bottom only, model.py:74-93); upsample = 1: the taps walk over the nearest-2x
  *           upsampled source (2 Hin x 2 Win) without materialising it (model.py:56-71).  M = frames * Hout * Wout.
+ *           upsample = 2 + 2 py + px (round 6, policy f32_split != 0 only): ONE OUTPUT PARITY of the same `conv3x3(nearest_upsample_2x(x))`
+ *           as a 2 x 2 convolution on x itself — W [N][4][Cpad] holds the merged taps (ccedit_amd/vae_f32.py: pack_f32_parities),
+ *           Hout x Wout = Hin x Win, stride 1, pad 1, no residual, M = frames * Hin * Win; the row of source pixel (y, x) is written to
+ *           pixel (2 y + py, 2 x + px) of `out` = the 2 Hin x 2 Win frames.  Four calls fill the tensor at 4/9 of the multiply-adds.
  * A and W 16-byte aligned, lda % 4 == 0, ldw % 4 == 0; out / res any row stride >= N (16-byte accesses when a multiple of 4).
  * Fixed summation order: repeated calls are bit-identical. */
 typedef struct CcGemmF32Desc {
