@@ -17,7 +17,7 @@ out = {}
 for name, prec, split in (("bf16", "bf16", 1), ("fp32 (six bf16 products)", "fp32", 1), ("fp32 (v_mfma_f32_32x32x2_f32)", "fp32", 0)):
     vae.precision = prec
     assert hip.lib().ccedit_policy_set(b"f32_split", split) == 0
-    vae.decode(z[:, :, :2].contiguous())
+    vae.decode(z)                      # (one untimed decode of the same size, as bench.py's clip: the caching allocator holds the blocks afterwards)
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
