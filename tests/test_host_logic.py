@@ -455,3 +455,22 @@ def test_generated_yamls_build_the_reference_state_dict(tmp_path, golden_dir, na
     assert all(net[k] == ref[k] for k in ref)
     assert sum(int(np.prod(s_)) for s_ in net.values()) == nparams
     assert engine.first_stage_model.precision == "fp32"
+
+
+def test_bench_reads_traffic_from_the_capture_of_this_build(tmp_path, monkeypatch):
+    """bench.py's `roofline.traffic` comes from the committed PMC capture whose `kernel_source_hash` is THIS build's (the newest round's
+    file otherwise, reported as stale): a fixed file name silently went stale when a later round re-captured (round 6)."""
+    import json
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "abc")
+    assert bench.pmc_traffic_file() == "r06_pmc_traffic.json"                      # nothing there: the name the note will mention
+    (prof / "r04_pmc_traffic.json").write_text(json.dumps({"kernel_source_hash": "abc"}))
+    (prof / "r05_pmc_traffic.json").write_text(json.dumps({"kernel_source_hash": "old"}))
+    (prof / "r05_pmc_traffic_tvi2v.json").write_text(json.dumps({"kernel_source_hash": "abc"}))
+    assert bench.pmc_traffic_file() == "r04_pmc_traffic.json"                      # the matching capture wins over the newer stale one
+    assert bench.pmc_traffic_file(True) == "r05_pmc_traffic_tvi2v.json"
+    (prof / "r04_pmc_traffic.json").write_text("not json")
+    assert bench.pmc_traffic_file() == "r05_pmc_traffic.json"                      # no match: the newest file (bench.py reports it stale)
