@@ -16,8 +16,10 @@ on 127.0.0.1, one per GPU.  `value` at N > 1 is BASELINE.json config 5 — N ind
 data-path collective; barrier on both sides, MAX time over ranks), `scaling: "weak"`.  The same line carries a `c4` object: config 4,
 ONE clip whose latent rows are sharded over the N ranks (parallel.RowShard: halo rows, all-reduced GroupNorm sums, head-parallel
 spatial attention through all-to-alls; `--shard-mode` selects another decomposition) — strong-scaling ms/step,
-`efficiency_per_gpu` against the single-GPU step measured in the same run, exchanges and bytes per step.  `--shard-frames` makes
-config 4 the headline `value` instead (`scaling: "strong"`).
+`efficiency_per_gpu` against the single-GPU step measured in the same run, exchanges and bytes per step.  That section runs in CHILD
+processes with a process group of their own (c4_in_children; `--c4-inline` = inside the benchmark processes under a watchdog): the
+sharded path has never met a multi-GPU node, and neither a crash in the runtime nor a stuck collective there may cost the replica line.
+`--shard-frames` makes config 4 the headline `value` instead (`scaling: "strong"`).
 
 Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region.
 """
@@ -275,6 +277,10 @@ def main():
     ap.add_argument("--no-tvi2v", action="store_true", help="skip the config-3 (TVI2V) step timing added to the default single-GPU line")
     ap.add_argument("--no-c4", action="store_true", help="N>1: skip the config-4 (one clip, rows sharded) object of the replica line")
     ap.add_argument("--c4-deadline", type=float, default=240.0, help="N>1: seconds the config-4 section may take before the line is emitted without it")
+    ap.add_argument("--c4-inline", action="store_true", help="N>1: run the config-4 section inside the benchmark processes (the round-5 form) instead of "
+                                                            "in child processes of their own")
+    ap.add_argument("--c4-child", action="store_true", help=argparse.SUPPRESS)          # internal: this process IS a config-4 child (see c4_in_children)
+    ap.add_argument("--c4-single-ms", type=float, default=0.0, help=argparse.SUPPRESS)  # internal: the parent's replica ms/step, for efficiency_per_gpu
     ap.add_argument("--attn", choices=["heads", "gather"], default="heads",
                     help="row-sharded spatial attention: all-to-all by head (heads) or all-gather of K/V (gather)")
     ap.add_argument("--dump-shapes", type=str, default="", help="write the GEMM launch shape sequence of one step (json)")
@@ -354,6 +360,20 @@ def main():
         if dist is not None:
             dt = max_over_ranks_ms(dt, dist, device, backend)
         return dt, o
+
+    if args.c4_child:
+        # config 4 in a process of its own (c4_in_children): ONE clip row-sharded over the ranks, the same clip on all ranks
+        set_inputs(*synth_inputs(device, seed=42), 7)
+        shards = install_shards(wrapper, args)
+        step(); step()
+        c4_dt, o4 = timed(args.steps)
+        assert torch.isfinite(o4).all()
+        info = shard_counters(shards, step, world, dist, wrapper)
+        if rank == 0:
+            print("C4_OBJECT " + json.dumps(c4_object(args, world, c4_dt / args.steps * 1e3, args.c4_single_ms, info)), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     # one-time initialisation, like building the model: the wrapper runs its first evaluation eagerly and captures the second into
     # a HIP graph (ccedit_amd/network.py) — with fewer than two warm-up steps that capture would fall into the timed region
@@ -572,7 +592,9 @@ def main():
     # ---- config 4 next to the replica value (default N > 1): ONE clip row-sharded over the ranks, timed LAST and under a watchdog — this
     # path has never met a multi-GPU node, and a stuck collective must not cost the replica line the driver's scaling
     # curve is computed from: if the sharded section does not finish in time every rank emits / exits without it.
-    if world > 1 and not shard and not args.no_c4:
+    if world > 1 and not shard and not args.no_c4 and not args.c4_inline:
+        extra["c4"] = c4_in_children(args, rank, world, dist, ms_per_step)
+    elif world > 1 and not shard and not args.no_c4:
         import threading
 
         def bail():
@@ -602,6 +624,42 @@ def main():
     if dist is not None:
         dist.barrier()                              # rank 0 may still have been profiling: leave together
         dist.destroy_process_group()
+
+
+def c4_in_children(args, rank, world, dist, single_ms):
+    """Config 4 next to the replica value, ISOLATED: every rank starts a child process (this file with --c4-child) and the children form a
+    process group of their own on another port, build the model again, time the row-sharded clip and hand the `c4` object to rank 0's
+    parent through stdout.  The sharded path has never met a multi-GPU node: a crash inside the runtime (capturing RCCL
+    collectives has produced those) or a stuck collective then costs the `c4` object — an `error` entry — and not the replica line the
+    driver's scaling curve is computed from.  The parents keep their GPUs' memory (a second model fits many times) and wait."""
+    import socket
+    import subprocess
+    port = [0]
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+    dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ, MASTER_PORT=str(port[0]), MASTER_ADDR="127.0.0.1")
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)           # the children's rank 0 hosts the store of their own group
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup), "--c4-child",
+           "--c4-single-ms", f"{single_ms:.4f}", "--shard-mode", args.shard_mode, "--attn", args.attn, "--workload", args.workload]
+    res = None
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.c4_deadline)
+        if rank == 0:
+            for ln in out.stdout.splitlines():
+                if ln.startswith("C4_OBJECT "):
+                    res = json.loads(ln[len("C4_OBJECT "):])
+                    res["isolation"] = "child processes with a process group of their own"
+            if res is None:
+                res = dict(error=f"the config-4 child of rank 0 exited with code {out.returncode} and no result; replica value unaffected",
+                           stderr_tail=out.stderr[-600:])
+    except subprocess.TimeoutExpired:
+        res = dict(error=f"the row-sharded section (child processes) did not finish within {args.c4_deadline} s; replica value unaffected")
+    except Exception as e:                   # (spawn failure etc.)
+        res = dict(error=f"{type(e).__name__}: {e}")
+    return res if rank == 0 else None
 
 
 def install_shards(wrapper, args):
