@@ -30,6 +30,43 @@ struct F32Pix {            // geometry of one pixel row of the tile (conv mode)
     int oy, ox;            // output coordinates times stride, minus pad (top-left tap position in the virtual source)
 };
 
+// Epilogue shared by the three GEMM kernels: a wave's 2 x 2 accumulator tiles (64 channels from n0, 64 pixels from m0) to rows of
+// `out` (+ bias, + residual).  Lane = pixel (column) l31 of tile tj; accumulator r = channel 8 (r / 4) + 4 hi + r % 4 of tile ti.
+// out_row(m): the row of GEMM row m (m itself, or its place in the up-sampled frame for a parity conv).
+template <typename OutRow>
+__device__ __forceinline__ void f32_store_tiles(const CcGemmF32Desc& d, const f32x16 (&acc)[2][2], int64_t m0, int n0, int l31, int hi, OutRow out_row) {
+    const bool vec = (d.ldc & 3) == 0 && (!d.res || (d.ldr & 3) == 0);
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int64_t m = m0 + tj * 32 + l31;
+        if (m >= d.M) continue;
+        float* orow = d.out + out_row(m) * d.ldc;
+        const float* rrow = d.res ? d.res + (size_t)m * d.ldr : nullptr;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + ti * 32 + 8 * q + 4 * hi;
+                if (n >= d.N) continue;
+                f32x4 v = {acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1], acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]};
+                if (vec && n + 3 < d.N) {
+                    if (d.bias) v += *(const f32x4*)(d.bias + n);
+                    if (rrow) v += *(const f32x4*)(rrow + n);
+                    *(f32x4*)(orow + n) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < d.N) {
+                            float o = v[e];
+                            if (d.bias) o += d.bias[n + e];
+                            if (rrow) o += rrow[n + e];
+                            orow[n + e] = o;
+                        }
+                }
+            }
+    }
+}
+
 template <bool CONV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void f32_gemm_kernel(const CcGemmF32Desc d) {
     __shared__ __attribute__((aligned(16))) float smem[2 * F_TILE];
@@ -134,37 +171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         __syncthreads();
     }
 
-    // epilogue: lane = pixel (column) l31 of tile tj; accumulator r = channel 8 (r / 4) + 4 hi + r % 4 of tile ti
-    const bool vec = (d.ldc & 3) == 0 && (!d.res || (d.ldr & 3) == 0);
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        const int64_t m = m0 + wc * 64 + tj * 32 + l31;
-        if (m >= d.M) continue;
-        float* orow = d.out + (size_t)m * d.ldc;
-        const float* rrow = d.res ? d.res + (size_t)m * d.ldr : nullptr;
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wr * 64 + ti * 32 + 8 * q + 4 * hi;
-                if (n >= d.N) continue;
-                f32x4 v = {acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1], acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]};
-                if (vec && n + 3 < d.N) {
-                    if (d.bias) v += *(const f32x4*)(d.bias + n);
-                    if (rrow) v += *(const f32x4*)(rrow + n);
-                    *(f32x4*)(orow + n) = v;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < d.N) {
-                            float o = v[e];
-                            if (d.bias) o += d.bias[n + e];
-                            if (rrow) o += rrow[n + e];
-                            orow[n + e] = o;
-                        }
-                }
-            }
-    }
+    f32_store_tiles(d, acc, m0 + wc * 64, n0 + wr * 64, l31, hi, [](int64_t m) { return (size_t)m; });
 }
 
 // ---- the same contraction on the bf16 matrix pipe: exact three-way operand split (policy f32_split, the default) ----
@@ -373,37 +380,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         __syncthreads();
     }
 
-    // epilogue: lane = pixel (column) l31 of tile tj; accumulator r = channel 8 (r / 4) + 4 hi + r % 4 of tile ti
-    const bool vec = (d.ldc & 3) == 0 && (!d.res || (d.ldr & 3) == 0);
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        const int64_t m = m0 + wc * 64 + tj * 32 + l31;
-        if (m >= d.M) continue;
-        float* orow = d.out + (size_t)m * d.ldc;
-        const float* rrow = d.res ? d.res + (size_t)m * d.ldr : nullptr;
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wr * 64 + ti * 32 + 8 * q + 4 * hi;
-                if (n >= d.N) continue;
-                f32x4 v = {acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1], acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]};
-                if (vec && n + 3 < d.N) {
-                    if (d.bias) v += *(const f32x4*)(d.bias + n);
-                    if (rrow) v += *(const f32x4*)(rrow + n);
-                    *(f32x4*)(orow + n) = v;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < d.N) {
-                            float o = v[e];
-                            if (d.bias) o += d.bias[n + e];
-                            if (rrow) o += rrow[n + e];
-                            orow[n + e] = o;
-                        }
-                }
-            }
-    }
+    f32_store_tiles(d, acc, m0 + wc * 64, n0 + wr * 64, l31, hi, [](int64_t m) { return (size_t)m; });
 }
 
 // ---- the pipelined form of the same kernel (large M, Cout > 128): ONE 16-wave workgroup per CU, tiles two K steps ahead ----
@@ -569,44 +546,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #endif
     }
 
-    const bool vec = (d.ldc & 3) == 0 && (!d.res || (d.ldr & 3) == 0);
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        const int64_t m = m0 + wc * 64 + tj * 32 + l31;
-        if (m >= d.M) continue;
-        size_t orow_i = (size_t)m;
+    f32_store_tiles(d, acc, m0 + wc * 64, n0 + wr * 64, l31, hi, [&](int64_t m) {
         if constexpr (PAR) {
             const int hw = d.Hin * d.Win;
             const int64_t f = m / hw;
             const int r = (int)(m - f * hw);
             const int y = r / d.Win, x = r - y * d.Win;
-            orow_i = ((size_t)f * 2 * d.Hin + 2 * y + ((d.upsample - 2) >> 1)) * (2 * d.Win) + 2 * x + ((d.upsample - 2) & 1);
+            return ((size_t)f * 2 * d.Hin + 2 * y + ((d.upsample - 2) >> 1)) * (2 * d.Win) + 2 * x + ((d.upsample - 2) & 1);
+        } else {
+            return (size_t)m;
         }
-        float* orow = d.out + orow_i * d.ldc;
-        const float* rrow = d.res ? d.res + (size_t)m * d.ldr : nullptr;
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wr * 64 + ti * 32 + 8 * q + 4 * hi;
-                if (n >= d.N) continue;
-                f32x4 v = {acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1], acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]};
-                if (vec && n + 3 < d.N) {
-                    if (d.bias) v += *(const f32x4*)(d.bias + n);
-                    if (rrow) v += *(const f32x4*)(rrow + n);
-                    *(f32x4*)(orow + n) = v;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < d.N) {
-                            float o = v[e];
-                            if (d.bias) o += d.bias[n + e];
-                            if (rrow) o += rrow[n + e];
-                            orow[n + e] = o;
-                        }
-                }
-            }
-    }
+    });
 }
 
 template <int MODE>
@@ -834,7 +784,7 @@ extern "C" int ccedit_gemm_f32(const CcGemmF32Desc* desc, void* stream) {
         const int ups = d.mode == 1 && d.upsample;
         CC_UNSUPPORTED(ups && !(d.stride == 1 && d.pad == 1), "ccedit_gemm_f32: the fused up-sampling gather takes stride 1, pad 1 (got %d, %d)", d.stride, d.pad);
         if (parity) return f32p_launch<3>(d, s);
-        if (cc_policy().f32_split == 1 && d.M >= 8192 && d.N > 128) {          // (2: always the two-workgroups-per-CU kernel)
+        if (cc_policy().f32_split == 1 && d.M >= 4096 && d.N > 128) {          // (2: always the two-workgroups-per-CU kernel)
             const int mode = ups ? 2 : d.mode;
             return mode == 2 ? f32p_launch<2>(d, s) : mode == 1 ? f32p_launch<1>(d, s) : f32p_launch<0>(d, s);
         }
