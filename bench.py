@@ -593,7 +593,10 @@ def main():
     # path has never met a multi-GPU node, and a stuck collective must not cost the replica line the driver's scaling
     # curve is computed from: if the sharded section does not finish in time every rank emits / exits without it.
     if world > 1 and not shard and not args.no_c4 and not args.c4_inline:
-        extra["c4"] = c4_in_children(args, rank, world, dist, ms_per_step)
+        try:
+            extra["c4"] = c4_in_children(args, rank, world, dist, ms_per_step)
+        except Exception as e:            # (the port broadcast: the only collective of the parents in this section)
+            extra["c4"] = dict(error=f"{type(e).__name__}: {e}")
     elif world > 1 and not shard and not args.no_c4:
         import threading
 
